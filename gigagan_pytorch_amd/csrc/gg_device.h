@@ -1,0 +1,73 @@
+// gg_device.h — the device-side vocabulary every kernel in csrc/ is written against (gfx950 / CDNA4).
+//
+// Kernels use: 64-lane wavefronts, `gg_mfma_32x32x16_bf16` (v_mfma_f32_32x32x16_bf16), 16-byte global
+// loads, LDS tiles, wave shuffles. bf16 is stored as raw `unsigned short` so that vector loads are plain
+// integer vectors and rounding is explicit (round-to-nearest-even, as torch's bf16 cast).
+//
+// The only conditional in this file selects the host-side kernel emulator used by tests/emu (fibers on
+// the CPU, same kernel sources, same C ABI) so that index math can be verified without a GPU. The
+// emulator is test infrastructure; the product library is always built with hipcc for gfx950.
+#pragma once
+#include <stdint.h>
+
+#if defined(GG_HOST_EMULATION)
+#include "gg_device_emu.h"
+#else
+
+#include <hip/hip_runtime.h>
+
+#define GG_DEVICE __device__ __forceinline__
+#define GG_HOST_DEVICE __host__ __device__ __forceinline__
+#define GG_KERNEL __global__
+#define GG_SHARED __shared__
+#define GG_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+#define GG_LAUNCH(kernel, grid, block, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
+
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 gg_bf16x8_native;
+
+GG_DEVICE void gg_sync() { __syncthreads(); }
+
+// D[i][j] += sum_k Aop[i][k] * Bop[k][j], 32x32x16, one wave.
+//   Aop: lane l holds Aop[i = l&31][k = 8*(l>>5) + e], e = 0..7
+//   Bop: lane l holds Bop[k = 8*(l>>5) + e][j = l&31]
+//   D  : lane l, reg r holds D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31]
+GG_DEVICE f32x16 gg_mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gg_bf16x8_native, a),
+                                                   __builtin_bit_cast(gg_bf16x8_native, b), c, 0, 0, 0);
+}
+
+GG_DEVICE float gg_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+GG_DEVICE float gg_shfl(float v, int src) { return __shfl(v, src, 64); }
+GG_DEVICE void gg_atomic_add(float* p, float v) { atomicAdd(p, v); }
+GG_DEVICE float gg_expf(float x) { return __expf(x); }
+GG_DEVICE float gg_rsqrtf(float x) { return rsqrtf(x); }
+
+#endif  // GG_HOST_EMULATION
+
+// ---- shared scalar helpers (same code on device and in the emulator) ------------------------------
+
+GG_HOST_DEVICE float gg_bf2f(bf16_t h) {
+    union { unsigned int u; float f; } x;
+    x.u = ((unsigned int)h) << 16;
+    return x.f;
+}
+
+// round-to-nearest-even fp32 -> bf16 (NaN kept quiet), identical to torch's .to(torch.bfloat16)
+GG_HOST_DEVICE bf16_t gg_f2bf(float f) {
+    union { unsigned int u; float f; } x;
+    x.f = f;
+    if ((x.u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((x.u >> 16) | 0x40u);
+    unsigned int lsb = (x.u >> 16) & 1u;
+    x.u += 0x7fffu + lsb;
+    return (bf16_t)(x.u >> 16);
+}
+

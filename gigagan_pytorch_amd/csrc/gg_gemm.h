@@ -1,0 +1,438 @@
+// gg_gemm.h — the one contraction kernel of the GigaGAN hot path: a batched, LDS-tiled bf16 MFMA GEMM
+// whose A operand can be an implicit im2col gather over an NHWC activation (stride-1 "same" convolution)
+// and whose operands can each be stored reduction-major ("KROW": the matrix is stored [k][m]) or
+// reduction-minor ("ROWK": stored [m][k]).  Every dense contraction of the reference's G+D step maps
+// onto it:
+//
+//   reference op (gigagan_pytorch.py)                     A                      B
+//   F.conv2d fwd / dgrad  (:407, :1608-1621, :1454-1470)  conv gather, ROWK      weights [co][tap][ci], ROWK
+//   conv weight gradient (autograd of the above)          conv gather, KROW      dy [pixel][co], KROW
+//   nn.Linear / 1x1 conv / EqualLinear (:530-536,:871)    dense ROWK             dense ROWK
+//   einsum('b i d, b j d -> b i j') (:574, :579)          q ROWK                 k ROWK
+//   einsum('b i j, b j d -> b i d') (:590)                attn ROWK              v KROW
+//   and their gradients (all four transposes).
+//
+// Tiling (CDNA4): 256 threads = 4 wavefronts of 64 lanes; block tile BM x BN x 32; each wave owns a
+// (BM/WM) x (BN/WN) sub-tile made of 32x32 MFMA tiles (v_mfma_f32_32x32x16_bf16, fp32 accumulate).
+// Operand tiles are staged global -> registers -> LDS with 16-byte loads, double-buffered in LDS (one
+// barrier per k-tile, next tile's global loads in flight during the MFMAs).  LDS rows are k-contiguous
+// with an 80-byte pitch, which makes the fragment `ds_read_b128`s conflict-free (MI355X_MICROARCH §LDS).
+// KROW operands are transposed while staging: each thread loads two k-rows x 8 columns and writes 8
+// packed (k, k+1) dwords (kp-fastest lane order => at most the free 2-way ds_write_b32 conflict).
+// The MFMA is issued with swapped operands (B-tile as the A operand) so that each lane's accumulator
+// registers run along N: a lane owns 4 consecutive output channels per register quad and stores them
+// with one 8-byte (bf16) or 16-byte (fp32) store.
+//
+// Algorithmic work per launch: 2*M*N*K*batch flops; algorithmic HBM bytes: (M*K + N*K + M*N)*2*batch
+// for dense operands, and for the conv gather the activation is counted once (H*W*C per image).
+#pragma once
+#include "gg_device.h"
+
+enum { GG_ACT_NONE = 0, GG_ACT_LRELU = 1, GG_ACT_GELU = 2, GG_ACT_SILU = 3 };
+
+struct GgGemmParams {
+    // problem: C[b][m][n] = epilogue( sum_k A[b][m][k] * B[b][n][k] )
+    int M, N, K;
+    int batch;
+    int splitk;       // >= 1; > 1: fp32 partials go to `partial`, finished by gg_splitk_reduce_kernel
+    int k_per_split;  // multiple of 32
+    // A operand. dense: element (m,k) at A[b*a_bs + m*lda + k] (ROWK) or A[b*a_bs + k*lda + m] (KROW)
+    const bf16_t* A;
+    long long a_bs;
+    int lda;
+    // B operand. element (n,k) at B[b*b_bs + n*ldb + k] (ROWK) or B[b*b_bs + k*ldb + n] (KROW)
+    const bf16_t* B;
+    long long b_bs;
+    int ldb;
+    // conv gather on A: activation [img][H][W][C] bf16, output grid H x W (stride 1, pad = (R-1)/2),
+    // reduction/gather index = (tap = kh*S + kw, cv) with cv in [0, CV); physical channel = cv % C.
+    int H, W, C, CV, R, S, pad;
+    const float* in_scale;  // optional [img][CV] multiplier applied to the gathered activation
+    // output / epilogue
+    void* Cout;
+    long long c_bs;
+    int ldc;
+    int c_f32;  // 0: bf16 output, 1: fp32 output
+    float alpha;
+    const float* bias;       // [N]
+    const float* out_scale;  // [m / rows_per_group][N]
+    int rows_per_group;
+    const float* noise;    // [M]
+    const float* noise_w;  // [N]
+    int act;
+    float act_slope;
+    float* partial;  // [batch][splitk][M][N] fp32
+};
+
+GG_DEVICE float gg_apply_act(float v, int act, float slope) {
+    if (act == GG_ACT_LRELU) return v > 0.f ? v : v * slope;
+    if (act == GG_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    if (act == GG_ACT_SILU) return v / (1.f + gg_expf(-v));
+    return v;
+}
+
+GG_DEVICE float gg_epilogue(const GgGemmParams& p, float acc, int m, int n) {
+    float v = acc * p.alpha;
+    if (p.out_scale) v *= p.out_scale[(long long)(m / p.rows_per_group) * p.N + n];
+    if (p.bias) v += p.bias[n];
+    if (p.noise) v += p.noise[m] * p.noise_w[n];
+    return gg_apply_act(v, p.act, p.act_slope);
+}
+
+// store 4 consecutive-n results of row m
+GG_DEVICE void gg_store4(const GgGemmParams& p, int b, int m, int n, const float* v) {
+    if (p.c_f32) {
+        float* c = (float*)p.Cout + (long long)b * p.c_bs + (long long)m * p.ldc + n;
+        if (n + 3 < p.N && (p.ldc & 3) == 0) {
+            f32x4 o = {v[0], v[1], v[2], v[3]};
+            *(f32x4*)c = o;
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (n + e < p.N) c[e] = v[e];
+        }
+    } else {
+        bf16_t* c = (bf16_t*)p.Cout + (long long)b * p.c_bs + (long long)m * p.ldc + n;
+        if (n + 3 < p.N && (p.ldc & 3) == 0) {
+            u16x4 o = {gg_f2bf(v[0]), gg_f2bf(v[1]), gg_f2bf(v[2]), gg_f2bf(v[3])};
+            *(u16x4*)c = o;
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (n + e < p.N) c[e] = gg_f2bf(v[e]);
+        }
+    }
+}
+
+#define GG_BK 32
+#define GG_LDS_PITCH 40  // bf16 elements per LDS row: 32 + 8 pad = 80 bytes
+
+// ---- operand tile loaders -------------------------------------------------------------------------
+// A loader fills `NV` 16-byte registers per thread for one k-tile; a matching store writes them to LDS.
+
+template <int ROWS>
+struct GgRowKLayout {  // ROWK: ROWS*4 vectors of 8 k-elements
+    static constexpr int NV = (ROWS * 4 + 255) / 256;
+};
+template <int ROWS>
+struct GgKRowLayout {  // KROW: 16 k-pairs x ROWS/8 column groups, 2 vectors each
+    static constexpr int ITEMS = 16 * (ROWS / 8);
+    static constexpr int NI = (ITEMS + 255) / 256;
+    static constexpr int NV = 2 * NI;
+};
+
+GG_DEVICE u16x8 gg_zero8() {
+    u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return z;
+}
+
+GG_DEVICE u16x8 gg_scale8(u16x8 v, const float* s) {
+    u16x8 o;
+    for (int e = 0; e < 8; ++e) o[e] = gg_f2bf(gg_bf2f(v[e]) * s[e]);
+    return o;
+}
+
+// dense ROWK: rows [r0, r0+ROWS) of a [nrows][K] matrix with pitch ld, k-tile at k0
+template <int ROWS>
+GG_DEVICE void gg_load_rowk_dense(u16x8* regs, const bf16_t* base, int ld, int nrows, int r0, int K,
+                                  int kend, int k0) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < GgRowKLayout<ROWS>::NV; ++i) {
+        int v = t + 256 * i;
+        int row = v >> 2, kv = v & 3;
+        u16x8 x = gg_zero8();
+        int r = r0 + row, k = k0 + kv * 8;
+        if (row < ROWS && r < nrows && k < kend) {
+            x = *(const u16x8*)(base + (long long)r * ld + k);
+            if (k + 8 > kend) {
+                for (int e = 0; e < 8; ++e)
+                    if (k + e >= kend) x[e] = 0;
+            }
+        }
+        regs[i] = x;
+    }
+    (void)K;
+}
+
+template <int ROWS>
+GG_DEVICE void gg_store_rowk(bf16_t (*s)[GG_LDS_PITCH], const u16x8* regs) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < GgRowKLayout<ROWS>::NV; ++i) {
+        int v = t + 256 * i;
+        int row = v >> 2, kv = v & 3;
+        if (row < ROWS) *(u16x8*)&s[row][kv * 8] = regs[i];
+    }
+}
+
+// dense KROW: matrix stored [k][ncols] with pitch ld; tile columns [c0, c0+ROWS), k-tile at k0.
+template <int ROWS>
+GG_DEVICE void gg_load_krow_dense(u16x8* regs, const bf16_t* base, int ld, int ncols, int c0, int kend,
+                                  int k0) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < GgKRowLayout<ROWS>::NI; ++i) {
+        int item = t + 256 * i;
+        int kp = item & 15, cg = item >> 4;
+        u16x8 x0 = gg_zero8(), x1 = gg_zero8();
+        int c = c0 + cg * 8, k = k0 + 2 * kp;
+        if (item < GgKRowLayout<ROWS>::ITEMS && c < ncols) {
+            if (k < kend) x0 = *(const u16x8*)(base + (long long)k * ld + c);
+            if (k + 1 < kend) x1 = *(const u16x8*)(base + (long long)(k + 1) * ld + c);
+            if (c + 8 > ncols) {
+                for (int e = 0; e < 8; ++e)
+                    if (c + e >= ncols) { x0[e] = 0; x1[e] = 0; }
+            }
+        }
+        regs[2 * i] = x0;
+        regs[2 * i + 1] = x1;
+    }
+}
+
+template <int ROWS>
+GG_DEVICE void gg_store_krow(bf16_t (*s)[GG_LDS_PITCH], const u16x8* regs) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < GgKRowLayout<ROWS>::NI; ++i) {
+        int item = t + 256 * i;
+        int kp = item & 15, cg = item >> 4;
+        if (item < GgKRowLayout<ROWS>::ITEMS) {
+            u16x8 x0 = regs[2 * i], x1 = regs[2 * i + 1];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                unsigned int d = (unsigned int)x0[e] | ((unsigned int)x1[e] << 16);
+                *(unsigned int*)&s[cg * 8 + e][2 * kp] = d;
+            }
+        }
+    }
+}
+
+// conv gather, ROWK: row m = output pixel (img, oh, ow); k = (tap, cv)
+struct GgConvRow {
+    long long img_off;  // img * H*W*C
+    int img, ih0, iw0, valid;
+};
+
+template <int ROWS>
+GG_DEVICE void gg_conv_rows_init(GgConvRow* rows, const GgGemmParams& p, int m0) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < GgRowKLayout<ROWS>::NV; ++i) {
+        int v = t + 256 * i;
+        int row = v >> 2;
+        int m = m0 + row;
+        GgConvRow r;
+        r.valid = (row < ROWS) && (m < p.M);
+        int hw = p.H * p.W;
+        int img = r.valid ? m / hw : 0;
+        int rem = r.valid ? m - img * hw : 0;
+        int oh = rem / p.W, ow = rem - oh * p.W;
+        r.img = img;
+        r.img_off = (long long)img * hw * p.C;
+        r.ih0 = oh - p.pad;
+        r.iw0 = ow - p.pad;
+        rows[i] = r;
+    }
+}
+
+template <int ROWS>
+GG_DEVICE void gg_load_rowk_conv(u16x8* regs, const GgConvRow* rows, const GgGemmParams& p, int kend,
+                                 int k0) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < GgRowKLayout<ROWS>::NV; ++i) {
+        int v = t + 256 * i;
+        int kv = v & 3;
+        int k = k0 + kv * 8;
+        u16x8 x = gg_zero8();
+        const GgConvRow& r = rows[i];
+        if (r.valid && k < kend) {
+            int tap = k / p.CV;
+            int cv = k - tap * p.CV;
+            int kh = tap / p.S, kw = tap - kh * p.S;
+            int ih = r.ih0 + kh, iw = r.iw0 + kw;
+            if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
+                int ci = (p.CV == p.C) ? cv : cv % p.C;
+                x = *(const u16x8*)(p.A + r.img_off + ((long long)ih * p.W + iw) * p.C + ci);
+                if (p.in_scale) x = gg_scale8(x, p.in_scale + (long long)r.img * p.CV + cv);
+            }
+        }
+        regs[i] = x;
+    }
+}
+
+// conv gather, KROW (weight gradient): k = output pixel, column = (tap, cv)
+template <int ROWS>
+GG_DEVICE void gg_load_krow_conv(u16x8* regs, const GgGemmParams& p, int c0, int kend, int k0) {
+    const int t = threadIdx.x;
+    const int hw = p.H * p.W;
+#pragma unroll
+    for (int i = 0; i < GgKRowLayout<ROWS>::NI; ++i) {
+        int item = t + 256 * i;
+        int kp = item & 15, cg = item >> 4;
+        u16x8 x[2] = {gg_zero8(), gg_zero8()};
+        int c = c0 + cg * 8;
+        if (item < GgKRowLayout<ROWS>::ITEMS && c < p.M) {
+            int tap = c / p.CV;
+            int cv = c - tap * p.CV;
+            int kh = tap / p.S, kw = tap - kh * p.S;
+            int ci = (p.CV == p.C) ? cv : cv % p.C;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int pix = k0 + 2 * kp + h;
+                if (pix < kend) {
+                    int img = pix / hw;
+                    int rem = pix - img * hw;
+                    int oh = rem / p.W, ow = rem - oh * p.W;
+                    int ih = oh - p.pad + kh, iw = ow - p.pad + kw;
+                    if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
+                        u16x8 y = *(const u16x8*)(p.A + (long long)img * hw * p.C +
+                                                  ((long long)ih * p.W + iw) * p.C + ci);
+                        if (p.in_scale) y = gg_scale8(y, p.in_scale + (long long)img * p.CV + cv);
+                        x[h] = y;
+                    }
+                }
+            }
+        }
+        regs[2 * i] = x[0];
+        regs[2 * i + 1] = x[1];
+    }
+}
+
+// ---- the kernel ---------------------------------------------------------------------------------
+
+template <int BM, int BN, int WM, int WN, bool A_KROW, bool B_KROW, bool A_CONV>
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_gemm_kernel(GgGemmParams p) {
+    static_assert(WM * WN == 4, "4 wavefronts per workgroup");
+    constexpr int WTM = BM / WM, WTN = BN / WN;  // per-wave tile
+    constexpr int TM = WTM / 32, TN = WTN / 32;  // 32x32 MFMA tiles per wave
+    static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+    constexpr int ANV = A_KROW ? GgKRowLayout<BM>::NV : GgRowKLayout<BM>::NV;
+    constexpr int BNV = B_KROW ? GgKRowLayout<BN>::NV : GgRowKLayout<BN>::NV;
+
+    GG_SHARED __attribute__((aligned(16))) bf16_t sA[2][BM][GG_LDS_PITCH];
+    GG_SHARED __attribute__((aligned(16))) bf16_t sB[2][BN][GG_LDS_PITCH];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int bz = blockIdx.z;
+    const int b = bz / p.splitk, ks = bz % p.splitk;
+    const int kbeg = ks * p.k_per_split;
+    int kend = kbeg + p.k_per_split;
+    if (kend > p.K) kend = p.K;
+
+    const bf16_t* Ab = p.A + (long long)b * p.a_bs;
+    const bf16_t* Bb = p.B + (long long)b * p.b_bs;
+
+    GgConvRow crow[A_CONV && !A_KROW ? ANV : 1];
+    if (A_CONV && !A_KROW) gg_conv_rows_init<BM>(crow, p, m0);
+
+    u16x8 ra[ANV], rb[BNV];
+
+    auto load_tiles = [&](int k0) {
+        if (A_CONV) {
+            if (A_KROW) gg_load_krow_conv<BM>(ra, p, m0, kend, k0);
+            else gg_load_rowk_conv<BM>(ra, crow, p, kend, k0);
+        } else {
+            if (A_KROW) gg_load_krow_dense<BM>(ra, Ab, p.lda, p.M, m0, kend, k0);
+            else gg_load_rowk_dense<BM>(ra, Ab, p.lda, p.M, m0, p.K, kend, k0);
+        }
+        if (B_KROW) gg_load_krow_dense<BN>(rb, Bb, p.ldb, p.N, n0, kend, k0);
+        else gg_load_rowk_dense<BN>(rb, Bb, p.ldb, p.N, n0, p.K, kend, k0);
+    };
+    auto store_tiles = [&](int buf) {
+        if (A_KROW) gg_store_krow<BM>(sA[buf], ra);
+        else gg_store_rowk<BM>(sA[buf], ra);
+        if (B_KROW) gg_store_krow<BN>(sB[buf], rb);
+        else gg_store_rowk<BN>(sB[buf], rb);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (kend > kbeg) ? (kend - kbeg + GG_BK - 1) / GG_BK : 0;
+    if (nk > 0) {
+        load_tiles(kbeg);
+        store_tiles(0);
+    }
+    gg_sync();
+
+    const int frow = lane & 31, fk = (lane >> 5) * 8;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        const bool has_next = (kt + 1 < nk);
+        if (has_next) load_tiles(kbeg + (kt + 1) * GG_BK);
+#pragma unroll
+        for (int kk = 0; kk < GG_BK / 16; ++kk) {
+            u16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *(const u16x8*)&sA[buf][wm * WTM + i * 32 + frow][kk * 16 + fk];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[j] = *(const u16x8*)&sB[buf][wn * WTN + j * 32 + frow][kk * 16 + fk];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    // swapped operands: D[n_local][m_local], so a lane's registers run along n
+                    acc[i][j] = gg_mfma_32x32x16_bf16(fb[j], fa[i], acc[i][j]);
+        }
+        if (has_next) store_tiles(buf ^ 1);
+        gg_sync();
+    }
+
+    // epilogue: lane owns output row m = ... + (lane & 31); register r is column
+    //   n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WTM + i * 32 + (lane & 31);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * WTN + j * 32 + 8 * g + 4 * hi;
+                if (n >= p.N) continue;
+                float v[4];
+                if (p.splitk > 1) {
+                    float* dst = p.partial + ((long long)bz * p.M + m) * p.N + n;
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.N) dst[e] = acc[i][j][g * 4 + e];
+                } else {
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = (n + e < p.N) ? gg_epilogue(p, acc[i][j][g * 4 + e], m, n + e) : 0.f;
+                    gg_store4(p, b, m, n, v);
+                }
+            }
+        }
+    }
+}
+
+// finishes a split-K launch: sums the fp32 partials and applies the epilogue
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_splitk_reduce_kernel(GgGemmParams p) {
+    const long long per = (long long)p.M * p.N;
+    const long long total = per * p.batch;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * 256) {
+        int b = (int)(idx / per);
+        long long rem = idx - (long long)b * per;
+        int m = (int)(rem / p.N), n = (int)(rem - (long long)m * p.N);
+        float s = 0.f;
+        for (int ks = 0; ks < p.splitk; ++ks)
+            s += p.partial[((long long)(b * p.splitk + ks) * p.M + m) * p.N + n];
+        float v = gg_epilogue(p, s, m, n);
+        if (p.c_f32) ((float*)p.Cout)[(long long)b * p.c_bs + (long long)m * p.ldc + n] = v;
+        else ((bf16_t*)p.Cout)[(long long)b * p.c_bs + (long long)m * p.ldc + n] = gg_f2bf(v);
+    }
+}

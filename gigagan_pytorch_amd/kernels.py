@@ -1,0 +1,142 @@
+"""Raw (non-autograd) launches of the C-ABI kernels on torch tensors. Layout glue only — no arithmetic."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _C
+from ._C import GemmDesc, ROWK, KROW, ptr
+
+_ACTS = {None: 0, 'none': 0, 'lrelu': 1, 'gelu': 2, 'silu': 3}
+_ws_cache: dict = {}
+
+
+def _workspace(nbytes: int, like: torch.Tensor) -> torch.Tensor:
+    """Per-device scratch owned by the caller side (PyTorch allocator); grows monotonically."""
+    key = (like.device.type, like.device.index)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=like.device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _run_gemm(d: GemmDesc, like: torch.Tensor):
+    L = _C.lib()
+    need = L.lib.gg_gemm_workspace_bytes(C.byref(d))
+    ws = _workspace(need, like) if need else None
+    rc = L.lib.gg_gemm_bf16(C.byref(d), ptr(ws), need, L.stream(like))
+    L.check(rc, 'gg_gemm_bf16')
+
+
+def _epilogue(d: GemmDesc, alpha, bias, out_scale, rows_per_group, noise, noise_w, act, act_slope, keep):
+    d.alpha = float(alpha)
+    for name, t in (('bias', bias), ('out_scale', out_scale), ('noise', noise), ('noise_w', noise_w)):
+        if t is not None:
+            assert t.dtype == torch.float32 and t.is_contiguous(), name
+            keep.append(t)
+            setattr(d, name, ptr(t))
+    d.rows_per_group = int(rows_per_group or 0)
+    d.act = _ACTS[act]
+    d.act_slope = float(act_slope)
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=True, out_dtype=torch.bfloat16,
+         alpha=1.0, bias=None, act=None, act_slope=0.2, out_scale=None, rows_per_group=0,
+         k_valid=None, m_valid=None, n_valid=None, out=None, force_splitk=0, force_tile=0):
+    """C[b] = act(alpha * op(A[b]) @ op(B[b])^T ...) for bf16 operands of shape ([batch,] rows, cols).
+
+    `trans_a=False`: A is stored (M, K) (k contiguous) -> ROWK; `trans_a=True`: stored (K, M) -> KROW.
+    `trans_b=True`: B is stored (N, K) -> ROWK (the nn.Linear weight layout); False: stored (K, N) -> KROW.
+    Row pitches must be multiples of 8 elements; `*_valid` give logical extents smaller than the storage.
+    """
+    L = _C.lib()
+    L.require(a, b, bias, out_scale)
+    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
+    if a.dim() == 2:
+        a = a.unsqueeze(0)
+    if b.dim() == 2:
+        b = b.unsqueeze(0)
+    assert a.stride(-1) == 1 and b.stride(-1) == 1
+    batch = max(a.shape[0], b.shape[0])
+    M = m_valid if m_valid is not None else (a.shape[2] if trans_a else a.shape[1])
+    Ka = a.shape[1] if trans_a else a.shape[2]
+    N = n_valid if n_valid is not None else (b.shape[1] if trans_b else b.shape[2])
+    Kb = b.shape[2] if trans_b else b.shape[1]
+    K = k_valid if k_valid is not None else Ka
+    assert min(Ka, Kb) >= K, (Ka, Kb, K)
+    if out is None:
+        out = torch.empty((batch, M, N), dtype=out_dtype, device=a.device)
+    assert out.stride(-1) == 1
+    keep = [a, b, out]
+    d = GemmDesc()
+    d.M, d.N, d.K, d.batch = M, N, K, batch
+    d.A, d.lda, d.a_layout = ptr(a), a.stride(1), (KROW if trans_a else ROWK)
+    d.a_batch_stride = a.stride(0) if a.shape[0] > 1 else 0
+    d.B, d.ldb, d.b_layout = ptr(b), b.stride(1), (ROWK if trans_b else KROW)
+    d.b_batch_stride = b.stride(0) if b.shape[0] > 1 else 0
+    d.C_out, d.ldc, d.c_is_f32 = ptr(out), out.stride(-2), int(out.dtype == torch.float32)
+    d.c_batch_stride = out.stride(0) if out.dim() == 3 else 0
+    d.force_splitk, d.force_tile = force_splitk, force_tile
+    _epilogue(d, alpha, bias, out_scale, rows_per_group, None, None, act, act_slope, keep)
+    _run_gemm(d, a)
+    return out
+
+
+def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, *, ksize: int, cv: int | None = None, in_scale=None,
+                out_dtype=torch.bfloat16, alpha=1.0, bias=None, act=None, act_slope=0.2, out_scale=None,
+                noise=None, noise_w=None, force_splitk=0, force_tile=0):
+    """Stride-1 'same' convolution of an NHWC bf16 activation x (n, H, W, C) with weights
+    w (Cout, ksize*ksize*CV) bf16 laid out [co][kh][kw][cv]; returns (n, H, W, Cout)."""
+    L = _C.lib()
+    L.require(x, w, in_scale, bias, out_scale, noise, noise_w)
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_contiguous() and w.is_contiguous()
+    n, H, Wd, Cc = x.shape
+    cv = cv or Cc
+    cout = w.shape[0]
+    assert w.shape[1] == ksize * ksize * cv, (w.shape, ksize, cv)
+    out = torch.empty((n, H, Wd, cout), dtype=out_dtype, device=x.device)
+    keep = [x, w, out]
+    d = GemmDesc()
+    d.M, d.N, d.K, d.batch = n * H * Wd, cout, ksize * ksize * cv, 1
+    d.A, d.a_layout, d.a_conv = ptr(x), ROWK, 1
+    d.B, d.ldb, d.b_layout = ptr(w), w.stride(0), ROWK
+    d.H, d.W, d.C, d.CV, d.R, d.S = H, Wd, Cc, cv, ksize, ksize
+    if in_scale is not None:
+        assert in_scale.dtype == torch.float32 and in_scale.shape == (n, cv) and in_scale.is_contiguous()
+        d.in_scale = ptr(in_scale)
+        keep.append(in_scale)
+    d.C_out, d.ldc, d.c_is_f32 = ptr(out), cout, int(out_dtype == torch.float32)
+    d.force_splitk, d.force_tile = force_splitk, force_tile
+    _epilogue(d, alpha, bias, out_scale, H * Wd if out_scale is not None else 0, noise, noise_w, act,
+              act_slope, keep)
+    _run_gemm(d, x)
+    return out
+
+
+def conv2d_wgrad_nhwc(x: torch.Tensor, dy: torch.Tensor, *, ksize: int, cv: int | None = None, in_scale=None,
+                      force_splitk=0, force_tile=0):
+    """Weight gradient of conv2d_nhwc: returns fp32 (ksize*ksize*CV, Cout) = sum over pixels of
+    gather(x)[pixel][(tap, cv)] * dy[pixel][co]."""
+    L = _C.lib()
+    L.require(x, dy, in_scale)
+    assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and x.is_contiguous() and dy.is_contiguous()
+    n, H, Wd, Cc = x.shape
+    cv = cv or Cc
+    cout = dy.shape[-1]
+    assert dy.shape[:3] == x.shape[:3]
+    out = torch.empty((ksize * ksize * cv, cout), dtype=torch.float32, device=x.device)
+    d = GemmDesc()
+    d.M, d.N, d.K, d.batch = ksize * ksize * cv, cout, n * H * Wd, 1
+    d.A, d.a_layout, d.a_conv = ptr(x), KROW, 1
+    d.B, d.ldb, d.b_layout = ptr(dy), cout, KROW
+    d.H, d.W, d.C, d.CV, d.R, d.S = H, Wd, Cc, cv, ksize, ksize
+    if in_scale is not None:
+        assert in_scale.dtype == torch.float32 and in_scale.shape == (n, cv) and in_scale.is_contiguous()
+        d.in_scale = ptr(in_scale)
+    d.C_out, d.ldc, d.c_is_f32 = ptr(out), cout, 1
+    d.alpha = 1.0
+    d.force_splitk, d.force_tile = force_splitk, force_tile
+    _run_gemm(d, x)
+    return out

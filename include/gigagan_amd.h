@@ -1,0 +1,75 @@
+/* gigagan_amd.h — C ABI of libgigagan_amd.so (hand-written gfx950 HIP kernels for the GigaGAN G+D step).
+ *
+ * The reference (lucidrains/gigagan-pytorch) has no native layer: every op below replaces a stock
+ * PyTorch call made from gigagan_pytorch/gigagan_pytorch.py ("gp.py"), cited per entry point. The Python
+ * host code in gigagan_pytorch_amd/ binds these with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions:
+ *  - plain pointers and sizes only; every buffer (inputs, outputs, workspaces) is owned by the caller;
+ *    nothing is allocated, freed or retained by the library; all pointers are device pointers.
+ *  - every call only ENQUEUES work on the caller's `stream` (a hipStream_t passed as void*); there is no
+ *    host synchronisation and no default-stream use, so calls are hipGraph-capture safe.
+ *  - return 0 = enqueued; < 0 = argument error (text via gg_last_error(), thread-local);
+ *    > 0 = hipError_t passthrough.
+ *  - bf16 tensors are raw 16-bit words (round-to-nearest-even), activations are NHWC.
+ */
+#ifndef GIGAGAN_AMD_H
+#define GIGAGAN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GG_ABI_VERSION 1
+
+int gg_version(void);
+const char* gg_last_error(void);
+/* 1 when this library was built for the host-side kernel emulator (tests only), 0 for the gfx950 build */
+int gg_is_emulator(void);
+
+enum { GG_ACT_NONE_ = 0, GG_ACT_LRELU_ = 1, GG_ACT_GELU_ = 2, GG_ACT_SILU_ = 3 };
+enum { GG_ROWK = 0, GG_KROW = 1 };
+
+/* One batched contraction C[b][m][n] = act(alpha * out_scale * sum_k A[b][m][k] B[b][n][k] + bias + noise).
+ *
+ * Replaces: F.conv2d forward/backward-data (gp.py:407 grouped modulated conv; nn.Conv2d at gp.py:1608-1621,
+ * :1454-1470, :1275-1281, :1656), conv weight gradients, nn.Linear / 1x1 nn.Conv2d / EqualLinear
+ * (gp.py:530-536, :726-740, :871-887, :1121, :1658), and the attention einsums (gp.py:574, :579, :590) with
+ * all their autograd transposes.
+ *
+ * a_layout / b_layout: GG_ROWK = operand stored [row][k] (k contiguous); GG_KROW = stored [k][row].
+ * Leading dimensions must be multiples of 8 elements and base pointers 16-byte aligned.
+ * a_conv != 0: A is an NHWC activation [n_img][H][W][C] gathered as a stride-1 "same" R x S convolution
+ *   (pad = (R-1)/2); with GG_ROWK the rows are output pixels (M = n_img*H*W) and k = (tap, cv);
+ *   with GG_KROW (weight gradient) k runs over output pixels (K = n_img*H*W) and rows are (tap, cv)
+ *   (M = R*S*CV). CV is the virtual channel count (CV % C == 0, physical channel = cv % C); in_scale,
+ *   if given, is an fp32 [n_img][CV] multiplier on the gathered activation (style modulation, gp.py:396).
+ * Epilogue order: acc*alpha -> *out_scale[m / rows_per_group][n] -> +bias[n] -> +noise[m]*noise_w[n]
+ *   -> activation (leaky-relu slope `act_slope`, exact-erf GELU, SiLU).
+ */
+typedef struct gg_gemm_desc {
+    int32_t M, N, K, batch;
+    const void* A; int64_t a_batch_stride; int32_t lda; int32_t a_layout; int32_t a_conv;
+    const void* B; int64_t b_batch_stride; int32_t ldb; int32_t b_layout;
+    int32_t H, W, C, CV, R, S;
+    const float* in_scale;
+    void* C_out; int64_t c_batch_stride; int32_t ldc; int32_t c_is_f32;
+    float alpha;
+    const float* bias;
+    const float* out_scale; int32_t rows_per_group;
+    const float* noise; const float* noise_w;
+    int32_t act; float act_slope;
+    int32_t force_splitk; /* 0 = heuristic */
+    int32_t force_tile;   /* 0 = heuristic; 1: 128x128, 2: 128x64, 3: 128x32 */
+} gg_gemm_desc;
+
+size_t gg_gemm_workspace_bytes(const gg_gemm_desc* d);
+int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GIGAGAN_AMD_H */

@@ -1,0 +1,63 @@
+// gg_device_emu.h — host-side stand-in for gg_device.h's device vocabulary (TEST INFRASTRUCTURE ONLY).
+//
+// Compiles the unmodified kernel sources in gigagan_pytorch_amd/csrc for the CPU: every HIP thread of a
+// workgroup is a ucontext fiber, `gg_sync()` is a fiber barrier, wave-collective operations (MFMA,
+// shuffles) rendezvous the 64 fibers of a wave and then apply the documented gfx950 lane mappings
+// (guide: cdna_hip_programming.md §3). This lets `pytest -m "not gpu"` check the kernels' index math,
+// LDS layouts, masking and epilogues through the same C ABI the GPU build exports. It is never loaded by
+// the product path (gigagan_pytorch_amd/_C.py loads only the hipcc-built library).
+#pragma once
+#include <stdint.h>
+#include <math.h>
+#include <string.h>
+#include <functional>
+
+#define GG_DEVICE static inline
+#define GG_HOST_DEVICE static inline
+#define GG_KERNEL static
+#define GG_SHARED static
+#define GG_LAUNCH_BOUNDS(n)
+
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct gg_emu_dim3 {
+    unsigned x, y, z;
+    gg_emu_dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+typedef gg_emu_dim3 dim3;
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return 0; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+
+extern gg_emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+void gg_emu_launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void gg_emu_syncthreads();
+f32x16 gg_emu_mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c);
+float gg_emu_shfl(float v, int src_lane);
+
+#define GG_LAUNCH(kernel, grid, block, stream, ...) \
+    gg_emu_launch(grid, block, [=]() { kernel(__VA_ARGS__); })
+
+static inline void gg_sync() { gg_emu_syncthreads(); }
+static inline f32x16 gg_mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c) {
+    return gg_emu_mfma_32x32x16_bf16(a, b, c);
+}
+static inline float gg_shfl_xor(float v, int mask) {
+    int lane = (int)(threadIdx.x & 63u);
+    return gg_emu_shfl(v, lane ^ mask);
+}
+static inline float gg_shfl(float v, int src) { return gg_emu_shfl(v, src & 63); }
+static inline void gg_atomic_add(float* p, float v) { *p += v; }
+
+static inline float gg_expf(float x) { return expf(x); }
+static inline float gg_rsqrtf(float x) { return 1.0f / sqrtf(x); }
