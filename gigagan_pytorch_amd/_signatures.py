@@ -1,6 +1,15 @@
-"""ctypes signatures of the element-wise / reduction entry points of include/gigagan_amd.h."""
+"""ctypes signatures of the element-wise / stencil entry points of include/gigagan_amd.h."""
 import ctypes as C
+
+_P = C.c_void_p
+_I = C.c_int32
 
 
 def declare(L):
-    pass
+    L.gg_resample_nhwc_bf16.restype = C.c_int
+    L.gg_resample_nhwc_bf16.argtypes = [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]
+    _F = C.c_float
+    L.gg_adamw_flat_f32.restype = C.c_int
+    L.gg_adamw_flat_f32.argtypes = [_P, _P, _P, _P, _P, C.c_int64, _F, _F, _F, _F, _F, _F, _F, _F, _P]
+    L.gg_ema_flat_f32.restype = C.c_int
+    L.gg_ema_flat_f32.argtypes = [_P, _P, C.c_int64, _F, _P]

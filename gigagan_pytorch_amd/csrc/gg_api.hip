@@ -189,3 +189,53 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     }
     return rc;
 }
+
+// ---- element-wise / stencil kernels -------------------------------------------------------------------
+
+static unsigned gg_grid_for(long long work_items) {
+    long long nb = (work_items + 255) / 256;
+    if (nb > 8192) nb = 8192;  // 256 CUs x 8 workgroups x 4: grid-stride the rest
+    if (nb < 1) nb = 1;
+    return (unsigned)nb;
+}
+
+extern "C" int gg_resample_nhwc_bf16(const void* in, void* out, int32_t n, int32_t ih, int32_t iw, int32_t oh,
+                                     int32_t ow, int32_t c, int32_t ty, int32_t tx, const int32_t* iy0,
+                                     const int32_t* ix0, const float* wy, const float* wx, void* stream) {
+    if (!in || !out || !iy0 || !ix0 || !wy || !wx) return gg_fail(-1, "gg_resample: null pointer");
+    if (n <= 0 || ih <= 0 || iw <= 0 || oh <= 0 || ow <= 0 || c <= 0 || ty <= 0 || tx <= 0)
+        return gg_fail(-2, "gg_resample: non-positive extent");
+    if ((c % 8) == 0 && ((((uintptr_t)in) | ((uintptr_t)out)) & 15))
+        return gg_fail(-3, "gg_resample: 16-byte alignment required when C %% 8 == 0");
+    GgResampleParams p;
+    p.in = (const bf16_t*)in; p.out = (bf16_t*)out;
+    p.n = n; p.IH = ih; p.IW = iw; p.OH = oh; p.OW = ow; p.C = c; p.TY = ty; p.TX = tx;
+    p.iy0 = iy0; p.ix0 = ix0; p.wy = wy; p.wx = wx;
+    long long total = (long long)n * oh * ow * ((c + 7) / 8);
+    GG_LAUNCH(gg_resample_kernel, dim3(gg_grid_for(total)), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+extern "C" int gg_adamw_flat_f32(float* p, const float* g, float* m, float* v, const uint8_t* flags, int64_t n,
+                                 float lr, float beta1, float beta2, float eps, float weight_decay,
+                                 float bias_corr1, float bias_corr2_sqrt, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || !flags) return gg_fail(-1, "gg_adamw: null pointer");
+    if (n <= 0 || (n % 256)) return gg_fail(-2, "gg_adamw: n must be a positive multiple of 256 (got %lld)", (long long)n);
+    if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15)
+        return gg_fail(-3, "gg_adamw: buffers must be 16-byte aligned");
+    if (bias_corr1 <= 0.f || bias_corr2_sqrt <= 0.f) return gg_fail(-4, "gg_adamw: bias corrections must be positive");
+    GgAdamWParams a;
+    a.p = p; a.g = g; a.m = m; a.v = v; a.flags = flags; a.n = n;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
+    a.bc1 = bias_corr1; a.bc2_sqrt = bias_corr2_sqrt; a.grad_scale = grad_scale;
+    GG_LAUNCH(gg_adamw_kernel, dim3(gg_grid_for(n / 4)), dim3(256), (hipStream_t)stream, a);
+    return gg_check_launch();
+}
+
+extern "C" int gg_ema_flat_f32(float* ema, const float* p, int64_t n, float one_minus_beta, void* stream) {
+    if (!ema || !p) return gg_fail(-1, "gg_ema: null pointer");
+    if (n <= 0 || (n % 4)) return gg_fail(-2, "gg_ema: n must be a positive multiple of 4");
+    if ((((uintptr_t)ema) | ((uintptr_t)p)) & 15) return gg_fail(-3, "gg_ema: buffers must be 16-byte aligned");
+    GG_LAUNCH(gg_ema_kernel, dim3(gg_grid_for(n / 4)), dim3(256), (hipStream_t)stream, ema, p, (long long)n, one_minus_beta);
+    return gg_check_launch();
+}

@@ -1,0 +1,587 @@
+"""GigaGAN trainer — the reference's constructor / set_dataloader / __call__(steps=) / generate / save / load
+surface (gp.py:1858-2750), re-provided without accelerate/DDP: one process per GPU, flat-buffer fused AdamW,
+RCCL all-reduce of the flat gradient buffers, no per-micro-batch host syncs (losses stay on the device until
+they are printed), D weight-gradients skipped in the G step (the reference computes and discards them).
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+from math import sqrt
+from pathlib import Path
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import distributed as gdist
+from . import ops
+from .discriminator import Discriminator
+from .ema import EMA
+from .generator import BaseGenerator, Generator
+from .modules import exists, default
+from .optimizer import get_optimizer
+from .version import __version__
+
+TrainDiscrLosses = namedtuple('TrainDiscrLosses', [
+    'divergence', 'multiscale_divergence', 'vision_aided_divergence', 'total_matching_aware_loss',
+    'gradient_penalty', 'aux_reconstruction'])
+
+TrainGenLosses = namedtuple('TrainGenLosses', [
+    'divergence', 'multiscale_divergence', 'total_vd_divergence', 'contrastive_loss'])
+
+
+def divisible_by(n, d):
+    return (n % d) == 0
+
+
+def cycle(dl):
+    while True:
+        for data in dl:
+            yield data
+
+
+def num_to_groups(num, divisor):
+    groups, rem = divmod(num, divisor)
+    return [divisor] * groups + ([rem] if rem > 0 else [])
+
+
+# ---- losses (gp.py:120-171) ------------------------------------------------------------------------------
+
+def gradient_penalty(images, outputs, grad_output_weights=None, weight=10, center=0.):
+    """R1-style penalty on d(sum_i w_i * out_i)/d images via double backward (gp.py:120-155)."""
+    if not isinstance(outputs, (list, tuple)):
+        outputs = [outputs]
+    if not exists(grad_output_weights):
+        grad_output_weights = (1,) * len(outputs)
+    gradients, *_ = torch.autograd.grad(
+        outputs=outputs, inputs=images,
+        grad_outputs=[torch.ones_like(o) * w for o, w in zip(outputs, grad_output_weights)],
+        create_graph=True, retain_graph=True, only_inputs=True)
+    gradients = gradients.float().flatten(1)
+    return weight * ((gradients.norm(2, dim=1) - center) ** 2).mean()
+
+
+def generator_hinge_loss(fake):
+    return fake.float().mean()
+
+
+def discriminator_hinge_loss(real, fake):
+    return (F.relu(1 + real.float()) + F.relu(1 - fake.float())).mean()
+
+
+def aux_matching_loss(real, fake):
+    """reference writes log(1+exp(-x)) (gp.py:171), which overflows to inf for x < -88; softplus is the same
+    function evaluated stably (documented deviation)."""
+    return (F.softplus(-real.float()) + F.softplus(-fake.float())).mean()
+
+
+class DiffAugment(nn.Module):
+    """random horizontal flip of image + rgbs (gp.py:193-220)."""
+
+    def __init__(self, *, prob, horizontal_flip, horizontal_flip_prob=0.5):
+        super().__init__()
+        assert 0 <= prob <= 1.
+        self.prob = prob
+        self.horizontal_flip = horizontal_flip
+        self.horizontal_flip_prob = horizontal_flip_prob
+
+    def forward(self, images, rgbs):
+        from random import random
+        if random() >= self.prob:
+            return images, rgbs
+        if random() < self.horizontal_flip_prob:
+            images = torch.flip(images, (-1,))
+            rgbs = [torch.flip(rgb, (-1,)) for rgb in rgbs]
+        return images, rgbs
+
+
+class GigaGAN(nn.Module):
+    def __init__(
+        self,
+        *,
+        generator,
+        discriminator,
+        vision_aided_discriminator=None,
+        diff_augment=None,
+        learning_rate=2e-4,
+        betas=(0.5, 0.9),
+        weight_decay=0.,
+        discr_aux_recon_loss_weight=1.,
+        multiscale_divergence_loss_weight=0.1,
+        vision_aided_divergence_loss_weight=0.5,
+        generator_contrastive_loss_weight=0.1,
+        matching_awareness_loss_weight=0.1,
+        calc_multiscale_loss_every=1,
+        apply_gradient_penalty_every=4,
+        resize_image_mode='bilinear',
+        train_upsampler=False,
+        log_steps_every=20,
+        create_ema_generator_at_init=True,
+        save_and_sample_every=1000,
+        early_save_thres_steps=2500,
+        early_save_and_sample_every=100,
+        num_samples=25,
+        model_folder='./gigagan-models',
+        results_folder='./gigagan-results',
+        sample_upsampler_dl=None,
+        accelerator=None,
+        accelerate_kwargs: dict = {},
+        find_unused_parameters=True,
+        amp=False,
+        mixed_precision_type='fp16',
+        device=None,
+    ):
+        super().__init__()
+        # `accelerator`, `accelerate_kwargs`, `find_unused_parameters` are accepted for drop-in compatibility; the
+        # MI355X build always computes bf16 operands / fp32 accumulation and needs no GradScaler.
+        if vision_aided_discriminator is not None:
+            raise NotImplementedError('VisionAidedDiscriminator needs a CLIP vision tower (out of scope, SURVEY.md §2)')
+
+        rk, local, ws = gdist.init_from_env('cuda' if torch.cuda.is_available() else 'cpu')
+        if device is None:
+            device = torch.device('cuda', local) if torch.cuda.is_available() else torch.device('cpu')
+        self._device = torch.device(device)
+
+        self.train_upsampler = train_upsampler
+        if train_upsampler:
+            from .unet_upsampler import UnetUpsampler
+            generator_klass = UnetUpsampler
+        else:
+            generator_klass = Generator
+
+        self.apply_gradient_penalty_every = apply_gradient_penalty_every
+        self.calc_multiscale_loss_every = calc_multiscale_loss_every
+
+        if isinstance(generator, dict):
+            generator = generator_klass(**generator)
+        if isinstance(discriminator, dict):
+            discriminator = Discriminator(**discriminator)
+        assert isinstance(generator, generator_klass)
+
+        if isinstance(diff_augment, dict):
+            diff_augment = DiffAugment(**diff_augment)
+        self.diff_augment = diff_augment
+
+        self.G = generator.to(self._device)
+        self.D = discriminator.to(self._device)
+        self.VD = None
+
+        if train_upsampler:
+            missing = set(discriminator.multiscale_input_resolutions) - set(generator.allowable_rgb_resolutions)
+            assert not missing, (f'only multiscale input resolutions of {generator.allowable_rgb_resolutions} is allowed '
+                                 'based on the unet input and output image size')
+
+        assert generator.unconditional == discriminator.unconditional
+        self.unconditional = generator.unconditional
+
+        # optimizers: NB the reference passes weight_decay= which its get_optimizer ignores (Appendix B.1)
+        self.G_opt = get_optimizer(self.G.parameters(), lr=learning_rate, betas=betas, weight_decay=weight_decay)
+        self.D_opt = get_optimizer(self.D.parameters(), lr=learning_rate, betas=betas, weight_decay=weight_decay,
+                                   inactive=self.D.unused_parameters())
+        gdist.broadcast_flat_params(self.G_opt.flat_p)
+        gdist.broadcast_flat_params(self.D_opt.flat_p)
+
+        self.has_ema_generator = False
+        if self.is_main and create_ema_generator_at_init:
+            self.create_ema_generator()
+
+        self.print(f'\nGenerator: {generator.total_params}\nDiscriminator: {discriminator.total_params}\n')
+
+        self.discr_aux_recon_loss_weight = discr_aux_recon_loss_weight
+        self.multiscale_divergence_loss_weight = multiscale_divergence_loss_weight
+        self.vision_aided_divergence_loss_weight = vision_aided_divergence_loss_weight
+        self.generator_contrastive_loss_weight = generator_contrastive_loss_weight
+        self.matching_awareness_loss_weight = matching_awareness_loss_weight
+        self.resize_image_mode = resize_image_mode
+        self.log_steps_every = log_steps_every
+
+        self.register_buffer('steps', torch.ones(1, dtype=torch.long))
+        self._steps_host = 1
+
+        self.save_and_sample_every = save_and_sample_every
+        self.early_save_thres_steps = early_save_thres_steps
+        self.early_save_and_sample_every = early_save_and_sample_every
+        self.num_samples = num_samples
+
+        self.train_dl = None
+        self._dl_iter = None
+        self.sample_upsampler_dl_iter = cycle(sample_upsampler_dl) if exists(sample_upsampler_dl) else None
+
+        self.results_folder = Path(results_folder)
+        self.model_folder = Path(model_folder)
+        self.results_folder.mkdir(exist_ok=True, parents=True)
+        self.model_folder.mkdir(exist_ok=True, parents=True)
+
+    # -- checkpointing (gp.py:2033-2108): same package layout as the reference ------------------------------
+    def save(self, path, overwrite=True):
+        path = Path(path)
+        path.parents[0].mkdir(exist_ok=True, parents=True)
+        assert overwrite or not path.exists()
+        pkg = dict(G=self.G.state_dict(), D=self.D.state_dict(), G_opt=self.G_opt.state_dict(),
+                   D_opt=self.D_opt.state_dict(), steps=self._steps_host, version=__version__)
+        if self.has_ema_generator:
+            pkg['G_ema'] = self.G_ema.state_dict()
+        torch.save(pkg, str(path))
+
+    def load(self, path, strict=False):
+        path = Path(path)
+        assert path.exists()
+        pkg = torch.load(str(path), map_location=self.device, weights_only=False)
+        if 'version' in pkg and pkg['version'] != __version__:
+            print(f"trying to load from version {pkg['version']}")
+        with torch.no_grad():
+            _load_into(self.G, pkg['G'], strict)
+            _load_into(self.D, pkg['D'], strict)
+            if self.has_ema_generator and 'G_ema' in pkg:
+                _load_into(self.G_ema, pkg['G_ema'], False)
+        if 'steps' in pkg:
+            self._steps_host = int(pkg['steps'])
+            self.steps.fill_(self._steps_host)
+        if 'G_opt' not in pkg or 'D_opt' not in pkg:
+            return
+        try:
+            self.G_opt.load_state_dict(pkg['G_opt'])
+            self.D_opt.load_state_dict(pkg['D_opt'])
+        except Exception as e:   # reference behaviour: optimizer state is best-effort
+            self.print(f'unable to load optimizers {e} - optimizer states will be reset')
+
+    # -- process topology ----------------------------------------------------------------------------------
+    @property
+    def device(self):
+        return self._device
+
+    @property
+    def unwrapped_G(self):
+        return self.G
+
+    @property
+    def unwrapped_D(self):
+        return self.D
+
+    @property
+    def need_vision_aided_discriminator(self):
+        return False
+
+    @property
+    def need_contrastive_loss(self):
+        return self.generator_contrastive_loss_weight > 0. and not self.unconditional
+
+    def print(self, msg):
+        if self.is_main:
+            print(msg)
+
+    @property
+    def is_distributed(self):
+        return gdist.is_distributed()
+
+    @property
+    def is_main(self):
+        return gdist.rank() == 0
+
+    @property
+    def is_local_main(self):
+        return self._device.index in (None, 0)
+
+    def resize_image_to(self, images, resolution):
+        return ops.impl.resize_bilinear(images, resolution)
+
+    def set_dataloader(self, dl):
+        assert not exists(self.train_dl), 'training dataloader has already been set'
+        self.train_dl = dl
+        self.train_dl_batch_size = dl.batch_size
+
+    @torch.inference_mode()
+    def generate(self, *args, **kwargs):
+        model = self.G_ema if self.has_ema_generator else self.G
+        model.eval()
+        return model(*args, **kwargs)
+
+    def create_ema_generator(self, update_every=10, update_after_step=100, decay=0.995):
+        if not self.is_main:
+            return
+        assert not self.has_ema_generator, 'EMA generator has already been created'
+        self.G_ema = EMA(self.G, update_every=update_every, update_after_step=update_after_step, beta=decay)
+        if self.G_opt.flat_p.device.type == 'cuda':
+            self.G_ema.attach_flat(self.G_opt.flat_p, self.G_opt._all, self.G_opt.offsets)
+        self.has_ema_generator = True
+
+    # -- one optimisation step -------------------------------------------------------------------------------
+    def generate_kwargs(self, dl_iter, batch_size):
+        maybe_text_kwargs = dict()
+        if self.train_upsampler or not self.unconditional:
+            assert exists(dl_iter)
+            if self.unconditional:
+                real_images = next(dl_iter)
+            else:
+                result = next(dl_iter)
+                assert isinstance(result, (tuple, list)), \
+                    'dataset should return a tuple of two items for text conditioned training, (images, texts)'
+                real_images, texts = result
+                if torch.is_tensor(texts):
+                    maybe_text_kwargs['text_encodings'] = texts[:batch_size].to(self.device)
+                else:
+                    maybe_text_kwargs['texts'] = texts[:batch_size]
+            real_images = real_images.to(self.device, non_blocking=True)
+
+        if self.train_upsampler:
+            size = self.G.input_image_size
+            lowres = ops.impl.resize_nearest(real_images, (size, size))
+            G_kwargs = dict(lowres_image=lowres)
+        else:
+            assert exists(batch_size)
+            G_kwargs = dict(batch_size=batch_size)
+
+        noise = torch.randn(batch_size, self.G.style_network.dim, device=self.device)
+        G_kwargs.update(noise=noise)
+        return G_kwargs, maybe_text_kwargs
+
+    def train_discriminator_step(self, dl_iter, grad_accum_every=1, apply_gradient_penalty=False,
+                                 calc_multiscale_loss=True):
+        dev = self.device
+        zero = torch.zeros((), device=dev)
+        total_divergence, total_gp_loss, total_aux_loss = zero.clone(), zero.clone(), zero.clone()
+        total_multiscale_divergence = zero.clone() if calc_multiscale_loss else None
+        has_matching_awareness = not self.unconditional and self.matching_awareness_loss_weight > 0.
+        total_matching_aware_loss = zero.clone()
+        all_text_kwargs, all_fake_images, all_fake_rgbs, all_real_images = [], [], [], []
+
+        self.G.train()
+        self.D.train()
+        self.D_opt.zero_grad()
+
+        for _ in range(grad_accum_every):
+            if self.unconditional:
+                real_images = next(dl_iter)
+                text_in = None
+            else:
+                result = next(dl_iter)
+                assert isinstance(result, (tuple, list)), \
+                    'dataset should return a tuple of two items for text conditioned training, (images, texts)'
+                real_images, text_in = result
+
+            real_images = real_images.to(dev, non_blocking=True).detach().requires_grad_()
+            real_images_rgbs = self.D.real_images_to_rgbs(real_images)
+            if exists(self.diff_augment):
+                real_images, real_images_rgbs = self.diff_augment(real_images, real_images_rgbs)
+            batch_size = real_images.shape[0]
+
+            G_kwargs, maybe_text_kwargs = self.generate_kwargs(dl_iter, batch_size)
+            if text_in is not None and not self.train_upsampler:
+                pass   # generate_kwargs drew its own (images, texts) pair exactly like the reference
+
+            with torch.no_grad():
+                images, rgbs = self.G(**G_kwargs, **maybe_text_kwargs, return_all_rgbs=True)
+                if has_matching_awareness:
+                    all_fake_images.append(images)
+                    all_fake_rgbs.append(rgbs)
+                    all_real_images.append(real_images.detach())
+                    all_text_kwargs.append(maybe_text_kwargs)
+                if exists(self.diff_augment):
+                    images, rgbs = self.diff_augment(images, rgbs)
+            images = images.detach().requires_grad_()
+            rgbs = [rgb.detach().requires_grad_() for rgb in rgbs]
+
+            fake_logits, fake_ms_logits, _ = self.D(images, rgbs, **maybe_text_kwargs,
+                                                    return_multiscale_outputs=calc_multiscale_loss, calc_aux_loss=False)
+            real_logits, real_ms_logits, aux_recon_losses = self.D(real_images, real_images_rgbs, **maybe_text_kwargs,
+                                                                   return_multiscale_outputs=calc_multiscale_loss,
+                                                                   calc_aux_loss=True)
+
+            divergence = discriminator_hinge_loss(real_logits, fake_logits)
+            total_divergence += divergence.detach() / grad_accum_every
+
+            multiscale_divergence = 0.
+            if self.multiscale_divergence_loss_weight > 0. and len(fake_ms_logits) > 0:
+                for ms_fake, ms_real in zip(fake_ms_logits, real_ms_logits):
+                    multiscale_divergence = multiscale_divergence + discriminator_hinge_loss(ms_real, ms_fake)
+                total_multiscale_divergence += multiscale_divergence.detach() / grad_accum_every
+
+            gp_loss = 0.
+            if apply_gradient_penalty:
+                w = self.multiscale_divergence_loss_weight
+                real_gp = gradient_penalty(real_images, outputs=[real_logits, *real_ms_logits],
+                                           grad_output_weights=[1., *(w,) * len(real_ms_logits)])
+                fake_gp = gradient_penalty(images, outputs=[fake_logits, *fake_ms_logits],
+                                           grad_output_weights=[1., *(w,) * len(fake_ms_logits)])
+                gp_loss = real_gp + fake_gp
+                total_gp_loss += torch.nan_to_num(gp_loss.detach(), nan=0.) / grad_accum_every
+
+            total_loss = divergence + gp_loss
+            if self.multiscale_divergence_loss_weight > 0.:
+                total_loss = total_loss + multiscale_divergence * self.multiscale_divergence_loss_weight
+            if self.discr_aux_recon_loss_weight > 0.:
+                aux_loss = sum(aux_recon_losses)
+                total_aux_loss += (aux_loss.detach() if torch.is_tensor(aux_loss) else aux_loss) / grad_accum_every
+                total_loss = total_loss + aux_loss * self.discr_aux_recon_loss_weight
+
+            (total_loss / grad_accum_every).backward()
+
+        if has_matching_awareness:
+            # mismatched (image, text) pairs: rotate the conditioning by one inside each micro-batch
+            for fake_images, fake_rgbs, real_images, tk in zip(all_fake_images, all_fake_rgbs, all_real_images,
+                                                               all_text_kwargs):
+                tk = {k: (v[1:] + v[:1] if isinstance(v, list) else torch.roll(v, -1, 0)) for k, v in tk.items()}
+                fake_logits, *_ = self.D(fake_images, fake_rgbs, **tk, return_multiscale_outputs=False,
+                                         calc_aux_loss=False)
+                real_rgbs = self.D.real_images_to_rgbs(real_images)
+                real_logits, *_ = self.D(real_images, real_rgbs, **tk, return_multiscale_outputs=False,
+                                         calc_aux_loss=False)
+                matching_loss = aux_matching_loss(real_logits, fake_logits)
+                total_matching_aware_loss = matching_loss.detach() / grad_accum_every
+                (matching_loss * self.matching_awareness_loss_weight / grad_accum_every).backward()
+
+        works = gdist.all_reduce_flat_grads(self.D_opt.flat_g)
+        gdist.wait_all(works)
+        self.D_opt.step(grad_scale=1. / gdist.world_size())
+
+        return TrainDiscrLosses(total_divergence, total_multiscale_divergence, 0., total_matching_aware_loss,
+                                total_gp_loss, total_aux_loss)
+
+    def train_generator_step(self, batch_size=None, dl_iter=None, grad_accum_every=1, calc_multiscale_loss=True):
+        dev = self.device
+        zero = torch.zeros((), device=dev)
+        total_divergence = zero.clone()
+        total_multiscale_divergence = zero.clone() if calc_multiscale_loss else None
+        contrastive_loss = 0.
+
+        self.G.train()
+        self.D.train()
+        self.G_opt.zero_grad()
+        # the reference leaves D's parameters requiring grad here, computes + all-reduces their gradients and then
+        # throws them away at the next D_opt.zero_grad() (gp.py:2254); skip that work
+        for p in self.D.parameters():
+            p.requires_grad_(False)
+        try:
+            for _ in range(grad_accum_every):
+                G_kwargs, maybe_text_kwargs = self.generate_kwargs(dl_iter, batch_size)
+                images, rgbs = self.G(**G_kwargs, **maybe_text_kwargs, return_all_rgbs=True)
+                if exists(self.diff_augment):
+                    images, rgbs = self.diff_augment(images, rgbs)
+
+                logits, ms_logits, _ = self.D(images, rgbs, **maybe_text_kwargs,
+                                              return_multiscale_outputs=calc_multiscale_loss, calc_aux_loss=False)
+                divergence = generator_hinge_loss(logits)
+                total_divergence += divergence.detach() / grad_accum_every
+                total_loss = divergence
+                if self.multiscale_divergence_loss_weight > 0. and len(ms_logits) > 0:
+                    ms_div = 0.
+                    for ms in ms_logits:
+                        ms_div = ms_div + generator_hinge_loss(ms)
+                    total_multiscale_divergence += ms_div.detach() / grad_accum_every
+                    total_loss = total_loss + ms_div * self.multiscale_divergence_loss_weight
+                (total_loss / grad_accum_every).backward()
+        finally:
+            for p in self.D.parameters():
+                p.requires_grad_(True)
+
+        if self.need_contrastive_loss and exists(getattr(self.G.text_encoder, 'clip', None)):
+            raise NotImplementedError('CLIP contrastive loss needs the external CLIP adapter (SURVEY.md §8f rank 2)')
+
+        works = gdist.all_reduce_flat_grads(self.G_opt.flat_g)
+        gdist.wait_all(works)
+        self.G_opt.step(grad_scale=1. / gdist.world_size())
+
+        if self.is_main and self.has_ema_generator:
+            self.G_ema.update()
+
+        return TrainGenLosses(total_divergence, total_multiscale_divergence, 0., contrastive_loss)
+
+    def train_step(self, dl_iter, batch_size, grad_accum_every=1):
+        """one iteration of the reference loop body (gp.py:2681-2748) without logging / sampling."""
+        steps = self._steps_host
+        apply_gp = self.apply_gradient_penalty_every > 0 and divisible_by(steps, self.apply_gradient_penalty_every)
+        calc_ms = self.calc_multiscale_loss_every > 0 and divisible_by(steps, self.calc_multiscale_loss_every)
+        d_losses = self.train_discriminator_step(dl_iter=dl_iter, grad_accum_every=grad_accum_every,
+                                                 apply_gradient_penalty=apply_gp, calc_multiscale_loss=calc_ms)
+        g_losses = self.train_generator_step(dl_iter=dl_iter, batch_size=batch_size,
+                                             grad_accum_every=grad_accum_every, calc_multiscale_loss=calc_ms)
+        self._steps_host += 1
+        self.steps += 1
+        return d_losses, g_losses
+
+    def sample(self, model, dl_iter, batch_size):
+        G_kwargs, maybe_text_kwargs = self.generate_kwargs(dl_iter, batch_size)
+        out = model(**G_kwargs, **maybe_text_kwargs)
+        if not self.train_upsampler:
+            return out
+        size = out.shape[-1]
+        lowres = ops.impl.resize_nearest(G_kwargs['lowres_image'], (size, size))
+        return torch.cat([lowres.to(out.dtype), out])
+
+    @torch.inference_mode()
+    def save_sample(self, batch_size, dl_iter=None):
+        milestone = self._steps_host // self.save_and_sample_every
+        nrow_mult = 2 if self.train_upsampler else 1
+        batches = num_to_groups(self.num_samples, batch_size)
+        if self.train_upsampler:
+            dl_iter = default(self.sample_upsampler_dl_iter, dl_iter)
+        assert exists(dl_iter)
+        models = [(self.G, f'sample-{milestone}.png')]
+        if self.has_ema_generator:
+            models.append((self.G_ema, f'ema-sample-{milestone}.png'))
+        for model, filename in models:
+            model.eval()
+            all_images = torch.cat([self.sample(model, dl_iter, n) for n in batches], dim=0).float().clamp_(0., 1.)
+            _save_image_grid(all_images, self.results_folder / filename, nrow=int(sqrt(self.num_samples)) * nrow_mult)
+        self.save(str(self.model_folder / f'model-{milestone}.ckpt'))
+
+    def forward(self, *, steps, grad_accum_every=1):
+        assert exists(self.train_dl), 'you need to set the dataloader by running .set_dataloader(dl: Dataloader)'
+        batch_size = self.train_dl_batch_size
+        dl_iter = cycle(self.train_dl)
+        last_gp_loss = last_ms_d = last_ms_g = 0.
+
+        for _ in range(steps):
+            step = self._steps_host
+            is_first_step = step == 1
+            d, g = self.train_step(dl_iter, batch_size, grad_accum_every)
+            if exists(d.gradient_penalty):
+                last_gp_loss = d.gradient_penalty
+            if exists(d.multiscale_divergence):
+                last_ms_d = d.multiscale_divergence
+            if exists(g.multiscale_divergence):
+                last_ms_g = g.multiscale_divergence
+
+            if is_first_step or divisible_by(step, self.log_steps_every):
+                losses = (('G', g.divergence), ('MSG', last_ms_g), ('VG', 0.), ('D', d.divergence), ('MSD', last_ms_d),
+                          ('VD', 0.), ('GP', last_gp_loss), ('SSL', d.aux_reconstruction), ('CL', g.contrastive_loss),
+                          ('MAL', d.total_matching_aware_loss))
+                self.print(' | '.join(f'{name}: {float(loss):.2f}' for name, loss in losses))
+
+            if self.is_main and (is_first_step or divisible_by(step, self.save_and_sample_every) or
+                                 (step <= self.early_save_thres_steps and divisible_by(step, self.early_save_and_sample_every))):
+                self.save_sample(batch_size, dl_iter)
+
+        self.print(f'complete {steps} training steps')
+
+
+def _load_into(module, state, strict):
+    """copy a state dict into existing storage (parameters are views into the optimizer's flat buffers, so
+    they must be written in place rather than re-pointed)."""
+    own = module.state_dict()
+    missing = [k for k in own if k not in state]
+    unexpected = [k for k in state if k not in own]
+    if strict and (missing or unexpected):
+        raise RuntimeError(f'state dict mismatch: missing {missing[:5]} unexpected {unexpected[:5]}')
+    for k, v in state.items():
+        if k in own and own[k].shape == v.shape:
+            own[k].copy_(v)
+
+
+def _save_image_grid(images, path, nrow):
+    """minimal PNG grid writer (the reference uses torchvision.utils.save_image)."""
+    try:
+        from PIL import Image
+    except Exception:
+        return
+    b, c, h, w = images.shape
+    ncol = max(nrow, 1)
+    nr = (b + ncol - 1) // ncol
+    grid = torch.zeros(c, nr * h, ncol * w)
+    for i in range(b):
+        r, cc = divmod(i, ncol)
+        grid[:, r * h:(r + 1) * h, cc * w:(cc + 1) * w] = images[i].cpu()
+    arr = (grid.permute(1, 2, 0).clamp(0, 1) * 255).round().byte().numpy()
+    if c == 1:
+        arr = arr[..., 0]
+    Image.fromarray(arr).save(str(path))

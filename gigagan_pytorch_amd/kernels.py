@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import math
 
 import torch
 
@@ -139,4 +140,130 @@ def conv2d_wgrad_nhwc(x: torch.Tensor, dy: torch.Tensor, *, ksize: int, cv: int 
     d.alpha = 1.0
     d.force_splitk, d.force_tile = force_splitk, force_tile
     _run_gemm(d, x)
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# separable banded resampling
+# --------------------------------------------------------------------------------------------------
+
+def _up2_matrix(L: int) -> torch.Tensor:
+    """1-D x2 bilinear upsampling, align_corners=False (nn.Upsample, gp.py:259): (2L, L)."""
+    m = torch.zeros(2 * L, L, dtype=torch.float64)
+    for i in range(L):
+        m[2 * i, max(i - 1, 0)] += 0.25
+        m[2 * i, i] += 0.75
+        m[2 * i + 1, i] += 0.75
+        m[2 * i + 1, min(i + 1, L - 1)] += 0.25
+    return m
+
+
+def _blur_matrix(L: int) -> torch.Tensor:
+    """1-D [1,2,1]/4 blur with reflect padding (kornia filter2d default border, gp.py:255): (L, L)."""
+    m = torch.zeros(L, L, dtype=torch.float64)
+    for j in range(L):
+        lo = j - 1 if j - 1 >= 0 else 1
+        hi = j + 1 if j + 1 < L else L - 2
+        m[j, lo] += 0.25
+        m[j, j] += 0.5
+        m[j, hi] += 0.25
+    return m
+
+
+def _bilinear_matrix(Lin: int, Lout: int) -> torch.Tensor:
+    """1-D F.interpolate(mode='bilinear', align_corners=False, antialias=False): (Lout, Lin)."""
+    m = torch.zeros(Lout, Lin, dtype=torch.float64)
+    scale = Lin / Lout
+    for j in range(Lout):
+        src = max((j + 0.5) * scale - 0.5, 0.0)
+        i0 = min(int(math.floor(src)), Lin - 1)
+        i1 = min(i0 + 1, Lin - 1)
+        lam = src - i0
+        m[j, i0] += 1.0 - lam
+        m[j, i1] += lam
+    return m
+
+
+def _nearest_matrix(Lin: int, Lout: int) -> torch.Tensor:
+    """1-D F.interpolate(mode='nearest'): src = floor(j * Lin / Lout)."""
+    m = torch.zeros(Lout, Lin, dtype=torch.float64)
+    scale = Lin / Lout
+    for j in range(Lout):
+        m[j, min(int(math.floor(j * scale)), Lin - 1)] = 1.0
+    return m
+
+
+def _band_tables(m: torch.Tensor):
+    """dense (out, in) matrix -> (taps, idx0 int32[out], weights fp32[out][taps])."""
+    nz = m != 0
+    out_len, in_len = m.shape
+    first = torch.where(nz.any(1), nz.float().argmax(1), torch.zeros(out_len, dtype=torch.long))
+    last = torch.where(nz.any(1), in_len - 1 - nz.flip(1).float().argmax(1), first)
+    taps = int((last - first).max().item()) + 1
+    idx = first[:, None] + torch.arange(taps)[None, :]
+    w = torch.where(idx < in_len, m.gather(1, idx.clamp(max=in_len - 1)), torch.zeros((), dtype=m.dtype))
+    return taps, first.to(torch.int32), w.to(torch.float32).contiguous()
+
+
+class ResampleSpec:
+    """Host-built tap tables for one 2-D separable resampling operator (and, lazily, its transpose)."""
+
+    _cache: dict = {}
+
+    def __init__(self, my: torch.Tensor, mx: torch.Tensor, key):
+        self.my, self.mx, self.key = my, mx, key
+        self.oh, self.ih = my.shape
+        self.ow, self.iw = mx.shape
+        self.ty, self.iy0, self.wy = _band_tables(my)
+        self.tx, self.ix0, self.wx = _band_tables(mx)
+        self._dev: dict = {}
+        self._t = None
+
+    def tables(self, device):
+        k = (device.type, device.index)
+        if k not in self._dev:
+            self._dev[k] = tuple(t.to(device) for t in (self.iy0, self.ix0, self.wy, self.wx))
+        return self._dev[k]
+
+    def transposed(self) -> 'ResampleSpec':
+        if self._t is None:
+            self._t = ResampleSpec._get(('T',) + self.key, lambda: (self.my.t().contiguous(), self.mx.t().contiguous()))
+            self._t._t = self
+        return self._t
+
+    @classmethod
+    def _get(cls, key, build):
+        if key not in cls._cache:
+            my, mx = build()
+            cls._cache[key] = ResampleSpec(my, mx, key)
+        return cls._cache[key]
+
+    @classmethod
+    def upsample_blur(cls, H, W):
+        return cls._get(('upblur', H, W), lambda: (_blur_matrix(2 * H) @ _up2_matrix(H), _blur_matrix(2 * W) @ _up2_matrix(W)))
+
+    @classmethod
+    def blur(cls, H, W):
+        return cls._get(('blur', H, W), lambda: (_blur_matrix(H), _blur_matrix(W)))
+
+    @classmethod
+    def bilinear(cls, H, W, OH, OW):
+        return cls._get(('bilinear', H, W, OH, OW), lambda: (_bilinear_matrix(H, OH), _bilinear_matrix(W, OW)))
+
+    @classmethod
+    def nearest(cls, H, W, OH, OW):
+        return cls._get(('nearest', H, W, OH, OW), lambda: (_nearest_matrix(H, OH), _nearest_matrix(W, OW)))
+
+
+def resample_nhwc(x: torch.Tensor, spec: ResampleSpec) -> torch.Tensor:
+    L = _C.lib()
+    L.require(x)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    n, H, W, Cc = x.shape
+    assert (H, W) == (spec.ih, spec.iw), ((H, W), (spec.ih, spec.iw))
+    iy0, ix0, wy, wx = spec.tables(x.device)
+    out = torch.empty((n, spec.oh, spec.ow, Cc), dtype=x.dtype, device=x.device)
+    rc = L.lib.gg_resample_nhwc_bf16(ptr(x), ptr(out), n, H, W, spec.oh, spec.ow, Cc, spec.ty, spec.tx,
+                                     ptr(iy0), ptr(ix0), ptr(wy), ptr(wx), L.stream(x))
+    L.check(rc, 'gg_resample_nhwc_bf16')
     return out

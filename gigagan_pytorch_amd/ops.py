@@ -1,0 +1,422 @@
+"""Functional op set of the GigaGAN G+D step on MI355X.
+
+Every function here takes / returns *logical NCHW* tensors (the reference's module-boundary convention);
+activations are stored channels_last (= NHWC in memory) bf16, parameters stay fp32.  All dense
+contractions run in the hand-written HIP kernels behind the C ABI (`kernels.py`), wrapped in
+`torch.autograd.Function`s that are closed under differentiation (conv <-> wgrad <-> conv, gemm <-> gemm),
+so the gradient penalty's double backward (reference gp.py:120-155) needs no special casing.  PyTorch is
+used for storage, autograd bookkeeping and the small pointwise glue listed in DESIGN.md §coverage.
+
+The active implementation is the module-level `impl` object.  The product default is `HipOps`; it raises
+if the native library or a GPU tensor is missing.  Tests install `oracle.torch_ops.OracleOps` (a plain
+fp32 restatement) through `use_impl()` to check the host-side model assembly on CPU.
+"""
+from __future__ import annotations
+
+import math
+from contextlib import contextmanager
+
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import kernels as K
+
+ACT_DTYPE = torch.bfloat16
+LRELU_SLOPE = 0.2
+
+
+# --------------------------------------------------------------------------------------------------
+# layout glue
+# --------------------------------------------------------------------------------------------------
+
+def to_act(x: torch.Tensor) -> torch.Tensor:
+    """logical NCHW tensor -> bf16, channels_last storage (no-op when already so)."""
+    if x.dtype != ACT_DTYPE:
+        x = x.to(ACT_DTYPE)
+    if x.dim() == 4:
+        x = x.contiguous(memory_format=torch.channels_last)
+    return x
+
+
+def nhwc(x: torch.Tensor) -> torch.Tensor:
+    """(b, C, H, W) channels_last -> the (b, H, W, C) contiguous view the kernels consume."""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x: torch.Tensor) -> torch.Tensor:
+    """(b, H, W, C) contiguous -> logical (b, C, H, W) with channels_last strides (a view)."""
+    return x.permute(0, 3, 1, 2)
+
+
+def _round8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """(O, I, kh, kw) any float dtype -> bf16 (O, kh*kw*I) with the reduction ordered [kh][kw][ci]."""
+    o = w.shape[0]
+    return w.permute(0, 2, 3, 1).reshape(o, -1).to(ACT_DTYPE).contiguous()
+
+
+def flip_transpose(w: torch.Tensor) -> torch.Tensor:
+    """weights of the adjoint (backward-data) convolution: spatial flip, in/out swapped."""
+    return w.flip(2, 3).transpose(0, 1)
+
+
+# --------------------------------------------------------------------------------------------------
+# autograd Functions over the HIP kernels (each one's backward is built from the others)
+# --------------------------------------------------------------------------------------------------
+
+class ConvFn(Function):
+    """y = conv_same(x * in_scale, w) [+ bias][-> leaky relu];  x: (b,H,W,C) bf16, w: (O,I,k,k) float."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, in_scale, act):
+        ksize = w.shape[-1]
+        wmat = pack_conv_weight(w)
+        y = K.conv2d_nhwc(x, wmat, ksize=ksize, in_scale=in_scale, bias=bias, act=act, act_slope=LRELU_SLOPE)
+        ctx.act = act
+        ctx.save_for_backward(x, w, in_scale, y if act else None)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, in_scale, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        if ctx.act == 'lrelu':
+            dz = dy * torch.where(y > 0, 1.0, LRELU_SLOPE).to(dy.dtype)
+        else:
+            dz = dy
+        dx = dw = db = ds = None
+        if ctx.needs_input_grad[0] or (in_scale is not None and ctx.needs_input_grad[3]):
+            dxs = ConvFn.apply(dz, flip_transpose(w), None, None, None)
+            if in_scale is None:
+                dx = dxs
+            else:
+                if ctx.needs_input_grad[3]:
+                    ds = (x.float() * dxs.float()).sum(dim=(1, 2))
+                dx = (dxs.float() * in_scale[:, None, None, :]).to(dxs.dtype)
+        if ctx.needs_input_grad[1]:
+            dw = WgradFn.apply(x, dz, in_scale, w.shape[-1]).to(w.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dz.float().sum(dim=(0, 1, 2))
+        return dx, dw, db, ds, None
+
+
+class WgradFn(Function):
+    """dw[o][i][kh][kw] = sum_pixels dy[p][o] * (x*in_scale)[p + (kh,kw)][i]  (fp32, parameter layout)."""
+
+    @staticmethod
+    def forward(ctx, x, dy, in_scale, ksize):
+        g = K.conv2d_wgrad_nhwc(x, dy, ksize=ksize, in_scale=in_scale)  # (k*k*C, O) fp32
+        c, o = x.shape[-1], dy.shape[-1]
+        ctx.ksize = ksize
+        ctx.save_for_backward(x, dy, in_scale)
+        return g.view(ksize, ksize, c, o).permute(3, 2, 0, 1).contiguous()
+
+    @staticmethod
+    def backward(ctx, ddw):
+        x, dy, in_scale = ctx.saved_tensors
+        dx = ddy = None
+        if ctx.needs_input_grad[0]:
+            dx = ConvFn.apply(dy, flip_transpose(ddw), None, None, None)
+            if in_scale is not None:
+                dx = (dx.float() * in_scale[:, None, None, :]).to(dx.dtype)
+        if ctx.needs_input_grad[1]:
+            ddy = ConvFn.apply(x, ddw, None, in_scale, None)
+        return dx, ddy, None, None
+
+
+class GemmFn(Function):
+    """out[b][r][c] = act(alpha * sum_t X[b](r,t) * Y[b](c,t) + bias[c]).
+
+    `x_red_last`: X stored (..., R, T) (reduction contiguous) else (..., T, R); same for Y.
+    bf16 operands, bf16 or fp32 result.  Logical extents may be smaller than storage (pitches are
+    multiples of 8); `dims = (R, C, T)`.
+    """
+
+    @staticmethod
+    def forward(ctx, x, y, x_red_last, y_red_last, dims, bias, act, alpha, out_f32):
+        R, Cc, T = dims
+        out = K.gemm(x, y, trans_a=not x_red_last, trans_b=y_red_last, m_valid=R, n_valid=Cc, k_valid=T,
+                     bias=bias, act=act, act_slope=LRELU_SLOPE, alpha=alpha,
+                     out_dtype=torch.float32 if out_f32 else ACT_DTYPE)
+        if x.dim() == 2 and y.dim() == 2:
+            out = out[0]
+        ctx.cfg = (x_red_last, y_red_last, dims, act, alpha, out_f32)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, y, out if act else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y, out = ctx.saved_tensors
+        x_red_last, y_red_last, (R, Cc, T), act, alpha, out_f32 = ctx.cfg
+        if act == 'lrelu':
+            dout = dout * torch.where(out > 0, 1.0, LRELU_SLOPE).to(dout.dtype)
+        elif act is not None:
+            raise RuntimeError('GemmFn: only the leaky-relu epilogue is differentiable; apply other activations outside')
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[5]:
+            db = dout.float().reshape(-1, dout.shape[-1]).sum(0)
+        g = dout.to(ACT_DTYPE)
+        if g.stride(-1) != 1 or g.stride(-2) % 8:
+            g = _pad_last(g.contiguous())
+        dx = dy = None
+        if ctx.needs_input_grad[0]:
+            if x_red_last:   # dX(r,t) = sum_c g(r,c) Y(c,t)
+                dx = GemmFn.apply(g, y, True, not y_red_last, (R, T, Cc), None, None, alpha, False)
+            else:            # stored (T,R): dX(t,r) = sum_c Y(c,t) g(r,c)
+                dx = GemmFn.apply(y, g, not y_red_last, True, (T, R, Cc), None, None, alpha, False)
+            dx = _fit(dx, x)
+        if ctx.needs_input_grad[1]:
+            if y_red_last:   # dY(c,t) = sum_r g(r,c) X(r,t)
+                dy = GemmFn.apply(g, x, False, not x_red_last, (Cc, T, R), None, None, alpha, False)
+            else:            # stored (T,C): dY(t,c) = sum_r X(r,t) g(r,c)
+                dy = GemmFn.apply(x, g, not x_red_last, False, (T, Cc, R), None, None, alpha, False)
+            dy = _fit(dy, y)
+        return dx, dy, None, None, None, db, None, None, None
+
+
+def _pad_last(t: torch.Tensor) -> torch.Tensor:
+    p = (-t.shape[-1]) % 8
+    return F.pad(t, (0, p)) if p else t
+
+
+def _fit(g: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+    """pad a logical-extent gradient with zeros up to the (aligned) storage shape of the operand; reduce over
+    a broadcast batch dimension."""
+    if g.dim() == 3 and like.dim() == 2:
+        g = g.sum(0) if g.shape[0] > 1 else g[0]
+    elif g.dim() == 3 and like.dim() == 3 and like.shape[0] == 1 and g.shape[0] > 1:
+        g = g.sum(0, keepdim=True)
+    pr, pc = like.shape[-2] - g.shape[-2], like.shape[-1] - g.shape[-1]
+    if pr or pc:
+        g = F.pad(g, (0, pc, 0, pr))
+    return g
+
+
+def matmul_nt(x: torch.Tensor, w: torch.Tensor, bias=None, act=None, out_f32=False) -> torch.Tensor:
+    """x (..., K) @ w(N, K)^T  — the nn.Linear contraction, on the HIP GEMM. K and N multiples of 8 are
+    native; other sizes are zero-padded by differentiable glue."""
+    lead = x.shape[:-1]
+    k, n = x.shape[-1], w.shape[0]
+    x2 = _pad_last(x.reshape(-1, k).to(ACT_DTYPE))
+    w2 = _pad_last(w.to(ACT_DTYPE))
+    out = GemmFn.apply(x2.contiguous(), w2.contiguous(), True, True, (x2.shape[0], n, k), bias, act, 1.0, out_f32)
+    return out.reshape(*lead, n)
+
+
+class ResampleFn(Function):
+    """Separable banded linear resampling of an NHWC tensor (bilinear x2 + binomial blur, bilinear resize,
+    and their adjoints), closed under differentiation: backward = the same kernel with the transposed
+    tables."""
+
+    @staticmethod
+    def forward(ctx, x, spec):
+        ctx.spec = spec
+        return K.resample_nhwc(x, spec)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ResampleFn.apply(dy.contiguous(), ctx.spec.transposed()), None
+
+
+# --------------------------------------------------------------------------------------------------
+# the op set
+# --------------------------------------------------------------------------------------------------
+
+class HipOps:
+    """MI355X implementation: HIP kernels for contractions/resampling, torch glue for pointwise pieces."""
+
+    name = 'hip'
+    act_dtype = ACT_DTYPE
+
+    # -- activations layout ------------------------------------------------------------------------
+    def prepare(self, x):
+        return to_act(x)
+
+    # -- convolution -------------------------------------------------------------------------------
+    def conv2d(self, x, weight, bias=None, act=None):
+        """stride-1 'same' conv (odd square kernel) — reference nn.Conv2d(…, padding=k//2) call sites."""
+        x = to_act(x)
+        o, i = weight.shape[0], weight.shape[1]
+        ip, op_ = _round8(i), _round8(o)
+        xh = nhwc(x)
+        if ip != i:
+            xh = F.pad(xh, (0, ip - i))
+            weight = F.pad(weight, (0, 0, 0, 0, 0, ip - i))
+        if op_ != o:
+            weight = F.pad(weight, (0, 0, 0, 0, 0, 0, 0, op_ - o))
+            if bias is not None:
+                bias = F.pad(bias, (0, op_ - o))
+        y = ConvFn.apply(xh, weight, None if bias is None else bias.float().contiguous(), None, act)
+        if op_ != o:
+            y = y[..., :o]
+        return nchw(y)
+
+    def linear(self, x, weight, bias=None, act=None):
+        return matmul_nt(x, weight, None if bias is None else bias.float().contiguous(), act)
+
+    # -- adaptive / modulated conv (gp.py:315-409) -----------------------------------------------
+    def modconv2d(self, x, weights, mod, kernel_mod=None, demod=True, eps=1e-8, noise=None, noise_weight=None,
+                  act=None):
+        x = to_act(x)
+        b, _, H, W = x.shape
+        N, O, I, k, _ = weights.shape
+        s = mod.float() + 1.0                                           # (b, I)
+        if N > 1:
+            a = kernel_mod.float().softmax(dim=-1)                      # (b, N)
+        else:
+            a = torch.ones((b, 1), device=x.device, dtype=torch.float32)
+        d = None
+        if demod:
+            d = demod_coefficients(weights, s, a, eps)                  # (b, O) fp32
+        Ip, Op = _round8(I), _round8(O)
+        xh = nhwc(x)
+        wts = weights
+        if Ip != I:
+            xh = F.pad(xh, (0, Ip - I))
+            wts = F.pad(wts, (0, 0, 0, 0, 0, Ip - I))
+            s = F.pad(s, (0, Ip - I))
+        if Op != O:
+            wts = F.pad(wts, (0, 0, 0, 0, 0, 0, 0, Op - O))
+        needs_grad = torch.is_grad_enabled() and any(
+            t is not None and t.requires_grad for t in (x, weights, mod, kernel_mod, noise_weight))
+        if not needs_grad:
+            y = fused_modconv_forward(xh, wts, s, a, d, noise, noise_weight, act, O, Op)
+            return nchw(y[..., :O] if Op != O else y)
+        # training path: one conv with the N kernels stacked along output channels, then the per-sample mix
+        Y = ConvFn.apply(xh, wts.reshape(N * Op, Ip, k, k), None, s.contiguous(), None)   # (b,H,W,N*Op)
+        y = (Y.view(b, H, W, N, Op).float() * a[:, None, None, :, None]).sum(dim=3)
+        if Op != O:
+            y = y[..., :O]
+        if d is not None:
+            y = y * d[:, None, None, :]
+        if noise is not None:
+            y = y + noise.permute(0, 2, 3, 1).float() * noise_weight.float().view(1, 1, 1, O)
+        if act == 'lrelu':
+            y = F.leaky_relu(y, LRELU_SLOPE)
+        return nchw(y.to(ACT_DTYPE))
+
+    # -- attention (gp.py:538-594 / :617-655): q (B,h,n,d), k/v (B,h,m,d) --------------------------
+    def attention(self, q, k, v, *, scale, l2=False, key_mask=None):
+        """softmax(sim * scale) v with sim = q.k (dot) or -|q-k|^2 (l2). `key_mask` (B, m) bool keeps keys."""
+        B, h, n, dh = q.shape
+        m = k.shape[2]
+        mp = _round8(m)
+        q2 = q.reshape(B * h, n, dh).to(ACT_DTYPE).contiguous()
+        k2 = k.reshape(B * h, m, dh).to(ACT_DTYPE)
+        v2 = v.reshape(B * h, m, dh).to(ACT_DTYPE)
+        if mp != m:
+            k2 = F.pad(k2, (0, 0, 0, mp - m))
+            v2 = F.pad(v2, (0, 0, 0, mp - m))
+        k2, v2 = k2.contiguous(), v2.contiguous()
+        qk = GemmFn.apply(q2, k2, True, True, (n, mp, dh), None, None, 1.0, True)       # fp32 (BH, n, mp)
+        if l2:
+            # -|q-k|^2*scale = scale*(2 q.k - |k|^2) - scale*|q|^2 ; the per-query term cancels in softmax
+            ksq = (k2.float() ** 2).sum(-1)
+            logits = (2.0 * qk - ksq[:, None, :]) * scale
+        else:
+            logits = qk * scale
+        neg = -torch.finfo(torch.float32).max
+        if mp != m:
+            col = torch.arange(mp, device=q.device)
+            logits = logits.masked_fill(col[None, None, :] >= m, neg)
+        if key_mask is not None:
+            km = F.pad(key_mask, (0, mp - m), value=False) if mp != m else key_mask
+            km = km[:, None, None, :].expand(B, h, 1, mp).reshape(B * h, 1, mp)
+            logits = logits.masked_fill(~km, neg)
+        attn = logits.softmax(dim=-1).to(ACT_DTYPE)
+        out = GemmFn.apply(attn, v2, True, False, (n, dh, mp), None, None, 1.0, False)  # (BH, n, dh)
+        return out.reshape(B, h, n, dh)
+
+    # -- norms / resampling ------------------------------------------------------------------------
+    def channel_rmsnorm(self, x, gamma):
+        """F.normalize(x, dim=1) * sqrt(C) * gamma (gp.py:224-232), fp32 statistics."""
+        x = to_act(x)
+        xf = x.float()
+        c = x.shape[1]
+        nrm = xf.norm(dim=1, keepdim=True).clamp(min=1e-12)
+        return (xf / nrm * (c ** 0.5) * gamma.float().view(1, c, 1, 1)).to(ACT_DTYPE)
+
+    def upsample_blur(self, x):
+        """nn.Upsample(x2, bilinear, align_corners=False) then the reflect-padded [1,2,1]^2/16 blur
+        (gp.py:246-261), as ONE separable-stencil kernel."""
+        x = to_act(x)
+        H, W = x.shape[-2:]
+        return nchw(ResampleFn.apply(nhwc(x), K.ResampleSpec.upsample_blur(H, W)))
+
+    def blur(self, x):
+        x = to_act(x)
+        H, W = x.shape[-2:]
+        return nchw(ResampleFn.apply(nhwc(x), K.ResampleSpec.blur(H, W)))
+
+    def resize_bilinear(self, x, size):
+        """F.interpolate(x, size, mode='bilinear') (align_corners=False, no antialias; gp.py:1683-1687)."""
+        H, W = x.shape[-2:]
+        size = (size, size) if isinstance(size, int) else tuple(size)
+        if (H, W) == size:
+            return x
+        xa = to_act(x)
+        return nchw(ResampleFn.apply(nhwc(xa), K.ResampleSpec.bilinear(H, W, *size)))
+
+    def resize_nearest(self, x, size):
+        H, W = x.shape[-2:]
+        size = (size, size) if isinstance(size, int) else tuple(size)
+        if (H, W) == size:
+            return x
+        xa = to_act(x)
+        return nchw(ResampleFn.apply(nhwc(xa), K.ResampleSpec.nearest(H, W, *size)))
+
+
+def demod_coefficients(weights, s, a, eps):
+    """d[b,o] = rsqrt(max(sum_{i,k} (sum_n a[b,n] W[n,o,i,k] s[b,i])^2, eps)) without materialising the
+    per-sample weights (gp.py:390-400): a Gram matrix over the kernel bank, contracted with s^2 and a a^T.
+    fp32 throughout (these are (b,O)-sized statistics)."""
+    N, O, I = weights.shape[:3]
+    wf = weights.float().flatten(3)                                     # (N, O, I, k*k)
+    gram = torch.einsum('noik,moik->nmoi', wf, wf)                      # (N, N, O, I)
+    t = torch.einsum('bi,nmoi->bnmo', s * s, gram)                      # (b, N, N, O)
+    sumsq = torch.einsum('bn,bm,bnmo->bo', a, a, t)
+    return sumsq.clamp(min=eps).rsqrt()
+
+
+def fused_modconv_forward(xh, wts, s, a, d, noise, noise_weight, act, O, Op):
+    """no-grad path: the whole adaptive conv (kernel mix, modulation, demodulation, noise, leaky-relu) as
+    ONE implicit-GEMM launch with the N kernels stacked along the reduction and batch folded into M."""
+    b, H, W, Ip = xh.shape
+    N, _, _, k, _ = wts.shape
+    insc = (a[:, :, None] * s[:, None, :]).reshape(b, N * Ip).contiguous()
+    wk = wts.permute(1, 3, 4, 0, 2).reshape(Op, k * k * N * Ip).to(ACT_DTYPE).contiguous()
+    out_scale = None
+    if d is not None:
+        out_scale = (F.pad(d, (0, Op - O)) if Op != O else d).contiguous()
+    nz = nw = None
+    if noise is not None:
+        nz = noise.reshape(-1).float().contiguous()
+        nw = noise_weight.reshape(-1).float()
+        nw = (F.pad(nw, (0, Op - O)) if Op != O else nw).contiguous()
+    return K.conv2d_nhwc(xh, wk, ksize=k, cv=N * Ip, in_scale=insc, out_scale=out_scale, noise=nz, noise_w=nw,
+                         act=act, act_slope=LRELU_SLOPE)
+
+
+impl = HipOps()
+
+
+@contextmanager
+def use_impl(new_impl):
+    """Swap the op implementation (tests only: installs the CPU oracle to check model assembly)."""
+    global impl
+    old = impl
+    impl = new_impl
+    try:
+        yield
+    finally:
+        impl = old
+
+
+def get_impl():
+    return impl

@@ -69,6 +69,26 @@ typedef struct gg_gemm_desc {
 size_t gg_gemm_workspace_bytes(const gg_gemm_desc* d);
 int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Separable banded linear resampling of an NHWC bf16 tensor:
+ *   out[n][oy][ox][c] = sum_{a<ty} sum_{b<tx} wy[oy*ty+a] * wx[ox*tx+b] * in[n][iy0[oy]+a][ix0[ox]+b][c]
+ * (taps that fall outside the input contribute zero). Replaces nn.Upsample(x2, bilinear) + kornia
+ * filter2d blur (gp.py:246-261) as one pass, F.interpolate bilinear / nearest (gp.py:1683-1687, :2210,
+ * unet_upsampler.py:33-61) and, with transposed tables, their backward passes. */
+int gg_resample_nhwc_bf16(const void* in, void* out, int32_t n, int32_t ih, int32_t iw, int32_t oh, int32_t ow,
+                          int32_t c, int32_t ty, int32_t tx, const int32_t* iy0, const int32_t* ix0,
+                          const float* wy, const float* wx, void* stream);
+
+/* Fused multi-tensor AdamW over flat fp32 buffers (replaces torch.optim.AdamW from optimizer.py:10-34,
+ * stepped at gp.py:2477 and :2596). n %% 256 == 0; flags[n/256]: bit0 = chunk is stepped, bit1 = decoupled
+ * weight decay applies. bias_corr1 = 1 - beta1^t, bias_corr2_sqrt = sqrt(1 - beta2^t); grad_scale
+ * multiplies the gradient first (e.g. 1/world_size after a summing all-reduce). */
+int gg_adamw_flat_f32(float* p, const float* g, float* m, float* v, const uint8_t* flags, int64_t n, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, float bias_corr1,
+                      float bias_corr2_sqrt, float grad_scale, void* stream);
+
+/* ema += (1 - beta) * (p - ema) over flat fp32 buffers (ema_pytorch update, gp.py:2603); n %% 4 == 0. */
+int gg_ema_flat_f32(float* ema, const float* p, int64_t n, float one_minus_beta, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
