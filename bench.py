@@ -1,0 +1,178 @@
+"""bench.py — images/sec of one full GigaGAN G+D training step (BASELINE.json metric), unconditional 256x256,
+per-GPU batch 32, bf16 operands / fp32 accumulation, synthetic data resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one iteration of `GigaGAN.forward`'s loop body: D-step (G forward under no_grad, D(fake), D(real),
+hinge + multi-scale + aux-recon losses, gradient penalty with double backward on every 4th step, fused AdamW)
+then G-step (G forward, D forward, backward to G, fused AdamW, EMA). K is rounded up to a multiple of 4 so
+the timed region always holds whole gradient-penalty cycles. Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+GF_PER_IMG = 1192.1       # algorithmic-minimum GFLOP per image per step, 4-step-cycle mean
+MFMA_PEAK_TF = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md
+C2_G = dict(dim_capacity=8, dim_max=512, style_network=dict(dim=64, depth=4), num_skip_layers_excite=4, unconditional=True)
+C2_D = dict(dim_capacity=16, dim_max=512, num_skip_layers_excite=4, unconditional=True)
+
+
+def build_gan(image_size, device, g_over=None, d_over=None):
+    from gigagan_pytorch_amd import GigaGAN
+    torch.manual_seed(0)
+    g = dict(C2_G, image_size=image_size, **(g_over or {}))
+    d = dict(C2_D, image_size=image_size, **(d_over or {}))
+    return GigaGAN(generator=g, discriminator=d, amp=True, mixed_precision_type='bf16', apply_gradient_penalty_every=4,
+                   calc_multiscale_loss_every=1, device=device, model_folder='/tmp/gg-bench-models',
+                   results_folder='/tmp/gg-bench-results')
+
+
+def cpu_baseline(max_seconds=40.0):
+    """The oracle (a fp32 PyTorch-CPU restatement of the reference, kind="port") timed on this box's host cores
+    on a bounded sample of the same workload: C2 model dims at 256x256, batch 2, one plain (non-GP) G+D step with
+    torch AdamW — the reference's own CPU throughput is nearly batch-independent."""
+    from gigagan_pytorch_amd import ops
+    from gigagan_pytorch_amd.generator import Generator
+    from gigagan_pytorch_amd.discriminator import Discriminator
+    from gigagan_pytorch_amd.gigagan import discriminator_hinge_loss, generator_hinge_loss
+    from oracle.torch_ops import OracleOps
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    bs, S = 2, 256
+    with ops.use_impl(OracleOps()):
+        G = Generator(image_size=S, **C2_G)
+        D = Discriminator(image_size=S, **C2_D)
+        g_opt = torch.optim.AdamW(G.parameters(), lr=2e-4, betas=(0.5, 0.9))
+        d_opt = torch.optim.AdamW(D.parameters(), lr=2e-4, betas=(0.5, 0.9))
+        real = torch.rand(bs, 3, S, S)
+        t0 = time.time()
+        # D step
+        with torch.no_grad():
+            img, rgbs = G(noise=torch.randn(bs, 64), return_all_rgbs=True)
+        fl, fms, _ = D(img, rgbs, calc_aux_loss=False)
+        rl, rms, aux = D(real, D.real_images_to_rgbs(real), calc_aux_loss=True)
+        loss = discriminator_hinge_loss(rl, fl) + 0.1 * sum(discriminator_hinge_loss(a, b) for a, b in zip(rms, fms)) + sum(aux)
+        d_opt.zero_grad(); loss.backward(); d_opt.step()
+        # G step
+        img, rgbs = G(noise=torch.randn(bs, 64), return_all_rgbs=True)
+        l, ms, _ = D(img, rgbs, calc_aux_loss=False)
+        loss = generator_hinge_loss(l) + 0.1 * sum(generator_hinge_loss(m) for m in ms)
+        g_opt.zero_grad(); loss.backward(); g_opt.step()
+        dt = time.time() - t0
+    return dict(value=bs / dt, unit='images/sec', cores=cores, kind='port',
+                sample=f'fp32 CPU oracle, C2 dims 256x256, batch {bs}, one plain G+D step (no gradient penalty), {dt:.1f} s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=4)
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--image-size', type=int, default=256)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile-cycle', action='store_true')
+    args = ap.parse_args()
+
+    from gigagan_pytorch_amd import distributed as gdist, kernels as K
+    from gigagan_pytorch_amd.data import SyntheticImages
+    from gigagan_pytorch_amd.gigagan import cycle
+    import torch.distributed as dist
+
+    rank, local, world = gdist.init_from_env('cuda')
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    assert world == args.gpus or world == 1, (world, args.gpus)
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+
+    steps = (args.steps + 3) // 4 * 4
+    warmup = args.warmup
+    gan = build_gan(args.image_size, dev)
+    dl = SyntheticImages(args.batch, args.image_size, device=dev, seed=rank)
+    it = cycle(dl)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up starts at the trainer's step 1; keep the timed region aligned to whole GP cycles
+    for _ in range(warmup):
+        gan.train_step(it, args.batch)
+    while (gan._steps_host - 1) % 4 != 0:   # align so that the K timed steps contain exactly K/4 GP steps
+        gan.train_step(it, args.batch)
+        warmup += 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        d_losses, g_losses = gan.train_step(it, args.batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = dt / steps * 1e3
+    value = args.batch * world * steps / dt
+
+    roofline = None
+    if rank == 0 and not args.no_profile_cycle:
+        # one extra GP cycle with per-launch HIP events around the contraction kernel (same stream)
+        K.profiler = K.GemmProfiler()
+        for _ in range(4):
+            gan.train_step(it, args.batch)
+        agg = K.profiler.summary()
+        K.profiler = None
+        if agg:
+            name, a = max(agg.items(), key=lambda kv: kv[1]['ms'])
+            tot_ms = sum(v['ms'] for v in agg.values())
+            tot_fl = sum(v['flops'] for v in agg.values())
+            achieved = a['flops'] / a['ms'] / 1e9
+            roofline = dict(bound='mfma', kernel=name, achieved=achieved, peak=MFMA_PEAK_TF, unit='TFLOP/s',
+                            frac=achieved / MFMA_PEAK_TF, traffic=None,
+                            avg_launch_us=a['ms'] / a['launches'] * 1e3, launches_per_step=a['launches'] / 4,
+                            all_gemm_kernels=dict(tflops=tot_fl / tot_ms / 1e9, ms_per_step=tot_ms / 4,
+                                                  frac_of_step=tot_ms / 4 / ms_per_step),
+                            step=dict(achieved=value / world * GF_PER_IMG / 1e3, peak=MFMA_PEAK_TF,
+                                      frac=value / world * GF_PER_IMG / 1e3 / MFMA_PEAK_TF,
+                                      note='whole-step algorithmic-minimum 1192.1 GF/img vs dense bf16 MFMA peak'))
+            Path(ROOT / 'gpurun_out').mkdir(exist_ok=True)
+            (ROOT / 'gpurun_out' / 'bench_gemm_breakdown.json').write_text(json.dumps(agg, indent=1))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        line = dict(
+            metric='images/sec G+D step, uncond 256x256 bs32', value=value, unit='images/sec', n_gpus=world,
+            steps=steps, warmup=warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling='weak',
+            vs_baseline=None, dtype='bf16', data='synthetic',
+            config=dict(workload=f'Unconditional GigaGAN image_size={args.image_size} dim_max=512 (G cap 8, D cap 16) '
+                                 f'bf16 bs={args.batch}/GPU, GP every 4th step', global_batch=args.batch * world,
+                        parallelism=f'dp{world}'),
+            roofline=roofline, cpu_baseline=cpu,
+            last_losses=dict(d=float(d_losses.divergence), g=float(g_losses.divergence)))
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

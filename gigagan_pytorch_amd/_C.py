@@ -61,6 +61,8 @@ class Library:
         L.gg_gemm_workspace_bytes.argtypes = [C.POINTER(GemmDesc)]
         L.gg_gemm_bf16.restype = C.c_int
         L.gg_gemm_bf16.argtypes = [C.POINTER(GemmDesc), C.c_void_p, C.c_size_t, C.c_void_p]
+        L.gg_gemm_plan.restype = C.c_int
+        L.gg_gemm_plan.argtypes = [C.POINTER(GemmDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         self._declare_elementwise()
         self.is_emulator = bool(L.gg_is_emulator())
         if L.gg_version() != 1:

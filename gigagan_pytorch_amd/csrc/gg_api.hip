@@ -148,6 +148,15 @@ extern "C" size_t gg_gemm_workspace_bytes(const gg_gemm_desc* d) {
     return (size_t)d->batch * pl.splitk * d->M * d->N * sizeof(float);
 }
 
+extern "C" int gg_gemm_plan(const gg_gemm_desc* d, int32_t* tile, int32_t* splitk) {
+    int rc = gg_validate_gemm(d);
+    if (rc) return rc;
+    GemmPlan pl = gg_plan_gemm(d);
+    if (tile) *tile = pl.tile;
+    if (splitk) *splitk = pl.splitk;
+    return 0;
+}
+
 extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = gg_validate_gemm(d);
     if (rc) return rc;

@@ -23,11 +23,49 @@ def _workspace(nbytes: int, like: torch.Tensor) -> torch.Tensor:
     return ws
 
 
+class GemmProfiler:
+    """optional per-launch HIP-event timing of the contraction kernel (bench.py's roofline leg). Events are
+    recorded on the stream the kernel is launched on (torch's current stream) and only read after a sync."""
+
+    def __init__(self):
+        self.records = []   # (key, flops, start_event, end_event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, flops, e0, e1 in self.records:
+            a = agg.setdefault(key, dict(launches=0, ms=0., flops=0.))
+            a['launches'] += 1
+            a['ms'] += e0.elapsed_time(e1)
+            a['flops'] += flops
+        return agg
+
+
+profiler: GemmProfiler | None = None
+
+
+def _kernel_key(d: GemmDesc, L) -> str:
+    tile, sk = C.c_int32(0), C.c_int32(0)
+    L.lib.gg_gemm_plan(C.byref(d), C.byref(tile), C.byref(sk))
+    bn = {1: 128, 2: 64, 3: 32}[tile.value]
+    wm, wn = (4, 1) if tile.value == 3 else (2, 2)
+    name = (f'gg_gemm_kernel<128,{bn},{wm},{wn},A_KROW={int(d.a_layout == KROW)},B_KROW={int(d.b_layout == KROW)},'
+            f'A_CONV={int(bool(d.a_conv))}>')
+    return name + ('+splitk' if sk.value > 1 else '')
+
+
 def _run_gemm(d: GemmDesc, like: torch.Tensor):
     L = _C.lib()
     need = L.lib.gg_gemm_workspace_bytes(C.byref(d))
     ws = _workspace(need, like) if need else None
-    rc = L.lib.gg_gemm_bf16(C.byref(d), ptr(ws), need, L.stream(like))
+    if profiler is not None and not L.is_emulator:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = L.lib.gg_gemm_bf16(C.byref(d), ptr(ws), need, L.stream(like))
+        e1.record()
+        profiler.records.append((_kernel_key(d, L), 2. * d.M * d.N * d.K * d.batch, e0, e1))
+    else:
+        rc = L.lib.gg_gemm_bf16(C.byref(d), ptr(ws), need, L.stream(like))
     L.check(rc, 'gg_gemm_bf16')
 
 

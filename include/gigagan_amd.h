@@ -67,6 +67,9 @@ typedef struct gg_gemm_desc {
 } gg_gemm_desc;
 
 size_t gg_gemm_workspace_bytes(const gg_gemm_desc* d);
+/* reports the launch plan the library will use for `d`: tile (1: 128x128, 2: 128x64, 3: 128x32) and the
+ * split-K factor; used by bench.py to attribute measured time to kernel instantiations. */
+int gg_gemm_plan(const gg_gemm_desc* d, int32_t* tile, int32_t* splitk);
 int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Separable banded linear resampling of an NHWC bf16 tensor:

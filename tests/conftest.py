@@ -1,0 +1,56 @@
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+EMU_LIB = ROOT / 'tests' / 'emu' / 'libgigagan_amd_emu.so'
+HIP_LIB = ROOT / 'gigagan_pytorch_amd' / 'libgigagan_amd.so'
+REFERENCE = Path('/root/reference')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def _ensure_built():
+    if not EMU_LIB.exists() or not HIP_LIB.exists():
+        sys.path.insert(0, str(ROOT))
+        import __graft_entry__ as g
+        g.build()
+
+
+@pytest.fixture(autouse=True)
+def _bind_library(request):
+    """CPU tests bind the C ABI compiled for the host-side kernel emulator; -m gpu tests bind the gfx950 build."""
+    from gigagan_pytorch_amd import _C
+    if request.node.get_closest_marker('gpu'):
+        if not torch.cuda.is_available():
+            pytest.skip('no GPU')
+        _C.bind(HIP_LIB)
+    else:
+        _ensure_built()
+        _C.bind(EMU_LIB)
+    yield
+
+
+@pytest.fixture
+def reference():
+    """the unmodified reference package, importable only where /root/reference exists (not on the GPU box)."""
+    if not REFERENCE.exists():
+        pytest.skip('/root/reference not present')
+    stubs = str(ROOT / 'tests' / 'oracle_stubs')
+    for p in (str(REFERENCE), stubs):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import gigagan_pytorch
+    return gigagan_pytorch
+
+
+def rel_err(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm().clamp(min=1e-12)).item()

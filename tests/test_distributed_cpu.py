@@ -1,0 +1,65 @@
+"""CPU suite: the N>1 data-parallel path with world_size 2 over gloo (RCCL on the GPU box)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from gigagan_pytorch_amd import distributed as gdist
+    gdist.init_from_env('cpu')
+    assert gdist.world_size() == world and gdist.rank() == rank
+    # flat gradient all-reduce: sum across ranks, mean folded into the optimizer's grad_scale
+    g = torch.full((1000,), float(rank + 1))
+    gdist.wait_all(gdist.all_reduce_flat_grads(g, n_slices=3))
+    ok = torch.allclose(g, torch.full((1000,), 3.0))
+    # parameter broadcast
+    p = torch.full((10,), float(rank))
+    gdist.broadcast_flat_params(p)
+    ok = ok and torch.equal(p, torch.zeros(10))
+    # differentiable equal-shard all_gather: backward keeps the local slice (reference distributed.py:62-68)
+    x = torch.full((2, 3), float(rank + 1), requires_grad=True)
+    out, sizes = gdist.all_gather(x)
+    (out * torch.arange(4.)[:, None]).sum().backward()
+    ok = ok and out.shape == (4, 3) and torch.equal(x.grad, torch.arange(4.)[rank * 2:(rank + 1) * 2, None].expand(2, 3))
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def test_data_parallel_equals_large_batch_gradient():
+    """splitting a batch over 2 'ranks' and averaging the flat gradients equals the full-batch gradient — what the
+    all-reduce + grad_scale=1/world computes (single process, no collective)."""
+    from gigagan_pytorch_amd import ops
+    from gigagan_pytorch_amd.discriminator import Discriminator
+    from oracle.torch_ops import OracleOps
+    from helpers import SMALL_D
+    torch.manual_seed(0)
+    D = Discriminator(**SMALL_D).eval()
+    imgs = torch.rand(4, 3, 32, 32)
+    with ops.use_impl(OracleOps()):
+        def grads(x):
+            l, ms, _ = D(x, D.real_images_to_rgbs(x), calc_aux_loss=False)
+            return torch.autograd.grad(l.mean() + sum(m.mean() for m in ms), [p for p in D.parameters()], allow_unused=True)
+        full = grads(imgs)
+        a, b = grads(imgs[:2]), grads(imgs[2:])
+    for f, x, y in zip(full, a, b):
+        if f is not None:
+            assert torch.allclose(f, (x + y) / 2, rtol=1e-3, atol=1e-5)

@@ -1,0 +1,176 @@
+"""CPU suite: the real kernel sources compiled for the host-side emulator, called through the same C ABI."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gigagan_pytorch_amd import kernels as K, ops, _C
+from oracle.torch_ops import OracleOps
+from helpers import rel_err, bf
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_c_abi_exports_every_declared_symbol():
+    header = (ROOT / 'include' / 'gigagan_amd.h').read_text()
+    names = set(re.findall(r'\b(gg_[a-z0-9_]+)\s*\(', header))
+    assert {'gg_gemm_bf16', 'gg_resample_nhwc_bf16', 'gg_adamw_flat_f32', 'gg_ema_flat_f32', 'gg_last_error'} <= names
+    for lib in (ROOT / 'gigagan_pytorch_amd' / 'libgigagan_amd.so', ROOT / 'tests' / 'emu' / 'libgigagan_amd_emu.so'):
+        h = ctypes.CDLL(str(lib))
+        for n in names:
+            assert hasattr(h, n), f'{lib.name} does not export {n}'
+    assert _C.Library(ROOT / 'gigagan_pytorch_amd' / 'libgigagan_amd.so').is_emulator is False
+
+
+def test_product_path_fails_loudly_without_gpu_tensors():
+    lib = _C.Library(ROOT / 'gigagan_pytorch_amd' / 'libgigagan_amd.so')
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        lib.require(torch.zeros(4))
+    with pytest.raises(RuntimeError, match='not found'):
+        _C.Library(ROOT / 'gigagan_pytorch_amd' / 'does_not_exist.so')
+
+
+def test_argument_errors_are_reported():
+    a = bf(torch.randn(16, 12)); b = bf(torch.randn(8, 12))   # pitch 12 is not a multiple of 8
+    with pytest.raises(RuntimeError, match='multiple of 8'):
+        K.gemm(a, b)
+
+
+@pytest.mark.parametrize('shape', [(130, 70, 100, 2), (64, 33, 1032, 1), (257, 129, 40, 3)])
+def test_gemm_all_layouts_tiles_and_splitk(shape):
+    M, N, Kd, batch = shape
+    torch.manual_seed(0)
+    Kp = (Kd + 7) // 8 * 8
+    a = bf(torch.randn(batch, M, Kp)); b = bf(torch.randn(batch, N, Kp))
+    ref = torch.einsum('bmk,bnk->bmn', a.float()[..., :Kd], b.float()[..., :Kd])
+    for tile in (1, 2, 3):
+        assert rel_err(K.gemm(a, b, k_valid=Kd, out_dtype=torch.float32, force_tile=tile), ref) < 1e-5
+    assert rel_err(K.gemm(a, b, k_valid=Kd, out_dtype=torch.float32, force_splitk=3), ref) < 1e-5
+    assert rel_err(K.gemm(a, b, k_valid=Kd), ref) < 4e-3     # bf16 output rounding
+
+
+def test_gemm_transposed_operands_and_epilogue():
+    torch.manual_seed(0)
+    M, N, Kd, batch = 72, 48, 50, 2
+    A = torch.randn(batch, M, Kd); B = torch.randn(batch, N, Kd)
+    pad = lambda t: F.pad(t, (0, (-t.shape[-1]) % 8))
+    ref = torch.einsum('bmk,bnk->bmn', bf(A).float(), bf(B).float())
+    for ta in (False, True):
+        for tb in (True, False):
+            a = bf(pad(A.transpose(1, 2).contiguous() if ta else A))
+            b = bf(pad(B if tb else B.transpose(1, 2).contiguous()))
+            out = K.gemm(a, b, trans_a=ta, trans_b=tb, k_valid=Kd, m_valid=M, n_valid=N, out_dtype=torch.float32)
+            assert rel_err(out, ref) < 1e-5, (ta, tb)
+    bias = torch.randn(N)
+    out = K.gemm(bf(pad(A)), bf(pad(B)), k_valid=Kd, bias=bias, act='lrelu', alpha=0.5, out_dtype=torch.float32)
+    assert rel_err(out, F.leaky_relu(ref * 0.5 + bias, 0.2)) < 1e-5
+
+
+@pytest.mark.parametrize('cfg', [(2, 8, 8, 16, 24, 3), (3, 5, 7, 8, 40, 7), (2, 16, 16, 32, 136, 1), (1, 4, 4, 64, 64, 3)])
+def test_conv_forward_dgrad_wgrad(cfg):
+    n, H, W, Ci, Co, ks = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(n, Ci, H, W)); w = bf(torch.randn(Co, Ci, ks, ks) * 0.1); dy = bf(torch.randn(n, Co, H, W))
+    xf, wf = x.float().requires_grad_(), w.float().requires_grad_()
+    ref = F.conv2d(xf, wf, padding=ks // 2)
+    ref.backward(dy.float())
+    xh, dyh = x.permute(0, 2, 3, 1).contiguous(), dy.permute(0, 2, 3, 1).contiguous()
+    wh = w.permute(0, 2, 3, 1).reshape(Co, -1).contiguous()
+    assert rel_err(K.conv2d_nhwc(xh, wh, ksize=ks, out_dtype=torch.float32).permute(0, 3, 1, 2), ref) < 1e-5
+    dw_ref = wf.grad.permute(2, 3, 1, 0).reshape(-1, Co)
+    assert rel_err(K.conv2d_wgrad_nhwc(xh, dyh, ksize=ks), dw_ref) < 1e-5
+    assert rel_err(K.conv2d_wgrad_nhwc(xh, dyh, ksize=ks, force_splitk=3), dw_ref) < 1e-5
+    wT = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Ci, -1).contiguous()
+    assert rel_err(K.conv2d_nhwc(dyh, wT, ksize=ks, out_dtype=torch.float32).permute(0, 3, 1, 2), xf.grad) < 1e-5
+
+
+def test_fused_adaptive_conv_single_launch():
+    """kernel mix + modulation + demod scale + noise + leaky-relu in ONE implicit-GEMM launch vs the oracle."""
+    torch.manual_seed(0)
+    H_, O_ = ops.HipOps(), OracleOps(bf16_operands=True)
+    x = torch.randn(2, 16, 8, 8); wm = torch.randn(2, 24, 16, 3, 3) * 0.1
+    mod = torch.randn(2, 16) * 0.5; km = torch.randn(2, 2); nz = torch.randn(2, 1, 8, 8); nw = torch.randn(24, 1, 1)
+    with torch.no_grad():
+        y = H_.modconv2d(x, wm, mod, km, noise=nz, noise_weight=nw, act='lrelu')
+    ref = O_.modconv2d(x, wm, mod, km, noise=nz, noise_weight=nw, act='lrelu')
+    assert rel_err(y, ref) < 1e-2
+    with torch.no_grad():   # toRGB: 1x1, single kernel, no demod, 3 output channels
+        wr = torch.randn(1, 3, 16, 1, 1) * 0.1
+        assert rel_err(H_.modconv2d(x, wr, mod, None, demod=False), O_.modconv2d(x, wr, mod, None, demod=False)) < 1e-2
+
+
+def test_ops_gradients_match_oracle():
+    torch.manual_seed(0)
+    H_, O_ = ops.HipOps(), OracleOps(bf16_operands=True)
+
+    def check(fn, inputs, tol=2e-2):
+        ih = [t.clone().requires_grad_() for t in inputs]; io = [t.clone().requires_grad_() for t in inputs]
+        yh, yo = fn(H_, *ih), fn(O_, *io)
+        g = torch.randn_like(yo)
+        gh = torch.autograd.grad(yh.float(), ih, g); go = torch.autograd.grad(yo, io, bf(g).float())
+        assert rel_err(yh, yo) < tol
+        for a, b in zip(gh, go):
+            assert rel_err(a, b) < 2 * tol      # bf16 operand rounding accumulates through the backward pass
+
+    x = torch.randn(2, 16, 8, 8)
+    check(lambda I, x, w, b: I.conv2d(x, w, b, act='lrelu'), [x, torch.randn(24, 16, 3, 3) * 0.1, torch.randn(24)])
+    check(lambda I, x, w: I.conv2d(x, w, None), [torch.randn(2, 3, 8, 8), torch.randn(16, 3, 7, 7) * 0.1])
+    check(lambda I, x, w, b: I.linear(x, w, b), [torch.randn(6, 20), torch.randn(5, 20), torch.randn(5)])
+    q, k, v = torch.randn(2, 2, 16, 16), torch.randn(2, 2, 17, 16), torch.randn(2, 2, 17, 16)
+    check(lambda I, q, k, v: I.attention(q, k, v, scale=0.25), [q, k, v])
+    check(lambda I, q, k, v: I.attention(q, k, v, scale=0.25, l2=True), [q, k, v])
+    check(lambda I, x, w, m, k: I.modconv2d(x, w, m, k), [x, torch.randn(2, 24, 16, 3, 3) * 0.1, torch.randn(2, 16) * 0.5, torch.randn(2, 2)])
+    check(lambda I, x: I.upsample_blur(x), [x])
+    check(lambda I, x: I.resize_bilinear(x, 4), [torch.rand(2, 3, 16, 16)])
+
+
+def test_conv_double_backward_matches_oracle():
+    """gradient-penalty pattern: d/dw of |d out / d x|^2 through ConvFn <-> WgradFn <-> ConvFn."""
+    torch.manual_seed(0)
+
+    def run(I):
+        x = torch.randn(2, 8, 6, 6).requires_grad_(); w = (torch.randn(8, 8, 3, 3) * 0.2).requires_grad_()
+        w2 = (torch.randn(8, 8, 3, 3) * 0.2).requires_grad_()
+        y = I.conv2d(I.conv2d(x, w, None), w2, None).float()
+        gx, = torch.autograd.grad(y.pow(2).sum(), x, create_graph=True)
+        return torch.autograd.grad(gx.float().pow(2).sum(), [w, w2])
+
+    torch.manual_seed(0); gh = run(ops.HipOps())
+    torch.manual_seed(0); go = run(OracleOps(bf16_operands=True))
+    for a, b in zip(gh, go):
+        assert rel_err(a, b) < 3e-2
+
+
+def test_resample_matches_reference_semantics():
+    torch.manual_seed(0)
+    O_ = OracleOps()
+    for shape in [(2, 8, 4, 4), (1, 16, 8, 6), (2, 3, 5, 5)]:
+        x = bf(torch.randn(*shape))
+        assert rel_err(ops.HipOps().upsample_blur(x), O_.upsample_blur(x.float())) < 4e-3
+    x = torch.rand(2, 3, 32, 32)
+    for size in (8, 16):
+        assert rel_err(ops.HipOps().resize_bilinear(x, size), F.interpolate(bf(x).float(), size, mode='bilinear')) < 4e-3
+    assert rel_err(ops.HipOps().resize_nearest(x, 16), F.interpolate(bf(x).float(), (16, 16))) == 0.
+
+
+def test_fused_adamw_and_ema_match_torch():
+    from gigagan_pytorch_amd.optimizer import FlatAdamW
+    torch.manual_seed(0)
+    p0, p1 = torch.nn.Parameter(torch.randn(50, 33)), torch.nn.Parameter(torch.randn(77))
+    p2 = torch.nn.Parameter(torch.randn(9, 9))     # inactive: never stepped, never decayed
+    r0, r1 = torch.nn.Parameter(p0.detach().clone()), torch.nn.Parameter(p1.detach().clone())
+    p2_before = p2.detach().clone()
+    fo = FlatAdamW([p0, p1, p2], lr=2e-4, betas=(0.5, 0.9), inactive=[p2])
+    to = torch.optim.AdamW([{'params': [r0]}, {'params': [r1], 'weight_decay': 0.}], lr=2e-4, betas=(0.5, 0.9), weight_decay=1e-2)
+    for _ in range(3):
+        g0, g1 = torch.randn_like(p0), torch.randn_like(p1)
+        fo.zero_grad()
+        p0.grad.add_(g0); p1.grad.add_(g1)
+        r0.grad, r1.grad = g0.clone(), g1.clone()
+        fo.step(); to.step()
+    assert rel_err(p0, r0) < 1e-6 and rel_err(p1, r1) < 1e-6
+    assert torch.equal(p2.detach(), p2_before)
+    assert rel_err(fo.state[p0]['exp_avg'], to.state[r0]['exp_avg']) < 1e-6

@@ -1,0 +1,190 @@
+"""GPU suite (-m gpu): the gfx950 kernels through the C ABI against the oracle, the reference golden fixtures,
+and size-independent properties at BASELINE config-2 shapes. Tolerances: the kernels compute bf16 x bf16 products
+with fp32 accumulation; against an oracle that rounds the same operands to bf16 the only differences are the
+accumulation order (fp32 outputs: 1e-4 relative L2) and the final bf16 store (4e-3)."""
+from pathlib import Path
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gigagan_pytorch_amd import kernels as K, ops, GigaGAN
+from gigagan_pytorch_amd.generator import Generator
+from gigagan_pytorch_amd.discriminator import Discriminator
+from gigagan_pytorch_amd.gigagan import gradient_penalty, cycle
+from gigagan_pytorch_amd.data import SyntheticImages
+from oracle.torch_ops import OracleOps
+from helpers import rel_err, bf, SMALL_G, SMALL_D, C1_G, C1_D
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / 'golden'
+F32_TOL, BF16_TOL = 1e-4, 4e-3
+
+
+def dev():
+    return torch.device('cuda', 0)
+
+
+def test_native_library_is_the_gfx950_build():
+    from gigagan_pytorch_amd import _C
+    assert _C.lib().is_emulator is False
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        K.gemm(bf(torch.randn(8, 8)), bf(torch.randn(8, 8)))
+
+
+@pytest.mark.parametrize('shape', [(130, 70, 104, 2), (257, 129, 40, 3), (1024, 1032, 64, 4), (512, 512, 4608, 1)])
+def test_gemm_vs_cpu_oracle(shape):
+    M, N, Kd, batch = shape
+    torch.manual_seed(0)
+    a = bf(torch.randn(batch, M, Kd)); b = bf(torch.randn(batch, N, Kd))
+    ref = torch.einsum('bmk,bnk->bmn', a.float(), b.float())          # CPU fp32 on bf16-rounded operands
+    ad, bd = a.to(dev()), b.to(dev())
+    for tile in (0, 1, 2, 3):
+        assert rel_err(K.gemm(ad, bd, out_dtype=torch.float32, force_tile=tile).cpu(), ref) < F32_TOL
+    assert rel_err(K.gemm(ad, bd, out_dtype=torch.float32, force_splitk=2).cpu(), ref) < F32_TOL
+    assert rel_err(K.gemm(ad, bd).cpu(), ref) < BF16_TOL
+    if M % 8 == 0 and N % 8 == 0:
+        at, bt = ad.transpose(1, 2).contiguous(), bd.transpose(1, 2).contiguous()
+        for ta, tb, x, y in ((True, True, at, bd), (False, False, ad, bt), (True, False, at, bt)):
+            assert rel_err(K.gemm(x, y, trans_a=ta, trans_b=tb, out_dtype=torch.float32).cpu(), ref) < F32_TOL
+
+
+def test_gemm_k_tail_and_epilogue():
+    torch.manual_seed(0)
+    a = bf(torch.randn(4, 256, 1032)); b = bf(torch.randn(4, 64, 1032)); bias = torch.randn(64)
+    ref = torch.einsum('bmk,bnk->bmn', a.float()[..., :1025], b.float()[..., :1025])
+    out = K.gemm(a.to(dev()), b.to(dev()), k_valid=1025, out_dtype=torch.float32)
+    assert rel_err(out.cpu(), ref) < F32_TOL
+    out = K.gemm(a.to(dev()), b.to(dev()), k_valid=1025, alpha=0.5, bias=bias.to(dev()), act='lrelu', out_dtype=torch.float32)
+    assert rel_err(out.cpu(), F.leaky_relu(ref * 0.5 + bias, 0.2)) < F32_TOL
+
+
+@pytest.mark.parametrize('cfg', [(2, 8, 8, 16, 24, 3), (3, 5, 7, 8, 40, 7), (2, 16, 16, 32, 136, 1), (4, 32, 32, 64, 64, 3),
+                                 (2, 64, 64, 128, 128, 3), (1, 4, 4, 512, 512, 3)])
+def test_conv_forward_dgrad_wgrad_vs_cpu_oracle(cfg):
+    n, H, W, Ci, Co, ks = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(n, Ci, H, W)); w = bf(torch.randn(Co, Ci, ks, ks) * 0.1); dy = bf(torch.randn(n, Co, H, W))
+    xf, wf = x.float().requires_grad_(), w.float().requires_grad_()
+    ref = F.conv2d(xf, wf, padding=ks // 2)
+    ref.backward(dy.float())
+    xh, dyh = x.permute(0, 2, 3, 1).contiguous().to(dev()), dy.permute(0, 2, 3, 1).contiguous().to(dev())
+    wh = w.permute(0, 2, 3, 1).reshape(Co, -1).contiguous().to(dev())
+    assert rel_err(K.conv2d_nhwc(xh, wh, ksize=ks, out_dtype=torch.float32).cpu().permute(0, 3, 1, 2), ref) < F32_TOL
+    assert rel_err(K.conv2d_wgrad_nhwc(xh, dyh, ksize=ks).cpu(), wf.grad.permute(2, 3, 1, 0).reshape(-1, Co)) < F32_TOL
+    wT = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Ci, -1).contiguous().to(dev())
+    assert rel_err(K.conv2d_nhwc(dyh, wT, ksize=ks, out_dtype=torch.float32).cpu().permute(0, 3, 1, 2), xf.grad) < F32_TOL
+
+
+def test_ops_match_reference_golden_fixture():
+    fx = torch.load(GOLD / 'ops_small.pt', weights_only=False)
+    H_ = ops.HipOps()
+    d = dev()
+    f = fx['modconv']
+    with torch.no_grad():
+        y = H_.modconv2d(f['x'].to(d), f['weights'].to(d), f['mod'].to(d), f['kernel_mod'].to(d))
+    assert rel_err(y.cpu(), f['y']) < 1e-2            # bf16 kernel vs fp32 reference output
+    y = H_.modconv2d(f['x'].to(d).requires_grad_(), f['weights'].to(d), f['mod'].to(d), f['kernel_mod'].to(d))
+    assert rel_err(y.cpu(), f['y']) < 1e-2            # training (stacked-output) path
+    f = fx['upsample']
+    assert rel_err(H_.upsample_blur(f['x'].to(d)).cpu(), f['y']) < 1e-2
+    f = fx['resize']
+    assert rel_err(H_.resize_bilinear(f['x'].to(d), 8).cpu(), f['y8']) < 1e-2
+    f = fx['rmsnorm']
+    assert rel_err(H_.channel_rmsnorm(f['x'].to(d), f['gamma'].to(d)).cpu(), f['y']) < 1e-2
+
+
+def test_ops_gradients_vs_oracle():
+    torch.manual_seed(0)
+    H_, O_ = ops.HipOps(), OracleOps(bf16_operands=True)
+    d = dev()
+
+    def check(fn, inputs, tol=2e-2):
+        ih = [t.clone().to(d).requires_grad_() for t in inputs]; io = [t.clone().requires_grad_() for t in inputs]
+        yh, yo = fn(H_, *ih), fn(O_, *io)
+        g = torch.randn_like(yo)
+        gh = torch.autograd.grad(yh.float(), ih, g.to(d)); go = torch.autograd.grad(yo, io, bf(g).float())
+        assert rel_err(yh.cpu(), yo) < tol
+        for a, b in zip(gh, go):
+            assert rel_err(a.cpu(), b) < 2 * tol
+
+    x = torch.randn(2, 16, 8, 8)
+    check(lambda I, x, w, b: I.conv2d(x, w, b, act='lrelu'), [x, torch.randn(24, 16, 3, 3) * 0.1, torch.randn(24)])
+    check(lambda I, x, w: I.conv2d(x, w, None), [torch.randn(2, 3, 8, 8), torch.randn(16, 3, 7, 7) * 0.1])
+    check(lambda I, x, w, b: I.linear(x, w, b), [torch.randn(6, 20), torch.randn(5, 20), torch.randn(5)])
+    q, k, v = torch.randn(2, 2, 16, 16), torch.randn(2, 2, 17, 16), torch.randn(2, 2, 17, 16)
+    check(lambda I, q, k, v: I.attention(q, k, v, scale=0.25), [q, k, v])
+    check(lambda I, q, k, v: I.attention(q, k, v, scale=0.25, l2=True), [q, k, v])
+    check(lambda I, x, w, m, k: I.modconv2d(x, w, m, k), [x, torch.randn(2, 24, 16, 3, 3) * 0.1, torch.randn(2, 16) * 0.5, torch.randn(2, 2)])
+    check(lambda I, x: I.upsample_blur(x), [x])
+    check(lambda I, x: I.resize_bilinear(x, 4), [torch.rand(2, 3, 16, 16)])
+
+
+def test_models_vs_reference_golden_fixture():
+    """generator images / discriminator logits / gradient penalty on the GPU vs the reference's fp32 CPU outputs."""
+    fx = torch.load(GOLD / 'model_small.pt', weights_only=False)
+    d = dev()
+    G, D = Generator(**SMALL_G), Discriminator(**SMALL_D)
+    G.load_state_dict(fx['G']); D.load_state_dict(fx['D'])
+    G, D = G.to(d), D.to(d).eval()
+    # per-layer noise comes from the device RNG, so reproduce the reference's CPU draws by replaying them
+    draws = []
+    torch.manual_seed(1)
+    for r in (4, 4, 8, 8, 16, 16, 32, 32):
+        draws.append(torch.randn(2, 1, r, r))
+    it = iter(draws)
+    orig = torch.randn
+    torch.randn = lambda *a, **k: next(it).to(k.get('device', 'cpu'))
+    try:
+        with torch.no_grad():
+            img, rgbs = G(noise=fx['z'].to(d), return_all_rgbs=True)
+    finally:
+        torch.randn = orig
+    assert rel_err(img.cpu(), fx['img']) < 3e-2
+    real = fx['real'].to(d).requires_grad_()
+    logits, ms, _ = D(real, D.real_images_to_rgbs(real), calc_aux_loss=False)
+    assert rel_err(logits.cpu(), fx['logits']) < 3e-2
+    for a, b in zip(ms, fx['ms']):
+        assert rel_err(a.cpu(), b) < 3e-2
+    gp = gradient_penalty(real, [logits, *ms], grad_output_weights=[1., *(0.1,) * len(ms)])
+    assert rel_err(gp.cpu(), fx['gp']) < 0.1          # second-order quantity through bf16 leaky-relu masks
+
+
+def test_train_step_runs_and_is_finite(tmp_path):
+    torch.manual_seed(0)
+    gan = GigaGAN(generator=dict(C1_G), discriminator=dict(C1_D), apply_gradient_penalty_every=2, device=dev(),
+                  model_folder=str(tmp_path / 'm'), results_folder=str(tmp_path / 'r'))
+    it = cycle(SyntheticImages(2, 64, device=dev()))
+    for _ in range(2):
+        d_l, g_l = gan.train_step(it, 2)
+    vals = [float(v) for v in (*d_l, *g_l) if v is not None]
+    assert all(v == v and abs(v) < 1e9 for v in vals), vals
+    assert float(d_l.gradient_penalty) > 0
+
+
+def test_config2_shapes_linearity_and_adjointness():
+    """size-independent properties at BASELINE config-2 sizes (batch 32): conv is linear in x, and
+    <conv(x, w), y> == <x, conv(y, flipT(w))> == <w, wgrad(x, y)> (fp32-accumulated inner products)."""
+    torch.manual_seed(0)
+    d = dev()
+    for (n, R, Ci, Co) in [(32, 64, 128, 64), (32, 256, 16, 16), (128, 32, 256, 256)]:
+        x = bf(torch.randn(n, R, R, Ci, device=d)); x2 = bf(torch.randn(n, R, R, Ci, device=d))
+        y = bf(torch.randn(n, R, R, Co, device=d))
+        w = bf(torch.randn(Co, Ci, 3, 3, device=d) * 0.05)
+        wh = w.permute(0, 2, 3, 1).reshape(Co, -1).contiguous()
+        wT = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Ci, -1).contiguous()
+        c1 = K.conv2d_nhwc(x, wh, ksize=3, out_dtype=torch.float32)
+        c2 = K.conv2d_nhwc(x2, wh, ksize=3, out_dtype=torch.float32)
+        xs = bf(x.float() + x2.float())
+        exact = (xs.float() == x.float() + x2.float())         # keep only positions where the bf16 sum is exact
+        c12 = K.conv2d_nhwc(torch.where(exact, xs, torch.zeros_like(xs)), wh, ksize=3, out_dtype=torch.float32)
+        cz1 = K.conv2d_nhwc(torch.where(exact, x, torch.zeros_like(x)), wh, ksize=3, out_dtype=torch.float32)
+        cz2 = K.conv2d_nhwc(torch.where(exact, x2, torch.zeros_like(x2)), wh, ksize=3, out_dtype=torch.float32)
+        assert rel_err(c12, cz1 + cz2) < 1e-4
+        lhs = (c1.double() * y.double()).sum()
+        dg = K.conv2d_nhwc(y, wT, ksize=3, out_dtype=torch.float32)
+        rhs = (dg.double() * x.double()).sum()
+        wg = K.conv2d_wgrad_nhwc(x, y, ksize=3)
+        rhs2 = (wg.double() * wh.t().double()).sum()
+        assert abs(lhs - rhs) / abs(lhs) < 1e-3 and abs(lhs - rhs2) / abs(lhs) < 1e-3
+        del c1, c2, c12, cz1, cz2, dg
