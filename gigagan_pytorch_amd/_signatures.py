@@ -13,3 +13,9 @@ def declare(L):
     L.gg_adamw_flat_f32.argtypes = [_P, _P, _P, _P, _P, C.c_int64, _F, _F, _F, _F, _F, _F, _F, _F, _P]
     L.gg_ema_flat_f32.restype = C.c_int
     L.gg_ema_flat_f32.argtypes = [_P, _P, C.c_int64, _F, _P]
+    L.gg_softmax_fwd.restype = C.c_int
+    L.gg_softmax_fwd.argtypes = [_P, _P, _P, C.c_int64, _I, _I, _I, _F, _P]
+    L.gg_softmax_bwd.restype = C.c_int
+    L.gg_softmax_bwd.argtypes = [_P, _P, _P, _P, C.c_int64, _I, _I, _I, _F, _P]
+    L.gg_bias_act_bwd.restype = C.c_int
+    L.gg_bias_act_bwd.argtypes = [_P, _P, _P, _P, C.c_int64, _I, _F, _P]

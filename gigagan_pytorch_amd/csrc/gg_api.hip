@@ -248,3 +248,54 @@ extern "C" int gg_ema_flat_f32(float* ema, const float* p, int64_t n, float one_
     GG_LAUNCH(gg_ema_kernel, dim3(gg_grid_for(n / 4)), dim3(256), (hipStream_t)stream, ema, p, (long long)n, one_minus_beta);
     return gg_check_launch();
 }
+
+static int gg_softmax_common(GgSoftmaxParams& p, int64_t rows, int32_t rows_per_batch, int32_t n_valid, int32_t ld,
+                             float alpha) {
+    if (rows <= 0 || rows_per_batch <= 0 || n_valid <= 0 || ld < n_valid) return gg_fail(-2, "gg_softmax: bad extents");
+    if (ld % 4 || ld > 256 * GG_SM_MAXV) return gg_fail(-3, "gg_softmax: ld must be a multiple of 4 and <= %d", 256 * GG_SM_MAXV);
+    if (rows % rows_per_batch) return gg_fail(-4, "gg_softmax: rows must be a multiple of rows_per_batch");
+    p.rows = rows; p.rows_per_batch = rows_per_batch; p.n_valid = n_valid; p.ld = ld; p.alpha = alpha;
+    return 0;
+}
+
+extern "C" int gg_softmax_fwd(const float* x, void* S, const float* bias, int64_t rows, int32_t rows_per_batch,
+                              int32_t n_valid, int32_t ld, float alpha, void* stream) {
+    if (!x || !S) return gg_fail(-1, "gg_softmax_fwd: null pointer");
+    GgSoftmaxParams p;
+    memset(&p, 0, sizeof(p));
+    int rc = gg_softmax_common(p, rows, rows_per_batch, n_valid, ld, alpha);
+    if (rc) return rc;
+    p.x = x; p.out = (bf16_t*)S; p.bias = bias;
+    long long waves = (rows + GG_SM_ROWS - 1) / GG_SM_ROWS;
+    GG_LAUNCH(gg_softmax_fwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+extern "C" int gg_softmax_bwd(const void* S, const void* dS, void* dx, float* dbias, int64_t rows,
+                              int32_t rows_per_batch, int32_t n_valid, int32_t ld, float alpha, void* stream) {
+    if (!S || !dS || !dx) return gg_fail(-1, "gg_softmax_bwd: null pointer");
+    GgSoftmaxParams p;
+    memset(&p, 0, sizeof(p));
+    int rc = gg_softmax_common(p, rows, rows_per_batch, n_valid, ld, alpha);
+    if (rc) return rc;
+    if (dbias && (rows_per_batch % GG_SM_ROWS)) return gg_fail(-5, "gg_softmax_bwd: rows_per_batch must be a multiple of %d when dbias is requested", GG_SM_ROWS);
+    p.S = (const bf16_t*)S; p.dS = (const bf16_t*)dS; p.out = (bf16_t*)dx; p.dbias = dbias;
+    long long waves = (rows + GG_SM_ROWS - 1) / GG_SM_ROWS;
+    GG_LAUNCH(gg_softmax_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+extern "C" int gg_bias_act_bwd(const void* dy, const void* y, void* dz, float* db, int64_t rows, int32_t C,
+                               float slope, void* stream) {
+    if (!dy) return gg_fail(-1, "gg_bias_act_bwd: null dy");
+    if ((y != nullptr) != (dz != nullptr)) return gg_fail(-1, "gg_bias_act_bwd: y and dz go together");
+    if (!y && !db) return gg_fail(-1, "gg_bias_act_bwd: nothing to do");
+    if (rows <= 0 || C <= 0 || (C % 8)) return gg_fail(-2, "gg_bias_act_bwd: need rows > 0 and C %% 8 == 0 (C=%d)", C);
+    GgBiasActBwdParams p;
+    p.dy = (const bf16_t*)dy; p.y = (const bf16_t*)y; p.dz = (bf16_t*)dz; p.db = db; p.rows = rows; p.C = C; p.slope = slope;
+    long long nb = (rows * (long long)(C / 8) + 2047) / 2048;   // ~8 vectors per thread
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    GG_LAUNCH(gg_bias_act_bwd_kernel, dim3((unsigned)nb), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}

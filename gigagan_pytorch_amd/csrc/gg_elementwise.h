@@ -119,3 +119,215 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_ema_kernel(float* ema, const float* p, l
         *(f32x4*)(ema + i * 4) = e;
     }
 }
+
+// ---- attention softmax over materialised logits (one wavefront per row) --------------------------------
+// fwd:  S[r][j] = softmax_j(alpha * x[r][j] + bias[r / rows_per_batch][j]),  j < n_valid; columns in
+//       [n_valid, ld) are written as 0.  x fp32 (pitch ld), S bf16 (pitch ld).
+// bwd:  u = S * (dS - sum_j S*dS);  dx = alpha * u (bf16);  dbias[batch][j] += sum_rows u (fp32 atomics,
+//       one per column per 16 rows).
+// Replaces sim*scale / masked_fill / softmax / casts of gp.py:584-588 (and their autograd) — six fp32
+// passes over the (b*h, n, n+1) similarity tensor — by one pass each way. HBM-bound:
+// fwd 6 B/element, bwd 6 B/element.
+#define GG_SM_MAXV 8       // register cache: up to 8 float4 per lane => rows of <= 2048 columns
+#define GG_SM_ROWS 16      // rows per wavefront (amortises the dbias atomics)
+
+struct GgSoftmaxParams {
+    const float* x;      // fwd input
+    const bf16_t* S;     // bwd input (fwd output)
+    const bf16_t* dS;    // bwd input
+    bf16_t* out;         // fwd: S ; bwd: dx
+    const float* bias;   // fwd, optional [nbatch][ld]
+    float* dbias;        // bwd, optional [nbatch][ld], pre-zeroed
+    long long rows;
+    int rows_per_batch, n_valid, ld;
+    float alpha;
+};
+
+GG_DEVICE float gg_wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, gg_shfl_xor(v, o));
+    return v;
+}
+GG_DEVICE float gg_wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += gg_shfl_xor(v, o);
+    return v;
+}
+
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_softmax_fwd_kernel(GgSoftmaxParams p) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nv = (p.ld + 255) / 256;
+    for (int rr = 0; rr < GG_SM_ROWS; ++rr) {
+        const long long r = wave * GG_SM_ROWS + rr;
+        if (r >= p.rows) break;   // wave-uniform
+        const float* xr = p.x + r * p.ld;
+        const float* br = p.bias ? p.bias + (r / p.rows_per_batch) * p.ld : nullptr;
+        f32x4 v[GG_SM_MAXV];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int t = 0; t < GG_SM_MAXV; ++t) {
+            if (t >= nv) break;
+            int j = t * 256 + lane * 4;
+            f32x4 z = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+            if (j < p.ld) {
+                f32x4 xv = *(const f32x4*)(xr + j);
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (br) bv = *(const f32x4*)(br + j);
+                for (int e = 0; e < 4; ++e)
+                    if (j + e < p.n_valid) z[e] = p.alpha * xv[e] + bv[e];
+            }
+            v[t] = z;
+            for (int e = 0; e < 4; ++e) mx = fmaxf(mx, z[e]);
+        }
+        mx = gg_wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < GG_SM_MAXV; ++t) {
+            if (t >= nv) break;
+            int j = t * 256 + lane * 4;
+            for (int e = 0; e < 4; ++e) {
+                float ex = (j + e < p.n_valid) ? gg_expf(v[t][e] - mx) : 0.f;
+                v[t][e] = ex;
+                sum += ex;
+            }
+        }
+        sum = gg_wave_sum(sum);
+        const float inv = 1.f / sum;
+        bf16_t* orow = p.out + r * p.ld;
+#pragma unroll
+        for (int t = 0; t < GG_SM_MAXV; ++t) {
+            if (t >= nv) break;
+            int j = t * 256 + lane * 4;
+            if (j < p.ld) {
+                u16x4 o = {gg_f2bf(v[t][0] * inv), gg_f2bf(v[t][1] * inv), gg_f2bf(v[t][2] * inv), gg_f2bf(v[t][3] * inv)};
+                *(u16x4*)(orow + j) = o;
+            }
+        }
+    }
+}
+
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_softmax_bwd_kernel(GgSoftmaxParams p) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nv = (p.ld + 255) / 256;
+    f32x4 colacc[GG_SM_MAXV];
+#pragma unroll
+    for (int t = 0; t < GG_SM_MAXV; ++t) colacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    long long acc_batch = -1;
+    // GG_SM_ROWS divides rows_per_batch (checked by the host), so one wave never straddles two batches
+    for (int rr = 0; rr < GG_SM_ROWS; ++rr) {
+        const long long r = wave * GG_SM_ROWS + rr;
+        if (r >= p.rows) break;
+        acc_batch = r / p.rows_per_batch;
+        const bf16_t* sr = p.S + r * p.ld;
+        const bf16_t* dr = p.dS + r * p.ld;
+        f32x4 s[GG_SM_MAXV], d[GG_SM_MAXV];
+        float dot = 0.f;
+#pragma unroll
+        for (int t = 0; t < GG_SM_MAXV; ++t) {
+            if (t >= nv) break;
+            int j = t * 256 + lane * 4;
+            f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+            if (j < p.ld) {
+                u16x4 a = *(const u16x4*)(sr + j);
+                u16x4 b = *(const u16x4*)(dr + j);
+                for (int e = 0; e < 4; ++e) {
+                    if (j + e < p.n_valid) {
+                        sv[e] = gg_bf2f(a[e]);
+                        dv[e] = gg_bf2f(b[e]);
+                    }
+                    dot += sv[e] * dv[e];
+                }
+            }
+            s[t] = sv;
+            d[t] = dv;
+        }
+        dot = gg_wave_sum(dot);
+        bf16_t* orow = p.out + r * p.ld;
+#pragma unroll
+        for (int t = 0; t < GG_SM_MAXV; ++t) {
+            if (t >= nv) break;
+            int j = t * 256 + lane * 4;
+            if (j < p.ld) {
+                float u[4];
+                for (int e = 0; e < 4; ++e) {
+                    u[e] = s[t][e] * (d[t][e] - dot);
+                    colacc[t][e] += u[e];
+                }
+                u16x4 o = {gg_f2bf(p.alpha * u[0]), gg_f2bf(p.alpha * u[1]), gg_f2bf(p.alpha * u[2]), gg_f2bf(p.alpha * u[3])};
+                *(u16x4*)(orow + j) = o;
+            }
+        }
+    }
+    if (p.dbias && acc_batch >= 0) {
+        float* db = p.dbias + acc_batch * p.ld;
+#pragma unroll
+        for (int t = 0; t < GG_SM_MAXV; ++t) {
+            if (t >= nv) break;
+            int j = t * 256 + lane * 4;
+            for (int e = 0; e < 4; ++e)
+                if (j + e < p.n_valid) gg_atomic_add(db + j + e, colacc[t][e]);
+        }
+    }
+}
+
+// ---- bias / activation backward ---------------------------------------------------------------------------
+// dz = dy * (y > 0 ? 1 : slope)  (skipped when y == null: dz aliases dy) and db[c] += sum_rows dz[row][c].
+// One pass instead of compare + where + cast + mul + float-cast + reduce (autograd of nn.Conv2d bias and
+// nn.LeakyReLU, gp.py:109, :1608-1621). x: [rows][C] bf16, C % 8 == 0. 4 B (+2 B) per element.
+struct GgBiasActBwdParams {
+    const bf16_t* dy;
+    const bf16_t* y;   // optional
+    bf16_t* dz;        // required iff y != null
+    float* db;         // optional [C], pre-zeroed
+    long long rows;
+    int C;
+    float slope;
+};
+
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_bias_act_bwd_kernel(GgBiasActBwdParams p) {
+    GG_SHARED float red[256][8];
+    const int ncg = p.C / 8;                       // column groups of 8 channels
+    const int t = threadIdx.x;
+    // thread -> (row lane, column group); column groups beyond 256 are looped
+    const int lanes_per_row = ncg < 256 ? ncg : 256;
+    const int row_lanes = 256 / lanes_per_row;
+    const int cgl = t % lanes_per_row, rl = t / lanes_per_row;
+    const long long rows_per_block = (p.rows + gridDim.x - 1) / gridDim.x;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > p.rows) r1 = p.rows;
+    for (int cg = cgl; cg < ncg; cg += lanes_per_row) {
+        float acc[8];
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        if (rl < row_lanes) {
+            for (long long r = r0 + rl; r < r1; r += row_lanes) {
+                const long long off = r * p.C + cg * 8;
+                u16x8 g = *(const u16x8*)(p.dy + off);
+                float f[8];
+                if (p.y) {
+                    u16x8 yv = *(const u16x8*)(p.y + off);
+                    u16x8 o;
+                    for (int e = 0; e < 8; ++e) {
+                        f[e] = gg_bf2f(g[e]) * (gg_bf2f(yv[e]) > 0.f ? 1.f : p.slope);
+                        o[e] = gg_f2bf(f[e]);
+                        f[e] = gg_bf2f(o[e]);
+                    }
+                    *(u16x8*)(p.dz + off) = o;
+                } else {
+                    for (int e = 0; e < 8; ++e) f[e] = gg_bf2f(g[e]);
+                }
+                for (int e = 0; e < 8; ++e) acc[e] += f[e];
+            }
+        }
+        if (p.db) {
+            for (int e = 0; e < 8; ++e) red[t][e] = (rl < row_lanes) ? acc[e] : 0.f;
+            gg_sync();
+            if (rl == 0) {
+                for (int k = 1; k < row_lanes; ++k)
+                    for (int e = 0; e < 8; ++e) acc[e] += red[k * lanes_per_row + cgl][e];
+                for (int e = 0; e < 8; ++e) gg_atomic_add(p.db + cg * 8 + e, acc[e]);
+            }
+            gg_sync();
+        }
+    }
+}

@@ -305,3 +305,50 @@ def resample_nhwc(x: torch.Tensor, spec: ResampleSpec) -> torch.Tensor:
                                      ptr(iy0), ptr(ix0), ptr(wy), ptr(wx), L.stream(x))
     L.check(rc, 'gg_resample_nhwc_bf16')
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# attention softmax, bias / activation backward
+# --------------------------------------------------------------------------------------------------
+
+def softmax_fwd(x: torch.Tensor, bias, alpha: float, n_valid: int) -> torch.Tensor:
+    """x fp32 (batch, rows, ld) -> bf16 softmax(alpha*x + bias[batch]) over the first n_valid columns."""
+    L = _C.lib()
+    L.require(x, bias)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3
+    nb, n, ld = x.shape
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.shape == (nb, ld) and bias.is_contiguous()
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    rc = L.lib.gg_softmax_fwd(ptr(x), ptr(out), ptr(bias), nb * n, n, n_valid, ld, alpha, L.stream(x))
+    L.check(rc, 'gg_softmax_fwd')
+    return out
+
+
+def softmax_bwd(S: torch.Tensor, dS: torch.Tensor, alpha: float, n_valid: int, want_dbias: bool):
+    """returns (dx bf16 = alpha*u, dbias fp32 (batch, ld) or None) with u = S*(dS - rowsum(S*dS))."""
+    L = _C.lib()
+    L.require(S, dS)
+    assert S.dtype == torch.bfloat16 and dS.dtype == torch.bfloat16 and S.is_contiguous() and dS.is_contiguous()
+    nb, n, ld = S.shape
+    dx = torch.empty_like(S)
+    dbias = torch.zeros((nb, ld), dtype=torch.float32, device=S.device) if want_dbias else None
+    rc = L.lib.gg_softmax_bwd(ptr(S), ptr(dS), ptr(dx), ptr(dbias), nb * n, n, n_valid, ld, alpha, L.stream(S))
+    L.check(rc, 'gg_softmax_bwd')
+    return dx, dbias
+
+
+def bias_act_bwd(dy: torch.Tensor, y, want_db: bool, slope: float = 0.2):
+    """dz = dy * lrelu'(y) (dz is dy itself when y is None) and db = column sums of dz (fp32) in one pass."""
+    L = _C.lib()
+    L.require(dy, y)
+    assert dy.dtype == torch.bfloat16 and dy.is_contiguous()
+    Cc = dy.shape[-1]
+    rows = dy.numel() // Cc
+    dz = torch.empty_like(dy) if y is not None else None
+    if y is not None:
+        assert y.dtype == torch.bfloat16 and y.is_contiguous() and y.shape == dy.shape
+    db = torch.zeros(Cc, dtype=torch.float32, device=dy.device) if want_db else None
+    rc = L.lib.gg_bias_act_bwd(ptr(dy), ptr(y), ptr(dz), ptr(db), rows, Cc, slope, L.stream(dy))
+    L.check(rc, 'gg_bias_act_bwd')
+    return (dz if dz is not None else dy), db

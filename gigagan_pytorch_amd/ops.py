@@ -85,11 +85,14 @@ class ConvFn(Function):
     def backward(ctx, dy):
         x, w, in_scale, y = ctx.saved_tensors
         dy = dy.contiguous()
-        if ctx.act == 'lrelu':
-            dz = dy * torch.where(y > 0, 1.0, LRELU_SLOPE).to(dy.dtype)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        db = None
+        if ctx.act == 'lrelu' or want_db:
+            dz, db = BiasActBwdFn.apply(dy, y if ctx.act == 'lrelu' else None, want_db)
+            db = db if want_db else None
         else:
             dz = dy
-        dx = dw = db = ds = None
+        dx = dw = ds = None
         if ctx.needs_input_grad[0] or (in_scale is not None and ctx.needs_input_grad[3]):
             dxs = ConvFn.apply(dz, flip_transpose(w), None, None, None)
             if in_scale is None:
@@ -100,9 +103,32 @@ class ConvFn(Function):
                 dx = (dxs.float() * in_scale[:, None, None, :]).to(dxs.dtype)
         if ctx.needs_input_grad[1]:
             dw = WgradFn.apply(x, dz, in_scale, w.shape[-1]).to(w.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dz.float().sum(dim=(0, 1, 2))
         return dx, dw, db, ds, None
+
+
+class BiasActBwdFn(Function):
+    """(dz, db) = (dy * lrelu'(y), column sums of dz) in one HIP pass; differentiable again (gradient penalty)
+    through plain tensor algebra, since dz is linear in dy with a piecewise-constant mask."""
+
+    @staticmethod
+    def forward(ctx, dy, y, want_db):
+        dz, db = K.bias_act_bwd(dy, y, want_db, LRELU_SLOPE)
+        ctx.save_for_backward(y)
+        if db is None:
+            db = dy.new_zeros((), dtype=torch.float32)
+        return dz, db
+
+    @staticmethod
+    def backward(ctx, g_dz, g_db):
+        y, = ctx.saved_tensors
+        g = g_dz
+        if g_db is not None and g_db.dim() == 1:
+            g = g_db.to(g_dz.dtype).view(1, 1, 1, -1) + (g if g is not None else 0)
+        if g is None:
+            return None, None, None
+        if y is not None:
+            g = g * torch.where(y > 0, 1.0, LRELU_SLOPE).to(g.dtype)
+        return g, None, None
 
 
 class WgradFn(Function):
@@ -178,6 +204,61 @@ class GemmFn(Function):
                 dy = GemmFn.apply(x, g, not x_red_last, False, (T, Cc, R), None, None, alpha, False)
             dy = _fit(dy, y)
         return dx, dy, None, None, None, db, None, None, None
+
+
+class AttnProbsFn(Function):
+    """attn = softmax_j(alpha * q k^T + bias) as bf16 (BH, n, mp): MFMA GEMM with fp32 logits + ONE fused
+    softmax pass; the fp32 logits never leave this Function. Backward = fused softmax-backward pass + two GEMMs,
+    all of them differentiable again (SoftmaxBwdFn / GemmFn), so the gradient penalty can pass through."""
+
+    @staticmethod
+    def forward(ctx, q, k, bias, alpha, m_valid):
+        n, mp, dh = q.shape[1], k.shape[1], q.shape[2]
+        qk = K.gemm(q, k, trans_a=False, trans_b=True, out_dtype=torch.float32)
+        attn = K.softmax_fwd(qk, bias, alpha, m_valid)
+        ctx.cfg = (alpha, m_valid, (n, mp, dh))
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(q, k, attn)
+        return attn
+
+    @staticmethod
+    def backward(ctx, dattn):
+        q, k, attn = ctx.saved_tensors
+        alpha, m_valid, (n, mp, dh) = ctx.cfg
+        dx, dbias = SoftmaxBwdFn.apply(attn, dattn.contiguous(), alpha, m_valid, ctx.has_bias)
+        dq = dk = None
+        if ctx.needs_input_grad[0]:   # dq(i,d) = sum_j dx(i,j) k(j,d)
+            dq = GemmFn.apply(dx, k, True, False, (n, dh, mp), None, None, 1.0, False)
+        if ctx.needs_input_grad[1]:   # dk(j,d) = sum_i dx(i,j) q(i,d)
+            dk = GemmFn.apply(dx, q, False, False, (mp, dh, n), None, None, 1.0, False)
+        return dq, dk, (dbias if ctx.has_bias else None), None, None
+
+
+class SoftmaxBwdFn(Function):
+    """(dx, dbias) = (alpha*u, column sums of u), u = S*(dS - rowsum(S*dS)); its own backward (second order,
+    gradient-penalty steps only) is written in tensor algebra."""
+
+    @staticmethod
+    def forward(ctx, S, dS, alpha, m_valid, want_dbias):
+        dx, dbias = K.softmax_bwd(S, dS, alpha, m_valid, want_dbias)
+        ctx.alpha = alpha
+        ctx.save_for_backward(S, dS)
+        if dbias is None:
+            dbias = S.new_zeros((), dtype=torch.float32)
+        return dx, dbias
+
+    @staticmethod
+    def backward(ctx, g_dx, g_dbias):
+        S, dS = ctx.saved_tensors
+        Sf, dSf = S.float(), dS.float()
+        gt = ctx.alpha * g_dx.float()
+        if g_dbias is not None and g_dbias.dim() == 2:
+            gt = gt + g_dbias[:, None, :]
+        r = (Sf * dSf).sum(-1, keepdim=True)
+        gs = (gt * Sf).sum(-1, keepdim=True)
+        g_dS = Sf * (gt - gs)
+        g_S = gt * (dSf - r) - dSf * gs
+        return g_S.to(S.dtype), g_dS.to(dS.dtype), None, None, None
 
 
 def _pad_last(t: torch.Tensor) -> torch.Tensor:
@@ -314,22 +395,19 @@ class HipOps:
             k2 = F.pad(k2, (0, 0, 0, mp - m))
             v2 = F.pad(v2, (0, 0, 0, mp - m))
         k2, v2 = k2.contiguous(), v2.contiguous()
-        qk = GemmFn.apply(q2, k2, True, True, (n, mp, dh), None, None, 1.0, True)       # fp32 (BH, n, mp)
+        # logits = alpha * q.k + bias[batch, key]:
+        #   dot: alpha = scale;  l2: -|q-k|^2*scale = 2*scale*q.k - scale*|k|^2 - scale*|q|^2, and the per-query
+        #   term cancels in the softmax, so alpha = 2*scale and bias = -scale*|k|^2. Key-padding masks are a bias too.
+        alpha = 2.0 * scale if l2 else scale
+        bias = None
         if l2:
-            # -|q-k|^2*scale = scale*(2 q.k - |k|^2) - scale*|q|^2 ; the per-query term cancels in softmax
-            ksq = (k2.float() ** 2).sum(-1)
-            logits = (2.0 * qk - ksq[:, None, :]) * scale
-        else:
-            logits = qk * scale
-        neg = -torch.finfo(torch.float32).max
-        if mp != m:
-            col = torch.arange(mp, device=q.device)
-            logits = logits.masked_fill(col[None, None, :] >= m, neg)
+            bias = -scale * (k2.float() ** 2).sum(-1)                                   # (BH, mp)
         if key_mask is not None:
             km = F.pad(key_mask, (0, mp - m), value=False) if mp != m else key_mask
-            km = km[:, None, None, :].expand(B, h, 1, mp).reshape(B * h, 1, mp)
-            logits = logits.masked_fill(~km, neg)
-        attn = logits.softmax(dim=-1).to(ACT_DTYPE)
+            neg = torch.zeros(km.shape, dtype=torch.float32, device=q.device).masked_fill(~km, -1e30)
+            neg = neg[:, None, :].expand(B, h, mp).reshape(B * h, mp)
+            bias = neg if bias is None else bias + neg
+        attn = AttnProbsFn.apply(q2, k2, None if bias is None else bias.contiguous(), alpha, m)   # bf16 (BH, n, mp)
         out = GemmFn.apply(attn, v2, True, False, (n, dh, mp), None, None, 1.0, False)  # (BH, n, dh)
         return out.reshape(B, h, n, dh)
 
@@ -378,9 +456,10 @@ def demod_coefficients(weights, s, a, eps):
     fp32 throughout (these are (b,O)-sized statistics)."""
     N, O, I = weights.shape[:3]
     wf = weights.float().flatten(3)                                     # (N, O, I, k*k)
-    gram = torch.einsum('noik,moik->nmoi', wf, wf)                      # (N, N, O, I)
-    t = torch.einsum('bi,nmoi->bnmo', s * s, gram)                      # (b, N, N, O)
-    sumsq = torch.einsum('bn,bm,bnmo->bo', a, a, t)
+    gram = (wf[:, None] * wf[None, :]).sum(-1)                          # (N, N, O, I) — pointwise, no tiny GEMMs
+    t = ((s * s) @ gram.reshape(N * N * O, I).t()).view(-1, N, N, O)    # (b, N, N, O): one (b x I)(I x N^2 O) GEMM
+    aa = a[:, :, None] * a[:, None, :]                                  # (b, N, N)
+    sumsq = (aa[..., None] * t).sum(dim=(1, 2))
     return sumsq.clamp(min=eps).rsqrt()
 
 

@@ -92,6 +92,23 @@ int gg_adamw_flat_f32(float* p, const float* g, float* m, float* v, const uint8_
 /* ema += (1 - beta) * (p - ema) over flat fp32 buffers (ema_pytorch update, gp.py:2603); n %% 4 == 0. */
 int gg_ema_flat_f32(float* ema, const float* p, int64_t n, float one_minus_beta, void* stream);
 
+/* Row softmax over materialised attention logits (replaces sim*scale, masked_fill, softmax and the dtype casts
+ * of gp.py:584-588 / :643-649 with one pass):
+ *   S[r][j] = softmax_j(alpha * x[r][j] + bias[r / rows_per_batch][j]) for j < n_valid, 0 for n_valid <= j < ld.
+ * x fp32 [rows][ld], S bf16 [rows][ld]; ld %% 4 == 0, ld <= 2048; bias optional fp32 [rows/rows_per_batch][ld]. */
+int gg_softmax_fwd(const float* x, void* S, const float* bias, int64_t rows, int32_t rows_per_batch, int32_t n_valid,
+                   int32_t ld, float alpha, void* stream);
+/* backward: u = S*(dS - sum_j S*dS); dx = alpha*u (bf16 [rows][ld]); if dbias != NULL, dbias[batch][j] += sum over
+ * the batch's rows of u (fp32, caller zeroes it; rows_per_batch %% 16 == 0). */
+int gg_softmax_bwd(const void* S, const void* dS, void* dx, float* dbias, int64_t rows, int32_t rows_per_batch,
+                   int32_t n_valid, int32_t ld, float alpha, void* stream);
+
+/* Backward of "+bias -> leaky-relu" (nn.Conv2d bias + nn.LeakyReLU autograd, gp.py:109, :1608-1621) in one pass:
+ * dz = dy * (y > 0 ? 1 : slope) when y != NULL (else dz is not written), db[c] += sum_rows dz[row][c] when db != NULL
+ * (fp32 [C], caller zeroes it). dy / y / dz: bf16 [rows][C], C %% 8 == 0. */
+int gg_bias_act_bwd(const void* dy, const void* y, void* dz, float* db, int64_t rows, int32_t C, float slope,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

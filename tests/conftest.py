@@ -18,9 +18,17 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+_built = False
+
+
 def _ensure_built():
-    if not EMU_LIB.exists() or not HIP_LIB.exists():
-        sys.path.insert(0, str(ROOT))
+    """(re)build stale native artefacts once per session where a compiler exists (mtime-aware)."""
+    global _built
+    if _built:
+        return
+    _built = True
+    import shutil
+    if shutil.which('hipcc') or not (EMU_LIB.exists() and HIP_LIB.exists()):
         import __graft_entry__ as g
         g.build()
 
