@@ -123,9 +123,13 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
 template <int BM, int BN, int WM, int WN>
 void gg_launch_gemm_tile(const GgGemmParams& p, bool akrow, bool bkrow, bool aconv, dim3 grid, hipStream_t s) {
     dim3 block(256);
+    // the plain epilogue (alpha only) is a separate instantiation: short-K launches (attention, K = 64) would
+    // otherwise spend most of their time in the bias / scale / noise / activation branches
+    const bool full = p.bias || p.out_scale || p.noise || p.act != GG_ACT_NONE;
 #define GG_CASE(AK, BK_, AC)                                                                     \
     if (akrow == AK && bkrow == BK_ && aconv == AC) {                                            \
-        GG_LAUNCH((gg_gemm_kernel<BM, BN, WM, WN, AK, BK_, AC>), grid, block, s, p);             \
+        if (full) GG_LAUNCH((gg_gemm_kernel<BM, BN, WM, WN, AK, BK_, AC, true>), grid, block, s, p);   \
+        else GG_LAUNCH((gg_gemm_kernel<BM, BN, WM, WN, AK, BK_, AC, false>), grid, block, s, p);       \
         return;                                                                                  \
     }
     GG_CASE(false, false, false)
@@ -174,6 +178,13 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     p.B = (const bf16_t*)d->B; p.b_bs = d->b_batch_stride; p.ldb = d->ldb;
     p.H = d->H; p.W = d->W; p.C = d->C; p.CV = d->CV; p.R = d->R; p.S = d->S; p.pad = (d->R - 1) / 2;
     p.in_scale = d->in_scale;
+    p.w_shift = p.hw_shift = -1;
+    if (d->a_conv && (d->W & (d->W - 1)) == 0 && ((d->H * d->W) & (d->H * d->W - 1)) == 0) {
+        int ws = 0, hs = 0;
+        while ((1 << ws) < d->W) ++ws;
+        while ((1 << hs) < d->H * d->W) ++hs;
+        p.w_shift = ws; p.hw_shift = hs;
+    }
     p.Cout = d->C_out; p.c_bs = d->c_batch_stride; p.ldc = d->ldc; p.c_f32 = d->c_is_f32;
     p.alpha = d->alpha;
     p.bias = d->bias; p.out_scale = d->out_scale; p.rows_per_group = d->rows_per_group;
@@ -285,6 +296,15 @@ extern "C" int gg_softmax_bwd(const void* S, const void* dS, void* dx, float* db
     return gg_check_launch();
 }
 
+static long long gg_bias_act_blocks(int64_t rows, int32_t C) {
+    long long nb = (rows * (long long)(C / 8) + 4095) / 4096;   // ~16 vectors per thread
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    return nb;
+}
+
+extern "C" int32_t gg_bias_act_bwd_partials(int64_t rows, int32_t C) { return (int32_t)gg_bias_act_blocks(rows, C); }
+
 extern "C" int gg_bias_act_bwd(const void* dy, const void* y, void* dz, float* db, int64_t rows, int32_t C,
                                float slope, void* stream) {
     if (!dy) return gg_fail(-1, "gg_bias_act_bwd: null dy");
@@ -293,9 +313,7 @@ extern "C" int gg_bias_act_bwd(const void* dy, const void* y, void* dz, float* d
     if (rows <= 0 || C <= 0 || (C % 8)) return gg_fail(-2, "gg_bias_act_bwd: need rows > 0 and C %% 8 == 0 (C=%d)", C);
     GgBiasActBwdParams p;
     p.dy = (const bf16_t*)dy; p.y = (const bf16_t*)y; p.dz = (bf16_t*)dz; p.db = db; p.rows = rows; p.C = C; p.slope = slope;
-    long long nb = (rows * (long long)(C / 8) + 2047) / 2048;   // ~8 vectors per thread
-    if (nb > 2048) nb = 2048;
-    if (nb < 1) nb = 1;
+    long long nb = gg_bias_act_blocks(rows, C);
     GG_LAUNCH(gg_bias_act_bwd_kernel, dim3((unsigned)nb), dim3(256), (hipStream_t)stream, p);
     return gg_check_launch();
 }

@@ -271,14 +271,15 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_softmax_bwd_kernel(GgSoftmaxParams p) {
 }
 
 // ---- bias / activation backward ---------------------------------------------------------------------------
-// dz = dy * (y > 0 ? 1 : slope)  (skipped when y == null: dz aliases dy) and db[c] += sum_rows dz[row][c].
+// dz = dy * (y > 0 ? 1 : slope)  (skipped when y == null: dz aliases dy) and per-workgroup partial column sums
+// db_part[wg][c] = sum over the workgroup's rows of dz[row][c] (a few hundred rows of [C] floats, summed by the caller).
 // One pass instead of compare + where + cast + mul + float-cast + reduce (autograd of nn.Conv2d bias and
 // nn.LeakyReLU, gp.py:109, :1608-1621). x: [rows][C] bf16, C % 8 == 0. 4 B (+2 B) per element.
 struct GgBiasActBwdParams {
     const bf16_t* dy;
     const bf16_t* y;   // optional
     bf16_t* dz;        // required iff y != null
-    float* db;         // optional [C], pre-zeroed
+    float* db;         // optional [gridDim.x][C] per-workgroup partial sums (summed by the caller: no atomics)
     long long rows;
     int C;
     float slope;
@@ -325,7 +326,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_bias_act_bwd_kernel(GgBiasActBwdParams p
             if (rl == 0) {
                 for (int k = 1; k < row_lanes; ++k)
                     for (int e = 0; e < 8; ++e) acc[e] += red[k * lanes_per_row + cgl][e];
-                for (int e = 0; e < 8; ++e) gg_atomic_add(p.db + cg * 8 + e, acc[e]);
+                for (int e = 0; e < 8; ++e) p.db[(long long)blockIdx.x * p.C + cg * 8 + e] = acc[e];
             }
             gg_sync();
         }

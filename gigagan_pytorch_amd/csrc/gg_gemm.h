@@ -47,6 +47,7 @@ struct GgGemmParams {
     // conv gather on A: activation [img][H][W][C] bf16, output grid H x W (stride 1, pad = (R-1)/2),
     // reduction/gather index = (tap = kh*S + kw, cv) with cv in [0, CV); physical channel = cv % C.
     int H, W, C, CV, R, S, pad;
+    int w_shift, hw_shift;  // log2(W), log2(H*W) when both are powers of two, else -1 (pixel decode by shifts)
     const float* in_scale;  // optional [img][CV] multiplier applied to the gathered activation
     // output / epilogue
     void* Cout;
@@ -238,6 +239,16 @@ template <int ROWS>
 GG_DEVICE void gg_load_rowk_conv(u16x8* regs, const GgConvRow* rows, const GgGemmParams& p, int kend,
                                  int k0) {
     const int t = threadIdx.x;
+    // CV % 32 == 0: the whole 32-wide k-tile lies inside one filter tap, so (kh, kw) are workgroup-uniform
+    // scalars computed once per k-tile instead of two integer divisions per 16-byte vector.
+    const bool uniform_tap = (p.CV & 31) == 0;
+    int u_kh = 0, u_kw = 0, u_cv0 = 0;
+    if (uniform_tap) {
+        int tap = k0 / p.CV;
+        u_cv0 = k0 - tap * p.CV;
+        u_kh = tap / p.S;
+        u_kw = tap - u_kh * p.S;
+    }
 #pragma unroll
     for (int i = 0; i < GgRowKLayout<ROWS>::NV; ++i) {
         int v = t + 256 * i;
@@ -246,9 +257,15 @@ GG_DEVICE void gg_load_rowk_conv(u16x8* regs, const GgConvRow* rows, const GgGem
         u16x8 x = gg_zero8();
         const GgConvRow& r = rows[i];
         if (r.valid && k < kend) {
-            int tap = k / p.CV;
-            int cv = k - tap * p.CV;
-            int kh = tap / p.S, kw = tap - kh * p.S;
+            int kh, kw, cv;
+            if (uniform_tap) {
+                kh = u_kh; kw = u_kw; cv = u_cv0 + kv * 8;
+            } else {
+                int tap = k / p.CV;
+                cv = k - tap * p.CV;
+                kh = tap / p.S;
+                kw = tap - kh * p.S;
+            }
             int ih = r.ih0 + kh, iw = r.iw0 + kw;
             if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
                 int ci = (p.CV == p.C) ? cv : cv % p.C;
@@ -261,33 +278,61 @@ GG_DEVICE void gg_load_rowk_conv(u16x8* regs, const GgConvRow* rows, const GgGem
 }
 
 // conv gather, KROW (weight gradient): k = output pixel, column = (tap, cv)
+struct GgConvCol {
+    int kh, kw, ci, cv, valid;
+};
+
 template <int ROWS>
-GG_DEVICE void gg_load_krow_conv(u16x8* regs, const GgGemmParams& p, int c0, int kend, int k0) {
+GG_DEVICE void gg_conv_cols_init(GgConvCol* cols, const GgGemmParams& p, int c0) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < GgKRowLayout<ROWS>::NI; ++i) {
+        int item = t + 256 * i;
+        int cg = item >> 4;
+        int c = c0 + cg * 8;
+        GgConvCol cc;
+        cc.valid = (item < GgKRowLayout<ROWS>::ITEMS) && (c < p.M);
+        int tap = cc.valid ? c / p.CV : 0;
+        cc.cv = cc.valid ? c - tap * p.CV : 0;
+        cc.kh = tap / p.S;
+        cc.kw = tap - cc.kh * p.S;
+        cc.ci = (p.CV == p.C) ? cc.cv : cc.cv % p.C;
+        cols[i] = cc;
+    }
+}
+
+template <int ROWS>
+GG_DEVICE void gg_load_krow_conv(u16x8* regs, const GgConvCol* cols, const GgGemmParams& p, int kend, int k0) {
     const int t = threadIdx.x;
     const int hw = p.H * p.W;
 #pragma unroll
     for (int i = 0; i < GgKRowLayout<ROWS>::NI; ++i) {
         int item = t + 256 * i;
-        int kp = item & 15, cg = item >> 4;
+        int kp = item & 15;
         u16x8 x[2] = {gg_zero8(), gg_zero8()};
-        int c = c0 + cg * 8;
-        if (item < GgKRowLayout<ROWS>::ITEMS && c < p.M) {
-            int tap = c / p.CV;
-            int cv = c - tap * p.CV;
-            int kh = tap / p.S, kw = tap - kh * p.S;
-            int ci = (p.CV == p.C) ? cv : cv % p.C;
+        const GgConvCol& cc = cols[i];
+        if (cc.valid) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 int pix = k0 + 2 * kp + h;
                 if (pix < kend) {
-                    int img = pix / hw;
-                    int rem = pix - img * hw;
-                    int oh = rem / p.W, ow = rem - oh * p.W;
-                    int ih = oh - p.pad + kh, iw = ow - p.pad + kw;
+                    int img, oh, ow;
+                    if (p.hw_shift >= 0) {
+                        img = pix >> p.hw_shift;
+                        int rem = pix & (hw - 1);
+                        oh = rem >> p.w_shift;
+                        ow = rem & (p.W - 1);
+                    } else {
+                        img = pix / hw;
+                        int rem = pix - img * hw;
+                        oh = rem / p.W;
+                        ow = rem - oh * p.W;
+                    }
+                    int ih = oh - p.pad + cc.kh, iw = ow - p.pad + cc.kw;
                     if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
                         u16x8 y = *(const u16x8*)(p.A + (long long)img * hw * p.C +
-                                                  ((long long)ih * p.W + iw) * p.C + ci);
-                        if (p.in_scale) y = gg_scale8(y, p.in_scale + (long long)img * p.CV + cv);
+                                                  ((long long)ih * p.W + iw) * p.C + cc.ci);
+                        if (p.in_scale) y = gg_scale8(y, p.in_scale + (long long)img * p.CV + cc.cv);
                         x[h] = y;
                     }
                 }
@@ -300,7 +345,7 @@ GG_DEVICE void gg_load_krow_conv(u16x8* regs, const GgGemmParams& p, int c0, int
 
 // ---- the kernel ---------------------------------------------------------------------------------
 
-template <int BM, int BN, int WM, int WN, bool A_KROW, bool B_KROW, bool A_CONV>
+template <int BM, int BN, int WM, int WN, bool A_KROW, bool B_KROW, bool A_CONV, bool FULL_EPI>
 GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_gemm_kernel(GgGemmParams p) {
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
     constexpr int WTM = BM / WM, WTN = BN / WN;  // per-wave tile
@@ -330,12 +375,14 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_gemm_kernel(GgGemmParams p) {
 
     GgConvRow crow[A_CONV && !A_KROW ? ANV : 1];
     if (A_CONV && !A_KROW) gg_conv_rows_init<BM>(crow, p, m0);
+    GgConvCol ccol[A_CONV && A_KROW ? GgKRowLayout<BM>::NI : 1];
+    if (A_CONV && A_KROW) gg_conv_cols_init<BM>(ccol, p, m0);
 
     u16x8 ra[ANV], rb[BNV];
 
     auto load_tiles = [&](int k0) {
         if (A_CONV) {
-            if (A_KROW) gg_load_krow_conv<BM>(ra, p, m0, kend, k0);
+            if (A_KROW) gg_load_krow_conv<BM>(ra, ccol, p, kend, k0);
             else gg_load_rowk_conv<BM>(ra, crow, p, kend, k0);
         } else {
             if (A_KROW) gg_load_krow_dense<BM>(ra, Ab, p.lda, p.M, m0, kend, k0);
@@ -410,8 +457,12 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_gemm_kernel(GgGemmParams p) {
                     for (int e = 0; e < 4; ++e)
                         if (n + e < p.N) dst[e] = acc[i][j][g * 4 + e];
                 } else {
-                    for (int e = 0; e < 4; ++e)
-                        v[e] = (n + e < p.N) ? gg_epilogue(p, acc[i][j][g * 4 + e], m, n + e) : 0.f;
+                    if (FULL_EPI) {
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = (n + e < p.N) ? gg_epilogue(p, acc[i][j][g * 4 + e], m, n + e) : 0.f;
+                    } else {
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e] * p.alpha;
+                    }
                     gg_store4(p, b, m, n, v);
                 }
             }

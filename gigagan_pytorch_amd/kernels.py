@@ -348,7 +348,9 @@ def bias_act_bwd(dy: torch.Tensor, y, want_db: bool, slope: float = 0.2):
     dz = torch.empty_like(dy) if y is not None else None
     if y is not None:
         assert y.dtype == torch.bfloat16 and y.is_contiguous() and y.shape == dy.shape
-    db = torch.zeros(Cc, dtype=torch.float32, device=dy.device) if want_db else None
-    rc = L.lib.gg_bias_act_bwd(ptr(dy), ptr(y), ptr(dz), ptr(db), rows, Cc, slope, L.stream(dy))
+    part = None
+    if want_db:
+        part = torch.empty((L.lib.gg_bias_act_bwd_partials(rows, Cc), Cc), dtype=torch.float32, device=dy.device)
+    rc = L.lib.gg_bias_act_bwd(ptr(dy), ptr(y), ptr(dz), ptr(part), rows, Cc, slope, L.stream(dy))
     L.check(rc, 'gg_bias_act_bwd')
-    return (dz if dz is not None else dy), db
+    return (dz if dz is not None else dy), (part.sum(0) if part is not None else None)

@@ -104,8 +104,10 @@ int gg_softmax_bwd(const void* S, const void* dS, void* dx, float* dbias, int64_
                    int32_t n_valid, int32_t ld, float alpha, void* stream);
 
 /* Backward of "+bias -> leaky-relu" (nn.Conv2d bias + nn.LeakyReLU autograd, gp.py:109, :1608-1621) in one pass:
- * dz = dy * (y > 0 ? 1 : slope) when y != NULL (else dz is not written), db[c] += sum_rows dz[row][c] when db != NULL
- * (fp32 [C], caller zeroes it). dy / y / dz: bf16 [rows][C], C %% 8 == 0. */
+ * dz = dy * (y > 0 ? 1 : slope) when y != NULL (else dz is not written); when db != NULL, db[w][c] receives workgroup
+ * w's partial column sums of dz (fp32 [gg_bias_act_bwd_partials(rows, C)][C]; the caller adds the rows up).
+ * dy / y / dz: bf16 [rows][C], C %% 8 == 0. */
+int32_t gg_bias_act_bwd_partials(int64_t rows, int32_t C);
 int gg_bias_act_bwd(const void* dy, const void* y, void* dz, float* db, int64_t rows, int32_t C, float slope,
                     void* stream);
 
