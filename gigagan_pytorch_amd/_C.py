@@ -39,6 +39,10 @@ class GemmDesc(C.Structure):
         ('noise', C.c_void_p), ('noise_w', C.c_void_p),
         ('act', C.c_int32), ('act_slope', C.c_float),
         ('force_splitk', C.c_int32), ('force_tile', C.c_int32),
+        ('conv_stride', C.c_int32), ('conv_pad', C.c_int32), ('bias_scale', C.c_float),
+        ('residual', C.c_void_p), ('ldr', C.c_int32), ('res_scale', C.c_float),
+        ('d2s', C.c_int32), ('d2s_taps', C.c_int32), ('d2s_c', C.c_int32), ('d2s_oh', C.c_int32),
+        ('d2s_ow', C.c_int32),
     ]
 
 
@@ -65,7 +69,7 @@ class Library:
         L.gg_gemm_plan.argtypes = [C.POINTER(GemmDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         self._declare_elementwise()
         self.is_emulator = bool(L.gg_is_emulator())
-        if L.gg_version() != 1:
+        if L.gg_version() != 2:
             raise RuntimeError(f'gigagan_pytorch_amd: ABI version mismatch in {path}')
 
     # filled in by _elementwise_signatures (kept separate so the table reads like the header)

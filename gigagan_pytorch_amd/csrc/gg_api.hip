@@ -2,12 +2,14 @@
 // Argument validation, tile / split-K selection and kernel launches; no allocation, no synchronisation.
 #include "gg_device.h"
 #include "gg_gemm.h"
+#include "gg_gemm2.h"
 #include "gg_elementwise.h"
 #include "../../include/gigagan_amd.h"
 
 #include <stdio.h>
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -59,16 +61,19 @@ int gg_validate_gemm(const gg_gemm_desc* d) {
     if (d->a_conv) {
         if (d->H <= 0 || d->W <= 0 || d->C <= 0 || d->CV <= 0 || d->R <= 0 || d->S <= 0)
             return gg_fail(-5, "gg_gemm: bad conv geometry");
-        if ((d->R & 1) == 0 || d->R != d->S) return gg_fail(-5, "gg_gemm: conv kernel must be odd and square");
+        if (d->R != d->S) return gg_fail(-5, "gg_gemm: conv kernel must be square");
+        if (d->conv_stride < 1 || d->conv_pad < 0) return gg_fail(-5, "gg_gemm: conv_stride must be >= 1 and conv_pad >= 0 (got %d, %d)", d->conv_stride, d->conv_pad);
+        if (d->H + 2 * d->conv_pad < d->R || d->W + 2 * d->conv_pad < d->S) return gg_fail(-5, "gg_gemm: conv window larger than the padded image");
         if (d->C % 8 || d->CV % d->C) return gg_fail(-6, "gg_gemm: conv needs C %% 8 == 0 and CV %% C == 0 (C=%d CV=%d)", d->C, d->CV);
         if (d->batch != 1) return gg_fail(-7, "gg_gemm: conv gather takes batch == 1 (images are folded into M or K)");
         long long red = (long long)d->R * d->S * d->CV;
+        const int oh = (d->H + 2 * d->conv_pad - d->R) / d->conv_stride + 1, ow = (d->W + 2 * d->conv_pad - d->S) / d->conv_stride + 1;
         if (d->a_layout == GG_ROWK) {
             if (d->K != red) return gg_fail(-8, "gg_gemm: conv fwd needs K == R*S*CV (%d vs %lld)", d->K, red);
-            if (d->M % (d->H * d->W)) return gg_fail(-8, "gg_gemm: conv fwd needs M %% (H*W) == 0");
+            if (d->M % (oh * ow)) return gg_fail(-8, "gg_gemm: conv fwd needs M %% (OH*OW) == 0");
         } else {
             if (d->M != red) return gg_fail(-8, "gg_gemm: conv wgrad needs M == R*S*CV (%d vs %lld)", d->M, red);
-            if (d->K % (d->H * d->W)) return gg_fail(-8, "gg_gemm: conv wgrad needs K %% (H*W) == 0");
+            if (d->K % (oh * ow)) return gg_fail(-8, "gg_gemm: conv wgrad needs K %% (OH*OW) == 0");
         }
     } else {
         if (d->lda % 8) return gg_fail(-9, "gg_gemm: lda must be a multiple of 8 (got %d)", d->lda);
@@ -87,36 +92,105 @@ int gg_validate_gemm(const gg_gemm_desc* d) {
     if (d->out_scale && d->rows_per_group <= 0) return gg_fail(-12, "gg_gemm: out_scale needs rows_per_group > 0");
     if ((d->noise != nullptr) != (d->noise_w != nullptr)) return gg_fail(-12, "gg_gemm: noise and noise_w go together");
     if (d->act < 0 || d->act > 3) return gg_fail(-13, "gg_gemm: unknown activation %d", d->act);
+    if (d->residual) {
+        if (d->ldr < d->N) return gg_fail(-14, "gg_gemm: ldr %d < N %d", d->ldr, d->N);
+        if (d->batch != 1) return gg_fail(-14, "gg_gemm: residual needs batch == 1");
+    }
+    if (d->d2s) {
+        if (d->d2s < 1 || d->d2s_taps < 1 || d->d2s_taps > d->d2s || d->d2s_c <= 0 || (d->d2s_c & 3) || d->d2s_oh <= 0 || d->d2s_ow <= 0)
+            return gg_fail(-15, "gg_gemm: bad depth-to-space geometry");
+        if (d->N != d->d2s_taps * d->d2s_taps * d->d2s_c) return gg_fail(-15, "gg_gemm: d2s needs N == taps^2 * d2s_c");
+        if (d->M % (d->d2s_oh * d->d2s_ow) || d->batch != 1) return gg_fail(-15, "gg_gemm: d2s needs M %% (oh*ow) == 0 and batch == 1");
+    }
     return 0;
+}
+
+bool gg_v2_eligible(const gg_gemm_desc* d) {
+    if (d->a_conv && d->a_layout == GG_ROWK && ((d->CV & 63) || d->R * d->S > 32)) return false;
+    return true;
+}
+
+int gg_v2_policy() {   // GG_GEMM_V2=0 disables the 8-wave kernel (A/B runs), =2 forces it wherever eligible
+    static int policy = -1;
+    if (policy < 0) {
+        const char* e = getenv("GG_GEMM_V2");
+        policy = e ? atoi(e) : 1;
+        if (policy < 0) policy = 1;
+    }
+    return policy;
+}
+
+// Launch planning by a small cost model (all times in microseconds, constants fitted to gpu_gemm_bench.py runs on
+// MI355X): a launch runs in ceil(workgroups / resident) rounds; a round of a tile costs its k-tiles times the
+// measured per-k-tile time plus a fixed prologue/epilogue; split-K adds the fp32 partial round trip and a launch.
+// What it encodes: a split or tile choice that leaves 1.1 rounds of workgroups costs as much as 2.0 rounds
+// (the weight gradients' 288-block launches measured 2x slower than their 252-block siblings).
+struct GgTileModel {
+    int tile, bm, bn, bk;
+    double us_per_ktile;   // one workgroup, one k-tile, chip fully occupied by such workgroups
+    int resident;          // workgroups resident on the chip at once (256 CUs x blocks per CU)
+    double fixed_us;
+};
+
+static const GgTileModel kTileModels[] = {
+    {1, 128, 128, 32, 1.95, 1024, 1.5},   // 40 KB LDS: 4 workgroups per CU
+    {2, 128, 64, 32, 1.75, 1280, 1.5},
+    {3, 128, 32, 32, 2.00, 1536, 1.5},
+    {4, 256, 256, 64, 2.25, 256, 3.0},
+    {5, 256, 128, 64, 1.45, 256, 3.0},
+};
+
+static double gg_plan_cost(const gg_gemm_desc* d, const GgTileModel& tm, int sk, int* k_per_split) {
+    const long long blocks = (long long)((d->M + tm.bm - 1) / tm.bm) * ((d->N + tm.bn - 1) / tm.bn) * d->batch;
+    const int ktiles = (d->K + tm.bk - 1) / tm.bk;
+    const int per = (ktiles + sk - 1) / sk;
+    if (k_per_split) *k_per_split = per * tm.bk;
+    const long long rounds = (blocks * sk + tm.resident - 1) / tm.resident;
+    double t = (double)rounds * (per * tm.us_per_ktile + tm.fixed_us);
+    if (sk > 1) t += 3.0 + (double)d->M * d->N * d->batch * 4.0 * (sk + 1) / 4.0e6;   // partials out + back at ~4 TB/s
+    return t;
 }
 
 GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     GemmPlan pl;
-    pl.tile = d->force_tile;
-    if (pl.tile < 1 || pl.tile > 3) pl.tile = d->N <= 32 ? 3 : (d->N <= 64 ? 2 : 1);
-    pl.bm = 128;
-    pl.bn = pl.tile == 1 ? 128 : (pl.tile == 2 ? 64 : 32);
-    long long tm = (d->M + pl.bm - 1) / pl.bm, tn = (d->N + pl.bn - 1) / pl.bn;
-    pl.blocks_mn = tm * tn;
-    long long blocks = pl.blocks_mn * d->batch;
-    int ktiles = (d->K + GG_BK - 1) / GG_BK;
-    int sk = d->force_splitk;
-    if (sk <= 0) {
-        sk = 1;
-        // fill 256 CUs x 2 workgroups when the M x N grid is small and the reduction is long
-        if (blocks < 384 && ktiles >= 16) {
-            long long want = (512 + blocks - 1) / blocks;
-            long long cap = ktiles / 8;  // keep >= 8 k-tiles (256 reduction elements) per split
-            if (want > cap) want = cap;
-            if (want > 256) want = 256;
-            if (want > 1) sk = (int)want;
+    const bool v2ok = gg_v2_eligible(d) && d->N >= 96 && d->M >= 192;
+    const int pol = gg_v2_policy();
+    const int v1_tile = d->N <= 32 ? 3 : (d->N <= 64 ? 2 : 1);
+    int forced = d->force_tile;
+    if (forced >= 4 && !gg_v2_eligible(d)) forced = 0;
+    if (forced < 0 || forced > 5) forced = 0;
+    double best = 1e30;
+    pl.tile = v1_tile; pl.splitk = 1;
+    for (const GgTileModel& tm : kTileModels) {
+        if (forced) {
+            if (tm.tile != forced) continue;
+        } else {
+            if (tm.tile <= 3 && tm.tile != v1_tile) continue;
+            if (tm.tile >= 4 && (!v2ok || !pol)) continue;
+            if (tm.tile == 4 && d->N < 192) continue;
+            if (pol >= 2 && v2ok && tm.tile <= 3) continue;
+        }
+        const int ktiles = (d->K + tm.bk - 1) / tm.bk;
+        int max_sk = ktiles / (tm.bk == 64 ? 4 : 8);   // keep >= 256 reduction elements per split
+        if (max_sk < 1) max_sk = 1;
+        if (max_sk > 256) max_sk = 256;
+        if ((long long)d->batch * max_sk > 65535) max_sk = (int)(65535 / d->batch);
+        int lo = 1, hi = max_sk;
+        if (d->force_splitk > 0) { lo = hi = d->force_splitk < ktiles ? d->force_splitk : ktiles; }
+        for (int sk = lo; sk <= hi; ++sk) {
+            const int per = (ktiles + sk - 1) / sk;
+            if ((ktiles + per - 1) / per != sk && d->force_splitk <= 0) continue;   // split counts that leave empty slices
+            double c = gg_plan_cost(d, tm, sk, nullptr);
+            if (c < best) { best = c; pl.tile = tm.tile; pl.splitk = sk; }
         }
     }
-    if (sk > ktiles) sk = ktiles;
-    int tiles_per = (ktiles + sk - 1) / sk;
-    sk = (ktiles + tiles_per - 1) / tiles_per;
-    pl.splitk = sk;
-    pl.k_per_split = tiles_per * GG_BK;
+    const GgTileModel& tm = kTileModels[pl.tile - 1];
+    pl.bm = tm.bm; pl.bn = tm.bn;
+    pl.blocks_mn = (long long)((d->M + tm.bm - 1) / tm.bm) * ((d->N + tm.bn - 1) / tm.bn);
+    const int ktiles = (d->K + tm.bk - 1) / tm.bk;
+    const int per = (ktiles + pl.splitk - 1) / pl.splitk;
+    pl.splitk = (ktiles + per - 1) / per;
+    pl.k_per_split = per * tm.bk;
     return pl;
 }
 
@@ -125,12 +199,33 @@ void gg_launch_gemm_tile(const GgGemmParams& p, bool akrow, bool bkrow, bool aco
     dim3 block(256);
     // the plain epilogue (alpha only) is a separate instantiation: short-K launches (attention, K = 64) would
     // otherwise spend most of their time in the bias / scale / noise / activation branches
-    const bool full = p.bias || p.out_scale || p.noise || p.act != GG_ACT_NONE;
+    const bool full = p.bias || p.out_scale || p.noise || p.residual || p.act != GG_ACT_NONE;
 #define GG_CASE(AK, BK_, AC)                                                                     \
     if (akrow == AK && bkrow == BK_ && aconv == AC) {                                            \
         if (full) GG_LAUNCH((gg_gemm_kernel<BM, BN, WM, WN, AK, BK_, AC, true>), grid, block, s, p);   \
         else GG_LAUNCH((gg_gemm_kernel<BM, BN, WM, WN, AK, BK_, AC, false>), grid, block, s, p);       \
         return;                                                                                  \
+    }
+    GG_CASE(false, false, false)
+    GG_CASE(false, true, false)
+    GG_CASE(true, false, false)
+    GG_CASE(true, true, false)
+    GG_CASE(false, false, true)
+    GG_CASE(false, true, true)
+    GG_CASE(true, false, true)
+    GG_CASE(true, true, true)
+#undef GG_CASE
+}
+
+template <int BM, int BN, int WM, int WN>
+void gg_launch_gemm2_tile(const GgGemmParams& p, bool akrow, bool bkrow, bool aconv, dim3 grid, hipStream_t s) {
+    dim3 block(GG2_NT);
+    const bool full = p.bias || p.out_scale || p.noise || p.residual || p.act != GG_ACT_NONE;
+#define GG_CASE(AK, BK_, AC)                                                                      \
+    if (akrow == AK && bkrow == BK_ && aconv == AC) {                                             \
+        if (full) GG_LAUNCH((gg_gemm2_kernel<BM, BN, WM, WN, AK, BK_, AC, true>), grid, block, s, p);   \
+        else GG_LAUNCH((gg_gemm2_kernel<BM, BN, WM, WN, AK, BK_, AC, false>), grid, block, s, p);       \
+        return;                                                                                   \
     }
     GG_CASE(false, false, false)
     GG_CASE(false, true, false)
@@ -176,18 +271,25 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     p.splitk = pl.splitk; p.k_per_split = pl.k_per_split;
     p.A = (const bf16_t*)d->A; p.a_bs = d->a_batch_stride; p.lda = d->lda;
     p.B = (const bf16_t*)d->B; p.b_bs = d->b_batch_stride; p.ldb = d->ldb;
-    p.H = d->H; p.W = d->W; p.C = d->C; p.CV = d->CV; p.R = d->R; p.S = d->S; p.pad = (d->R - 1) / 2;
+    p.H = d->H; p.W = d->W; p.C = d->C; p.CV = d->CV; p.R = d->R; p.S = d->S;
+    p.pad = d->conv_pad; p.stride = d->conv_stride;
     p.in_scale = d->in_scale;
     p.w_shift = p.hw_shift = -1;
-    if (d->a_conv && (d->W & (d->W - 1)) == 0 && ((d->H * d->W) & (d->H * d->W - 1)) == 0) {
-        int ws = 0, hs = 0;
-        while ((1 << ws) < d->W) ++ws;
-        while ((1 << hs) < d->H * d->W) ++hs;
-        p.w_shift = ws; p.hw_shift = hs;
+    if (d->a_conv) {
+        p.OH = (d->H + 2 * d->conv_pad - d->R) / d->conv_stride + 1;
+        p.OW = (d->W + 2 * d->conv_pad - d->S) / d->conv_stride + 1;
+        if ((p.OW & (p.OW - 1)) == 0 && ((p.OH * p.OW) & (p.OH * p.OW - 1)) == 0) {
+            int ws = 0, hs = 0;
+            while ((1 << ws) < p.OW) ++ws;
+            while ((1 << hs) < p.OH * p.OW) ++hs;
+            p.w_shift = ws; p.hw_shift = hs;
+        }
     }
     p.Cout = d->C_out; p.c_bs = d->c_batch_stride; p.ldc = d->ldc; p.c_f32 = d->c_is_f32;
     p.alpha = d->alpha;
-    p.bias = d->bias; p.out_scale = d->out_scale; p.rows_per_group = d->rows_per_group;
+    p.bias = d->bias; p.bias_scale = d->bias_scale; p.out_scale = d->out_scale; p.rows_per_group = d->rows_per_group;
+    p.residual = (const bf16_t*)d->residual; p.ldr = d->ldr; p.res_scale = d->res_scale;
+    p.d2s = d->d2s; p.d2s_t = d->d2s_taps; p.d2s_c = d->d2s_c; p.d2s_oh = d->d2s_oh; p.d2s_ow = d->d2s_ow;
     p.noise = d->noise; p.noise_w = d->noise_w;
     p.act = d->act; p.act_slope = d->act_slope;
     p.partial = (float*)workspace;
@@ -195,7 +297,10 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)pl.blocks_mn, 1, (unsigned)(d->batch * pl.splitk));
     bool akrow = d->a_layout == GG_KROW, bkrow = d->b_layout == GG_KROW, aconv = d->a_conv != 0;
-    if (pl.tile == 1) gg_launch_gemm_tile<128, 128, 2, 2>(p, akrow, bkrow, aconv, grid, s);
+    dim3 grid2((unsigned)(pl.blocks_mn * d->batch * pl.splitk), 1, 1);
+    if (pl.tile == 4) gg_launch_gemm2_tile<256, 256, 2, 4>(p, akrow, bkrow, aconv, grid2, s);
+    else if (pl.tile == 5) gg_launch_gemm2_tile<256, 128, 2, 4>(p, akrow, bkrow, aconv, grid2, s);
+    else if (pl.tile == 1) gg_launch_gemm_tile<128, 128, 2, 2>(p, akrow, bkrow, aconv, grid, s);
     else if (pl.tile == 2) gg_launch_gemm_tile<128, 64, 2, 2>(p, akrow, bkrow, aconv, grid, s);
     else gg_launch_gemm_tile<128, 32, 4, 1>(p, akrow, bkrow, aconv, grid, s);
     rc = gg_check_launch();

@@ -45,6 +45,17 @@ GG_DEVICE f32x16 gg_mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c) {
                                                    __builtin_bit_cast(gg_bf16x8_native, b), c, 0, 0, 0);
 }
 
+// ds_read_b64_tr_b16: every lane supplies the LDS address of 4 contiguous bf16 (8-byte aligned); inside each group
+// of 16 lanes, lane i receives element (i & 3) of the quads addressed by lanes 4*j + (i >> 2), j = 0..3 (measured on
+// gfx950 with tests/probes/tr_probe.hip). With lane s pointing at row (s >> 2), columns 4*(s & 3).. of a
+// [4 k][16 m] block this hands lane i the 4 k-values of column i: a k-contiguous MFMA fragment out of a tile that
+// is stored reduction-major.
+typedef __attribute__((ext_vector_type(4))) short gg_s16x4_native;
+GG_DEVICE u16x4 gg_lds_read_tr16(const bf16_t* p) {
+    gg_s16x4_native r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gg_s16x4_native __attribute__((address_space(3)))*)p);
+    return __builtin_bit_cast(u16x4, r);
+}
+
 GG_DEVICE float gg_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 GG_DEVICE float gg_shfl(float v, int src) { return __shfl(v, src, 64); }
 GG_DEVICE void gg_atomic_add(float* p, float v) { atomicAdd(p, v); }

@@ -44,10 +44,11 @@ struct GgGemmParams {
     const bf16_t* B;
     long long b_bs;
     int ldb;
-    // conv gather on A: activation [img][H][W][C] bf16, output grid H x W (stride 1, pad = (R-1)/2),
-    // reduction/gather index = (tap = kh*S + kw, cv) with cv in [0, CV); physical channel = cv % C.
-    int H, W, C, CV, R, S, pad;
-    int w_shift, hw_shift;  // log2(W), log2(H*W) when both are powers of two, else -1 (pixel decode by shifts)
+    // conv gather on A: activation [img][H][W][C] bf16, output grid OH x OW, input pixel of output (oh, ow) and
+    // tap (kh, kw) is (oh*stride - pad + kh, ow*stride - pad + kw); reduction/gather index = (tap = kh*S + kw, cv)
+    // with cv in [0, CV); physical channel = cv % C.
+    int H, W, C, CV, R, S, pad, stride, OH, OW;
+    int w_shift, hw_shift;  // log2(OW), log2(OH*OW) when both are powers of two, else -1 (pixel decode by shifts)
     const float* in_scale;  // optional [img][CV] multiplier applied to the gathered activation
     // output / epilogue
     void* Cout;
@@ -56,12 +57,20 @@ struct GgGemmParams {
     int c_f32;  // 0: bf16 output, 1: fp32 output
     float alpha;
     const float* bias;       // [N]
+    float bias_scale;        // multiplies the bias (lets alpha scale conv + bias together)
     const float* out_scale;  // [m / rows_per_group][N]
     int rows_per_group;
     const float* noise;    // [M]
     const float* noise_w;  // [N]
     int act;
     float act_slope;
+    const bf16_t* residual;  // optional bf16 [M][ldr] added after the activation (times res_scale)
+    int ldr;
+    float res_scale;
+    // depth-to-space scatter store (adjoint of a stride-`d2s` gather): column n = (tap, c) with c in [0, d2s_c),
+    // row m = (img, oh, ow) on the d2s_oh x d2s_ow grid; element goes to pixel (oh*d2s + tap/d2s_t, ow*d2s + tap%d2s_t)
+    // of an [img][d2s_oh*d2s][d2s_ow*d2s][d2s_c] tensor. d2s == 0: plain [m][ldc] store.
+    int d2s, d2s_t, d2s_c, d2s_oh, d2s_ow;
     float* partial;  // [batch][splitk][M][N] fp32
 };
 
@@ -75,15 +84,29 @@ GG_DEVICE float gg_apply_act(float v, int act, float slope) {
 GG_DEVICE float gg_epilogue(const GgGemmParams& p, float acc, int m, int n) {
     float v = acc * p.alpha;
     if (p.out_scale) v *= p.out_scale[(long long)(m / p.rows_per_group) * p.N + n];
-    if (p.bias) v += p.bias[n];
+    if (p.bias) v += p.bias[n] * p.bias_scale;
     if (p.noise) v += p.noise[m] * p.noise_w[n];
-    return gg_apply_act(v, p.act, p.act_slope);
+    v = gg_apply_act(v, p.act, p.act_slope);
+    if (p.residual) v += gg_bf2f(p.residual[(long long)m * p.ldr + n]) * p.res_scale;
+    return v;
+}
+
+// element offset of output (m, n) for the depth-to-space scatter store (n .. n+3 stay inside one tap: d2s_c % 4 == 0)
+GG_DEVICE long long gg_d2s_offset(const GgGemmParams& p, int m, int n) {
+    const int tap = n / p.d2s_c, c = n - tap * p.d2s_c;
+    const int ty = tap / p.d2s_t, tx = tap - ty * p.d2s_t;
+    const int hw = p.d2s_oh * p.d2s_ow;
+    const int img = m / hw, rem = m - img * hw;
+    const int oh = rem / p.d2s_ow, ow = rem - oh * p.d2s_ow;
+    const long long W2 = (long long)p.d2s_ow * p.d2s;
+    return (((long long)img * p.d2s_oh * p.d2s + oh * p.d2s + ty) * W2 + (ow * p.d2s + tx)) * p.d2s_c + c;
 }
 
 // store 4 consecutive-n results of row m
 GG_DEVICE void gg_store4(const GgGemmParams& p, int b, int m, int n, const float* v) {
+    const long long off = p.d2s ? gg_d2s_offset(p, m, n) : (long long)b * p.c_bs + (long long)m * p.ldc + n;
     if (p.c_f32) {
-        float* c = (float*)p.Cout + (long long)b * p.c_bs + (long long)m * p.ldc + n;
+        float* c = (float*)p.Cout + off;
         if (n + 3 < p.N && (p.ldc & 3) == 0) {
             f32x4 o = {v[0], v[1], v[2], v[3]};
             *(f32x4*)c = o;
@@ -92,7 +115,7 @@ GG_DEVICE void gg_store4(const GgGemmParams& p, int b, int m, int n, const float
                 if (n + e < p.N) c[e] = v[e];
         }
     } else {
-        bf16_t* c = (bf16_t*)p.Cout + (long long)b * p.c_bs + (long long)m * p.ldc + n;
+        bf16_t* c = (bf16_t*)p.Cout + off;
         if (n + 3 < p.N && (p.ldc & 3) == 0) {
             u16x4 o = {gg_f2bf(v[0]), gg_f2bf(v[1]), gg_f2bf(v[2]), gg_f2bf(v[3])};
             *(u16x4*)c = o;
@@ -223,14 +246,14 @@ GG_DEVICE void gg_conv_rows_init(GgConvRow* rows, const GgGemmParams& p, int m0)
         int m = m0 + row;
         GgConvRow r;
         r.valid = (row < ROWS) && (m < p.M);
-        int hw = p.H * p.W;
+        int hw = p.OH * p.OW;
         int img = r.valid ? m / hw : 0;
         int rem = r.valid ? m - img * hw : 0;
-        int oh = rem / p.W, ow = rem - oh * p.W;
+        int oh = rem / p.OW, ow = rem - oh * p.OW;
         r.img = img;
-        r.img_off = (long long)img * hw * p.C;
-        r.ih0 = oh - p.pad;
-        r.iw0 = ow - p.pad;
+        r.img_off = (long long)img * p.H * p.W * p.C;
+        r.ih0 = oh * p.stride - p.pad;
+        r.iw0 = ow * p.stride - p.pad;
         rows[i] = r;
     }
 }
@@ -304,7 +327,7 @@ GG_DEVICE void gg_conv_cols_init(GgConvCol* cols, const GgGemmParams& p, int c0)
 template <int ROWS>
 GG_DEVICE void gg_load_krow_conv(u16x8* regs, const GgConvCol* cols, const GgGemmParams& p, int kend, int k0) {
     const int t = threadIdx.x;
-    const int hw = p.H * p.W;
+    const int hw = p.OH * p.OW;
 #pragma unroll
     for (int i = 0; i < GgKRowLayout<ROWS>::NI; ++i) {
         int item = t + 256 * i;
@@ -321,16 +344,16 @@ GG_DEVICE void gg_load_krow_conv(u16x8* regs, const GgConvCol* cols, const GgGem
                         img = pix >> p.hw_shift;
                         int rem = pix & (hw - 1);
                         oh = rem >> p.w_shift;
-                        ow = rem & (p.W - 1);
+                        ow = rem & (p.OW - 1);
                     } else {
                         img = pix / hw;
                         int rem = pix - img * hw;
-                        oh = rem / p.W;
-                        ow = rem - oh * p.W;
+                        oh = rem / p.OW;
+                        ow = rem - oh * p.OW;
                     }
-                    int ih = oh - p.pad + cc.kh, iw = ow - p.pad + cc.kw;
+                    int ih = oh * p.stride - p.pad + cc.kh, iw = ow * p.stride - p.pad + cc.kw;
                     if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
-                        u16x8 y = *(const u16x8*)(p.A + (long long)img * hw * p.C +
+                        u16x8 y = *(const u16x8*)(p.A + (long long)img * p.H * p.W * p.C +
                                                   ((long long)ih * p.W + iw) * p.C + cc.ci);
                         if (p.in_scale) y = gg_scale8(y, p.in_scale + (long long)img * p.CV + cc.cv);
                         x[h] = y;
@@ -483,7 +506,8 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_splitk_reduce_kernel(GgGemmParams p) {
         for (int ks = 0; ks < p.splitk; ++ks)
             s += p.partial[((long long)(b * p.splitk + ks) * p.M + m) * p.N + n];
         float v = gg_epilogue(p, s, m, n);
-        if (p.c_f32) ((float*)p.Cout)[(long long)b * p.c_bs + (long long)m * p.ldc + n] = v;
-        else ((bf16_t*)p.Cout)[(long long)b * p.c_bs + (long long)m * p.ldc + n] = gg_f2bf(v);
+        const long long off = p.d2s ? gg_d2s_offset(p, m, n) : (long long)b * p.c_bs + (long long)m * p.ldc + n;
+        if (p.c_f32) ((float*)p.Cout)[off] = v;
+        else ((bf16_t*)p.Cout)[off] = gg_f2bf(v);
     }
 }

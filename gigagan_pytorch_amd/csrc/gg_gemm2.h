@@ -1,0 +1,373 @@
+// gg_gemm2.h — the large-tile variant of the contraction kernel (gg_gemm.h) for the MFMA-bound layers of the
+// GigaGAN step: the discriminator's 128..512-channel 3x3 convolutions, their data/weight gradients, and the
+// generator's low-resolution adaptive convolutions (reference gp.py:402-409, :1608-1621, :1454-1470).
+//
+// Same operand model, conv gather, epilogue and split-K contract as gg_gemm_kernel; what changes is the tiling:
+//   * 512 threads = 8 wavefronts (two per SIMD), block tile BM x BN with BM = 256, BN in {256, 128}, k-tile 64;
+//     each wave owns (BM/WM) x (BN/WN) = 128 x 64 (or 128 x 32) outputs = 4 x 2 (4 x 1) MFMA 32x32 tiles, so one
+//     k-tile costs a wave 24 ds_read_b128 for 32 v_mfma_f32_32x32x16_bf16 (v1: 8 reads per 8 MFMAs).
+//   * LDS rows hold 64 k-elements at a 144-byte pitch (9 sixteen-byte slots: 9*r mod 16 is injective on every
+//     16-lane ds_read_b128 service group, MI355X_MICROARCH §LDS), double buffered: 2*(BM+BN)*144 B <= 144 KiB,
+//     one workgroup per CU.
+//   * register staging ordered as "write the staged tile after the barrier, re-issue the next global loads at
+//     once" (cdna_hip_programming.md T14/G15): the global loads of tile t+2 are in flight during the MFMAs of
+//     tile t, one barrier per k-tile.
+//   * conv gather with CV % 64 == 0: a k-tile lies inside one filter tap, so the tap offset is a scalar and each
+//     staged 16-byte vector needs one add and one mask test (per-row corner offset + tap-validity bitmask are
+//     computed once per workgroup).
+//   * reduction-major ("KROW") operands — both operands of a weight gradient — are staged UNTRANSPOSED, [k][column]
+//     rows of 16-byte vectors exactly as they sit in HBM (pitch = 2*COLS + 64 bytes, so the four k-rows a
+//     transpose read touches fall on different 64-byte bank quarters), and the k-contiguous MFMA fragments are
+//     produced by ds_read_b64_tr_b16 (two per fragment). No per-element transposing ds_write_b32 pass as in v1.
+//   * XCD-aware tile order over a flattened 1-D grid: the dispatcher places block b on XCD b % 8; consecutive logical
+//     work items (output tile fastest, then k-slice / batch) are remapped onto the same XCD so that the N-tiles of
+//     one M-tile, vertically adjacent pixel rows and — for weight gradients — all output tiles of one pixel slice
+//     share that XCD's L2.
+#pragma once
+#include "gg_gemm.h"
+
+#define GG2_BK 64
+#define GG2_PITCH 72   // bf16 elements per LDS row: 64 + 8 pad = 144 bytes
+#define GG2_NT 512
+
+// ---- staging loaders (512 threads) -------------------------------------------------------------------------
+
+template <int ROWS>
+struct Gg2RowK {   // ROWS x 64 tile as ROWS*8 vectors of 8 k-elements: vector v = t + 512*i -> row v>>3, chunk v&7
+    static constexpr int NV = ROWS * 8 / GG2_NT;
+};
+template <int COLS>
+struct Gg2KRow {   // 64 k-rows x COLS columns kept reduction-major: vector v = t + 512*i -> k-row v / (COLS/8), group v % (COLS/8)
+    static constexpr int CG = COLS / 8;                 // 16-byte column groups per k-row (divides 512)
+    static constexpr int NV = 64 * CG / GG2_NT;
+    static constexpr int KSTEP = GG2_NT / CG;           // k-row distance between a thread's successive vectors
+    static constexpr int PITCH = COLS * 2 + 64;         // bytes
+    static constexpr int BYTES = 64 * PITCH;
+};
+template <int ROWS>
+struct Gg2RowKBytes {
+    static constexpr int BYTES = ROWS * GG2_PITCH * 2;
+};
+
+template <int ROWS>
+GG_DEVICE void gg2_load_rowk_dense(u16x8* regs, const bf16_t* base, int ld, int nrows, int r0, int kend, int k0) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < Gg2RowK<ROWS>::NV; ++i) {
+        int v = t + GG2_NT * i;
+        int row = v >> 3, kc = v & 7;
+        u16x8 x = gg_zero8();
+        int r = r0 + row, k = k0 + kc * 8;
+        if (r < nrows && k < kend) {
+            x = *(const u16x8*)(base + (long long)r * ld + k);
+            if (k + 8 > kend) {
+                for (int e = 0; e < 8; ++e)
+                    if (k + e >= kend) x[e] = 0;
+            }
+        }
+        regs[i] = x;
+    }
+}
+
+template <int ROWS>
+GG_DEVICE void gg2_store_rowk(bf16_t (*s)[GG2_PITCH], const u16x8* regs) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < Gg2RowK<ROWS>::NV; ++i) {
+        int v = t + GG2_NT * i;
+        *(u16x8*)&s[v >> 3][(v & 7) * 8] = regs[i];
+    }
+}
+
+template <int COLS>
+GG_DEVICE void gg2_load_krow_dense(u16x8* regs, const bf16_t* base, int ld, int ncols, int c0, int kend, int k0) {
+    const int t = threadIdx.x;
+    const int cg = t % Gg2KRow<COLS>::CG, kr = t / Gg2KRow<COLS>::CG;
+    const int c = c0 + cg * 8;
+#pragma unroll
+    for (int i = 0; i < Gg2KRow<COLS>::NV; ++i) {
+        int k = k0 + kr + Gg2KRow<COLS>::KSTEP * i;
+        u16x8 x = gg_zero8();
+        if (c < ncols && k < kend) {
+            x = *(const u16x8*)(base + (long long)k * ld + c);
+            if (c + 8 > ncols) {
+                for (int e = 0; e < 8; ++e)
+                    if (c + e >= ncols) x[e] = 0;
+            }
+        }
+        regs[i] = x;
+    }
+}
+
+template <int COLS>
+GG_DEVICE void gg2_store_krow(char* tile, const u16x8* regs) {
+    const int t = threadIdx.x;
+    const int cg = t % Gg2KRow<COLS>::CG, kr = t / Gg2KRow<COLS>::CG;
+#pragma unroll
+    for (int i = 0; i < Gg2KRow<COLS>::NV; ++i)
+        *(u16x8*)(tile + (kr + Gg2KRow<COLS>::KSTEP * i) * Gg2KRow<COLS>::PITCH + cg * 16) = regs[i];
+}
+
+// k-contiguous MFMA fragment (lane l: tile column col0 + (l & 31), k = kk*16 + 8*(l >> 5) + 0..7) out of a
+// reduction-major tile: two transpose reads, each fed by the 16 lanes of a group pointing at a [4 k][16 col] block
+template <int COLS>
+GG_DEVICE u16x8 gg2_frag_krow(const char* tile, int col0, int kk, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const int col = col0 + (g & 1) * 16 + 4 * (i & 3);
+    const int row = kk * 16 + (g >> 1) * 8 + (i >> 2);
+    const char* p0 = tile + row * Gg2KRow<COLS>::PITCH + col * 2;
+    u16x4 a = gg_lds_read_tr16((const bf16_t*)p0);
+    u16x4 b = gg_lds_read_tr16((const bf16_t*)(p0 + 4 * Gg2KRow<COLS>::PITCH));
+    u16x8 f = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return f;
+}
+
+// conv gather, ROWK, CV % 64 == 0: per staged row the element offset of its window corner and a tap-validity mask
+struct Gg2ConvRow {
+    long long corner;   // ((img*H + oh*stride - pad) * W + ow*stride - pad) * C  (may point before the tensor)
+    unsigned int mask;  // bit (kh*S + kw) set when that tap reads inside the image; 0 for rows beyond M
+    int img;
+};
+
+template <int ROWS>
+GG_DEVICE void gg2_conv_rows_init(Gg2ConvRow* rows, const GgGemmParams& p, int m0) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < Gg2RowK<ROWS>::NV; ++i) {
+        int v = t + GG2_NT * i;
+        int m = m0 + (v >> 3);
+        Gg2ConvRow r;
+        r.corner = 0; r.mask = 0; r.img = 0;
+        if (m < p.M) {
+            int hw = p.OH * p.OW;
+            int img = m / hw, rem = m - img * hw;
+            int oh = rem / p.OW, ow = rem - oh * p.OW;
+            int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+            r.img = img;
+            r.corner = (((long long)img * p.H + ih0) * p.W + iw0) * p.C;
+            unsigned int mask = 0;
+            for (int kh = 0; kh < p.R; ++kh)
+                for (int kw = 0; kw < p.S; ++kw) {
+                    int ih = ih0 + kh, iw = iw0 + kw;
+                    if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) mask |= 1u << (kh * p.S + kw);
+                }
+            r.mask = mask;
+        }
+        rows[i] = r;
+    }
+}
+
+template <int ROWS>
+GG_DEVICE void gg2_load_rowk_conv(u16x8* regs, const Gg2ConvRow* rows, const GgGemmParams& p, int kend, int k0) {
+    const int t = threadIdx.x;
+    // workgroup-uniform: the tap of this k-tile and its element offset from a window corner
+    const int tap = k0 / p.CV;
+    const int cv0 = k0 - tap * p.CV;
+    const int kh = tap / p.S, kw = tap - kh * p.S;
+    const long long tap_off = ((long long)kh * p.W + kw) * p.C;
+    const bool tile_live = k0 < kend;
+#pragma unroll
+    for (int i = 0; i < Gg2RowK<ROWS>::NV; ++i) {
+        int v = t + GG2_NT * i;
+        int kc = v & 7;
+        u16x8 x = gg_zero8();
+        const Gg2ConvRow& r = rows[i];
+        int cv = cv0 + kc * 8;
+        if (tile_live && ((r.mask >> tap) & 1u) && k0 + kc * 8 < kend) {
+            int ci = (p.CV == p.C) ? cv : cv % p.C;
+            x = *(const u16x8*)(p.A + r.corner + tap_off + ci);
+            if (p.in_scale) x = gg_scale8(x, p.in_scale + (long long)r.img * p.CV + cv);
+        }
+        regs[i] = x;
+    }
+}
+
+// conv gather, KROW (weight gradient): k = output pixel, column = (tap, cv); a thread stages ONE column group
+template <int COLS>
+GG_DEVICE GgConvCol gg2_conv_col_init(const GgGemmParams& p, int c0) {
+    const int c = c0 + (threadIdx.x % Gg2KRow<COLS>::CG) * 8;
+    GgConvCol cc;
+    cc.valid = c < p.M;
+    int tap = cc.valid ? c / p.CV : 0;
+    cc.cv = cc.valid ? c - tap * p.CV : 0;
+    cc.kh = tap / p.S;
+    cc.kw = tap - cc.kh * p.S;
+    cc.ci = (p.CV == p.C) ? cc.cv : cc.cv % p.C;
+    return cc;
+}
+
+template <int COLS>
+GG_DEVICE void gg2_load_krow_conv(u16x8* regs, const GgConvCol& cc, const GgGemmParams& p, int kend, int k0) {
+    const int kr = threadIdx.x / Gg2KRow<COLS>::CG;
+    const int hw = p.OH * p.OW;
+#pragma unroll
+    for (int i = 0; i < Gg2KRow<COLS>::NV; ++i) {
+        int pix = k0 + kr + Gg2KRow<COLS>::KSTEP * i;
+        u16x8 x = gg_zero8();
+        if (cc.valid && pix < kend) {
+            int img, oh, ow;
+            if (p.hw_shift >= 0) {
+                img = pix >> p.hw_shift;
+                int rem = pix & (hw - 1);
+                oh = rem >> p.w_shift;
+                ow = rem & (p.OW - 1);
+            } else {
+                img = pix / hw;
+                int rem = pix - img * hw;
+                oh = rem / p.OW;
+                ow = rem - oh * p.OW;
+            }
+            int ih = oh * p.stride - p.pad + cc.kh, iw = ow * p.stride - p.pad + cc.kw;
+            if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
+                x = *(const u16x8*)(p.A + (((long long)img * p.H + ih) * p.W + iw) * p.C + cc.ci);
+                if (p.in_scale) x = gg_scale8(x, p.in_scale + (long long)img * p.CV + cc.cv);
+            }
+        }
+        regs[i] = x;
+    }
+}
+
+// ---- the kernel ---------------------------------------------------------------------------------------------
+
+template <int BM, int BN, int WM, int WN, bool A_KROW, bool B_KROW, bool A_CONV, bool FULL_EPI>
+GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_gemm2_kernel(GgGemmParams p) {
+    static_assert(WM * WN == 8, "8 wavefronts per workgroup");
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+    constexpr int ANV = A_KROW ? Gg2KRow<BM>::NV : Gg2RowK<BM>::NV;
+    constexpr int BNV = B_KROW ? Gg2KRow<BN>::NV : Gg2RowK<BN>::NV;
+    constexpr int ABYTES = A_KROW ? Gg2KRow<BM>::BYTES : Gg2RowKBytes<BM>::BYTES;
+    constexpr int BBYTES = B_KROW ? Gg2KRow<BN>::BYTES : Gg2RowKBytes<BN>::BYTES;
+
+    // one LDS object: [buffer 0: A tile | B tile][buffer 1: A tile | B tile]
+    GG_SHARED __attribute__((aligned(16))) char smem[2 * (ABYTES + BBYTES)];
+    auto tileA = [&](int buf) { return smem + buf * (ABYTES + BBYTES); };
+    auto tileB = [&](int buf) { return smem + buf * (ABYTES + BBYTES) + ABYTES; };
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware tile order (block b runs on XCD b % 8): XCD x works through a contiguous range of logical tiles
+    const int nwg = gridDim.x;
+    const int xq = nwg >> 3, xr = nwg & 7;
+    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+    const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + pos;
+    // flattened grid, output tile fastest: the tiles of one (batch, k-slice) follow each other on one XCD, so a weight
+    // gradient's pixel slice (both operands stream over the same pixels) is fetched into that XCD's L2 once
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_mn = tiles_n * ((p.M + BM - 1) / BM);
+    const int bz = wg / tiles_mn, tile = wg - bz * tiles_mn;
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int b = bz / p.splitk, ks = bz % p.splitk;
+    const int kbeg = ks * p.k_per_split;
+    int kend = kbeg + p.k_per_split;
+    if (kend > p.K) kend = p.K;
+
+    const bf16_t* Ab = p.A + (long long)b * p.a_bs;
+    const bf16_t* Bb = p.B + (long long)b * p.b_bs;
+
+    Gg2ConvRow crow[A_CONV && !A_KROW ? ANV : 1];
+    if (A_CONV && !A_KROW) gg2_conv_rows_init<BM>(crow, p, m0);
+    GgConvCol ccol;
+    ccol.kh = ccol.kw = ccol.ci = ccol.cv = ccol.valid = 0;
+    if (A_CONV && A_KROW) ccol = gg2_conv_col_init<BM>(p, m0);
+
+    u16x8 ra[ANV], rb[BNV];
+
+    auto load_tiles = [&](int k0) {
+        if (A_CONV) {
+            if (A_KROW) gg2_load_krow_conv<BM>(ra, ccol, p, kend, k0);
+            else gg2_load_rowk_conv<BM>(ra, crow, p, kend, k0);
+        } else {
+            if (A_KROW) gg2_load_krow_dense<BM>(ra, Ab, p.lda, p.M, m0, kend, k0);
+            else gg2_load_rowk_dense<BM>(ra, Ab, p.lda, p.M, m0, kend, k0);
+        }
+        if (B_KROW) gg2_load_krow_dense<BN>(rb, Bb, p.ldb, p.N, n0, kend, k0);
+        else gg2_load_rowk_dense<BN>(rb, Bb, p.ldb, p.N, n0, kend, k0);
+    };
+    auto store_tiles = [&](int buf) {
+        if (A_KROW) gg2_store_krow<BM>(tileA(buf), ra);
+        else gg2_store_rowk<BM>((bf16_t(*)[GG2_PITCH])tileA(buf), ra);
+        if (B_KROW) gg2_store_krow<BN>(tileB(buf), rb);
+        else gg2_store_rowk<BN>((bf16_t(*)[GG2_PITCH])tileB(buf), rb);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (kend > kbeg) ? (kend - kbeg + GG2_BK - 1) / GG2_BK : 0;
+    if (nk > 0) {
+        load_tiles(kbeg);
+        store_tiles(0);
+        if (nk > 1) load_tiles(kbeg + GG2_BK);
+    }
+    gg_sync();
+
+    const int frow = lane & 31, fk = (lane >> 5) * 8;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        // tile kt+1 sits in the staging registers (its loads were issued one MFMA phase ago): park it in the
+        // other LDS buffer (free since the barrier that ended iteration kt-1), then put tile kt+2 in flight
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        if (kt + 2 < nk) load_tiles(kbeg + (kt + 2) * GG2_BK);
+#pragma unroll
+        for (int kk = 0; kk < GG2_BK / 16; ++kk) {
+            u16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (A_KROW) fa[i] = gg2_frag_krow<BM>(tileA(buf), wm * WTM + i * 32, kk, lane);
+                else fa[i] = *(const u16x8*)&((const bf16_t(*)[GG2_PITCH])tileA(buf))[wm * WTM + i * 32 + frow][kk * 16 + fk];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (B_KROW) fb[j] = gg2_frag_krow<BN>(tileB(buf), wn * WTN + j * 32, kk, lane);
+                else fb[j] = *(const u16x8*)&((const bf16_t(*)[GG2_PITCH])tileB(buf))[wn * WTN + j * 32 + frow][kk * 16 + fk];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = gg_mfma_32x32x16_bf16(fb[j], fa[i], acc[i][j]);   // swapped: lane registers run along n
+        }
+        gg_sync();
+    }
+
+    // epilogue (same fragment ownership as gg_gemm_kernel): lane owns row m = ... + (lane & 31); register r holds
+    // column n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WTM + i * 32 + (lane & 31);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * WTN + j * 32 + 8 * g + 4 * hi;
+                if (n >= p.N) continue;
+                float v[4];
+                if (p.splitk > 1) {
+                    float* dst = p.partial + ((long long)bz * p.M + m) * p.N + n;
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.N) dst[e] = acc[i][j][g * 4 + e];
+                } else {
+                    if (FULL_EPI) {
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = (n + e < p.N) ? gg_epilogue(p, acc[i][j][g * 4 + e], m, n + e) : 0.f;
+                    } else {
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e] * p.alpha;
+                    }
+                    gg_store4(p, b, m, n, v);
+                }
+            }
+        }
+    }
+}

@@ -42,15 +42,21 @@ class GemmProfiler:
 
 
 profiler: GemmProfiler | None = None
+plan_log: list | None = None    # when a list: (tile, splitk) of every launch is appended (tuning scripts)
 
 
 def _kernel_key(d: GemmDesc, L) -> str:
     tile, sk = C.c_int32(0), C.c_int32(0)
     L.lib.gg_gemm_plan(C.byref(d), C.byref(tile), C.byref(sk))
-    bn = {1: 128, 2: 64, 3: 32}[tile.value]
-    wm, wn = (4, 1) if tile.value == 3 else (2, 2)
-    name = (f'gg_gemm_kernel<128,{bn},{wm},{wn},A_KROW={int(d.a_layout == KROW)},B_KROW={int(d.b_layout == KROW)},'
-            f'A_CONV={int(bool(d.a_conv))}>')
+    if tile.value >= 4:
+        bn = {4: 256, 5: 128}[tile.value]
+        name = (f'gg_gemm2_kernel<256,{bn},2,4,A_KROW={int(d.a_layout == KROW)},B_KROW={int(d.b_layout == KROW)},'
+                f'A_CONV={int(bool(d.a_conv))}>')
+    else:
+        bn = {1: 128, 2: 64, 3: 32}[tile.value]
+        wm, wn = (4, 1) if tile.value == 3 else (2, 2)
+        name = (f'gg_gemm_kernel<128,{bn},{wm},{wn},A_KROW={int(d.a_layout == KROW)},B_KROW={int(d.b_layout == KROW)},'
+                f'A_CONV={int(bool(d.a_conv))}>')
     return name + ('+splitk' if sk.value > 1 else '')
 
 
@@ -58,6 +64,10 @@ def _run_gemm(d: GemmDesc, like: torch.Tensor):
     L = _C.lib()
     need = L.lib.gg_gemm_workspace_bytes(C.byref(d))
     ws = _workspace(need, like) if need else None
+    if plan_log is not None:
+        tile, sk = C.c_int32(0), C.c_int32(0)
+        L.lib.gg_gemm_plan(C.byref(d), C.byref(tile), C.byref(sk))
+        plan_log.append((tile.value, sk.value))
     if profiler is not None and not L.is_emulator:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -69,8 +79,14 @@ def _run_gemm(d: GemmDesc, like: torch.Tensor):
     L.check(rc, 'gg_gemm_bf16')
 
 
-def _epilogue(d: GemmDesc, alpha, bias, out_scale, rows_per_group, noise, noise_w, act, act_slope, keep):
+def _epilogue(d: GemmDesc, alpha, bias, out_scale, rows_per_group, noise, noise_w, act, act_slope, keep,
+              bias_scale=1.0, residual=None, res_scale=1.0):
     d.alpha = float(alpha)
+    d.bias_scale = float(bias_scale)
+    if residual is not None:
+        assert residual.dtype == torch.bfloat16 and residual.is_contiguous()
+        keep.append(residual)
+        d.residual, d.ldr, d.res_scale = ptr(residual), residual.shape[-1], float(res_scale)
     for name, t in (('bias', bias), ('out_scale', out_scale), ('noise', noise), ('noise_w', noise_w)):
         if t is not None:
             assert t.dtype == torch.float32 and t.is_contiguous(), name
@@ -123,61 +139,102 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=True, out_d
     return out
 
 
-def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, *, ksize: int, cv: int | None = None, in_scale=None,
-                out_dtype=torch.bfloat16, alpha=1.0, bias=None, act=None, act_slope=0.2, out_scale=None,
-                noise=None, noise_w=None, force_splitk=0, force_tile=0):
-    """Stride-1 'same' convolution of an NHWC bf16 activation x (n, H, W, C) with weights
-    w (Cout, ksize*ksize*CV) bf16 laid out [co][kh][kw][cv]; returns (n, H, W, Cout)."""
+def _conv_out(size: int, ksize: int, stride: int, pad: int) -> int:
+    return (size + 2 * pad - ksize) // stride + 1
+
+
+def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, *, ksize: int, stride: int = 1, pad: int | None = None,
+                cv: int | None = None, in_scale=None, out_dtype=torch.bfloat16, alpha=1.0, bias=None, bias_scale=1.0,
+                act=None, act_slope=0.2, out_scale=None, noise=None, noise_w=None, residual=None, res_scale=1.0,
+                force_splitk=0, force_tile=0):
+    """Convolution of an NHWC bf16 activation x (n, H, W, C) with weights w (Cout, ksize*ksize*CV) bf16 laid out
+    [co][kh][kw][cv]; window stride `stride`, zero padding `pad` (default: 'same', ksize//2); returns
+    (n, OH, OW, Cout) = act(alpha*conv*out_scale + bias*bias_scale + noise) + residual*res_scale."""
     L = _C.lib()
-    L.require(x, w, in_scale, bias, out_scale, noise, noise_w)
+    L.require(x, w, in_scale, bias, out_scale, noise, noise_w, residual)
     assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_contiguous() and w.is_contiguous()
     n, H, Wd, Cc = x.shape
     cv = cv or Cc
+    pad = ksize // 2 if pad is None else pad
+    OH, OW = _conv_out(H, ksize, stride, pad), _conv_out(Wd, ksize, stride, pad)
     cout = w.shape[0]
     assert w.shape[1] == ksize * ksize * cv, (w.shape, ksize, cv)
-    out = torch.empty((n, H, Wd, cout), dtype=out_dtype, device=x.device)
+    out = torch.empty((n, OH, OW, cout), dtype=out_dtype, device=x.device)
     keep = [x, w, out]
     d = GemmDesc()
-    d.M, d.N, d.K, d.batch = n * H * Wd, cout, ksize * ksize * cv, 1
+    d.M, d.N, d.K, d.batch = n * OH * OW, cout, ksize * ksize * cv, 1
     d.A, d.a_layout, d.a_conv = ptr(x), ROWK, 1
     d.B, d.ldb, d.b_layout = ptr(w), w.stride(0), ROWK
     d.H, d.W, d.C, d.CV, d.R, d.S = H, Wd, Cc, cv, ksize, ksize
+    d.conv_stride, d.conv_pad = stride, pad
     if in_scale is not None:
         assert in_scale.dtype == torch.float32 and in_scale.shape == (n, cv) and in_scale.is_contiguous()
         d.in_scale = ptr(in_scale)
         keep.append(in_scale)
     d.C_out, d.ldc, d.c_is_f32 = ptr(out), cout, int(out_dtype == torch.float32)
     d.force_splitk, d.force_tile = force_splitk, force_tile
-    _epilogue(d, alpha, bias, out_scale, H * Wd if out_scale is not None else 0, noise, noise_w, act,
-              act_slope, keep)
+    if residual is not None:
+        assert residual.shape == out.shape
+    _epilogue(d, alpha, bias, out_scale, OH * OW if out_scale is not None else 0, noise, noise_w, act,
+              act_slope, keep, bias_scale=bias_scale, residual=residual, res_scale=res_scale)
     _run_gemm(d, x)
     return out
 
 
-def conv2d_wgrad_nhwc(x: torch.Tensor, dy: torch.Tensor, *, ksize: int, cv: int | None = None, in_scale=None,
-                      force_splitk=0, force_tile=0):
-    """Weight gradient of conv2d_nhwc: returns fp32 (ksize*ksize*CV, Cout) = sum over pixels of
+def conv2d_wgrad_nhwc(x: torch.Tensor, dy: torch.Tensor, *, ksize: int, stride: int = 1, pad: int | None = None,
+                      cv: int | None = None, in_scale=None, force_splitk=0, force_tile=0):
+    """Weight gradient of conv2d_nhwc: returns fp32 (ksize*ksize*CV, Cout) = sum over output pixels of
     gather(x)[pixel][(tap, cv)] * dy[pixel][co]."""
     L = _C.lib()
     L.require(x, dy, in_scale)
     assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and x.is_contiguous() and dy.is_contiguous()
     n, H, Wd, Cc = x.shape
     cv = cv or Cc
+    pad = ksize // 2 if pad is None else pad
+    OH, OW = _conv_out(H, ksize, stride, pad), _conv_out(Wd, ksize, stride, pad)
     cout = dy.shape[-1]
-    assert dy.shape[:3] == x.shape[:3]
+    assert tuple(dy.shape[:3]) == (n, OH, OW), (dy.shape, (n, OH, OW))
     out = torch.empty((ksize * ksize * cv, cout), dtype=torch.float32, device=x.device)
     d = GemmDesc()
-    d.M, d.N, d.K, d.batch = ksize * ksize * cv, cout, n * H * Wd, 1
+    d.M, d.N, d.K, d.batch = ksize * ksize * cv, cout, n * OH * OW, 1
     d.A, d.a_layout, d.a_conv = ptr(x), KROW, 1
     d.B, d.ldb, d.b_layout = ptr(dy), cout, KROW
     d.H, d.W, d.C, d.CV, d.R, d.S = H, Wd, Cc, cv, ksize, ksize
+    d.conv_stride, d.conv_pad = stride, pad
     if in_scale is not None:
         assert in_scale.dtype == torch.float32 and in_scale.shape == (n, cv) and in_scale.is_contiguous()
         d.in_scale = ptr(in_scale)
     d.C_out, d.ldc, d.c_is_f32 = ptr(out), cout, 1
     d.alpha = 1.0
+    d.bias_scale = 1.0
     d.force_splitk, d.force_tile = force_splitk, force_tile
     _run_gemm(d, x)
+    return out
+
+
+def conv2d_dgrad_d2s(dy: torch.Tensor, w: torch.Tensor, *, cell: int, taps: int, alpha=1.0, force_splitk=0,
+                     force_tile=0):
+    """Data gradient of a stride-`cell` convolution whose windows do not overlap (taps <= cell: the stride-2 1x1
+    residual conv and space-to-depth + 1x1): dy (n, oh, ow, Cout) bf16, w (Cout, taps*taps*C) bf16 laid out
+    [co][ty][tx][c]; returns dx (n, oh*cell, ow*cell, C) bf16 with dx[pixel(oh*cell+ty, ow*cell+tx)][c] =
+    alpha * sum_co dy[oh, ow][co] * w[co][(ty, tx, c)] and zeros at pixels no tap reaches."""
+    L = _C.lib()
+    L.require(dy, w)
+    assert dy.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and dy.is_contiguous() and w.is_contiguous()
+    n, oh, ow, cout = dy.shape
+    assert w.shape[0] == cout and w.shape[1] % (taps * taps) == 0
+    c = w.shape[1] // (taps * taps)
+    alloc = torch.empty if taps == cell else torch.zeros
+    out = alloc((n, oh * cell, ow * cell, c), dtype=torch.bfloat16, device=dy.device)
+    d = GemmDesc()
+    d.M, d.N, d.K, d.batch = n * oh * ow, taps * taps * c, cout, 1
+    d.A, d.lda, d.a_layout = ptr(dy), cout, ROWK
+    d.B, d.ldb, d.b_layout = ptr(w), w.stride(0), KROW
+    d.C_out, d.ldc, d.c_is_f32 = ptr(out), taps * taps * c, 0
+    d.alpha, d.bias_scale = float(alpha), 1.0
+    d.d2s, d.d2s_taps, d.d2s_c, d.d2s_oh, d.d2s_ow = cell, taps, c, oh, ow
+    d.force_splitk, d.force_tile = force_splitk, force_tile
+    _run_gemm(d, dy)
     return out
 
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 1
+#define GG_ABI_VERSION 2
 
 int gg_version(void);
 const char* gg_last_error(void);
@@ -42,13 +42,20 @@ enum { GG_ROWK = 0, GG_KROW = 1 };
  *
  * a_layout / b_layout: GG_ROWK = operand stored [row][k] (k contiguous); GG_KROW = stored [k][row].
  * Leading dimensions must be multiples of 8 elements and base pointers 16-byte aligned.
- * a_conv != 0: A is an NHWC activation [n_img][H][W][C] gathered as a stride-1 "same" R x S convolution
- *   (pad = (R-1)/2); with GG_ROWK the rows are output pixels (M = n_img*H*W) and k = (tap, cv);
- *   with GG_KROW (weight gradient) k runs over output pixels (K = n_img*H*W) and rows are (tap, cv)
- *   (M = R*S*CV). CV is the virtual channel count (CV % C == 0, physical channel = cv % C); in_scale,
- *   if given, is an fp32 [n_img][CV] multiplier on the gathered activation (style modulation, gp.py:396).
- * Epilogue order: acc*alpha -> *out_scale[m / rows_per_group][n] -> +bias[n] -> +noise[m]*noise_w[n]
- *   -> activation (leaky-relu slope `act_slope`, exact-erf GELU, SiLU).
+ * a_conv != 0: A is an NHWC activation [n_img][H][W][C] gathered as an R x S convolution window with stride
+ *   `conv_stride` and zero padding `conv_pad` (output grid OH = (H + 2*pad - R)/stride + 1, same for OW): 3x3 / 7x7 /
+ *   1x1 "same" convs (stride 1, pad (R-1)/2), the stride-2 1x1 residual conv (gp.py:1612: R = 1, stride 2, pad 0) and
+ *   space-to-depth + 1x1 (gp.py:289-293: R = 2, stride 2, pad 0, weights ordered [co][s1][s2][c]).
+ *   With GG_ROWK the rows are output pixels (M = n_img*OH*OW) and k = (tap, cv); with GG_KROW (weight gradient) k
+ *   runs over output pixels (K = n_img*OH*OW) and rows are (tap, cv) (M = R*S*CV). CV is the virtual channel count
+ *   (CV % C == 0, physical channel = cv % C); in_scale, if given, is an fp32 [n_img][CV] multiplier on the gathered
+ *   activation (style modulation, gp.py:396).
+ * Epilogue order: acc*alpha -> *out_scale[m / rows_per_group][n] -> +bias[n]*bias_scale -> +noise[m]*noise_w[n]
+ *   -> activation (leaky-relu slope `act_slope`, exact-erf GELU, SiLU) -> +residual[m][n]*res_scale.
+ * d2s != 0: depth-to-space scatter store, the adjoint of a stride-`d2s` gather (data gradient of the two stride-2
+ *   convs above): column n = (tap, c), c < d2s_c, tap = ty*d2s_taps + tx; row m = (img, oh, ow) on the d2s_oh x d2s_ow
+ *   grid; the element is written to pixel (oh*d2s + ty, ow*d2s + tx) of an [img][d2s_oh*d2s][d2s_ow*d2s][d2s_c] tensor
+ *   (pixels no tap maps to are not touched: pre-zero them). d2s_c %% 4 == 0.
  */
 typedef struct gg_gemm_desc {
     int32_t M, N, K, batch;
@@ -63,12 +70,17 @@ typedef struct gg_gemm_desc {
     const float* noise; const float* noise_w;
     int32_t act; float act_slope;
     int32_t force_splitk; /* 0 = heuristic */
-    int32_t force_tile;   /* 0 = heuristic; 1: 128x128, 2: 128x64, 3: 128x32 */
+    int32_t force_tile;   /* 0 = heuristic; 1: 128x128, 2: 128x64, 3: 128x32 (4 waves); 4: 256x256, 5: 256x128 (8 waves) */
+    int32_t conv_stride;  /* >= 1 */
+    int32_t conv_pad;     /* >= 0 */
+    float bias_scale;     /* multiplies bias (set 1.0f) */
+    const void* residual; int32_t ldr; float res_scale;   /* bf16 [M][ldr], optional */
+    int32_t d2s, d2s_taps, d2s_c, d2s_oh, d2s_ow;
 } gg_gemm_desc;
 
 size_t gg_gemm_workspace_bytes(const gg_gemm_desc* d);
-/* reports the launch plan the library will use for `d`: tile (1: 128x128, 2: 128x64, 3: 128x32) and the
- * split-K factor; used by bench.py to attribute measured time to kernel instantiations. */
+/* reports the launch plan the library will use for `d`: tile (1: 128x128, 2: 128x64, 3: 128x32, 4: 256x256,
+ * 5: 256x128) and the split-K factor; used by bench.py to attribute measured time to kernel instantiations. */
 int gg_gemm_plan(const gg_gemm_desc* d, int32_t* tile, int32_t* splitk);
 int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -44,6 +44,7 @@ void gg_emu_launch(dim3 grid, dim3 block, const std::function<void()>& body);
 void gg_emu_syncthreads();
 f32x16 gg_emu_mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c);
 float gg_emu_shfl(float v, int src_lane);
+u16x4 gg_emu_lds_read_tr16(const bf16_t* p);
 
 #define GG_LAUNCH(kernel, grid, block, stream, ...) \
     gg_emu_launch(grid, block, [=]() { kernel(__VA_ARGS__); })
@@ -52,6 +53,7 @@ static inline void gg_sync() { gg_emu_syncthreads(); }
 static inline f32x16 gg_mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c) {
     return gg_emu_mfma_32x32x16_bf16(a, b, c);
 }
+static inline u16x4 gg_lds_read_tr16(const bf16_t* p) { return gg_emu_lds_read_tr16(p); }
 static inline float gg_shfl_xor(float v, int mask) {
     int lane = (int)(threadIdx.x & 63u);
     return gg_emu_shfl(v, lane ^ mask);

@@ -23,6 +23,7 @@ struct WaveState {
     unsigned gen = 0;
     u16x8 a[64], b[64];
     float f[64];
+    u16x4 q[64];
 };
 
 ucontext_t g_sched;
@@ -106,6 +107,21 @@ float gg_emu_shfl(float v, int src_lane) {
     float r = w.f[src_lane & 63];
     wave_sync();
     return r;
+}
+
+// ds_read_b64_tr_b16 as measured on gfx950 (tests/probes/tr_probe.hip): inside each group of 16 lanes, lane i
+// receives element (i & 3) of the 4-element quads addressed by lanes 4*j + (i >> 2), j = 0..3.
+u16x4 gg_emu_lds_read_tr16(const bf16_t* p) {
+    WaveState& w = g_waves[g_cur / 64];
+    int lane = g_cur & 63;
+    u16x4 mine = {p[0], p[1], p[2], p[3]};
+    w.q[lane] = mine;
+    wave_sync();
+    int g = lane >> 4, i = lane & 15;
+    u16x4 out;
+    for (int j = 0; j < 4; ++j) out[j] = w.q[g * 16 + 4 * j + (i >> 2)][i & 3];
+    wave_sync();
+    return out;
 }
 
 void gg_emu_launch(dim3 grid, dim3 block, const std::function<void()>& body) {

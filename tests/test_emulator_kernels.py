@@ -174,3 +174,102 @@ def test_fused_adamw_and_ema_match_torch():
     assert rel_err(p0, r0) < 1e-6 and rel_err(p1, r1) < 1e-6
     assert torch.equal(p2.detach(), p2_before)
     assert rel_err(fo.state[p0]['exp_avg'], to.state[r0]['exp_avg']) < 1e-6
+
+
+# ---- 8-wave large-tile kernel (gg_gemm2.h) and the generalised conv geometry ---------------------------------
+
+@pytest.mark.parametrize('tile', [4, 5])
+def test_gemm2_dense_all_layouts(tile):
+    torch.manual_seed(0)
+    M, N, Kd, batch = 264, 136, 136, 2
+    A = torch.randn(batch, M, Kd); B = torch.randn(batch, N, Kd)
+    ref = torch.einsum('bmk,bnk->bmn', bf(A).float(), bf(B).float())
+    for ta in (False, True):
+        for tb in (True, False):
+            a = bf(A.transpose(1, 2).contiguous() if ta else A)
+            b = bf(B if tb else B.transpose(1, 2).contiguous())
+            out = K.gemm(a, b, trans_a=ta, trans_b=tb, out_dtype=torch.float32, force_tile=tile)
+            assert rel_err(out, ref) < 1e-5, (ta, tb)
+    out = K.gemm(bf(A), bf(B), out_dtype=torch.float32, force_tile=tile, force_splitk=2)
+    assert rel_err(out, ref) < 1e-5
+    bias = torch.randn(N)
+    out = K.gemm(bf(A), bf(B), bias=bias, act='lrelu', alpha=0.5, out_dtype=torch.float32, force_tile=tile)
+    assert rel_err(out, F.leaky_relu(ref * 0.5 + bias, 0.2)) < 1e-5
+
+
+@pytest.mark.parametrize('cfg', [(2, 12, 12, 64, 136, 3, 4), (1, 9, 7, 128, 128, 3, 5), (3, 8, 8, 64, 104, 1, 5)])
+def test_gemm2_conv_forward_dgrad_wgrad(cfg):
+    n, H, W, Ci, Co, ks, tile = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(n, Ci, H, W)); w = bf(torch.randn(Co, Ci, ks, ks) * 0.1); dy = bf(torch.randn(n, Co, H, W))
+    xf, wf = x.float().requires_grad_(), w.float().requires_grad_()
+    ref = F.conv2d(xf, wf, padding=ks // 2)
+    ref.backward(dy.float())
+    xh, dyh = x.permute(0, 2, 3, 1).contiguous(), dy.permute(0, 2, 3, 1).contiguous()
+    wh = w.permute(0, 2, 3, 1).reshape(Co, -1).contiguous()
+    out = K.conv2d_nhwc(xh, wh, ksize=ks, out_dtype=torch.float32, force_tile=tile)
+    assert rel_err(out.permute(0, 3, 1, 2), ref) < 1e-5
+    dw_ref = wf.grad.permute(2, 3, 1, 0).reshape(-1, Co)
+    assert rel_err(K.conv2d_wgrad_nhwc(xh, dyh, ksize=ks, force_tile=tile), dw_ref) < 1e-5
+    assert rel_err(K.conv2d_wgrad_nhwc(xh, dyh, ksize=ks, force_tile=tile, force_splitk=2), dw_ref) < 1e-5
+    if Co % 64 == 0:
+        wT = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Ci, -1).contiguous()
+        dx = K.conv2d_nhwc(dyh, wT, ksize=ks, out_dtype=torch.float32, force_tile=tile)
+        assert rel_err(dx.permute(0, 3, 1, 2), xf.grad) < 1e-5
+
+
+def test_gemm2_conv_in_scale_virtual_channels_and_epilogue():
+    """the no-grad adaptive-conv launch shape: CV = 2*C virtual channels, per-sample in_scale, out_scale, noise."""
+    torch.manual_seed(0)
+    n, H, W, C, O = 2, 6, 6, 32, 128
+    x = bf(torch.randn(n, H, W, C)); w = bf(torch.randn(O, 9 * 2 * C) * 0.1)
+    insc = torch.rand(n, 2 * C) + 0.5; osc = torch.rand(n, O) + 0.5
+    nz = torch.randn(n * H * W); nw = torch.randn(O)
+    res = bf(torch.randn(n, H, W, O))
+    outs = [K.conv2d_nhwc(x, w, ksize=3, cv=2 * C, in_scale=insc, out_scale=osc, noise=nz, noise_w=nw, act='lrelu',
+                          residual=res, res_scale=0.5, out_dtype=torch.float32, force_tile=t) for t in (1, 4)]
+    assert rel_err(outs[1], outs[0]) < 1e-5
+    # independent restatement
+    xs = bf(torch.cat([x.float(), x.float()], -1) * insc[:, None, None, :]).float()        # (n,H,W,2C)
+    wk = w.float().view(O, 3, 3, 2 * C).permute(0, 3, 1, 2)
+    y = F.conv2d(xs.permute(0, 3, 1, 2), wk, padding=1).permute(0, 2, 3, 1)
+    y = y * osc[:, None, None, :] + nz.view(n, H, W, 1) * nw
+    y = F.leaky_relu(y, 0.2) + 0.5 * res.float()
+    assert rel_err(outs[1], y) < 1e-5
+
+
+@pytest.mark.parametrize('tile', [0, 4])
+def test_strided_convs_and_depth_to_space_dgrad(tile):
+    """stride-2 1x1 (gp.py:1612) and space-to-depth + 1x1 (gp.py:289-293) as gather variants, with the
+    depth-to-space scatter store as their data gradient."""
+    torch.manual_seed(0)
+    n, H, W, C, O = 2, 8, 8, 64, 128
+    x = bf(torch.randn(n, C, H, W)); xh = x.permute(0, 2, 3, 1).contiguous()
+    # (a) 1x1 stride 2
+    w1 = bf(torch.randn(O, C, 1, 1) * 0.1)
+    xf, wf = x.float().requires_grad_(), w1.float().requires_grad_()
+    ref = F.conv2d(xf, wf, stride=2)
+    dy = bf(torch.randn_like(ref)); ref.backward(dy.float())
+    dyh = dy.permute(0, 2, 3, 1).contiguous()
+    w1h = w1.reshape(O, C).contiguous()
+    out = K.conv2d_nhwc(xh, w1h, ksize=1, stride=2, pad=0, out_dtype=torch.float32, force_tile=tile)
+    assert rel_err(out.permute(0, 3, 1, 2), ref) < 1e-5
+    assert rel_err(K.conv2d_wgrad_nhwc(xh, dyh, ksize=1, stride=2, pad=0, force_tile=tile), wf.grad.reshape(O, C).t()) < 1e-5
+    dx = K.conv2d_dgrad_d2s(dyh, w1h, cell=2, taps=1, force_tile=tile)
+    assert rel_err(dx.permute(0, 3, 1, 2), xf.grad) < 4e-3
+    # (b) space-to-depth + 1x1: reference channel order (c, s1, s2); kernel weight order [co][s1][s2][c]
+    w2 = bf(torch.randn(O, 4 * C, 1, 1) * 0.1)
+    xf, wf = x.float().requires_grad_(), w2.float().requires_grad_()
+    s2d = xf.reshape(n, C, H // 2, 2, W // 2, 2).permute(0, 1, 3, 5, 2, 4).reshape(n, 4 * C, H // 2, W // 2)
+    ref = F.conv2d(s2d, wf)
+    ref.backward(dy.float())
+    w2h = w2.reshape(O, C, 2, 2).permute(0, 2, 3, 1).reshape(O, 4 * C).contiguous()
+    bias = torch.randn(O); res = bf(torch.randn(n, H // 2, W // 2, O))
+    out = K.conv2d_nhwc(xh, w2h, ksize=2, stride=2, pad=0, out_dtype=torch.float32, force_tile=tile,
+                        alpha=0.7, bias=bias, bias_scale=0.7, residual=res)
+    assert rel_err(out, 0.7 * (ref.detach().permute(0, 2, 3, 1) + bias) + res.float()) < 1e-5
+    dw = K.conv2d_wgrad_nhwc(xh, dyh, ksize=2, stride=2, pad=0, force_tile=tile)          # ((s1,s2,c), O)
+    dw_ref = wf.grad.reshape(O, C, 2, 2).permute(2, 3, 1, 0).reshape(4 * C, O)
+    assert rel_err(dw, dw_ref) < 1e-5
+    dx = K.conv2d_dgrad_d2s(dyh, w2h, cell=2, taps=2, force_tile=tile)
+    assert rel_err(dx.permute(0, 3, 1, 2), xf.grad) < 4e-3

@@ -76,6 +76,57 @@ def test_conv_forward_dgrad_wgrad_vs_cpu_oracle(cfg):
     assert rel_err(K.conv2d_nhwc(dyh, wT, ksize=ks, out_dtype=torch.float32).cpu().permute(0, 3, 1, 2), xf.grad) < F32_TOL
 
 
+@pytest.mark.parametrize('cfg', [(4, 32, 32, 64, 128, 3, 5), (2, 64, 64, 128, 256, 3, 4), (8, 16, 16, 256, 512, 3, 4),
+                                 (16, 8, 8, 512, 512, 3, 4), (4, 32, 32, 256, 1024, 1, 4)])
+def test_large_tile_kernel_conv_vs_cpu_oracle(cfg):
+    """the 8-wave 256-row tile kernel (gg_gemm2.h): forward, data gradient, weight gradient (with and without
+    split-K) against fp32 CPU convolution of the same bf16 operands."""
+    n, H, W, Ci, Co, ks, tile = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(n, Ci, H, W)); w = bf(torch.randn(Co, Ci, ks, ks) * 0.05); dy = bf(torch.randn(n, Co, H, W))
+    xf, wf = x.float().requires_grad_(), w.float().requires_grad_()
+    ref = F.conv2d(xf, wf, padding=ks // 2)
+    ref.backward(dy.float())
+    xh, dyh = x.permute(0, 2, 3, 1).contiguous().to(dev()), dy.permute(0, 2, 3, 1).contiguous().to(dev())
+    wh = w.permute(0, 2, 3, 1).reshape(Co, -1).contiguous().to(dev())
+    out = K.conv2d_nhwc(xh, wh, ksize=ks, out_dtype=torch.float32, force_tile=tile)
+    assert rel_err(out.cpu().permute(0, 3, 1, 2), ref) < F32_TOL
+    dw_ref = wf.grad.permute(2, 3, 1, 0).reshape(-1, Co)
+    assert rel_err(K.conv2d_wgrad_nhwc(xh, dyh, ksize=ks, force_tile=tile).cpu(), dw_ref) < F32_TOL
+    assert rel_err(K.conv2d_wgrad_nhwc(xh, dyh, ksize=ks, force_tile=tile, force_splitk=1).cpu(), dw_ref) < F32_TOL
+    wT = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Ci, -1).contiguous().to(dev())
+    dx = K.conv2d_nhwc(dyh, wT, ksize=ks, out_dtype=torch.float32, force_tile=tile)
+    assert rel_err(dx.cpu().permute(0, 3, 1, 2), xf.grad) < F32_TOL
+
+
+def test_strided_convs_and_depth_to_space_vs_cpu_oracle():
+    torch.manual_seed(0)
+    n, H, W, C, O = 4, 16, 16, 64, 128
+    x = bf(torch.randn(n, C, H, W)); xh = x.permute(0, 2, 3, 1).contiguous().to(dev())
+    w2 = bf(torch.randn(O, 4 * C, 1, 1) * 0.1)
+    xf, wf = x.float().requires_grad_(), w2.float().requires_grad_()
+    s2d = xf.reshape(n, C, H // 2, 2, W // 2, 2).permute(0, 1, 3, 5, 2, 4).reshape(n, 4 * C, H // 2, W // 2)
+    ref = F.conv2d(s2d, wf)
+    dy = bf(torch.randn_like(ref)); ref.backward(dy.float())
+    dyh = dy.permute(0, 2, 3, 1).contiguous().to(dev())
+    w2h = w2.reshape(O, C, 2, 2).permute(0, 2, 3, 1).reshape(O, 4 * C).contiguous().to(dev())
+    for tile in (0, 1, 5):
+        out = K.conv2d_nhwc(xh, w2h, ksize=2, stride=2, pad=0, out_dtype=torch.float32, force_tile=tile)
+        assert rel_err(out.cpu().permute(0, 3, 1, 2), ref) < F32_TOL
+        dw = K.conv2d_wgrad_nhwc(xh, dyh, ksize=2, stride=2, pad=0, force_tile=tile)
+        assert rel_err(dw.cpu(), wf.grad.reshape(O, C, 2, 2).permute(2, 3, 1, 0).reshape(4 * C, O)) < F32_TOL
+        dx = K.conv2d_dgrad_d2s(dyh, w2h, cell=2, taps=2, force_tile=tile)
+        assert rel_err(dx.cpu().permute(0, 3, 1, 2), xf.grad) < BF16_TOL
+    w1 = bf(torch.randn(O, C, 1, 1) * 0.1)
+    xf, wf = x.float().requires_grad_(), w1.float().requires_grad_()
+    ref = F.conv2d(xf, wf, stride=2); ref.backward(dy.float())
+    w1h = w1.reshape(O, C).contiguous().to(dev())
+    out = K.conv2d_nhwc(xh, w1h, ksize=1, stride=2, pad=0, out_dtype=torch.float32)
+    assert rel_err(out.cpu().permute(0, 3, 1, 2), ref) < F32_TOL
+    dx = K.conv2d_dgrad_d2s(dyh, w1h, cell=2, taps=1)
+    assert rel_err(dx.cpu().permute(0, 3, 1, 2), xf.grad) < BF16_TOL
+
+
 def test_ops_match_reference_golden_fixture():
     fx = torch.load(GOLD / 'ops_small.pt', weights_only=False)
     H_ = ops.HipOps()
