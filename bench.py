@@ -137,7 +137,10 @@ def main():
         for _ in range(4):
             gan.train_step(it, args.batch)
         agg = K.profiler.summary()
+        shapes = K.profiler.shape_summary()
         K.profiler = None
+        Path(ROOT / 'gpurun_out').mkdir(exist_ok=True)
+        (ROOT / 'gpurun_out' / 'bench_gemm_shapes.json').write_text(json.dumps(shapes, indent=1))
         if agg:
             name, a = max(agg.items(), key=lambda kv: kv[1]['ms'])
             tot_ms = sum(v['ms'] for v in agg.values())

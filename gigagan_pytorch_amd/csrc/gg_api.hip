@@ -105,9 +105,11 @@ int gg_validate_gemm(const gg_gemm_desc* d) {
     return 0;
 }
 
+bool gg_v2_has_variant(const gg_gemm_desc* d);
+
 bool gg_v2_eligible(const gg_gemm_desc* d) {
     if (d->a_conv && d->a_layout == GG_ROWK && ((d->CV & 63) || d->R * d->S > 32)) return false;
-    return true;
+    return gg_v2_has_variant(d);
 }
 
 int gg_v2_policy() {   // GG_GEMM_V2=0 disables the 8-wave kernel (A/B runs), =2 forces it wherever eligible
@@ -217,24 +219,35 @@ void gg_launch_gemm_tile(const GgGemmParams& p, bool akrow, bool bkrow, bool aco
 #undef GG_CASE
 }
 
+// the 8-wave kernel is instantiated for the layout / epilogue combinations the step uses: row-major x row-major
+// (conv forward / data gradient, linear) with either epilogue; reduction-major x reduction-major (weight gradients)
+// and the two mixed dense layouts (attention transposes, depth-to-space data gradient) with the plain epilogue
+bool gg_v2_has_variant(const gg_gemm_desc* d) {
+    const bool akrow = d->a_layout == GG_KROW, bkrow = d->b_layout == GG_KROW, aconv = d->a_conv != 0;
+    const bool full = d->bias || d->out_scale || d->noise || d->residual || d->act != GG_ACT_NONE;
+    if (!akrow && !bkrow) return true;
+    if (full) return false;
+    if (akrow && bkrow) return true;
+    return !aconv;
+}
+
 template <int BM, int BN, int WM, int WN>
 void gg_launch_gemm2_tile(const GgGemmParams& p, bool akrow, bool bkrow, bool aconv, dim3 grid, hipStream_t s) {
     dim3 block(GG2_NT);
     const bool full = p.bias || p.out_scale || p.noise || p.residual || p.act != GG_ACT_NONE;
-#define GG_CASE(AK, BK_, AC)                                                                      \
-    if (akrow == AK && bkrow == BK_ && aconv == AC) {                                             \
-        if (full) GG_LAUNCH((gg_gemm2_kernel<BM, BN, WM, WN, AK, BK_, AC, true>), grid, block, s, p);   \
-        else GG_LAUNCH((gg_gemm2_kernel<BM, BN, WM, WN, AK, BK_, AC, false>), grid, block, s, p);       \
+#define GG_CASE(AK, BK_, AC, FE)                                                                  \
+    if (akrow == AK && bkrow == BK_ && aconv == AC && full == FE) {                               \
+        GG_LAUNCH((gg_gemm2_kernel<BM, BN, WM, WN, AK, BK_, AC, FE>), grid, block, s, p);          \
         return;                                                                                   \
     }
-    GG_CASE(false, false, false)
-    GG_CASE(false, true, false)
-    GG_CASE(true, false, false)
-    GG_CASE(true, true, false)
-    GG_CASE(false, false, true)
-    GG_CASE(false, true, true)
-    GG_CASE(true, false, true)
-    GG_CASE(true, true, true)
+    GG_CASE(false, false, false, false)
+    GG_CASE(false, false, false, true)
+    GG_CASE(false, false, true, false)
+    GG_CASE(false, false, true, true)
+    GG_CASE(true, true, false, false)
+    GG_CASE(true, true, true, false)
+    GG_CASE(false, true, false, false)
+    GG_CASE(true, false, false, false)
 #undef GG_CASE
 }
 

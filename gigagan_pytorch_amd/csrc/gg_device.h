@@ -36,6 +36,17 @@ typedef __attribute__((ext_vector_type(8))) __bf16 gg_bf16x8_native;
 
 GG_DEVICE void gg_sync() { __syncthreads(); }
 
+// The kernel-argument struct re-read through the kernarg segment pointer behind a compiler barrier: fields that only
+// the epilogue needs are then fetched AFTER the main loop instead of sitting in SGPRs (and, once those run out, in
+// scratch) for the whole kernel. `by_value` is the kernel's by-value parameter (first and only argument).
+template <typename T>
+GG_DEVICE const T* gg_late_params(const T& by_value) {
+    (void)by_value;
+    const T* kp = (const T*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return kp;
+}
+
 // D[i][j] += sum_k Aop[i][k] * Bop[k][j], 32x32x16, one wave.
 //   Aop: lane l holds Aop[i = l&31][k = 8*(l>>5) + e], e = 0..7
 //   Bop: lane l holds Bop[k = 8*(l>>5) + e][j = l&31]

@@ -227,6 +227,121 @@ GG_DEVICE void gg2_load_krow_conv(u16x8* regs, const GgConvCol& cc, const GgGemm
     }
 }
 
+// ---- epilogue -----------------------------------------------------------------------------------------------
+// Every accumulator index below is a compile-time constant by construction (template recursion, one (i, j, g)
+// register quad per step). A `#pragma unroll` nest over the full epilogue body exceeds clang's pragma-unroll budget
+// for the 256x256 tile; the accumulators were then indexed dynamically, i.e. demoted to scratch memory for the WHOLE
+// kernel — measured 4x slower.
+//
+// Two store paths:
+//  * direct: each lane stores its 4-column quads itself (fp32 outputs, split-K partials, the depth-to-space scatter,
+//    ragged N). 8 or 16 bytes per lane and 32 different rows per instruction.
+//  * staged (bf16 [m][ldc] outputs, N % 4 == 0): the wave parks its 128 x WTN sub-tile in LDS (pitch WTN*2 + 8 bytes:
+//    conflict-free ds_write_b64 / ds_read_b64) and writes it back row-contiguous — 16 lanes cover 128 contiguous bytes
+//    of one output row — with the residual read the same way. Short-K launches (1x1 convs, attention projections) are
+//    bound by this store pass, not by the MFMAs.
+
+GG_DEVICE f32x4 gg_ld4(const float* p) { return *(const f32x4*)p; }
+
+// activation( acc*alpha * out_scale + bias*bias_scale + noise*noise_w ) for one quad of 4 consecutive columns
+template <bool FULL_EPI>
+GG_DEVICE void gg2_quad_math(const GgGemmParams& e, float* v, int m, int n, f32x4 cb, f32x4 cnw, float nz) {
+    for (int q = 0; q < 4; ++q) v[q] *= e.alpha;
+    if (FULL_EPI) {
+        if (e.out_scale) {
+            const float* os = e.out_scale + (long long)(m / e.rows_per_group) * e.N + n;
+            for (int q = 0; q < 4; ++q)
+                if (n + q < e.N) v[q] *= os[q];
+        }
+        for (int q = 0; q < 4; ++q) v[q] += cb[q] + nz * cnw[q];
+        if (e.act != GG_ACT_NONE)
+            for (int q = 0; q < 4; ++q) v[q] = gg_apply_act(v[q], e.act, e.act_slope);
+    }
+}
+
+// per-column epilogue operands of the quad starting at column n (zeros where absent / out of range)
+GG_DEVICE void gg2_quad_columns(const GgGemmParams& e, int n, f32x4& cb, f32x4& cnw) {
+    cb = (f32x4){0.f, 0.f, 0.f, 0.f};
+    cnw = cb;
+    if (n >= e.N) return;
+    const bool vec = (n + 3 < e.N) && ((e.N & 3) == 0);
+    if (e.bias) {
+        if (vec && (((unsigned long long)e.bias) & 15) == 0) cb = gg_ld4(e.bias + n);
+        else
+            for (int q = 0; q < 4; ++q)
+                if (n + q < e.N) cb[q] = e.bias[n + q];
+        for (int q = 0; q < 4; ++q) cb[q] *= e.bias_scale;
+    }
+    if (e.noise) {
+        if (vec && (((unsigned long long)e.noise_w) & 15) == 0) cnw = gg_ld4(e.noise_w + n);
+        else
+            for (int q = 0; q < 4; ++q)
+                if (n + q < e.N) cnw[q] = e.noise_w[n + q];
+    }
+}
+
+// IDX = jg * TM + i: the column quad (j, g) is the slow index so that its operands are fetched once for the TM rows
+template <int IDX, int TM, int TN, bool FULL_EPI, bool STAGED>
+GG_DEVICE void gg2_epilogue_step(const f32x16 (&acc)[TM][TN], const GgGemmParams& e, int b, int bz, int m_lane, int n_lane,
+                                 char* stage, int stage_pitch, int lane, f32x4 cb, f32x4 cnw) {
+    if constexpr (IDX < TM * TN * 4) {
+        constexpr int jg = IDX / TM, i = IDX % TM, j = jg / 4, g = jg % 4;
+        const int m = m_lane + i * 32, n = n_lane + j * 32 + 8 * g;
+        if (FULL_EPI && i == 0) gg2_quad_columns(e, n, cb, cnw);
+        if (STAGED || (m < e.M && n < e.N)) {
+            float v[4] = {acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
+            if (!STAGED && e.splitk > 1) {
+                float* dst = e.partial + ((long long)bz * e.M + m) * e.N + n;
+                if (n + 3 < e.N && (e.N & 3) == 0) {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    *(f32x4*)dst = o;
+                } else {
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < e.N) dst[q] = v[q];
+                }
+            } else {
+                const float nz = (FULL_EPI && e.noise && m < e.M) ? e.noise[m] : 0.f;
+                gg2_quad_math<FULL_EPI>(e, v, m < e.M ? m : 0, n, cb, cnw, nz);
+                if (STAGED) {
+                    u16x4 o = {gg_f2bf(v[0]), gg_f2bf(v[1]), gg_f2bf(v[2]), gg_f2bf(v[3])};
+                    *(u16x4*)(stage + (i * 32 + (lane & 31)) * stage_pitch + (j * 32 + 8 * g + 4 * (lane >> 5)) * 2) = o;
+                } else {
+                    if (FULL_EPI && e.residual) {
+                        for (int q = 0; q < 4; ++q)
+                            if (n + q < e.N) v[q] += gg_bf2f(e.residual[(long long)m * e.ldr + n + q]) * e.res_scale;
+                    }
+                    gg_store4(e, b, m, n, v);
+                }
+            }
+        }
+        gg2_epilogue_step<IDX + 1, TM, TN, FULL_EPI, STAGED>(acc, e, b, bz, m_lane, n_lane, stage, stage_pitch, lane, cb, cnw);
+    }
+}
+
+// write-back of a staged WTM x WTN sub-tile: lane -> (row lane / (WTN/4) + it * rows_per_pass, 4 columns)
+template <int WTM, int WTN>
+GG_DEVICE void gg2_stage_writeback(const GgGemmParams& e, int b, const char* stage, int stage_pitch, int m_wave, int n_wave,
+                                   int lane) {
+    constexpr int QPR = WTN / 4;          // quads (8-byte pieces) per row: 16 (WTN 64) or 8 (WTN 32)
+    constexpr int RPP = 64 / QPR;         // rows per pass
+    const int qc = lane % QPR, rr = lane / QPR;
+    const int n = n_wave + qc * 4;
+    bf16_t* cbase = (bf16_t*)e.Cout + (long long)b * e.c_bs;
+#pragma unroll 4
+    for (int it = 0; it < WTM / RPP; ++it) {
+        const int row = it * RPP + rr;
+        const int m = m_wave + row;
+        if (m < e.M && n < e.N) {
+            u16x4 o = *(const u16x4*)(stage + row * stage_pitch + qc * 8);
+            if (e.residual) {
+                u16x4 r = *(const u16x4*)(e.residual + (long long)m * e.ldr + n);
+                for (int q = 0; q < 4; ++q) o[q] = gg_f2bf(gg_bf2f(o[q]) + gg_bf2f(r[q]) * e.res_scale);
+            }
+            *(u16x4*)(cbase + (long long)m * e.ldc + n) = o;
+        }
+    }
+}
+
 // ---- the kernel ---------------------------------------------------------------------------------------------
 
 template <int BM, int BN, int WM, int WN, bool A_KROW, bool B_KROW, bool A_CONV, bool FULL_EPI>
@@ -341,33 +456,23 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_gemm2_kernel(GgGemmParams p) {
     }
 
     // epilogue (same fragment ownership as gg_gemm_kernel): lane owns row m = ... + (lane & 31); register r holds
-    // column n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    const int hi = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * WTM + i * 32 + (lane & 31);
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * WTN + j * 32 + 8 * g + 4 * hi;
-                if (n >= p.N) continue;
-                float v[4];
-                if (p.splitk > 1) {
-                    float* dst = p.partial + ((long long)bz * p.M + m) * p.N + n;
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < p.N) dst[e] = acc[i][j][g * 4 + e];
-                } else {
-                    if (FULL_EPI) {
-                        for (int e = 0; e < 4; ++e)
-                            v[e] = (n + e < p.N) ? gg_epilogue(p, acc[i][j][g * 4 + e], m, n + e) : 0.f;
-                    } else {
-                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e] * p.alpha;
-                    }
-                    gg_store4(p, b, m, n, v);
-                }
-            }
-        }
+    // column n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5). The argument struct is copied from the kernarg segment HERE
+    // (gg_late_params) so that epilogue-only fields do not occupy registers during the main loop.
+    const GgGemmParams e = *gg_late_params(p);
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const int m_wave = m0 + wm * WTM, n_wave = n0 + wn * WTN;
+    const bool staged = e.splitk == 1 && !e.c_f32 && !e.d2s && (e.N & 3) == 0 && (e.ldc & 3) == 0 &&
+                        (!e.residual || (e.ldr & 3) == 0);
+    if (staged) {
+        constexpr int SP = WTN * 2 + 8;                      // stage pitch in bytes
+        static_assert(8 * WTM * SP <= 2 * (ABYTES + BBYTES), "staging area must fit the operand tiles' LDS");
+        char* stage = smem + wave * (WTM * SP);              // (the barrier that ended the k-loop freed the tiles)
+        gg2_epilogue_step<0, TM, TN, FULL_EPI, true>(acc, e, b, bz, m_wave + (lane & 31), n_wave + 4 * (lane >> 5), stage, SP,
+                                                     lane, z4, z4);
+        gg_sync();
+        gg2_stage_writeback<WTM, WTN>(e, b, stage, SP, m_wave, n_wave, lane);
+    } else {
+        gg2_epilogue_step<0, TM, TN, FULL_EPI, false>(acc, e, b, bz, m_wave + (lane & 31), n_wave + 4 * (lane >> 5), nullptr, 0,
+                                                      lane, z4, z4);
     }
 }

@@ -29,11 +29,22 @@ class GemmProfiler:
 
     def __init__(self):
         self.records = []   # (key, flops, start_event, end_event)
+        self.shapes = []    # same, keyed by kernel + problem shape
 
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
         for key, flops, e0, e1 in self.records:
+            a = agg.setdefault(key, dict(launches=0, ms=0., flops=0.))
+            a['launches'] += 1
+            a['ms'] += e0.elapsed_time(e1)
+            a['flops'] += flops
+        return agg
+
+    def shape_summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, flops, e0, e1 in self.shapes:
             a = agg.setdefault(key, dict(launches=0, ms=0., flops=0.))
             a['launches'] += 1
             a['ms'] += e0.elapsed_time(e1)
@@ -57,7 +68,7 @@ def _kernel_key(d: GemmDesc, L) -> str:
         wm, wn = (4, 1) if tile.value == 3 else (2, 2)
         name = (f'gg_gemm_kernel<128,{bn},{wm},{wn},A_KROW={int(d.a_layout == KROW)},B_KROW={int(d.b_layout == KROW)},'
                 f'A_CONV={int(bool(d.a_conv))}>')
-    return name + ('+splitk' if sk.value > 1 else '')
+    return name + ('+splitk' if sk.value > 1 else ''), sk.value
 
 
 def _run_gemm(d: GemmDesc, like: torch.Tensor):
@@ -73,7 +84,10 @@ def _run_gemm(d: GemmDesc, like: torch.Tensor):
         e0.record()
         rc = L.lib.gg_gemm_bf16(C.byref(d), ptr(ws), need, L.stream(like))
         e1.record()
-        profiler.records.append((_kernel_key(d, L), 2. * d.M * d.N * d.K * d.batch, e0, e1))
+        key, sk = _kernel_key(d, L)
+        profiler.records.append((key, 2. * d.M * d.N * d.K * d.batch, e0, e1))
+        profiler.shapes.append((f'{key} M={d.M} N={d.N} K={d.K} b={d.batch} sk={sk} sc={int(bool(d.in_scale))}',
+                                2. * d.M * d.N * d.K * d.batch, e0, e1))
     else:
         rc = L.lib.gg_gemm_bf16(C.byref(d), ptr(ws), need, L.stream(like))
     L.check(rc, 'gg_gemm_bf16')

@@ -50,6 +50,8 @@ u16x4 gg_emu_lds_read_tr16(const bf16_t* p);
     gg_emu_launch(grid, block, [=]() { kernel(__VA_ARGS__); })
 
 static inline void gg_sync() { gg_emu_syncthreads(); }
+template <typename T>
+static inline const T* gg_late_params(const T& by_value) { return &by_value; }
 static inline f32x16 gg_mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c) {
     return gg_emu_mfma_32x32x16_bf16(a, b, c);
 }

@@ -236,6 +236,13 @@ def test_gemm2_conv_in_scale_virtual_channels_and_epilogue():
     y = y * osc[:, None, None, :] + nz.view(n, H, W, 1) * nw
     y = F.leaky_relu(y, 0.2) + 0.5 * res.float()
     assert rel_err(outs[1], y) < 1e-5
+    # bf16 output: the LDS-staged row-contiguous store path of the 8-wave kernel (residual added on the way out)
+    for t in (4, 5):
+        ob = K.conv2d_nhwc(x, w, ksize=3, cv=2 * C, in_scale=insc, out_scale=osc, noise=nz, noise_w=nw, act='lrelu',
+                           residual=res, res_scale=0.5, force_tile=t)
+        assert ob.dtype == torch.bfloat16 and rel_err(ob, y) < 4e-3
+        ob = K.conv2d_nhwc(x, w, ksize=3, cv=2 * C, in_scale=insc, force_tile=t)          # plain epilogue, staged
+        assert rel_err(ob, F.conv2d(xs.permute(0, 3, 1, 2), wk, padding=1).permute(0, 2, 3, 1)) < 4e-3
 
 
 @pytest.mark.parametrize('tile', [0, 4])
