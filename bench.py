@@ -30,14 +30,14 @@ C2_G = dict(dim_capacity=8, dim_max=512, style_network=dict(dim=64, depth=4), nu
 C2_D = dict(dim_capacity=16, dim_max=512, num_skip_layers_excite=4, unconditional=True)
 
 
-def build_gan(image_size, device, g_over=None, d_over=None):
+def build_gan(image_size, device, g_over=None, d_over=None, use_hip_graphs=None):
     from gigagan_pytorch_amd import GigaGAN
     torch.manual_seed(0)
     g = dict(C2_G, image_size=image_size, **(g_over or {}))
     d = dict(C2_D, image_size=image_size, **(d_over or {}))
     return GigaGAN(generator=g, discriminator=d, amp=True, mixed_precision_type='bf16', apply_gradient_penalty_every=4,
                    calc_multiscale_loss_every=1, device=device, model_folder='/tmp/gg-bench-models',
-                   results_folder='/tmp/gg-bench-results')
+                   results_folder='/tmp/gg-bench-results', use_hip_graphs=use_hip_graphs)
 
 
 def cpu_baseline(max_seconds=40.0):
@@ -86,6 +86,7 @@ def main():
     ap.add_argument('--image-size', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile-cycle', action='store_true')
+    ap.add_argument('--no-graphs', action='store_true', help='issue every launch eagerly instead of replaying hipGraphs')
     args = ap.parse_args()
 
     from gigagan_pytorch_amd import distributed as gdist, kernels as K
@@ -101,7 +102,7 @@ def main():
 
     steps = (args.steps + 3) // 4 * 4
     warmup = args.warmup
-    gan = build_gan(args.image_size, dev)
+    gan = build_gan(args.image_size, dev, use_hip_graphs=False if args.no_graphs else None)
     dl = SyntheticImages(args.batch, args.image_size, device=dev, seed=rank)
     it = cycle(dl)
 
@@ -133,12 +134,14 @@ def main():
     roofline = None
     if rank == 0 and not args.no_profile_cycle:
         # one extra GP cycle with per-launch HIP events around the contraction kernel (same stream)
+        graphs_were_on, gan.use_hip_graphs = gan.use_hip_graphs, False   # HIP events cannot be recorded inside a replay
         K.profiler = K.GemmProfiler()
         for _ in range(4):
             gan.train_step(it, args.batch)
         agg = K.profiler.summary()
         shapes = K.profiler.shape_summary()
         K.profiler = None
+        gan.use_hip_graphs = graphs_were_on
         Path(ROOT / 'gpurun_out').mkdir(exist_ok=True)
         (ROOT / 'gpurun_out' / 'bench_gemm_shapes.json').write_text(json.dumps(shapes, indent=1))
         if agg:
@@ -168,7 +171,7 @@ def main():
             vs_baseline=None, dtype='bf16', data='synthetic',
             config=dict(workload=f'Unconditional GigaGAN image_size={args.image_size} dim_max=512 (G cap 8, D cap 16) '
                                  f'bf16 bs={args.batch}/GPU, GP every 4th step', global_batch=args.batch * world,
-                        parallelism=f'dp{world}'),
+                        parallelism=f'dp{world}', hip_graphs=bool(gan.use_hip_graphs)),
             roofline=roofline, cpu_baseline=cpu,
             last_losses=dict(d=float(d_losses.divergence), g=float(g_losses.divergence)))
         print(json.dumps(line), flush=True)

@@ -414,6 +414,22 @@ extern "C" int gg_softmax_bwd(const void* S, const void* dS, void* dx, float* db
     return gg_check_launch();
 }
 
+extern "C" int gg_softmax_bwd2(const void* S, const void* dS, const void* g_dx, const float* g_dbias, void* g_S, void* g_dS,
+                               int64_t rows, int32_t rows_per_batch, int32_t n_valid, int32_t ld, float alpha, void* stream) {
+    if (!S || !dS || !g_S || !g_dS) return gg_fail(-1, "gg_softmax_bwd2: null pointer");
+    if (!g_dx && !g_dbias) return gg_fail(-1, "gg_softmax_bwd2: no incoming gradient");
+    if (rows <= 0 || rows_per_batch <= 0 || n_valid <= 0 || ld < n_valid) return gg_fail(-2, "gg_softmax_bwd2: bad extents");
+    if (ld % 4 || ld > 256 * GG_SM_MAXV) return gg_fail(-3, "gg_softmax_bwd2: ld must be a multiple of 4 and <= %d", 256 * GG_SM_MAXV);
+    if (rows % rows_per_batch) return gg_fail(-4, "gg_softmax_bwd2: rows must be a multiple of rows_per_batch");
+    GgSoftmaxBwd2Params p;
+    p.S = (const bf16_t*)S; p.dS = (const bf16_t*)dS; p.g_dx = (const bf16_t*)g_dx; p.g_dbias = g_dbias;
+    p.g_S = (bf16_t*)g_S; p.g_dS = (bf16_t*)g_dS;
+    p.rows = rows; p.rows_per_batch = rows_per_batch; p.n_valid = n_valid; p.ld = ld; p.alpha = alpha;
+    long long waves = (rows + GG_SM_ROWS - 1) / GG_SM_ROWS;
+    GG_LAUNCH(gg_softmax_bwd2_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
 static long long gg_bias_act_blocks(int64_t rows, int32_t C) {
     long long nb = (rows * (long long)(C / 8) + 4095) / 4096;   // ~16 vectors per thread
     if (nb > 1024) nb = 1024;

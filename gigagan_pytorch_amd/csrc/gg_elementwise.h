@@ -270,6 +270,80 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_softmax_bwd_kernel(GgSoftmaxParams p) {
     }
 }
 
+// second-order pass of the attention softmax (gradient-penalty steps differentiate the backward above):
+//   given the incoming gradients g_dx (w.r.t. dx) and g_dbias (w.r.t. dbias), with gt = alpha*g_dx + g_dbias[batch]:
+//     r = sum_j S*dS,  gs = sum_j gt*S,   g_dS = S*(gt - gs),   g_S = gt*(dS - r) - dS*gs
+// one wavefront per row, one pass: replaces ~12 fp32 tensor-algebra passes over the (b*h, n, n+1) tensors.
+struct GgSoftmaxBwd2Params {
+    const bf16_t* S;
+    const bf16_t* dS;
+    const bf16_t* g_dx;     // optional
+    const float* g_dbias;   // optional [nbatch][ld]
+    bf16_t* g_S;
+    bf16_t* g_dS;
+    long long rows;
+    int rows_per_batch, n_valid, ld;
+    float alpha;
+};
+
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_softmax_bwd2_kernel(GgSoftmaxBwd2Params p) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nv = (p.ld + 255) / 256;
+    for (int rr = 0; rr < GG_SM_ROWS; ++rr) {
+        const long long r = wave * GG_SM_ROWS + rr;
+        if (r >= p.rows) break;   // wave-uniform
+        const bf16_t* sr = p.S + r * p.ld;
+        const bf16_t* dr = p.dS + r * p.ld;
+        const bf16_t* gr = p.g_dx ? p.g_dx + r * p.ld : nullptr;
+        const float* br = p.g_dbias ? p.g_dbias + (r / p.rows_per_batch) * p.ld : nullptr;
+        f32x4 s[GG_SM_MAXV], d[GG_SM_MAXV], g[GG_SM_MAXV];
+        float rsum = 0.f, gsum = 0.f;
+#pragma unroll
+        for (int t = 0; t < GG_SM_MAXV; ++t) {
+            if (t >= nv) break;
+            int j = t * 256 + lane * 4;
+            f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dv = sv, gv = sv;
+            if (j < p.ld) {
+                u16x4 a = *(const u16x4*)(sr + j);
+                u16x4 b = *(const u16x4*)(dr + j);
+                u16x4 c = {0, 0, 0, 0};
+                if (gr) c = *(const u16x4*)(gr + j);
+                f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+                if (br) bb = *(const f32x4*)(br + j);
+                for (int e = 0; e < 4; ++e) {
+                    if (j + e < p.n_valid) {
+                        sv[e] = gg_bf2f(a[e]);
+                        dv[e] = gg_bf2f(b[e]);
+                        gv[e] = p.alpha * gg_bf2f(c[e]) + bb[e];
+                    }
+                    rsum += sv[e] * dv[e];
+                    gsum += gv[e] * sv[e];
+                }
+            }
+            s[t] = sv; d[t] = dv; g[t] = gv;
+        }
+        rsum = gg_wave_sum(rsum);
+        gsum = gg_wave_sum(gsum);
+        bf16_t* os = p.g_S + r * p.ld;
+        bf16_t* od = p.g_dS + r * p.ld;
+#pragma unroll
+        for (int t = 0; t < GG_SM_MAXV; ++t) {
+            if (t >= nv) break;
+            int j = t * 256 + lane * 4;
+            if (j < p.ld) {
+                u16x4 o1, o2;
+                for (int e = 0; e < 4; ++e) {
+                    o1[e] = gg_f2bf(g[t][e] * (d[t][e] - rsum) - d[t][e] * gsum);
+                    o2[e] = gg_f2bf(s[t][e] * (g[t][e] - gsum));
+                }
+                *(u16x4*)(os + j) = o1;
+                *(u16x4*)(od + j) = o2;
+            }
+        }
+    }
+}
+
 // ---- bias / activation backward ---------------------------------------------------------------------------
 // dz = dy * (y > 0 ? 1 : slope)  (skipped when y == null: dz aliases dy) and per-workgroup partial column sums
 // db_part[wg][c] = sum over the workgroup's rows of dz[row][c] (a few hundred rows of [C] floats, summed by the caller).

@@ -56,8 +56,13 @@ class SimpleDecoder(nn.Module):
             total = p * p
             num = max(int(self.frac_patches * total), 1)
             batch_arange = torch.arange(batch, device=fmap.device)[..., None]
-            # drawn on the CPU generator exactly like the reference (gp.py:1310), then moved
-            perm = torch.randn((batch, total)).sort(dim=-1).indices[..., :num].to(fmap.device)
+            # the reference draws this on the CPU generator whatever the device (gp.py:1310): a host sync + H2D copy
+            # per call, and not hipGraph-capturable. On the GPU the same distribution is drawn on the device
+            # generator; `reference_rng = True` restores the reference's CPU stream (parity tests).
+            if fmap.device.type == 'cuda' and not getattr(self, 'reference_rng', False):
+                perm = torch.randn((batch, total), device=fmap.device).sort(dim=-1).indices[..., :num]
+            else:
+                perm = torch.randn((batch, total)).sort(dim=-1).indices[..., :num].to(fmap.device)
             fmap, orig_image = (t[batch_arange, perm].flatten(0, 1) for t in (fmap, orig_image))
         recon = self.net(fmap)
         return F.mse_loss(recon.float(), orig_image.float())
@@ -186,6 +191,9 @@ class Discriminator(nn.Module):
 
             from_rgb = Conv2d(channels, dim_in, 7, padding=3)
             residual_conv = Conv2d(dim_in, dim_out, 1, stride=(2 if should_downsample else 1))
+            if should_downsample:
+                # (downsample(x) + residual) * c  ==  c * downsample(x) + [c * residual]: the residual conv carries c
+                residual_conv.out_scale = self.residual_scale
             resnet_block = nn.Sequential(*conv_lrelu(dim_in, dim_out), *conv_lrelu(dim_out, dim_out))
 
             predictor = None
@@ -319,9 +327,9 @@ class Discriminator(nn.Module):
                     multiscale_outputs.append(predictor(x[:batch_prev_stage], **pred_kwargs))
 
             if exists(downsample):
-                x = downsample(x)
-
-            x = (x + residual) * self.residual_scale
+                x = downsample(x, residual=residual, scale=self.residual_scale)   # merge fused into the conv epilogue
+            else:
+                x = (x + residual) * self.residual_scale
 
             if exists(recon_decoder) and calc_aux_loss:
                 # reference behaviour (Appendix B.5): first `batch` rows of the post-downsample tensor

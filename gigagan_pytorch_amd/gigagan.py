@@ -130,6 +130,7 @@ class GigaGAN(nn.Module):
         amp=False,
         mixed_precision_type='fp16',
         device=None,
+        use_hip_graphs=None,
     ):
         super().__init__()
         # `accelerator`, `accelerate_kwargs`, `find_unused_parameters` are accepted for drop-in compatibility; the
@@ -206,6 +207,14 @@ class GigaGAN(nn.Module):
         self.train_dl = None
         self._dl_iter = None
         self.sample_upsampler_dl_iter = cycle(sample_upsampler_dl) if exists(sample_upsampler_dl) else None
+
+        # hipGraph replay of the forward+backward of each step kind (plain D, gradient-penalty D, G): the step is
+        # ~8k small launches, i.e. host-bound when issued eagerly. Unconditional, tensor-only steps qualify; the
+        # optimizer, the gradient all-reduce and the EMA stay outside the graphs.
+        if use_hip_graphs is None:
+            use_hip_graphs = self._device.type == 'cuda'
+        self.use_hip_graphs = bool(use_hip_graphs) and self._device.type == 'cuda'
+        self._graphs: dict = {}
 
         self.results_folder = Path(results_folder)
         self.model_folder = Path(model_folder)
@@ -335,91 +344,158 @@ class GigaGAN(nn.Module):
         G_kwargs.update(noise=noise)
         return G_kwargs, maybe_text_kwargs
 
+    # -- hipGraph capture of one step kind ---------------------------------------------------------------------
+    def _graphable(self, grad_accum_every):
+        return (self.use_hip_graphs and grad_accum_every == 1 and self.unconditional and not self.train_upsampler
+                and not exists(self.diff_augment))
+
+    def _run_graphed(self, key, fn, static_inputs=()):
+        """replay (capturing on first use) the hipGraph of `fn`, a closure over static input buffers that returns a
+        tuple of device tensors. Falls back to eager execution for good if the capture is refused."""
+        entry = self._graphs.get(key)
+        if entry is None:
+            try:
+                side = torch.cuda.Stream(device=self._device)
+                side.wait_stream(torch.cuda.current_stream(self._device))
+                with torch.cuda.stream(side):
+                    fn()                      # warm-up on a side stream (allocator, lazily built tables, workspaces)
+                torch.cuda.current_stream(self._device).wait_stream(side)
+                torch.cuda.synchronize(self._device)
+                graph = torch.cuda.CUDAGraph()
+                ops.pack_cache_clear()        # the graph must contain its own weight packing launches ...
+                with torch.cuda.graph(graph):
+                    outs = fn()
+                ops.pack_cache_clear()        # ... and nothing outside may keep tensors of its private pool
+                entry = self._graphs[key] = (graph, outs)
+            except Exception as e:   # noqa: BLE001 - any capture failure means "run eagerly"
+                self.print(f'hipGraph capture of the {key} step failed ({type(e).__name__}: {e}); running eagerly')
+                self.use_hip_graphs = False
+                self._graphs.clear()
+                torch.cuda.synchronize(self._device)
+                return fn()
+        graph, outs = entry
+        graph.replay()
+        return outs
+
+    def _d_micro(self, real_images, text_in, dl_iter, grad_accum_every, apply_gradient_penalty, calc_multiscale_loss,
+                 collect=None):
+        """forward + backward of ONE discriminator micro-batch (gp.py:2262-2430); returns detached loss pieces."""
+        dev = self.device
+        # the reference marks the images as requiring grad in every step (gp.py:2269, :2307); the gradient w.r.t. the
+        # input images is only consumed by the gradient penalty, so plain steps skip that part of the backward
+        real_images = real_images.to(dev, non_blocking=True).detach()
+        if apply_gradient_penalty:
+            real_images.requires_grad_()
+        real_images_rgbs = self.D.real_images_to_rgbs(real_images)
+        if exists(self.diff_augment):
+            real_images, real_images_rgbs = self.diff_augment(real_images, real_images_rgbs)
+        batch_size = real_images.shape[0]
+
+        G_kwargs, maybe_text_kwargs = self.generate_kwargs(dl_iter, batch_size)
+
+        with torch.no_grad():
+            images, rgbs = self.G(**G_kwargs, **maybe_text_kwargs, return_all_rgbs=True)
+            if collect is not None:
+                collect.append((images, rgbs, real_images.detach(), maybe_text_kwargs))
+            if exists(self.diff_augment):
+                images, rgbs = self.diff_augment(images, rgbs)
+        images = images.detach()
+        rgbs = [rgb.detach() for rgb in rgbs]
+        if apply_gradient_penalty:
+            images.requires_grad_()
+            for rgb in rgbs:
+                rgb.requires_grad_()
+
+        fake_logits, fake_ms_logits, _ = self.D(images, rgbs, **maybe_text_kwargs,
+                                                return_multiscale_outputs=calc_multiscale_loss, calc_aux_loss=False)
+        real_logits, real_ms_logits, aux_recon_losses = self.D(real_images, real_images_rgbs, **maybe_text_kwargs,
+                                                               return_multiscale_outputs=calc_multiscale_loss,
+                                                               calc_aux_loss=True)
+
+        zero = torch.zeros((), device=dev)
+        divergence = discriminator_hinge_loss(real_logits, fake_logits)
+
+        multiscale_divergence = 0.
+        ms_detached = zero
+        if self.multiscale_divergence_loss_weight > 0. and len(fake_ms_logits) > 0:
+            for ms_fake, ms_real in zip(fake_ms_logits, real_ms_logits):
+                multiscale_divergence = multiscale_divergence + discriminator_hinge_loss(ms_real, ms_fake)
+            ms_detached = multiscale_divergence.detach()
+
+        gp_loss = 0.
+        gp_detached = zero
+        if apply_gradient_penalty:
+            w = self.multiscale_divergence_loss_weight
+            real_gp = gradient_penalty(real_images, outputs=[real_logits, *real_ms_logits],
+                                       grad_output_weights=[1., *(w,) * len(real_ms_logits)])
+            fake_gp = gradient_penalty(images, outputs=[fake_logits, *fake_ms_logits],
+                                       grad_output_weights=[1., *(w,) * len(fake_ms_logits)])
+            gp_loss = real_gp + fake_gp
+            gp_detached = torch.nan_to_num(gp_loss.detach(), nan=0.)
+
+        total_loss = divergence + gp_loss
+        if self.multiscale_divergence_loss_weight > 0.:
+            total_loss = total_loss + multiscale_divergence * self.multiscale_divergence_loss_weight
+        aux_detached = zero
+        if self.discr_aux_recon_loss_weight > 0.:
+            aux_loss = sum(aux_recon_losses)
+            if torch.is_tensor(aux_loss):
+                aux_detached = aux_loss.detach()
+            total_loss = total_loss + aux_loss * self.discr_aux_recon_loss_weight
+
+        (total_loss / grad_accum_every).backward()
+        return divergence.detach(), ms_detached, gp_detached, aux_detached
+
     def train_discriminator_step(self, dl_iter, grad_accum_every=1, apply_gradient_penalty=False,
                                  calc_multiscale_loss=True):
         dev = self.device
         zero = torch.zeros((), device=dev)
-        total_divergence, total_gp_loss, total_aux_loss = zero.clone(), zero.clone(), zero.clone()
-        total_multiscale_divergence = zero.clone() if calc_multiscale_loss else None
         has_matching_awareness = not self.unconditional and self.matching_awareness_loss_weight > 0.
         total_matching_aware_loss = zero.clone()
-        all_text_kwargs, all_fake_images, all_fake_rgbs, all_real_images = [], [], [], []
+        collected = [] if has_matching_awareness else None
 
         self.G.train()
         self.D.train()
-        self.D_opt.zero_grad()
 
-        for _ in range(grad_accum_every):
-            if self.unconditional:
-                real_images = next(dl_iter)
-                text_in = None
-            else:
-                result = next(dl_iter)
-                assert isinstance(result, (tuple, list)), \
-                    'dataset should return a tuple of two items for text conditioned training, (images, texts)'
-                real_images, text_in = result
+        if self._graphable(grad_accum_every):
+            real = next(dl_iter)
+            key = ('D', bool(apply_gradient_penalty), bool(calc_multiscale_loss), tuple(real.shape))
+            static_real = self._graphs.get(('in',) + key)
+            if static_real is None:
+                static_real = self._graphs[('in',) + key] = torch.empty_like(real, device=dev)
+            static_real.copy_(real, non_blocking=True)
 
-            real_images = real_images.to(dev, non_blocking=True).detach().requires_grad_()
-            real_images_rgbs = self.D.real_images_to_rgbs(real_images)
-            if exists(self.diff_augment):
-                real_images, real_images_rgbs = self.diff_augment(real_images, real_images_rgbs)
-            batch_size = real_images.shape[0]
+            def fn():
+                self.D_opt.zero_grad()
+                return self._d_micro(static_real, None, None, 1, apply_gradient_penalty, calc_multiscale_loss)
 
-            G_kwargs, maybe_text_kwargs = self.generate_kwargs(dl_iter, batch_size)
-            if text_in is not None and not self.train_upsampler:
-                pass   # generate_kwargs drew its own (images, texts) pair exactly like the reference
-
-            with torch.no_grad():
-                images, rgbs = self.G(**G_kwargs, **maybe_text_kwargs, return_all_rgbs=True)
-                if has_matching_awareness:
-                    all_fake_images.append(images)
-                    all_fake_rgbs.append(rgbs)
-                    all_real_images.append(real_images.detach())
-                    all_text_kwargs.append(maybe_text_kwargs)
-                if exists(self.diff_augment):
-                    images, rgbs = self.diff_augment(images, rgbs)
-            images = images.detach().requires_grad_()
-            rgbs = [rgb.detach().requires_grad_() for rgb in rgbs]
-
-            fake_logits, fake_ms_logits, _ = self.D(images, rgbs, **maybe_text_kwargs,
-                                                    return_multiscale_outputs=calc_multiscale_loss, calc_aux_loss=False)
-            real_logits, real_ms_logits, aux_recon_losses = self.D(real_images, real_images_rgbs, **maybe_text_kwargs,
-                                                                   return_multiscale_outputs=calc_multiscale_loss,
-                                                                   calc_aux_loss=True)
-
-            divergence = discriminator_hinge_loss(real_logits, fake_logits)
-            total_divergence += divergence.detach() / grad_accum_every
-
-            multiscale_divergence = 0.
-            if self.multiscale_divergence_loss_weight > 0. and len(fake_ms_logits) > 0:
-                for ms_fake, ms_real in zip(fake_ms_logits, real_ms_logits):
-                    multiscale_divergence = multiscale_divergence + discriminator_hinge_loss(ms_real, ms_fake)
-                total_multiscale_divergence += multiscale_divergence.detach() / grad_accum_every
-
-            gp_loss = 0.
-            if apply_gradient_penalty:
-                w = self.multiscale_divergence_loss_weight
-                real_gp = gradient_penalty(real_images, outputs=[real_logits, *real_ms_logits],
-                                           grad_output_weights=[1., *(w,) * len(real_ms_logits)])
-                fake_gp = gradient_penalty(images, outputs=[fake_logits, *fake_ms_logits],
-                                           grad_output_weights=[1., *(w,) * len(fake_ms_logits)])
-                gp_loss = real_gp + fake_gp
-                total_gp_loss += torch.nan_to_num(gp_loss.detach(), nan=0.) / grad_accum_every
-
-            total_loss = divergence + gp_loss
-            if self.multiscale_divergence_loss_weight > 0.:
-                total_loss = total_loss + multiscale_divergence * self.multiscale_divergence_loss_weight
-            if self.discr_aux_recon_loss_weight > 0.:
-                aux_loss = sum(aux_recon_losses)
-                total_aux_loss += (aux_loss.detach() if torch.is_tensor(aux_loss) else aux_loss) / grad_accum_every
-                total_loss = total_loss + aux_loss * self.discr_aux_recon_loss_weight
-
-            (total_loss / grad_accum_every).backward()
+            total_divergence, total_multiscale_divergence, total_gp_loss, total_aux_loss = self._run_graphed(key, fn)
+            if not calc_multiscale_loss:
+                total_multiscale_divergence = None
+        else:
+            total_divergence, total_gp_loss, total_aux_loss = zero.clone(), zero.clone(), zero.clone()
+            total_multiscale_divergence = zero.clone() if calc_multiscale_loss else None
+            self.D_opt.zero_grad()
+            for _ in range(grad_accum_every):
+                if self.unconditional:
+                    real_images = next(dl_iter)
+                    text_in = None
+                else:
+                    result = next(dl_iter)
+                    assert isinstance(result, (tuple, list)), \
+                        'dataset should return a tuple of two items for text conditioned training, (images, texts)'
+                    real_images, text_in = result
+                d, ms, gp, aux = self._d_micro(real_images, text_in, dl_iter, grad_accum_every, apply_gradient_penalty,
+                                               calc_multiscale_loss, collect=collected)
+                total_divergence += d / grad_accum_every
+                if calc_multiscale_loss:
+                    total_multiscale_divergence += ms / grad_accum_every
+                total_gp_loss += gp / grad_accum_every
+                total_aux_loss += aux / grad_accum_every
 
         if has_matching_awareness:
             # mismatched (image, text) pairs: rotate the conditioning by one inside each micro-batch
-            for fake_images, fake_rgbs, real_images, tk in zip(all_fake_images, all_fake_rgbs, all_real_images,
-                                                               all_text_kwargs):
+            for fake_images, fake_rgbs, real_images, tk in collected:
                 tk = {k: (v[1:] + v[:1] if isinstance(v, list) else torch.roll(v, -1, 0)) for k, v in tk.items()}
                 fake_logits, *_ = self.D(fake_images, fake_rgbs, **tk, return_multiscale_outputs=False,
                                          calc_aux_loss=False)
@@ -437,39 +513,60 @@ class GigaGAN(nn.Module):
         return TrainDiscrLosses(total_divergence, total_multiscale_divergence, 0., total_matching_aware_loss,
                                 total_gp_loss, total_aux_loss)
 
+    def _g_micro(self, batch_size, dl_iter, grad_accum_every, calc_multiscale_loss):
+        """forward + backward of ONE generator micro-batch (gp.py:2516-2580)."""
+        dev = self.device
+        zero = torch.zeros((), device=dev)
+        G_kwargs, maybe_text_kwargs = self.generate_kwargs(dl_iter, batch_size)
+        images, rgbs = self.G(**G_kwargs, **maybe_text_kwargs, return_all_rgbs=True)
+        if exists(self.diff_augment):
+            images, rgbs = self.diff_augment(images, rgbs)
+
+        logits, ms_logits, _ = self.D(images, rgbs, **maybe_text_kwargs,
+                                      return_multiscale_outputs=calc_multiscale_loss, calc_aux_loss=False)
+        divergence = generator_hinge_loss(logits)
+        total_loss = divergence
+        ms_detached = zero
+        if self.multiscale_divergence_loss_weight > 0. and len(ms_logits) > 0:
+            ms_div = 0.
+            for ms in ms_logits:
+                ms_div = ms_div + generator_hinge_loss(ms)
+            ms_detached = ms_div.detach()
+            total_loss = total_loss + ms_div * self.multiscale_divergence_loss_weight
+        (total_loss / grad_accum_every).backward()
+        return divergence.detach(), ms_detached
+
     def train_generator_step(self, batch_size=None, dl_iter=None, grad_accum_every=1, calc_multiscale_loss=True):
         dev = self.device
         zero = torch.zeros((), device=dev)
-        total_divergence = zero.clone()
-        total_multiscale_divergence = zero.clone() if calc_multiscale_loss else None
         contrastive_loss = 0.
 
         self.G.train()
         self.D.train()
-        self.G_opt.zero_grad()
         # the reference leaves D's parameters requiring grad here, computes + all-reduces their gradients and then
         # throws them away at the next D_opt.zero_grad() (gp.py:2254); skip that work
         for p in self.D.parameters():
             p.requires_grad_(False)
         try:
-            for _ in range(grad_accum_every):
-                G_kwargs, maybe_text_kwargs = self.generate_kwargs(dl_iter, batch_size)
-                images, rgbs = self.G(**G_kwargs, **maybe_text_kwargs, return_all_rgbs=True)
-                if exists(self.diff_augment):
-                    images, rgbs = self.diff_augment(images, rgbs)
+            if self._graphable(grad_accum_every):
+                key = ('G', int(batch_size), bool(calc_multiscale_loss))
 
-                logits, ms_logits, _ = self.D(images, rgbs, **maybe_text_kwargs,
-                                              return_multiscale_outputs=calc_multiscale_loss, calc_aux_loss=False)
-                divergence = generator_hinge_loss(logits)
-                total_divergence += divergence.detach() / grad_accum_every
-                total_loss = divergence
-                if self.multiscale_divergence_loss_weight > 0. and len(ms_logits) > 0:
-                    ms_div = 0.
-                    for ms in ms_logits:
-                        ms_div = ms_div + generator_hinge_loss(ms)
-                    total_multiscale_divergence += ms_div.detach() / grad_accum_every
-                    total_loss = total_loss + ms_div * self.multiscale_divergence_loss_weight
-                (total_loss / grad_accum_every).backward()
+                def fn():
+                    self.G_opt.zero_grad()
+                    return self._g_micro(batch_size, None, 1, calc_multiscale_loss)
+
+                total_divergence, total_multiscale_divergence = self._run_graphed(key, fn)
+                if not calc_multiscale_loss:
+                    total_multiscale_divergence = None
+            else:
+                total_divergence = zero.clone()
+                total_multiscale_divergence = zero.clone() if calc_multiscale_loss else None
+                self.G_opt.zero_grad()
+                for _ in range(grad_accum_every):
+                    d, ms = self._g_micro(batch_size, dl_iter, grad_accum_every, calc_multiscale_loss)
+                    total_divergence += d / grad_accum_every
+                    if calc_multiscale_loss:
+                        total_multiscale_divergence += ms / grad_accum_every
         finally:
             for p in self.D.parameters():
                 p.requires_grad_(True)
@@ -556,6 +653,7 @@ class GigaGAN(nn.Module):
 
 
 def _load_into(module, state, strict):
+    ops.bump_weight_epoch()
     """copy a state dict into existing storage (parameters are views into the optimizer's flat buffers, so
     they must be written in place rather than re-pointed)."""
     own = module.state_dict()

@@ -409,6 +409,23 @@ def softmax_bwd(S: torch.Tensor, dS: torch.Tensor, alpha: float, n_valid: int, w
     return dx, dbias
 
 
+def softmax_bwd2(S: torch.Tensor, dS: torch.Tensor, g_dx, g_dbias, alpha: float, n_valid: int):
+    """second-order softmax pass: returns (g_S, g_dS) bf16 for incoming gradients g_dx (bf16) / g_dbias (fp32)."""
+    L = _C.lib()
+    L.require(S, dS, g_dx, g_dbias)
+    assert S.dtype == torch.bfloat16 and dS.dtype == torch.bfloat16 and S.is_contiguous() and dS.is_contiguous()
+    nb, n, ld = S.shape
+    if g_dx is not None:
+        assert g_dx.dtype == torch.bfloat16 and g_dx.is_contiguous() and g_dx.shape == S.shape
+    if g_dbias is not None:
+        assert g_dbias.dtype == torch.float32 and g_dbias.is_contiguous() and g_dbias.shape == (nb, ld)
+    g_S, g_dS = torch.empty_like(S), torch.empty_like(S)
+    rc = L.lib.gg_softmax_bwd2(ptr(S), ptr(dS), ptr(g_dx), ptr(g_dbias), ptr(g_S), ptr(g_dS), nb * n, n, n_valid, ld, alpha,
+                               L.stream(S))
+    L.check(rc, 'gg_softmax_bwd2')
+    return g_S, g_dS
+
+
 def bias_act_bwd(dy: torch.Tensor, y, want_db: bool, slope: float = 0.2):
     """dz = dy * lrelu'(y) (dz is dy itself when y is None) and db = column sums of dz (fp32) in one pass."""
     L = _C.lib()

@@ -39,15 +39,15 @@ class Conv2d(nn.Conv2d):
     stride 2 is only used with 1x1 kernels (gp.py:1612) and is a pixel sub-sampling in front of a GEMM."""
 
     act = None
+    out_scale = 1.0     # y = out_scale * (conv + bias): lets a following "(a + b) * c" merge be folded into its producers
 
     def forward(self, x):
         k = self.kernel_size[0]
         if self.stride[0] != 1:
-            assert k == 1 and self.padding[0] == 0
-            x = x[:, :, ::self.stride[0], ::self.stride[1]]
+            assert k == 1 and self.padding[0] == 0 and self.stride[0] == 2
         else:
             assert self.padding[0] == k // 2
-        return ops.impl.conv2d(x, self.weight, self.bias, act=self.act)
+        return ops.impl.conv2d(x, self.weight, self.bias, act=self.act, stride=self.stride[0], scale=self.out_scale)
 
 
 class Linear(nn.Linear):
@@ -143,8 +143,17 @@ def space_to_depth(x):
     return x.reshape(b, c * 4, h // 2, w // 2)
 
 
-def Downsample(dim):
-    return nn.Sequential(Placeholder(space_to_depth), Conv2d(dim * 4, dim, 1))
+class Downsample(nn.Sequential):
+    """space-to-depth 2x2 -> 1x1 conv 4C -> C (gp.py:289-293), same container layout as the reference
+    (index 0: rearrange, index 1: conv); executed as ONE 2x2 / stride-2 gather conv, optionally with the
+    discriminator's residual merge `(x + residual) * scale` (gp.py:1826) in its epilogue."""
+
+    def __init__(self, dim):
+        super().__init__(Placeholder(space_to_depth), Conv2d(dim * 4, dim, 1))
+
+    def forward(self, x, residual=None, scale=1.0):
+        conv = self[1]
+        return ops.impl.downsample(x, conv.weight, conv.bias, residual=residual, scale=scale)
 
 
 class PixelShuffleUpsample(nn.Module):

@@ -64,37 +64,121 @@ def flip_transpose(w: torch.Tensor) -> torch.Tensor:
     return w.flip(2, 3).transpose(0, 1)
 
 
+# ---- packed-weight cache -----------------------------------------------------------------------------------------
+# A parameter is packed to the kernels' bf16 layouts at most once per optimizer step: the forward layout
+# [co][kh][kw][ci], the data-gradient layout [ci][kh'][kw'][co] (flipped), and for space-to-depth convs
+# [co][s1][s2][c]. Keyed by the Parameter object; invalidated by `bump_weight_epoch()` (FlatAdamW.step, state-dict
+# loads) and bypassed for anything that is not a leaf Parameter (second-order "weights" in gradient-penalty steps).
+_weight_epoch = 0
+
+
+def bump_weight_epoch():
+    """invalidate every cached pack (optimizer step, state-dict load, start/end of a hipGraph capture)."""
+    global _weight_epoch
+    _weight_epoch += 1
+
+
+pack_cache_clear = bump_weight_epoch
+
+
+def _pad_oi(w: torch.Tensor, o_to: int, i_to: int) -> torch.Tensor:
+    o, i = w.shape[0], w.shape[1]
+    if o_to != o or i_to != i:
+        w = F.pad(w, (0, 0, 0, 0, 0, i_to - i, 0, o_to - o))
+    return w
+
+
+def packed_weight(w: torch.Tensor, kind: str) -> torch.Tensor:
+    """bf16 GEMM operand for conv weights w (O, I, k, k):
+         'fwd'  -> (O8, k*k*I8)  [co][kh][kw][ci]           (forward B operand / depth-to-space data gradient)
+         'bwd'  -> (I8, k*k*O8)  [ci][kh'][kw'][co] flipped (stride-1 data gradient B operand)
+         's2d'  -> w is the reference's (O, 4C, 1, 1) over channels (c, s1, s2): (O8, 4*C8) [co][s1][s2][c]
+       channel counts are zero-padded to multiples of 8 (the kernels' 16-byte vectors)."""
+    cacheable = isinstance(w, torch.nn.Parameter)
+    if cacheable:       # the cache lives on the Parameter object itself: (epoch, {kind: packed})
+        slot = getattr(w, '_gg_packed', None)
+        if slot is not None and slot[0] == _weight_epoch and kind in slot[1]:
+            return slot[1][kind]
+    with torch.no_grad():
+        wd = w.detach()
+        if wd.dim() == 5:       # AdaptiveConv2DMod bank (N, O, I, k, k): the N kernels stacked along output channels
+            n, o = wd.shape[0], wd.shape[1]
+            assert n == 1 or o % 8 == 0, 'stacked kernel banks need O % 8 == 0'
+            wd = wd.reshape(n * o, *wd.shape[2:])
+        if kind == 's2d':
+            o, c4 = wd.shape[0], wd.shape[1]
+            c = c4 // 4
+            wr = wd.reshape(o, c, 2, 2)
+            wr = _pad_oi(wr, _round8(o), _round8(c))
+            out = wr.permute(0, 2, 3, 1).reshape(wr.shape[0], -1).to(ACT_DTYPE).contiguous()
+        else:
+            wp = _pad_oi(wd, _round8(wd.shape[0]), _round8(wd.shape[1]))
+            if kind == 'fwd':
+                out = wp.permute(0, 2, 3, 1).reshape(wp.shape[0], -1).to(ACT_DTYPE).contiguous()
+            elif kind == 'bwd':
+                out = wp.flip(2, 3).permute(1, 2, 3, 0).reshape(wp.shape[1], -1).to(ACT_DTYPE).contiguous()
+            else:
+                raise ValueError(kind)
+    if cacheable:
+        slot = getattr(w, '_gg_packed', None)
+        if slot is None or slot[0] != _weight_epoch:
+            slot = (_weight_epoch, {})
+            w._gg_packed = slot
+        slot[1][kind] = out
+    return out
+
+
 # --------------------------------------------------------------------------------------------------
 # autograd Functions over the HIP kernels (each one's backward is built from the others)
 # --------------------------------------------------------------------------------------------------
+# Geometry of a conv: (ksize, stride, pad, wkind). wkind 'oihw': w is (O, I, k, k); 's2d': w is the reference's
+# (O, 4C, 1, 1) 1x1 conv over space-to-depth channels, executed as a 2x2 / stride-2 window over the un-rearranged
+# input. Activations are (b, H, W, C8) bf16 with C8 = channels rounded up to 8 (zero padded).
+
+def _geom_k(geom):
+    return geom[0]
+
 
 class ConvFn(Function):
-    """y = conv_same(x * in_scale, w) [+ bias][-> leaky relu];  x: (b,H,W,C) bf16, w: (O,I,k,k) float."""
+    """y = act(alpha * (conv(x * in_scale, w) + bias)) + residual ;  x: (b,H,W,C8) bf16, w: float parameter layout."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, in_scale, act):
-        ksize = w.shape[-1]
-        wmat = pack_conv_weight(w)
-        y = K.conv2d_nhwc(x, wmat, ksize=ksize, in_scale=in_scale, bias=bias, act=act, act_slope=LRELU_SLOPE)
-        ctx.act = act
+    def forward(ctx, x, w, bias, in_scale, act, geom, alpha, residual):
+        ksize, stride, pad, wkind = geom
+        wmat = packed_weight(w, 's2d' if wkind == 's2d' else 'fwd')
+        o8 = wmat.shape[0]
+        b8 = bias
+        if bias is not None and bias.shape[0] != o8:
+            b8 = F.pad(bias, (0, o8 - bias.shape[0]))
+        y = K.conv2d_nhwc(x, wmat, ksize=ksize, stride=stride, pad=pad, in_scale=in_scale, bias=b8, bias_scale=alpha,
+                          alpha=alpha, act=act, act_slope=LRELU_SLOPE, residual=residual)
+        ctx.act, ctx.geom, ctx.alpha = act, geom, alpha
         ctx.save_for_backward(x, w, in_scale, y if act else None)
         ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        ctx.n_bias = bias.shape[0] if bias is not None else 0
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, in_scale, y = ctx.saved_tensors
+        geom, alpha = ctx.geom, ctx.alpha
         dy = dy.contiguous()
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         db = None
         if ctx.act == 'lrelu' or want_db:
             dz, db = BiasActBwdFn.apply(dy, y if ctx.act == 'lrelu' else None, want_db)
-            db = db if want_db else None
+            if want_db:
+                db = db[:ctx.n_bias]
+                if alpha != 1.0:
+                    db = db * alpha
+            else:
+                db = None
         else:
             dz = dy
         dx = dw = ds = None
         if ctx.needs_input_grad[0] or (in_scale is not None and ctx.needs_input_grad[3]):
-            dxs = ConvFn.apply(dz, flip_transpose(w), None, None, None)
+            dxs = DgradFn.apply(dz, w, geom, alpha, x.shape[1], x.shape[2])
             if in_scale is None:
                 dx = dxs
             else:
@@ -102,13 +186,46 @@ class ConvFn(Function):
                     ds = (x.float() * dxs.float()).sum(dim=(1, 2))
                 dx = (dxs.float() * in_scale[:, None, None, :]).to(dxs.dtype)
         if ctx.needs_input_grad[1]:
-            dw = WgradFn.apply(x, dz, in_scale, w.shape[-1]).to(w.dtype)
-        return dx, dw, db, ds, None
+            dw = WgradFn.apply(x, dz, in_scale, geom, alpha, tuple(w.shape)).to(w.dtype)
+        return dx, dw, db, ds, None, None, None, (dy if ctx.has_res and ctx.needs_input_grad[7] else None)
+
+
+class DgradFn(Function):
+    """data gradient of ConvFn: dx = alpha * conv^T(dz, w). Stride-1 'same' convs run the forward kernel on the
+    flipped/transposed weights; the non-overlapping stride-2 windows (1x1 stride 2, space-to-depth) run a dense GEMM
+    with the depth-to-space scatter store."""
+
+    @staticmethod
+    def forward(ctx, dz, w, geom, alpha, H, W):
+        ksize, stride, pad, wkind = geom
+        if stride == 1:
+            wmat = packed_weight(w, 'bwd')
+            dx = K.conv2d_nhwc(dz, wmat, ksize=ksize, stride=1, pad=ksize - 1 - pad, alpha=alpha)
+        else:
+            assert pad == 0 and ksize <= stride
+            wmat = packed_weight(w, 's2d' if wkind == 's2d' else 'fwd')
+            dx = K.conv2d_dgrad_d2s(dz, wmat, cell=stride, taps=ksize, alpha=alpha)
+            assert dx.shape[1] == H and dx.shape[2] == W
+        ctx.geom, ctx.alpha = geom, alpha
+        ctx.save_for_backward(dz, w)
+        return dx
+
+    @staticmethod
+    def backward(ctx, g):
+        dz, w = ctx.saved_tensors
+        geom, alpha = ctx.geom, ctx.alpha
+        g = g.contiguous()
+        ddz = dw = None
+        if ctx.needs_input_grad[0]:     # linear in dz: the adjoint of the adjoint is the forward conv
+            ddz = ConvFn.apply(g, w, None, None, None, geom, alpha, None)
+        if ctx.needs_input_grad[1]:     # dL/dw[co][tap][ci] = alpha * sum_p dz[p][co] * g[p + tap][ci]
+            dw = WgradFn.apply(g, dz, None, geom, alpha, tuple(w.shape)).to(w.dtype)
+        return ddz, dw, None, None, None, None
 
 
 class BiasActBwdFn(Function):
-    """(dz, db) = (dy * lrelu'(y), column sums of dz) in one HIP pass; differentiable again (gradient penalty)
-    through plain tensor algebra, since dz is linear in dy with a piecewise-constant mask."""
+    """(dz, db) = (dy * lrelu'(y), column sums of dz) in one HIP pass. Linear in dy with a piecewise-constant mask,
+    so its own backward (gradient penalty) is the same kernel applied to the incoming gradient."""
 
     @staticmethod
     def forward(ctx, dy, y, want_db):
@@ -127,32 +244,45 @@ class BiasActBwdFn(Function):
         if g is None:
             return None, None, None
         if y is not None:
-            g = g * torch.where(y > 0, 1.0, LRELU_SLOPE).to(g.dtype)
+            g, _ = BiasActBwdFn.apply(g.contiguous(), y, False)
         return g, None, None
 
 
 class WgradFn(Function):
-    """dw[o][i][kh][kw] = sum_pixels dy[p][o] * (x*in_scale)[p + (kh,kw)][i]  (fp32, parameter layout)."""
+    """dw[o][i][kh][kw] = alpha * sum_pixels dy[p][o] * (x*in_scale)[window(p) + (kh,kw)][i]  (fp32, parameter layout)."""
 
     @staticmethod
-    def forward(ctx, x, dy, in_scale, ksize):
-        g = K.conv2d_wgrad_nhwc(x, dy, ksize=ksize, in_scale=in_scale)  # (k*k*C, O) fp32
-        c, o = x.shape[-1], dy.shape[-1]
-        ctx.ksize = ksize
+    def forward(ctx, x, dy, in_scale, geom, alpha, wshape):
+        ksize, stride, pad, wkind = geom
+        g = K.conv2d_wgrad_nhwc(x, dy, ksize=ksize, stride=stride, pad=pad, in_scale=in_scale)  # (k*k*C8, O8) fp32
+        c8, o8 = x.shape[-1], dy.shape[-1]
+        ctx.geom, ctx.alpha, ctx.wshape = geom, alpha, wshape
         ctx.save_for_backward(x, dy, in_scale)
-        return g.view(ksize, ksize, c, o).permute(3, 2, 0, 1).contiguous()
+        g = g.view(ksize, ksize, c8, o8)
+        if wkind == 's2d':
+            o, c = wshape[0], wshape[1] // 4
+            g = g[:, :, :c, :o].permute(3, 2, 0, 1).reshape(wshape)        # (O, C, s1, s2) -> (O, 4C, 1, 1)
+        elif len(wshape) == 5:   # kernel bank (N, O, I, k, k) stacked along output channels
+            n, o, i = wshape[0], wshape[1], wshape[2]
+            g = g[:, :, :i, :n * o].permute(3, 2, 0, 1).reshape(wshape)
+        else:
+            g = g[:, :, :wshape[1], :wshape[0]].permute(3, 2, 0, 1)
+        if alpha != 1.0:
+            g = g * alpha
+        return g.contiguous()
 
     @staticmethod
     def backward(ctx, ddw):
         x, dy, in_scale = ctx.saved_tensors
+        geom, alpha = ctx.geom, ctx.alpha
         dx = ddy = None
         if ctx.needs_input_grad[0]:
-            dx = ConvFn.apply(dy, flip_transpose(ddw), None, None, None)
+            dx = DgradFn.apply(dy, ddw, geom, alpha, x.shape[1], x.shape[2])
             if in_scale is not None:
                 dx = (dx.float() * in_scale[:, None, None, :]).to(dx.dtype)
         if ctx.needs_input_grad[1]:
-            ddy = ConvFn.apply(x, ddw, None, in_scale, None)
-        return dx, ddy, None, None
+            ddy = ConvFn.apply(x, ddw, None, in_scale, None, geom, alpha, None)
+        return dx, ddy, None, None, None, None
 
 
 class GemmFn(Function):
@@ -236,12 +366,12 @@ class AttnProbsFn(Function):
 
 class SoftmaxBwdFn(Function):
     """(dx, dbias) = (alpha*u, column sums of u), u = S*(dS - rowsum(S*dS)); its own backward (second order,
-    gradient-penalty steps only) is written in tensor algebra."""
+    gradient-penalty steps only) is one fused HIP pass too (gg_softmax_bwd2); third order is not provided."""
 
     @staticmethod
     def forward(ctx, S, dS, alpha, m_valid, want_dbias):
         dx, dbias = K.softmax_bwd(S, dS, alpha, m_valid, want_dbias)
-        ctx.alpha = alpha
+        ctx.alpha, ctx.m_valid = alpha, m_valid
         ctx.save_for_backward(S, dS)
         if dbias is None:
             dbias = S.new_zeros((), dtype=torch.float32)
@@ -250,15 +380,12 @@ class SoftmaxBwdFn(Function):
     @staticmethod
     def backward(ctx, g_dx, g_dbias):
         S, dS = ctx.saved_tensors
-        Sf, dSf = S.float(), dS.float()
-        gt = ctx.alpha * g_dx.float()
-        if g_dbias is not None and g_dbias.dim() == 2:
-            gt = gt + g_dbias[:, None, :]
-        r = (Sf * dSf).sum(-1, keepdim=True)
-        gs = (gt * Sf).sum(-1, keepdim=True)
-        g_dS = Sf * (gt - gs)
-        g_S = gt * (dSf - r) - dSf * gs
-        return g_S.to(S.dtype), g_dS.to(dS.dtype), None, None, None
+        gb = g_dbias if (g_dbias is not None and g_dbias.dim() == 2) else None
+        if g_dx is None and gb is None:
+            return None, None, None, None, None
+        g_S, g_dS = K.softmax_bwd2(S, dS, None if g_dx is None else g_dx.contiguous(),
+                                   None if gb is None else gb.float().contiguous(), ctx.alpha, ctx.m_valid)
+        return g_S, g_dS, None, None, None
 
 
 def _pad_last(t: torch.Tensor) -> torch.Tensor:
@@ -320,22 +447,33 @@ class HipOps:
         return to_act(x)
 
     # -- convolution -------------------------------------------------------------------------------
-    def conv2d(self, x, weight, bias=None, act=None):
-        """stride-1 'same' conv (odd square kernel) — reference nn.Conv2d(…, padding=k//2) call sites."""
+    def conv2d(self, x, weight, bias=None, act=None, stride=1, scale=1.0):
+        """scale * (conv(x, w) + bias) [-> leaky relu]: stride-1 'same' conv (odd square kernel) — the reference's
+        nn.Conv2d(…, padding=k//2) call sites — or the stride-2 1x1 residual conv (gp.py:1612), whose pixel
+        sub-sampling is part of the kernel's gather."""
         x = to_act(x)
-        o, i = weight.shape[0], weight.shape[1]
-        ip, op_ = _round8(i), _round8(o)
+        o, i, k = weight.shape[0], weight.shape[1], weight.shape[-1]
+        assert stride == 1 or k == 1
         xh = nhwc(x)
+        ip = _round8(i)
         if ip != i:
             xh = F.pad(xh, (0, ip - i))
-            weight = F.pad(weight, (0, 0, 0, 0, 0, ip - i))
-        if op_ != o:
-            weight = F.pad(weight, (0, 0, 0, 0, 0, 0, 0, op_ - o))
-            if bias is not None:
-                bias = F.pad(bias, (0, op_ - o))
-        y = ConvFn.apply(xh, weight, None if bias is None else bias.float().contiguous(), None, act)
-        if op_ != o:
+        geom = (k, stride, k // 2 if stride == 1 else 0, 'oihw')
+        y = ConvFn.apply(xh, weight, None if bias is None else bias.float().contiguous(), None, act, geom, float(scale),
+                         None)
+        if y.shape[-1] != o:
             y = y[..., :o]
+        return nchw(y)
+
+    def downsample(self, x, weight, bias=None, residual=None, scale=1.0):
+        """scale * (conv1x1(space_to_depth(x), w) + bias) + residual  (gp.py:289-293 and the residual merge
+        gp.py:1826): one launch of the 2x2 / stride-2 gather with the merge in its epilogue."""
+        x = to_act(x)
+        o = weight.shape[0]
+        assert weight.shape[1] == 4 * x.shape[1] and x.shape[1] % 8 == 0 and o % 8 == 0
+        res = None if residual is None else nhwc(to_act(residual))
+        y = ConvFn.apply(nhwc(x), weight, None if bias is None else bias.float().contiguous(), None, None,
+                         (2, 2, 0, 's2d'), float(scale), res)
         return nchw(y)
 
     def linear(self, x, weight, bias=None, act=None):
@@ -357,20 +495,21 @@ class HipOps:
             d = demod_coefficients(weights, s, a, eps)                  # (b, O) fp32
         Ip, Op = _round8(I), _round8(O)
         xh = nhwc(x)
-        wts = weights
-        if Ip != I:
-            xh = F.pad(xh, (0, Ip - I))
-            wts = F.pad(wts, (0, 0, 0, 0, 0, Ip - I))
-            s = F.pad(s, (0, Ip - I))
-        if Op != O:
-            wts = F.pad(wts, (0, 0, 0, 0, 0, 0, 0, Op - O))
         needs_grad = torch.is_grad_enabled() and any(
             t is not None and t.requires_grad for t in (x, weights, mod, kernel_mod, noise_weight))
+        if Ip != I:
+            xh = F.pad(xh, (0, Ip - I))
+            s = F.pad(s, (0, Ip - I))
         if not needs_grad:
+            wts = weights
+            if Ip != I:
+                wts = F.pad(wts, (0, 0, 0, 0, 0, Ip - I))
+            if Op != O:
+                wts = F.pad(wts, (0, 0, 0, 0, 0, 0, 0, Op - O))
             y = fused_modconv_forward(xh, wts, s, a, d, noise, noise_weight, act, O, Op)
             return nchw(y[..., :O] if Op != O else y)
         # training path: one conv with the N kernels stacked along output channels, then the per-sample mix
-        Y = ConvFn.apply(xh, wts.reshape(N * Op, Ip, k, k), None, s.contiguous(), None)   # (b,H,W,N*Op)
+        Y = ConvFn.apply(xh, weights, None, s.contiguous(), None, (k, 1, k // 2, 'oihw'), 1.0, None)   # (b,H,W,N*Op)
         y = (Y.view(b, H, W, N, Op).float() * a[:, None, None, :, None]).sum(dim=3)
         if Op != O:
             y = y[..., :O]

@@ -92,9 +92,18 @@ class FlatAdamW(torch.optim.Optimizer):
                                      ptr(self.flags), self.total, lr, b1, b2, eps, self.wd,
                                      1. - b1 ** t, math.sqrt(1. - b2 ** t), grad_scale, L.stream(self.flat_p))
         L.check(rc, 'gg_adamw_flat_f32')
-        for p in self._all:
-            if id(p) not in self._inactive:
-                self.state[p]['step'] = torch.tensor(float(t))
+        from . import ops
+        ops.bump_weight_epoch()      # packed bf16 copies of the parameters are stale now
+        self._steps_dirty = True
+
+    def state_dict(self):
+        # per-parameter `step` tensors (torch AdamW layout) are only materialised when somebody looks at them
+        if getattr(self, '_steps_dirty', False):
+            for p in self._all:
+                if id(p) not in self._inactive:
+                    self.state[p]['step'] = torch.tensor(float(self.step_count))
+            self._steps_dirty = False
+        return super().state_dict()
 
     def load_state_dict(self, state_dict):
         """accept a torch AdamW state dict (reference checkpoints) and copy it into the flat buffers."""

@@ -115,6 +115,13 @@ int gg_softmax_fwd(const float* x, void* S, const float* bias, int64_t rows, int
 int gg_softmax_bwd(const void* S, const void* dS, void* dx, float* dbias, int64_t rows, int32_t rows_per_batch,
                    int32_t n_valid, int32_t ld, float alpha, void* stream);
 
+/* second-order pass of the attention softmax (gradient-penalty steps differentiate gg_softmax_bwd; replaces the
+ * autograd of gp.py:584-588's backward): with gt = alpha*g_dx + g_dbias[batch] (either may be NULL = zero),
+ * r = sum_j S*dS, gs = sum_j gt*S:  g_dS = S*(gt - gs),  g_S = gt*(dS - r) - dS*gs.  All bf16 [rows][ld] except
+ * g_dbias fp32 [rows/rows_per_batch][ld]. */
+int gg_softmax_bwd2(const void* S, const void* dS, const void* g_dx, const float* g_dbias, void* g_S, void* g_dS,
+                    int64_t rows, int32_t rows_per_batch, int32_t n_valid, int32_t ld, float alpha, void* stream);
+
 /* Backward of "+bias -> leaky-relu" (nn.Conv2d bias + nn.LeakyReLU autograd, gp.py:109, :1608-1621) in one pass:
  * dz = dy * (y > 0 ? 1 : slope) when y != NULL (else dz is not written); when db != NULL, db[w][c] receives workgroup
  * w's partial column sums of dz (fp32 [gg_bias_act_bwd_partials(rows, C)][C]; the caller adds the rows up).

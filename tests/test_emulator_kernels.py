@@ -280,3 +280,38 @@ def test_strided_convs_and_depth_to_space_dgrad(tile):
     assert rel_err(dw, dw_ref) < 1e-5
     dx = K.conv2d_dgrad_d2s(dyh, w2h, cell=2, taps=2, force_tile=tile)
     assert rel_err(dx.permute(0, 3, 1, 2), xf.grad) < 4e-3
+
+
+def test_softmax_second_order_pass_matches_tensor_algebra():
+    torch.manual_seed(0)
+    nb, n, m, ld = 2, 16, 21, 24
+    S = torch.zeros(nb, n, ld); S[..., :m] = torch.randn(nb, n, m).softmax(-1)
+    S, dS, g_dx = bf(S), bf(torch.randn(nb, n, ld)), bf(torch.randn(nb, n, ld))
+    g_db = torch.randn(nb, ld)
+    alpha = 0.7
+    Sf, dSf = S.float()[..., :m], dS.float()[..., :m]
+    gt = alpha * g_dx.float()[..., :m] + g_db[:, None, :m]
+    r = (Sf * dSf).sum(-1, keepdim=True); gs = (gt * Sf).sum(-1, keepdim=True)
+    ref_gdS = Sf * (gt - gs); ref_gS = gt * (dSf - r) - dSf * gs
+    g_S, g_dS = K.softmax_bwd2(S, dS, g_dx, g_db, alpha, m)
+    assert rel_err(g_S[..., :m], ref_gS) < 4e-3 and rel_err(g_dS[..., :m], ref_gdS) < 4e-3
+    assert float(g_S[..., m:].abs().max()) == 0 and float(g_dS[..., m:].abs().max()) == 0
+    g_S, g_dS = K.softmax_bwd2(S, dS, g_dx, None, alpha, m)
+    gt = alpha * g_dx.float()[..., :m]; gs = (gt * Sf).sum(-1, keepdim=True)
+    assert rel_err(g_dS[..., :m], Sf * (gt - gs)) < 4e-3
+
+
+def test_attention_double_backward_matches_oracle():
+    """gradient-penalty pattern through the attention Functions (fused softmax fwd / bwd / second-order passes)."""
+    def run(I, l2):
+        torch.manual_seed(0)
+        q = (torch.randn(1, 2, 16, 16) * 0.5).requires_grad_(); k = (torch.randn(1, 2, 17, 16) * 0.5).requires_grad_()
+        v = torch.randn(1, 2, 17, 16).requires_grad_()
+        out = I.attention(q, k, v, scale=0.25, l2=l2).float()
+        gq, = torch.autograd.grad(out.pow(2).sum(), q, create_graph=True)
+        return torch.autograd.grad(gq.float().pow(2).sum(), [k, v])
+
+    for l2 in (False, True):
+        gh = run(ops.HipOps(), l2); go = run(OracleOps(bf16_operands=True), l2)
+        for a, b in zip(gh, go):
+            assert rel_err(a, b) < 6e-2, l2
