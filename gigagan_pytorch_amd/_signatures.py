@@ -23,3 +23,15 @@ def declare(L):
     L.gg_bias_act_bwd_partials.argtypes = [C.c_int64, _I]
     L.gg_softmax_bwd2.restype = C.c_int
     L.gg_softmax_bwd2.argtypes = [_P, _P, _P, _P, _P, _P, C.c_int64, _I, _I, _I, _F, _P]
+    L.gg_modulate_fwd.restype = C.c_int
+    L.gg_modulate_fwd.argtypes = [_P, _P, _P, _I, _I, _I, _P]
+    L.gg_modulate_bwd.restype = C.c_int
+    L.gg_modulate_bwd.argtypes = [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]
+    L.gg_modmix_fwd.restype = C.c_int
+    L.gg_modmix_fwd.argtypes = [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P]
+    L.gg_modmix_bwd.restype = C.c_int
+    L.gg_modmix_bwd.argtypes = [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]
+    L.gg_attn_fwd.restype = C.c_int
+    L.gg_attn_fwd.argtypes = [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P]
+    L.gg_attn_bwd.restype = C.c_int
+    L.gg_attn_bwd.argtypes = [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P]

@@ -4,6 +4,8 @@
 #include "gg_gemm.h"
 #include "gg_gemm2.h"
 #include "gg_elementwise.h"
+#include "gg_modconv.h"
+#include "gg_attention.h"
 #include "../../include/gigagan_amd.h"
 
 #include <stdio.h>
@@ -449,5 +451,111 @@ extern "C" int gg_bias_act_bwd(const void* dy, const void* y, void* dz, float* d
     p.dy = (const bf16_t*)dy; p.y = (const bf16_t*)y; p.dz = (bf16_t*)dz; p.db = db; p.rows = rows; p.C = C; p.slope = slope;
     long long nb = gg_bias_act_blocks(rows, C);
     GG_LAUNCH(gg_bias_act_bwd_kernel, dim3((unsigned)nb), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+// ---- adaptive-conv passes (gg_modconv.h) ------------------------------------------------------------------------
+
+extern "C" int gg_modulate_fwd(const void* x, const float* s, void* out, int32_t b, int32_t P, int32_t C, void* stream) {
+    if (!x || !s || !out) return gg_fail(-1, "gg_modulate_fwd: null pointer");
+    if (b <= 0 || P <= 0 || C <= 0 || (C % 8)) return gg_fail(-2, "gg_modulate_fwd: need positive extents and C %% 8 == 0 (C=%d)", C);
+    GgModulateParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)x; p.s = s; p.out = (bf16_t*)out; p.b = b; p.P = P; p.C = C; p.chunks = 1;
+    GG_LAUNCH(gg_modulate_kernel, dim3(gg_grid_for((long long)b * P * (C / 8))), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+extern "C" int gg_modulate_bwd(const void* g, const void* x, const float* s, void* dx, float* ds_part, int32_t b, int32_t P,
+                               int32_t C, int32_t chunks, void* stream) {
+    if (!g || !x || !s || !dx || !ds_part) return gg_fail(-1, "gg_modulate_bwd: null pointer");
+    if (b <= 0 || P <= 0 || C <= 0 || (C % 8) || chunks <= 0) return gg_fail(-2, "gg_modulate_bwd: bad extents (C=%d chunks=%d)", C, chunks);
+    GgModulateParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)x; p.g = (const bf16_t*)g; p.s = s; p.out = (bf16_t*)dx; p.ds_part = ds_part;
+    p.b = b; p.P = P; p.C = C; p.chunks = chunks;
+    GG_LAUNCH(gg_modulate_bwd_kernel, dim3((unsigned)(b * chunks)), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+static int gg_modmix_common(GgModMixParams& p, int32_t b, int32_t P, int32_t O, int32_t Os, int32_t N, int32_t act, float slope) {
+    if (b <= 0 || P <= 0 || O <= 0 || (O % 8) || Os < O || (Os % 8) || N < 1 || N > GG_MIX_MAXN)
+        return gg_fail(-2, "gg_modmix: bad extents (O=%d Os=%d N=%d)", O, Os, N);
+    if (act < 0 || act > 1) return gg_fail(-3, "gg_modmix: activation must be none (0) or leaky-relu (1)");
+    p.b = b; p.P = P; p.O = O; p.Os = Os; p.N = N; p.act = act; p.slope = slope;
+    return 0;
+}
+
+extern "C" int gg_modmix_fwd(const void* Y, const float* a, const float* d, const float* noise, const float* noise_w, void* y,
+                             int32_t b, int32_t P, int32_t O, int32_t Os, int32_t N, int32_t act, float slope, void* stream) {
+    if (!Y || !a || !y) return gg_fail(-1, "gg_modmix_fwd: null pointer");
+    if ((noise != nullptr) != (noise_w != nullptr)) return gg_fail(-1, "gg_modmix_fwd: noise and noise_w go together");
+    GgModMixParams p;
+    memset(&p, 0, sizeof(p));
+    int rc = gg_modmix_common(p, b, P, O, Os, N, act, slope);
+    if (rc) return rc;
+    p.Y = (const bf16_t*)Y; p.a = a; p.d = d; p.noise = noise; p.noise_w = noise_w; p.y = (bf16_t*)y; p.chunks = 1;
+    GG_LAUNCH(gg_modmix_fwd_kernel, dim3(gg_grid_for((long long)b * P * (O / 8))), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+extern "C" int gg_modmix_bwd(const void* dy, const void* y, const void* Y, const float* a, const float* d, const float* noise,
+                             void* dY, float* da_part, float* dd_part, float* dnw_part, int32_t b, int32_t P, int32_t O,
+                             int32_t Os, int32_t N, int32_t chunks, int32_t act, float slope, void* stream) {
+    if (!dy || !Y || !a || !dY) return gg_fail(-1, "gg_modmix_bwd: null pointer");
+    if (act == 1 && !y) return gg_fail(-1, "gg_modmix_bwd: the leaky-relu mask needs the forward output");
+    if ((d != nullptr) != (dd_part != nullptr)) return gg_fail(-1, "gg_modmix_bwd: d and dd_part go together");
+    if ((noise != nullptr) != (dnw_part != nullptr)) return gg_fail(-1, "gg_modmix_bwd: noise and dnw_part go together");
+    if (chunks <= 0) return gg_fail(-2, "gg_modmix_bwd: chunks must be positive");
+    GgModMixParams p;
+    memset(&p, 0, sizeof(p));
+    int rc = gg_modmix_common(p, b, P, O, Os, N, act, slope);
+    if (rc) return rc;
+    p.dy = (const bf16_t*)dy; p.y = (bf16_t*)y; p.Y = (const bf16_t*)Y; p.a = a; p.d = d; p.noise = noise;
+    p.dY = (bf16_t*)dY; p.da_part = da_part; p.dd_part = dd_part; p.dnw_part = dnw_part; p.chunks = chunks;
+    GG_LAUNCH(gg_modmix_bwd_kernel, dim3((unsigned)(b * chunks)), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+// ---- fused self-attention (gg_attention.h) ------------------------------------------------------------------------
+
+static int gg_attn_common(GgAttnParams& p, const void* q, const void* k, const void* v, const void* k0, const void* v0,
+                          int32_t B, int32_t n, int32_t h, float alpha, float beta) {
+    if (!q || !k || !v || !k0 || !v0) return gg_fail(-1, "gg_attn: null pointer");
+    if (B <= 0 || h <= 0 || n <= 0 || (n % 128)) return gg_fail(-2, "gg_attn: need n %% 128 == 0 tokens (got %d)", n);
+    if ((long long)B * h > 65535) return gg_fail(-2, "gg_attn: B*h exceeds grid.y");
+    if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)k0) | ((uintptr_t)v0)) & 15)
+        return gg_fail(-3, "gg_attn: operands must be 16-byte aligned");
+    memset(&p, 0, sizeof(p));
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.k0 = (const bf16_t*)k0; p.v0 = (const bf16_t*)v0;
+    p.B = B; p.n = n; p.h = h; p.alpha = alpha; p.beta = beta;
+    return 0;
+}
+
+extern "C" int gg_attn_fwd(const void* q, const void* k, const void* v, const void* k0, const void* v0, void* o, float* lse,
+                           int32_t B, int32_t n, int32_t h, float alpha, float beta, void* stream) {
+    GgAttnParams p;
+    int rc = gg_attn_common(p, q, k, v, k0, v0, B, n, h, alpha, beta);
+    if (rc) return rc;
+    if (!o || !lse) return gg_fail(-1, "gg_attn_fwd: null output");
+    p.o = (bf16_t*)o; p.lse = lse;
+    GG_LAUNCH(gg_attn_fwd_kernel, dim3((unsigned)(n / 128), (unsigned)(B * h)), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+extern "C" int gg_attn_bwd(const void* q, const void* k, const void* v, const void* k0, const void* v0, const void* o,
+                           const float* lse, const void* d_o, float* dvec, void* dq, void* dk, void* dv, float* null_part,
+                           int32_t B, int32_t n, int32_t h, float alpha, float beta, void* stream) {
+    GgAttnParams p;
+    int rc = gg_attn_common(p, q, k, v, k0, v0, B, n, h, alpha, beta);
+    if (rc) return rc;
+    if (!o || !lse || !d_o || !dvec || !dq || !dk || !dv || !null_part) return gg_fail(-1, "gg_attn_bwd: null pointer");
+    p.o = (bf16_t*)o; p.lse = (float*)lse; p.d_o = (const bf16_t*)d_o; p.dvec = dvec;
+    p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.null_part = null_part;
+    dim3 grid((unsigned)(n / 128), (unsigned)(B * h));
+    GG_LAUNCH(gg_attn_bwd_dq_kernel, grid, dim3(256), (hipStream_t)stream, p);
+    rc = gg_check_launch();
+    if (rc) return rc;
+    GG_LAUNCH(gg_attn_bwd_dkv_kernel, grid, dim3(256), (hipStream_t)stream, p);
     return gg_check_launch();
 }

@@ -1,0 +1,449 @@
+// gg_attention.h — fused (flash-style) self-attention of the GigaGAN generator / discriminator blocks
+// (reference SelfAttention.forward gp.py:538-594): heads of dimension 64 over n = H*W image tokens plus ONE learned
+// null key/value (gp.py:534, :568), dot-product similarity (generator, gp.py:574) or negative squared L2 distance
+// (discriminator, gp.py:577-580), softmax, A·V — without materialising the (b*h, n, n+1) similarity tensor
+// (4.3 GB in fp32 at the discriminator's 32x32 stage, batch 32).
+//
+// Tensors: q, k, v, o, do, dq, dk, dv are [B][n][h*64] bf16 — exactly what the 1x1 projections read and write, so no
+// head split / merge copies exist. lse, dvec are [B*h][n] fp32. k0, v0: the null key / value, [h][64] bf16.
+//
+// logits:  x_ij = alpha * q_i.k_j + beta * |k_j|^2      (dot: alpha = scale, beta = 0;
+//                                                         L2:  alpha = 2*scale, beta = -scale; the -scale*|q_i|^2 term is
+//                                                         constant along j and cancels in the softmax)
+// The null key is folded in as the initial state of the online softmax (m = x_i0, l = 1, O = v0), which keeps the
+// key loop free of ragged tiles.
+//
+// Mapping (64-lane wavefronts, v_mfma_f32_32x32x16_bf16): every contraction is issued "transposed", e.g.
+// S^T = K Q^T, so that the MFMA result leaves lane l with 16 values of ONE query (or key) — the softmax row
+// statistics are lane-local plus one exchange with lane l^32 — and the same registers are, after bf16 packing, the
+// k-contiguous B operand of the next MFMA (P^T for O^T = V^T P^T): the reduction index is simply re-labelled
+// (slot (c, hi, e) <-> row 16c + 4hi + (e&3) + 8(e>>2) of the 32-row block), which only changes which LDS rows the
+// other operand's transpose reads (ds_read_b64_tr_b16) start from. No cross-lane movement of P.
+//
+// Work per launch: forward 4*n*(n+1)*64 flops per head; backward 2.5x that, recomputing P in both backward kernels
+// (dq: 3 contractions, dk/dv: 4). HBM traffic: q, k, v, o (+ gradients) once per head.
+#pragma once
+#include "gg_device.h"
+
+#define GGA_D 64
+#define GGA_KP 72                  // bf16 pitch of row-major [row][d] tiles (144 B: conflict-free ds_read_b128)
+#define GGA_TP 192                 // byte pitch of transpose-read tiles [row][d] (4 consecutive rows -> 4 bank quarters)
+
+struct GgAttnParams {
+    const bf16_t* q;
+    const bf16_t* k;
+    const bf16_t* v;
+    const bf16_t* k0;   // [h][64]
+    const bf16_t* v0;   // [h][64]
+    bf16_t* o;          // fwd out / bwd in
+    float* lse;         // [B*h][n]  fwd out / bwd in
+    const bf16_t* d_o;  // bwd in
+    float* dvec;        // [B*h][n]  written by the dq kernel (rowsum(dO * O)), read by the dk/dv kernel
+    bf16_t* dq;
+    bf16_t* dk;
+    bf16_t* dv;
+    float* null_part;   // [blocks of the dq kernel][3][64]: partial sums of dk0 (q part), dv0, and [2][0] = dbias0
+    int B, n, h;
+    float alpha, beta;
+};
+
+// ---- fragment helpers ----------------------------------------------------------------------------------------
+
+// B-operand fragments straight from global memory: lane l -> token row0 + (l & 31), d = kk*16 + 8*(l >> 5) + 0..7
+GG_DEVICE void gga_load_frags(u16x8* f, const bf16_t* base, long long row_stride, int row0, int lane) {
+    const bf16_t* p = base + (long long)(row0 + (lane & 31)) * row_stride + 8 * (lane >> 5);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) f[kk] = *(const u16x8*)(p + kk * 16);
+}
+
+GG_DEVICE u16x8 gga_frag_rowk(const bf16_t (*tile)[GGA_KP], int row0, int kk, int lane) {
+    return *(const u16x8*)&tile[row0 + (lane & 31)][kk * 16 + 8 * (lane >> 5)];
+}
+
+// A-operand fragment of the TRANSPOSE of a [row][d] tile: lane l -> d = d0 + (l & 31), reduction slots (hi = l >> 5, e)
+// <-> rows rb + 4*hi + (e & 3) + 8*(e >> 2)   (rb = first row of the 16-row group (block, c))
+GG_DEVICE u16x8 gga_frag_tr(const char* tile, int d0, int rb, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const char* p = tile + (rb + 4 * (g >> 1) + (i >> 2)) * GGA_TP + (d0 + (g & 1) * 16 + 4 * (i & 3)) * 2;
+    u16x4 a = gg_lds_read_tr16((const bf16_t*)p);
+    u16x4 b = gg_lds_read_tr16((const bf16_t*)(p + 8 * GGA_TP));
+    u16x8 f = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return f;
+}
+
+// registers 8c .. 8c+7 of an MFMA result, packed to bf16: the lane-local B operand of the follow-up contraction
+GG_DEVICE u16x8 gga_pack8(const f32x16& v, int c) {
+    u16x8 f;
+    for (int e = 0; e < 8; ++e) f[e] = gg_f2bf(v[8 * c + e]);
+    return f;
+}
+
+// stage a 64-token x 64-d tile (tokens t0 .. t0+63 of one (batch, head)) into LDS, row-major and/or transpose-read form
+// (256 threads: thread -> token t / 4... 8 threads per token, 16 bytes each); optionally the squared norms of the rows
+GG_DEVICE void gga_stage_tile(const bf16_t* base, long long row_stride, int t0, bf16_t (*rowk)[GGA_KP], char* tr, float* sq) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int v = t + 256 * it;
+        const int row = v >> 3, c8 = v & 7;
+        u16x8 x = *(const u16x8*)(base + (long long)(t0 + row) * row_stride + c8 * 8);
+        if (rowk) *(u16x8*)&rowk[row][c8 * 8] = x;
+        if (tr) *(u16x8*)(tr + row * GGA_TP + c8 * 16) = x;
+        if (sq) {
+            float s = 0.f;
+            for (int e = 0; e < 8; ++e) { float f = gg_bf2f(x[e]); s += f * f; }
+            s += gg_shfl_xor(s, 1);
+            s += gg_shfl_xor(s, 2);
+            s += gg_shfl_xor(s, 4);
+            if (c8 == 0) sq[row] = s;
+        }
+    }
+}
+
+// the value of per-row array `arr` (LDS) at the 4 consecutive rows owned by register quad g of an MFMA result
+GG_DEVICE f32x4 gga_rows4(const float* arr, int blk, int g, int lane) {
+    return *(const f32x4*)(arr + blk * 32 + 8 * g + 4 * (lane >> 5));
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------------
+// grid: (n / 128, B*h); 256 threads; wave w owns queries q0 + 32w .. +31
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_fwd_kernel(GgAttnParams p) {
+    GG_SHARED __attribute__((aligned(16))) bf16_t sK[64][GGA_KP];
+    GG_SHARED __attribute__((aligned(16))) char sV[64 * GGA_TP];
+    GG_SHARED __attribute__((aligned(16))) float sKsq[64];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
+    const int bh = blockIdx.y, b = bh / p.h, hd = bh % p.h;
+    const long long rs = (long long)p.h * GGA_D;
+    const bf16_t* qb = p.q + (long long)b * p.n * rs + hd * GGA_D;
+    const bf16_t* kb = p.k + (long long)b * p.n * rs + hd * GGA_D;
+    const bf16_t* vb = p.v + (long long)b * p.n * rs + hd * GGA_D;
+    const int qi0 = blockIdx.x * 128 + wave * 32;
+
+    u16x8 qf[4];
+    gga_load_frags(qf, qb, rs, qi0, lane);
+
+    // null key / value: initial state of the online softmax
+    float m, l = 1.f;
+    f32x16 ot[2];
+    {
+        const bf16_t* k0 = p.k0 + hd * GGA_D;
+        float dot = 0.f, sq = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            u16x8 kv = *(const u16x8*)(k0 + kk * 16 + 8 * hi);
+            for (int e = 0; e < 8; ++e) {
+                float kf = gg_bf2f(kv[e]);
+                dot += gg_bf2f(qf[kk][e]) * kf;
+                sq += kf * kf;
+            }
+        }
+        dot += gg_shfl_xor(dot, 32);
+        sq += gg_shfl_xor(sq, 32);
+        m = p.alpha * dot + p.beta * sq;
+        const bf16_t* v0 = p.v0 + hd * GGA_D;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[db][r] = gg_bf2f(v0[db * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi]);
+    }
+
+    for (int j0 = 0; j0 < p.n; j0 += 64) {
+        gg_sync();
+        gga_stage_tile(kb, rs, j0, sK, nullptr, sKsq);
+        gga_stage_tile(vb, rs, j0, nullptr, sV, nullptr);
+        gg_sync();
+
+        f32x16 st[2];
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[jb][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) st[jb] = gg_mfma_32x32x16_bf16(gga_frag_rowk(sK, jb * 32, kk, lane), qf[kk], st[jb]);
+        }
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 ks = gga_rows4(sKsq, jb, g, lane);
+                for (int e = 0; e < 4; ++e) {
+                    float x = p.alpha * st[jb][4 * g + e] + p.beta * ks[e];
+                    st[jb][4 * g + e] = x;
+                    mx = fmaxf(mx, x);
+                }
+            }
+        mx = fmaxf(mx, gg_shfl_xor(mx, 32));
+        const float mn = fmaxf(m, mx);
+        const float corr = gg_expf(m - mn);
+        float rowsum = 0.f;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pv = gg_expf(st[jb][r] - mn);
+                st[jb][r] = pv;
+                rowsum += pv;
+            }
+        rowsum += gg_shfl_xor(rowsum, 32);
+        l = l * corr + rowsum;
+        m = mn;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[db][r] *= corr;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                u16x8 pf = gga_pack8(st[jb], c);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    ot[db] = gg_mfma_32x32x16_bf16(gga_frag_tr(sV, db * 32, jb * 32 + 16 * c, lane), pf, ot[db]);
+            }
+    }
+
+    const float inv = 1.f / l;
+    const int qi = qi0 + (lane & 31);
+    bf16_t* orow = p.o + ((long long)b * p.n + qi) * rs + hd * GGA_D;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u16x4 o4 = {gg_f2bf(ot[db][4 * g + 0] * inv), gg_f2bf(ot[db][4 * g + 1] * inv), gg_f2bf(ot[db][4 * g + 2] * inv),
+                        gg_f2bf(ot[db][4 * g + 3] * inv)};
+            *(u16x4*)(orow + db * 32 + 8 * g + 4 * hi) = o4;
+        }
+    if (hi == 0) p.lse[(long long)bh * p.n + qi] = m + logf(l);
+}
+
+// ---- backward, part 1: dq (+ rowsum(dO*O), + the null key/value partial gradients) ---------------------------------
+// grid: (n / 128, B*h); wave w owns queries q0 + 32w .. +31
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dq_kernel(GgAttnParams p) {
+    GG_SHARED __attribute__((aligned(16))) bf16_t sK[64][GGA_KP];
+    GG_SHARED __attribute__((aligned(16))) bf16_t sV[64][GGA_KP];
+    GG_SHARED __attribute__((aligned(16))) char sKt[64 * GGA_TP];
+    GG_SHARED __attribute__((aligned(16))) float sKsq[64];
+    GG_SHARED float sRed[4][3][64];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
+    const int bh = blockIdx.y, b = bh / p.h, hd = bh % p.h;
+    const long long rs = (long long)p.h * GGA_D;
+    const long long boff = (long long)b * p.n * rs + hd * GGA_D;
+    const int qi0 = blockIdx.x * 128 + wave * 32;
+    const int qi = qi0 + (lane & 31);
+
+    u16x8 qf[4], dof[4];
+    gga_load_frags(qf, p.q + boff, rs, qi0, lane);
+    gga_load_frags(dof, p.d_o + boff, rs, qi0, lane);
+    float dsum = 0.f;   // D_i = sum_d dO_i[d] * O_i[d]
+    {
+        u16x8 of[4];
+        gga_load_frags(of, p.o + boff, rs, qi0, lane);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            for (int e = 0; e < 8; ++e) dsum += gg_bf2f(dof[kk][e]) * gg_bf2f(of[kk][e]);
+        dsum += gg_shfl_xor(dsum, 32);
+    }
+    const float lse = p.lse[(long long)bh * p.n + qi];
+    if (hi == 0) p.dvec[(long long)bh * p.n + qi] = dsum;
+
+    f32x16 dqt[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqt[db][r] = 0.f;
+
+    // null key: ds0 = p0 * (dO_i . v0 - D_i); dq_i += ds0 * k0 (alpha applied at the end); partial sums for dk0 / dv0
+    {
+        const bf16_t* k0 = p.k0 + hd * GGA_D;
+        const bf16_t* v0 = p.v0 + hd * GGA_D;
+        float dot = 0.f, sq = 0.f, dp0 = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            u16x8 kv = *(const u16x8*)(k0 + kk * 16 + 8 * hi);
+            u16x8 vv = *(const u16x8*)(v0 + kk * 16 + 8 * hi);
+            for (int e = 0; e < 8; ++e) {
+                float kf = gg_bf2f(kv[e]);
+                dot += gg_bf2f(qf[kk][e]) * kf;
+                sq += kf * kf;
+                dp0 += gg_bf2f(dof[kk][e]) * gg_bf2f(vv[e]);
+            }
+        }
+        dot += gg_shfl_xor(dot, 32);
+        sq += gg_shfl_xor(sq, 32);
+        dp0 += gg_shfl_xor(dp0, 32);
+        const float p0 = gg_expf(p.alpha * dot + p.beta * sq - lse);
+        const float ds0 = p0 * (dp0 - dsum);
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dqt[db][r] = ds0 * gg_bf2f(k0[db * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi]);
+        // sums over this wave's 32 queries: dk0[d] += ds0 * q_i[d], dv0[d] += p0 * dO_i[d], dbias0 += ds0
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            for (int e = 0; e < 8; ++e) {
+                float a = ds0 * gg_bf2f(qf[kk][e]);
+                float c = p0 * gg_bf2f(dof[kk][e]);
+                for (int o = 1; o < 32; o <<= 1) { a += gg_shfl_xor(a, o); c += gg_shfl_xor(c, o); }
+                if ((lane & 31) == 0) {
+                    sRed[wave][0][kk * 16 + 8 * hi + e] = a;
+                    sRed[wave][1][kk * 16 + 8 * hi + e] = c;
+                }
+            }
+        float s0 = ds0;
+        for (int o = 1; o < 32; o <<= 1) s0 += gg_shfl_xor(s0, o);
+        if (lane == 0) sRed[wave][2][0] = s0;
+    }
+
+    for (int j0 = 0; j0 < p.n; j0 += 64) {
+        gg_sync();
+        gga_stage_tile(p.k + boff, rs, j0, sK, sKt, sKsq);
+        gga_stage_tile(p.v + boff, rs, j0, sV, nullptr, nullptr);
+        gg_sync();
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            f32x16 st, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                st = gg_mfma_32x32x16_bf16(gga_frag_rowk(sK, jb * 32, kk, lane), qf[kk], st);
+                dp = gg_mfma_32x32x16_bf16(gga_frag_rowk(sV, jb * 32, kk, lane), dof[kk], dp);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 ks = gga_rows4(sKsq, jb, g, lane);
+                for (int e = 0; e < 4; ++e) {
+                    float pv = gg_expf(p.alpha * st[4 * g + e] + p.beta * ks[e] - lse);
+                    st[4 * g + e] = pv * (dp[4 * g + e] - dsum);      // dS^T
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                u16x8 dsf = gga_pack8(st, c);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    dqt[db] = gg_mfma_32x32x16_bf16(gga_frag_tr(sKt, db * 32, jb * 32 + 16 * c, lane), dsf, dqt[db]);
+            }
+        }
+    }
+
+    bf16_t* dqrow = p.dq + ((long long)b * p.n + qi) * rs + hd * GGA_D;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u16x4 o4 = {gg_f2bf(dqt[db][4 * g + 0] * p.alpha), gg_f2bf(dqt[db][4 * g + 1] * p.alpha),
+                        gg_f2bf(dqt[db][4 * g + 2] * p.alpha), gg_f2bf(dqt[db][4 * g + 3] * p.alpha)};
+            *(u16x4*)(dqrow + db * 32 + 8 * g + 4 * hi) = o4;
+        }
+    gg_sync();
+    if (threadIdx.x < 192) {
+        const int which = threadIdx.x >> 6, d = threadIdx.x & 63;
+        float s = 0.f;
+        if (which < 2 || d == 0)
+            for (int w = 0; w < 4; ++w) s += sRed[w][which][d];
+        p.null_part[(((long long)bh * gridDim.x + blockIdx.x) * 3 + which) * 64 + d] = s;
+    }
+}
+
+// ---- backward, part 2: dk, dv ----------------------------------------------------------------------------------
+// grid: (n / 128, B*h); wave w owns keys j0 + 32w .. +31 and loops over all queries
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dkv_kernel(GgAttnParams p) {
+    GG_SHARED __attribute__((aligned(16))) bf16_t sQ[64][GGA_KP];
+    GG_SHARED __attribute__((aligned(16))) bf16_t sDO[64][GGA_KP];
+    GG_SHARED __attribute__((aligned(16))) char sQt[64 * GGA_TP];
+    GG_SHARED __attribute__((aligned(16))) char sDOt[64 * GGA_TP];
+    GG_SHARED __attribute__((aligned(16))) float sLse[64];
+    GG_SHARED __attribute__((aligned(16))) float sD[64];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
+    const int bh = blockIdx.y, b = bh / p.h, hd = bh % p.h;
+    const long long rs = (long long)p.h * GGA_D;
+    const long long boff = (long long)b * p.n * rs + hd * GGA_D;
+    const int kj0 = blockIdx.x * 128 + wave * 32;
+    const int kj = kj0 + (lane & 31);
+
+    u16x8 kf[4], vf[4];
+    gga_load_frags(kf, p.k + boff, rs, kj0, lane);
+    gga_load_frags(vf, p.v + boff, rs, kj0, lane);
+    float ksq = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        for (int e = 0; e < 8; ++e) { float f = gg_bf2f(kf[kk][e]); ksq += f * f; }
+    ksq += gg_shfl_xor(ksq, 32);
+    const float bias = p.beta * ksq;
+
+    f32x16 dkt[2], dvt[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dkt[db][r] = 0.f; dvt[db][r] = 0.f; }
+    float dbias = 0.f;
+
+    for (int i0 = 0; i0 < p.n; i0 += 64) {
+        gg_sync();
+        gga_stage_tile(p.q + boff, rs, i0, sQ, sQt, nullptr);
+        gga_stage_tile(p.d_o + boff, rs, i0, sDO, sDOt, nullptr);
+        if (threadIdx.x < 64) {
+            sLse[threadIdx.x] = p.lse[(long long)bh * p.n + i0 + threadIdx.x];
+            sD[threadIdx.x] = p.dvec[(long long)bh * p.n + i0 + threadIdx.x];
+        }
+        gg_sync();
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                s = gg_mfma_32x32x16_bf16(gga_frag_rowk(sQ, ib * 32, kk, lane), kf[kk], s);
+                dp = gg_mfma_32x32x16_bf16(gga_frag_rowk(sDO, ib * 32, kk, lane), vf[kk], dp);
+            }
+            f32x16 pr;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 ls = gga_rows4(sLse, ib, g, lane);
+                f32x4 dd = gga_rows4(sD, ib, g, lane);
+                for (int e = 0; e < 4; ++e) {
+                    float pv = gg_expf(p.alpha * s[4 * g + e] + bias - ls[e]);
+                    pr[4 * g + e] = pv;
+                    float ds = pv * (dp[4 * g + e] - dd[e]);
+                    s[4 * g + e] = ds;
+                    dbias += ds;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                u16x8 pf = gga_pack8(pr, c), dsf = gga_pack8(s, c);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    dvt[db] = gg_mfma_32x32x16_bf16(gga_frag_tr(sDOt, db * 32, ib * 32 + 16 * c, lane), pf, dvt[db]);
+                    dkt[db] = gg_mfma_32x32x16_bf16(gga_frag_tr(sQt, db * 32, ib * 32 + 16 * c, lane), dsf, dkt[db]);
+                }
+            }
+        }
+    }
+    dbias += gg_shfl_xor(dbias, 32);
+
+    // dk_j = alpha * sum_i dS_ij q_i + dbias_j * 2*beta*k_j   (d/dk of beta*|k|^2)
+    const bf16_t* krow = p.k + boff + (long long)kj * rs;
+    bf16_t* dkrow = p.dk + boff + (long long)kj * rs;
+    bf16_t* dvrow = p.dv + boff + (long long)kj * rs;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = db * 32 + 8 * g + 4 * hi;
+            u16x4 k4 = *(const u16x4*)(krow + d);
+            u16x4 dk4, dv4;
+            for (int e = 0; e < 4; ++e) {
+                dk4[e] = gg_f2bf(p.alpha * dkt[db][4 * g + e] + 2.f * p.beta * dbias * gg_bf2f(k4[e]));
+                dv4[e] = gg_f2bf(dvt[db][4 * g + e]);
+            }
+            *(u16x4*)(dkrow + d) = dk4;
+            *(u16x4*)(dvrow + d) = dv4;
+        }
+}

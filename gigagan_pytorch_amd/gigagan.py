@@ -406,11 +406,15 @@ class GigaGAN(nn.Module):
             for rgb in rgbs:
                 rgb.requires_grad_()
 
-        fake_logits, fake_ms_logits, _ = self.D(images, rgbs, **maybe_text_kwargs,
-                                                return_multiscale_outputs=calc_multiscale_loss, calc_aux_loss=False)
-        real_logits, real_ms_logits, aux_recon_losses = self.D(real_images, real_images_rgbs, **maybe_text_kwargs,
-                                                               return_multiscale_outputs=calc_multiscale_loss,
-                                                               calc_aux_loss=True)
+        ops.second_order = bool(apply_gradient_penalty)    # these graphs are differentiated twice
+        try:
+            fake_logits, fake_ms_logits, _ = self.D(images, rgbs, **maybe_text_kwargs,
+                                                    return_multiscale_outputs=calc_multiscale_loss, calc_aux_loss=False)
+            real_logits, real_ms_logits, aux_recon_losses = self.D(real_images, real_images_rgbs, **maybe_text_kwargs,
+                                                                   return_multiscale_outputs=calc_multiscale_loss,
+                                                                   calc_aux_loss=True)
+        finally:
+            ops.second_order = False
 
         zero = torch.zeros((), device=dev)
         divergence = discriminator_hinge_loss(real_logits, fake_logits)

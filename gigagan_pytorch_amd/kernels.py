@@ -442,3 +442,110 @@ def bias_act_bwd(dy: torch.Tensor, y, want_db: bool, slope: float = 0.2):
     rc = L.lib.gg_bias_act_bwd(ptr(dy), ptr(y), ptr(dz), ptr(part), rows, Cc, slope, L.stream(dy))
     L.check(rc, 'gg_bias_act_bwd')
     return (dz if dz is not None else dy), (part.sum(0) if part is not None else None)
+
+
+# --------------------------------------------------------------------------------------------------
+# the bf16 passes around the adaptive convolution (gg_modconv.h)
+# --------------------------------------------------------------------------------------------------
+
+def _chunks(P: int, C: int) -> int:
+    """workgroups per image for the per-image reductions: ~4096 16-byte vectors each, at most 64."""
+    return max(1, min(64, (P * (C // 8) + 4095) // 4096))
+
+
+def modulate(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    """x (b, H, W, C) bf16 * s (b, C) fp32 -> bf16."""
+    L = _C.lib()
+    L.require(x, s)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and s.dtype == torch.float32 and s.is_contiguous()
+    b, H, W, Cc = x.shape
+    assert s.shape == (b, Cc)
+    out = torch.empty_like(x)
+    rc = L.lib.gg_modulate_fwd(ptr(x), ptr(s), ptr(out), b, H * W, Cc, L.stream(x))
+    L.check(rc, 'gg_modulate_fwd')
+    return out
+
+
+def modulate_bwd(g: torch.Tensor, x: torch.Tensor, s: torch.Tensor):
+    """returns (dx = g*s bf16, ds (b, C) fp32 = sum over pixels of g*x)."""
+    L = _C.lib()
+    L.require(g, x, s)
+    assert g.dtype == torch.bfloat16 and g.is_contiguous() and x.is_contiguous() and g.shape == x.shape
+    b, H, W, Cc = x.shape
+    ch = _chunks(H * W, Cc)
+    dx = torch.empty_like(x)
+    part = torch.empty((b, ch, Cc), dtype=torch.float32, device=x.device)
+    rc = L.lib.gg_modulate_bwd(ptr(g), ptr(x), ptr(s), ptr(dx), ptr(part), b, H * W, Cc, ch, L.stream(x))
+    L.check(rc, 'gg_modulate_bwd')
+    return dx, (part.sum(1) if ch > 1 else part[:, 0])
+
+
+def modmix_fwd(Y: torch.Tensor, a: torch.Tensor, d, noise, noise_w, O: int, N: int, act):
+    """Y (b, H, W, N*Os) bf16 -> y (b, H, W, O) bf16 = act(d * sum_n a_n Y_n + noise_w * noise)."""
+    L = _C.lib()
+    L.require(Y, a, d, noise, noise_w)
+    assert Y.dtype == torch.bfloat16 and Y.is_contiguous()
+    b, H, W, tot = Y.shape
+    Os = tot // N
+    y = torch.empty((b, H, W, O), dtype=torch.bfloat16, device=Y.device)
+    rc = L.lib.gg_modmix_fwd(ptr(Y), ptr(a), ptr(d), ptr(noise), ptr(noise_w), ptr(y), b, H * W, O, Os, N,
+                             1 if act == 'lrelu' else 0, 0.2, L.stream(Y))
+    L.check(rc, 'gg_modmix_fwd')
+    return y
+
+
+def modmix_bwd(dy: torch.Tensor, y, Y: torch.Tensor, a: torch.Tensor, d, noise, O: int, N: int, act):
+    """returns (dY like Y, da (b, N) or None, dd (b, O) or None, dnw (O,) or None)."""
+    L = _C.lib()
+    L.require(dy, y, Y, a, d, noise)
+    assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and Y.is_contiguous()
+    b, H, W, tot = Y.shape
+    Os = tot // N
+    ch = _chunks(H * W, O)
+    dev = Y.device
+    dY = torch.empty_like(Y) if Os == O else torch.zeros_like(Y)
+    da = torch.empty((b, ch, N), dtype=torch.float32, device=dev) if N > 1 else None
+    dd = torch.empty((b, ch, O), dtype=torch.float32, device=dev) if d is not None else None
+    dnw = torch.empty((b, ch, O), dtype=torch.float32, device=dev) if noise is not None else None
+    rc = L.lib.gg_modmix_bwd(ptr(dy), ptr(y), ptr(Y), ptr(a), ptr(d), ptr(noise), ptr(dY), ptr(da), ptr(dd), ptr(dnw),
+                             b, H * W, O, Os, N, ch, 1 if act == 'lrelu' else 0, 0.2, L.stream(Y))
+    L.check(rc, 'gg_modmix_bwd')
+    return (dY, None if da is None else da.sum(1), None if dd is None else dd.sum(1),
+            None if dnw is None else dnw.sum((0, 1)))
+
+
+# --------------------------------------------------------------------------------------------------
+# fused self-attention (gg_attention.h)
+# --------------------------------------------------------------------------------------------------
+
+def attn_fwd(q, k, v, k0, v0, heads: int, alpha: float, beta: float):
+    """q, k, v (B, n, heads*64) bf16; k0, v0 (heads, 64) bf16 -> (o (B, n, heads*64) bf16, lse (B*heads, n) fp32)."""
+    L = _C.lib()
+    L.require(q, k, v, k0, v0)
+    for t in (q, k, v, k0, v0):
+        assert t.dtype == torch.bfloat16 and t.is_contiguous()
+    B, n, hd = q.shape
+    assert hd == heads * 64 and k.shape == q.shape and v.shape == q.shape and k0.shape == (heads, 64)
+    o = torch.empty_like(q)
+    lse = torch.empty((B * heads, n), dtype=torch.float32, device=q.device)
+    rc = L.lib.gg_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(k0), ptr(v0), ptr(o), ptr(lse), B, n, heads, alpha, beta, L.stream(q))
+    L.check(rc, 'gg_attn_fwd')
+    return o, lse
+
+
+def attn_bwd(q, k, v, k0, v0, o, lse, d_o, heads: int, alpha: float, beta: float):
+    """returns (dq, dk, dv bf16 like q; dk0_q (heads, 64) fp32 = alpha * sum dS_i0 q_i; dv0 (heads, 64) fp32;
+    dbias0 (heads,) fp32 = sum dS_i0)."""
+    L = _C.lib()
+    L.require(q, k, v, k0, v0, o, lse, d_o)
+    B, n, hd = q.shape
+    assert d_o.dtype == torch.bfloat16 and d_o.is_contiguous() and d_o.shape == q.shape
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    dvec = torch.empty_like(lse)
+    nblk = n // 128
+    part = torch.empty((B, heads, nblk, 3, 64), dtype=torch.float32, device=q.device)
+    rc = L.lib.gg_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(k0), ptr(v0), ptr(o), ptr(lse), ptr(d_o), ptr(dvec), ptr(dq), ptr(dk),
+                           ptr(dv), ptr(part), B, n, heads, alpha, beta, L.stream(q))
+    L.check(rc, 'gg_attn_bwd')
+    s = part.sum(dim=(0, 2))                 # (heads, 3, 64)
+    return dq, dk, dv, s[:, 0] * alpha, s[:, 1], s[:, 2, 0]

@@ -228,6 +228,18 @@ def _heads(t, h):
     return t.reshape(b, h, c // h, x * y).transpose(2, 3)
 
 
+def self_attention_unfused(impl, q, k, v, null_kv, heads, scale, l2):
+    """reference data flow of SelfAttention.forward (gp.py:562-592): split heads, prepend the null key / value,
+    similarity -> softmax -> aggregate (through `impl.attention`), merge heads."""
+    b, _, x, y = q.shape
+    q, k, v = (_heads(t, heads) for t in (q, k, v))
+    nk, nv = (t[None, :, None, :].expand(b, -1, -1, -1).to(q.dtype) for t in null_kv)
+    k = torch.cat((nk, k), dim=2)
+    v = torch.cat((nv, v), dim=2)
+    out = impl.attention(q, k, v, scale=scale, l2=l2)
+    return out.transpose(2, 3).reshape(b, -1, x, y)
+
+
 class SelfAttention(nn.Module):
     def __init__(self, dim, dim_head=64, heads=8, dot_product=False):
         super().__init__()
@@ -248,12 +260,7 @@ class SelfAttention(nn.Module):
         fmap = self.norm(fmap)
         q, v = self.to_q(fmap), self.to_v(fmap)
         k = self.to_k(fmap) if exists(self.to_k) else q
-        q, k, v = (_heads(t, h) for t in (q, k, v))
-        nk, nv = (t[None, :, None, :].expand(b, -1, -1, -1).to(q.dtype) for t in self.null_kv)
-        k = torch.cat((nk, k), dim=2)
-        v = torch.cat((nv, v), dim=2)
-        out = ops.impl.attention(q, k, v, scale=self.scale, l2=not self.dot_product)
-        out = out.transpose(2, 3).reshape(b, -1, x, y)
+        out = ops.impl.self_attention(q, k, v, self.null_kv, heads=h, scale=self.scale, l2=not self.dot_product)
         return self.to_out(out)
 
 

@@ -24,6 +24,7 @@ from . import kernels as K
 
 ACT_DTYPE = torch.bfloat16
 LRELU_SLOPE = 0.2
+second_order = False   # set (by the trainer) while a graph that will be differentiated twice is being built
 
 
 # --------------------------------------------------------------------------------------------------
@@ -285,6 +286,66 @@ class WgradFn(Function):
         return dx, ddy, None, None, None, None
 
 
+class ModulateFn(Function):
+    """xs = x * s[b, :] (the weight modulation `weights * (mod + 1)` of gp.py:394-396 moved onto the activation);
+    backward in one pass: dx = g * s and ds = sum over pixels of g * x. First order only (generator path)."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.save_for_backward(x, s)
+        return K.modulate(x, s)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, s = ctx.saved_tensors
+        dx, ds = K.modulate_bwd(g.contiguous(), x, s)
+        return (dx if ctx.needs_input_grad[0] else None), (ds if ctx.needs_input_grad[1] else None)
+
+
+class ModMixFn(Function):
+    """y = act(d[b,o] * sum_n a[b,n] * Y[..., n*Os + o] + noise_w[o] * noise[b,p]) — the per-sample kernel mix,
+    demodulation, noise and leaky-relu after the stacked conv — one bf16 pass forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, Y, a, d, noise, noise_w, O, N, act):
+        y = K.modmix_fwd(Y, a, d, noise, noise_w, O, N, act)
+        ctx.cfg = (O, N, act)
+        ctx.save_for_backward(Y, a, d, noise, y if act else None)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        Y, a, d, noise, y = ctx.saved_tensors
+        O, N, act = ctx.cfg
+        dY, da, dd, dnw = K.modmix_bwd(dy.contiguous(), y, Y, a, d, noise, O, N, act)
+        return dY, (da if N > 1 else None), dd, None, dnw, None, None, None
+
+
+class FlashAttnFn(Function):
+    """fused self-attention over [B][n][heads*64] projections with the learned null key / value (gg_attention.h):
+    forward saves only o and the per-query log-sum-exp; backward = two kernels (dq; dk/dv) that recompute P.
+    First order only: graphs that are differentiated twice (gradient penalty) use the unfused Functions."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, k0, v0, heads, alpha, beta):
+        k0b, v0b = k0.to(ACT_DTYPE).contiguous(), v0.to(ACT_DTYPE).contiguous()
+        o, lse = K.attn_fwd(q, k, v, k0b, v0b, heads, alpha, beta)
+        ctx.cfg = (heads, alpha, beta)
+        ctx.save_for_backward(q, k, v, k0b, v0b, o, lse)
+        return o
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_o):
+        q, k, v, k0b, v0b, o, lse = ctx.saved_tensors
+        heads, alpha, beta = ctx.cfg
+        dq, dk, dv, dk0q, dv0, dbias0 = K.attn_bwd(q, k, v, k0b, v0b, o, lse, d_o.contiguous(), heads, alpha, beta)
+        dk0 = dk0q + (2.0 * beta) * dbias0[:, None] * k0b.float()
+        return dq, dk, dv, dk0, dv0, None, None, None
+
+
 class GemmFn(Function):
     """out[b][r][c] = act(alpha * sum_t X[b](r,t) * Y[b](c,t) + bias[c]).
 
@@ -508,8 +569,24 @@ class HipOps:
                 wts = F.pad(wts, (0, 0, 0, 0, 0, 0, 0, Op - O))
             y = fused_modconv_forward(xh, wts, s, a, d, noise, noise_weight, act, O, Op)
             return nchw(y[..., :O] if Op != O else y)
-        # training path: one conv with the N kernels stacked along output channels, then the per-sample mix
-        Y = ConvFn.apply(xh, weights, None, s.contiguous(), None, (k, 1, k // 2, 'oihw'), 1.0, None)   # (b,H,W,N*Op)
+        # training path: modulate -> ONE conv with the N kernels stacked along output channels -> mix/demod/noise/act
+        geom = (k, 1, k // 2, 'oihw')
+        if not second_order:
+            xs = ModulateFn.apply(xh, s.contiguous())
+            Y = ConvFn.apply(xs, weights, None, None, None, geom, 1.0, None)              # (b, H, W, N*Op)
+            if N == 1 and d is None and noise is None and act is None:
+                y = Y
+            else:
+                d8 = None if d is None else (F.pad(d, (0, Op - O)) if Op != O else d).contiguous()
+                nz = nw = None
+                if noise is not None:
+                    nz = noise.reshape(b, H * W).float().contiguous()
+                    nw = noise_weight.reshape(-1).float()
+                    nw = (F.pad(nw, (0, Op - O)) if Op != O else nw).contiguous()
+                y = ModMixFn.apply(Y, a.contiguous(), d8, nz, nw, Op, N, act)
+            return nchw(y[..., :O] if Op != O else y)
+        # twice-differentiable variant (a modulated conv inside a gradient-penalty graph: text-conditional predictor)
+        Y = ConvFn.apply(xh, weights, None, s.contiguous(), None, geom, 1.0, None)
         y = (Y.view(b, H, W, N, Op).float() * a[:, None, None, :, None]).sum(dim=3)
         if Op != O:
             y = y[..., :O]
@@ -549,6 +626,18 @@ class HipOps:
         attn = AttnProbsFn.apply(q2, k2, None if bias is None else bias.contiguous(), alpha, m)   # bf16 (BH, n, mp)
         out = GemmFn.apply(attn, v2, True, False, (n, dh, mp), None, None, 1.0, False)  # (BH, n, dh)
         return out.reshape(B, h, n, dh)
+
+    def self_attention(self, q, k, v, null_kv, *, heads, scale, l2):
+        """SelfAttention.forward after the projections (gp.py:562-592); q, k, v logical (b, heads*d, x, y)."""
+        b, c, x, y = q.shape
+        n = x * y
+        if c == heads * 64 and n % 128 == 0 and not second_order:
+            qh, kh, vh = (nhwc(to_act(t)).view(b, n, c) for t in (q, k, v))
+            alpha, beta = (2.0 * scale, -scale) if l2 else (scale, 0.0)
+            o = FlashAttnFn.apply(qh, kh, vh, null_kv[0], null_kv[1], heads, alpha, beta)
+            return nchw(o.view(b, x, y, c))
+        from .modules import self_attention_unfused
+        return self_attention_unfused(self, q, k, v, null_kv, heads, scale, l2)
 
     # -- norms / resampling ------------------------------------------------------------------------
     def channel_rmsnorm(self, x, gamma):

@@ -130,6 +130,41 @@ int32_t gg_bias_act_bwd_partials(int64_t rows, int32_t C);
 int gg_bias_act_bwd(const void* dy, const void* y, void* dz, float* db, int64_t rows, int32_t C, float slope,
                     void* stream);
 
+/* ---- the bf16 passes around the adaptive / style-modulated convolution (AdaptiveConv2DMod.forward gp.py:344-409,
+ * Noise gp.py:925-940, leaky_relu gp.py:109) in its batched form
+ *     y[b] = act( d[b,o] * sum_n a[b,n] * conv(W_n, x[b] * s[b,:]) + noise_w[o] * noise[b,p] ).
+ * Activations are [b][P pixels][C] bf16, C %% 8 == 0; per-image reductions come back as per-workgroup partial sums
+ * [b][chunks][...] (the caller sums over `chunks`). */
+/* xs = x * s[b,:]  (the weight modulation of gp.py:394-396 moved onto the activation). */
+int gg_modulate_fwd(const void* x, const float* s, void* out, int32_t b, int32_t P, int32_t C, void* stream);
+/* dx = g * s[b,:],  ds_part[b][chunk][c] = partial sums over pixels of g * x. */
+int gg_modulate_bwd(const void* g, const void* x, const float* s, void* dx, float* ds_part, int32_t b, int32_t P, int32_t C,
+                    int32_t chunks, void* stream);
+/* y = act(d[b,o] * sum_n a[b,n] * Y[b][p][n*Os + o] + noise_w[o] * noise[b][p]); d / noise optional; act 0 none, 1 leaky
+ * relu; N <= 4 stacked kernels with per-kernel pitch Os >= O. */
+int gg_modmix_fwd(const void* Y, const float* a, const float* d, const float* noise, const float* noise_w, void* y, int32_t b,
+                  int32_t P, int32_t O, int32_t Os, int32_t N, int32_t act, float slope, void* stream);
+/* gradient of gg_modmix_fwd: dz = dy * act'(y); dY[b][p][n*Os + o] = a[b,n] * d[b,o] * dz; partial sums
+ * da_part[b][chunk][n] = sum dz * d * Y_n, dd_part[b][chunk][o] = sum_p dz * sum_n a_n Y_n (iff d), dnw_part[b][chunk][o] =
+ * sum_p dz * noise (iff noise). */
+int gg_modmix_bwd(const void* dy, const void* y, const void* Y, const float* a, const float* d, const float* noise, void* dY,
+                  float* da_part, float* dd_part, float* dnw_part, int32_t b, int32_t P, int32_t O, int32_t Os, int32_t N,
+                  int32_t chunks, int32_t act, float slope, void* stream);
+
+/* ---- fused self-attention (replaces SelfAttention.forward's einsum / softmax / einsum, gp.py:573-590, and its autograd)
+ * q, k, v, o, d_o, dq, dk, dv: [B][n][h*64] bf16 (the layout the 1x1 projections produce / consume), head dim 64,
+ * n %% 128 == 0; k0, v0: the learned null key / value [h][64] bf16 (gp.py:534, :568), prepended to every sequence;
+ * logits x_ij = alpha * q_i.k_j + beta * |k_j|^2  (dot product: alpha = scale, beta = 0; squared-L2 distance:
+ * alpha = 2*scale, beta = -scale); lse: [B*h][n] fp32 log-sum-exp of each query's logits (saved for the backward).
+ * gg_attn_bwd also needs dvec [B*h][n] fp32 scratch and returns the null token's partial gradients in
+ * null_part [B*h * n/128][3][64] fp32: [0] = sum_i dS_i0 q_i (multiply by alpha), [1] = sum_i P_i0 dO_i (= dv0),
+ * [2][0] = sum_i dS_i0 (d/d bias0); the caller sums over blocks and batch. */
+int gg_attn_fwd(const void* q, const void* k, const void* v, const void* k0, const void* v0, void* o, float* lse, int32_t B,
+                int32_t n, int32_t h, float alpha, float beta, void* stream);
+int gg_attn_bwd(const void* q, const void* k, const void* v, const void* k0, const void* v0, const void* o, const float* lse,
+                const void* d_o, float* dvec, void* dq, void* dk, void* dv, float* null_part, int32_t B, int32_t n, int32_t h,
+                float alpha, float beta, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -315,3 +315,65 @@ def test_attention_double_backward_matches_oracle():
         gh = run(ops.HipOps(), l2); go = run(OracleOps(bf16_operands=True), l2)
         for a, b in zip(gh, go):
             assert rel_err(a, b) < 6e-2, l2
+
+
+def test_adaptive_conv_training_path_all_gradients():
+    """modulate -> stacked conv -> mix/demod/noise/lrelu Functions: every input gradient against the oracle."""
+    torch.manual_seed(0)
+    H_, O_ = ops.HipOps(), OracleOps(bf16_operands=True)
+    x = torch.randn(2, 16, 6, 6); w = torch.randn(2, 24, 16, 3, 3) * 0.1; mod = torch.randn(2, 16) * 0.5
+    km = torch.randn(2, 2); nz = torch.randn(2, 1, 6, 6); nw = torch.randn(24, 1, 1) * 0.5
+
+    def run(I):
+        ins = [t.clone().requires_grad_() for t in (x, w, mod, km, nw)]
+        y = I.modconv2d(ins[0], ins[1], ins[2], ins[3], noise=nz, noise_weight=ins[4], act='lrelu')
+        g = torch.autograd.grad(y.float(), ins, torch.ones_like(y.float()) * torch.linspace(-1, 1, y.numel()).view_as(y))
+        return y, g
+
+    yh, gh = run(H_); yo, go = run(O_)
+    assert rel_err(yh, yo) < 2e-2
+    for a, b, name in zip(gh, go, ('x', 'weights', 'mod', 'kernel_mod', 'noise_weight')):
+        assert rel_err(a, b) < 5e-2, name
+    # toRGB: single kernel, 1x1, no demodulation, 3 output channels
+    wr = torch.randn(1, 3, 16, 1, 1) * 0.1
+
+    def run_rgb(I):
+        ins = [t.clone().requires_grad_() for t in (x, wr, mod)]
+        y = I.modconv2d(ins[0], ins[1], ins[2], None, demod=False)
+        return y, torch.autograd.grad(y.float().pow(2).sum(), ins)
+
+    yh, gh = run_rgb(H_); yo, go = run_rgb(O_)
+    assert rel_err(yh, yo) < 2e-2
+    for a, b in zip(gh, go):
+        assert rel_err(a, b) < 5e-2
+
+
+@pytest.mark.parametrize('l2', [False, True])
+def test_fused_attention_forward_backward_vs_reference(l2):
+    """flash-style attention kernels (null key/value folded into the online-softmax state) vs plain tensor algebra."""
+    torch.manual_seed(0)
+    B, n, h = 1, 128, 2
+    scale = 64 ** -0.5
+    q = bf(torch.randn(B, n, h * 64) * 0.7); v = bf(torch.randn(B, n, h * 64))
+    k = q.clone() if l2 else bf(torch.randn(B, n, h * 64) * 0.7)
+    k0 = bf(torch.randn(h, 64) * 0.7); v0 = bf(torch.randn(h, 64))
+    alpha, beta = (2 * scale, -scale) if l2 else (scale, 0.)
+    d_o = bf(torch.randn(B, n, h * 64))
+
+    def ref(q, k, v, k0, v0):
+        qh, kh, vh = (t.view(B, n, h, 64).permute(0, 2, 1, 3) for t in (q, k, v))          # (B,h,n,64)
+        kk = torch.cat((k0[None, :, None, :].expand(B, -1, -1, -1), kh), 2)
+        vv = torch.cat((v0[None, :, None, :].expand(B, -1, -1, -1), vh), 2)
+        x = alpha * qh @ kk.transpose(-1, -2) + beta * (kk * kk).sum(-1)[:, :, None, :]
+        o = x.softmax(-1) @ vv
+        return o.permute(0, 2, 1, 3).reshape(B, n, h * 64), x.logsumexp(-1).reshape(B * h, n)
+
+    ins = [t.float().requires_grad_() for t in (q, k, v, k0, v0)]
+    o_ref, lse_ref = ref(*ins)
+    g = torch.autograd.grad(o_ref, ins, d_o.float())
+    o, lse = K.attn_fwd(q, k, v, k0, v0, h, alpha, beta)
+    assert rel_err(o, o_ref) < 6e-3 and rel_err(lse, lse_ref) < 1e-4
+    dq, dk, dv, dk0q, dv0, dbias0 = K.attn_bwd(q, k, v, k0, v0, o, lse, d_o, h, alpha, beta)
+    assert rel_err(dq, g[0]) < 2e-2 and rel_err(dk, g[1]) < 2e-2 and rel_err(dv, g[2]) < 2e-2
+    dk0 = dk0q + 2 * beta * dbias0[:, None] * k0.float()
+    assert rel_err(dk0, g[3]) < 2e-2 and rel_err(dv0, g[4]) < 2e-2

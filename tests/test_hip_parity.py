@@ -127,6 +127,38 @@ def test_strided_convs_and_depth_to_space_vs_cpu_oracle():
     assert rel_err(dx.cpu().permute(0, 3, 1, 2), xf.grad) < BF16_TOL
 
 
+@pytest.mark.parametrize('cfg', [(2, 1024, 8, True), (4, 256, 8, False), (1, 1024, 2, False)])
+def test_fused_attention_vs_cpu_reference(cfg):
+    """flash-style attention kernels at the model's shapes against fp32 tensor algebra on the same bf16 inputs."""
+    B, n, h, l2 = cfg
+    torch.manual_seed(0)
+    scale = 64 ** -0.5
+    q = bf(torch.randn(B, n, h * 64) * 0.7); v = bf(torch.randn(B, n, h * 64))
+    k = q.clone() if l2 else bf(torch.randn(B, n, h * 64) * 0.7)
+    k0 = bf(torch.randn(h, 64) * 0.7); v0 = bf(torch.randn(h, 64))
+    alpha, beta = (2 * scale, -scale) if l2 else (scale, 0.)
+    d_o = bf(torch.randn(B, n, h * 64))
+
+    def ref(q, k, v, k0, v0):
+        qh, kh, vh = (t.view(B, n, h, 64).permute(0, 2, 1, 3) for t in (q, k, v))
+        kk = torch.cat((k0[None, :, None, :].expand(B, -1, -1, -1), kh), 2)
+        vv = torch.cat((v0[None, :, None, :].expand(B, -1, -1, -1), vh), 2)
+        x = alpha * qh @ kk.transpose(-1, -2) + beta * (kk * kk).sum(-1)[:, :, None, :]
+        return (x.softmax(-1) @ vv).permute(0, 2, 1, 3).reshape(B, n, h * 64), x.logsumexp(-1).reshape(B * h, n)
+
+    ins = [t.float().requires_grad_() for t in (q, k, v, k0, v0)]
+    o_ref, lse_ref = ref(*ins)
+    g = torch.autograd.grad(o_ref, ins, d_o.float())
+    d = dev()
+    qd, kd, vd, k0d, v0d, dod = (t.to(d) for t in (q, k, v, k0, v0, d_o))
+    o, lse = K.attn_fwd(qd, kd, vd, k0d, v0d, h, alpha, beta)
+    assert rel_err(o.cpu(), o_ref) < 6e-3 and rel_err(lse.cpu(), lse_ref) < 1e-4
+    dq, dk, dv, dk0q, dv0, dbias0 = K.attn_bwd(qd, kd, vd, k0d, v0d, o, lse, dod, h, alpha, beta)
+    assert rel_err(dq.cpu(), g[0]) < 2e-2 and rel_err(dk.cpu(), g[1]) < 2e-2 and rel_err(dv.cpu(), g[2]) < 2e-2
+    dk0 = dk0q.cpu() + 2 * beta * dbias0.cpu()[:, None] * k0.float()
+    assert rel_err(dk0, g[3]) < 2e-2 and rel_err(dv0.cpu(), g[4]) < 2e-2
+
+
 def test_ops_match_reference_golden_fixture():
     fx = torch.load(GOLD / 'ops_small.pt', weights_only=False)
     H_ = ops.HipOps()
