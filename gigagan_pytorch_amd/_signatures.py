@@ -35,3 +35,11 @@ def declare(L):
     L.gg_attn_fwd.argtypes = [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P]
     L.gg_attn_bwd.restype = C.c_int
     L.gg_attn_bwd.argtypes = [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P]
+    L.gg_rmsnorm_blocks.restype = C.c_int32
+    L.gg_rmsnorm_blocks.argtypes = [C.c_int64]
+    L.gg_rmsnorm_fwd.restype = C.c_int
+    L.gg_rmsnorm_fwd.argtypes = [_P, _P, _P, C.c_int64, _I, _F, _P]
+    L.gg_rmsnorm_bwd.restype = C.c_int
+    L.gg_rmsnorm_bwd.argtypes = [_P, _P, _P, _P, _P, C.c_int64, _I, _F, _P]
+    L.gg_rmsnorm_bwd2.restype = C.c_int
+    L.gg_rmsnorm_bwd2.argtypes = [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _I, _F, _P]

@@ -559,3 +559,44 @@ extern "C" int gg_attn_bwd(const void* q, const void* k, const void* v, const vo
     GG_LAUNCH(gg_attn_bwd_dkv_kernel, grid, dim3(256), (hipStream_t)stream, p);
     return gg_check_launch();
 }
+
+// ---- ChannelRMSNorm passes ------------------------------------------------------------------------------------------
+
+static int gg_rms_launch(int mode, const void* x, const void* g, const void* v, const float* gamma, void* out0, void* out1,
+                         float* dgamma_part, int64_t rows, int32_t C, int32_t blocks, float eps, void* stream) {
+    if (!x || !gamma || !out0) return gg_fail(-1, "gg_rmsnorm: null pointer");
+    if (rows <= 0 || C <= 0 || (C % 8) || C > 512 * GG_RMS_MAXV) return gg_fail(-2, "gg_rmsnorm: need C %% 8 == 0 and C <= %d (C=%d)", 512 * GG_RMS_MAXV, C);
+    if (blocks <= 0) return gg_fail(-2, "gg_rmsnorm: blocks must be positive");
+    GgRmsParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)x; p.g = (const bf16_t*)g; p.v = (const bf16_t*)v; p.gamma = gamma;
+    p.out0 = (bf16_t*)out0; p.out1 = (bf16_t*)out1; p.dgamma_part = dgamma_part; p.rows = rows; p.C = C; p.eps = eps;
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 0) GG_LAUNCH(gg_rmsnorm_kernel<0>, dim3((unsigned)blocks), dim3(256), s, p);
+    else if (mode == 1) GG_LAUNCH(gg_rmsnorm_kernel<1>, dim3((unsigned)blocks), dim3(256), s, p);
+    else GG_LAUNCH(gg_rmsnorm_kernel<2>, dim3((unsigned)blocks), dim3(256), s, p);
+    return gg_check_launch();
+}
+
+extern "C" int32_t gg_rmsnorm_blocks(int64_t rows) {
+    long long nb = (rows + 15) / 16;     // >= 4 rows per wavefront
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    return (int32_t)nb;
+}
+
+extern "C" int gg_rmsnorm_fwd(const void* x, const float* gamma, void* y, int64_t rows, int32_t C, float eps, void* stream) {
+    return gg_rms_launch(0, x, nullptr, nullptr, gamma, y, nullptr, nullptr, rows, C, gg_rmsnorm_blocks(rows), eps, stream);
+}
+
+extern "C" int gg_rmsnorm_bwd(const void* x, const void* g, const float* gamma, void* dx, float* dgamma_part, int64_t rows,
+                              int32_t C, float eps, void* stream) {
+    if (!g) return gg_fail(-1, "gg_rmsnorm_bwd: null gradient");
+    return gg_rms_launch(1, x, g, nullptr, gamma, dx, nullptr, dgamma_part, rows, C, gg_rmsnorm_blocks(rows), eps, stream);
+}
+
+extern "C" int gg_rmsnorm_bwd2(const void* x, const void* g, const void* v, const float* gamma, void* gx, void* gg,
+                               float* dgamma_part, int64_t rows, int32_t C, float eps, void* stream) {
+    if (!g || !v || !gg) return gg_fail(-1, "gg_rmsnorm_bwd2: null pointer");
+    return gg_rms_launch(2, x, g, v, gamma, gx, gg, dgamma_part, rows, C, gg_rmsnorm_blocks(rows), eps, stream);
+}

@@ -406,3 +406,113 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_bias_act_bwd_kernel(GgBiasActBwdParams p
         }
     }
 }
+
+// ---- ChannelRMSNorm (gp.py:224-232): y = x / max(|x|, eps) * sqrt(C) * gamma over the channel axis ---------------
+// NHWC makes the reduction contiguous: one wavefront per pixel row, 8 channels (16 bytes) per lane per pass, fp32
+// statistics. Three passes exist because gradient-penalty steps differentiate the backward as well:
+//   fwd :  y = s/n * x * gamma                                   (n = max(|x|, eps), s = sqrt(C))
+//   bwd :  h = gamma*g;  dx = s/n * (h - u (u.h)),  dgamma[c] += s/n * x_c * g_c        (u = x/n; eps branch: dx = s/eps*h)
+//   bwd2:  for an incoming v (gradient w.r.t. dx):   gg = gamma * s/n * (v - u (u.v)),   dgamma[c] += g_c * s/n * (v - u (u.v))_c
+//          gx = -s/n^2 * ( u (v.h - (u.v)(u.h)) + (u.h) (v - u (u.v)) + (u.v) (h - u (u.h)) )
+// replacing ~10 (fwd+bwd) and ~40 (second order) fp32 tensor-algebra passes. 2 B read + 2 B written per element (fwd).
+#define GG_RMS_MAXV 4   // up to 4 x 512 = 2048 channels
+
+struct GgRmsParams {
+    const bf16_t* x;      // [rows][C]
+    const bf16_t* g;      // bwd/bwd2: gradient w.r.t. y
+    const bf16_t* v;      // bwd2: gradient w.r.t. dx
+    const float* gamma;   // [C]
+    bf16_t* out0;         // fwd: y ; bwd: dx ; bwd2: gx
+    bf16_t* out1;         // bwd2: gg
+    float* dgamma_part;   // bwd / bwd2: [gridDim.x][C] partial sums (optional)
+    long long rows;
+    int C;
+    float eps;
+};
+
+template <int MODE>   // 0 fwd, 1 bwd, 2 bwd2
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_rmsnorm_kernel(GgRmsParams p) {
+    GG_SHARED float red[4][GG_RMS_MAXV * 512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = (p.C + 511) / 512;
+    const float s = sqrtf((float)p.C);
+    float dgam[GG_RMS_MAXV][8];
+#pragma unroll
+    for (int t = 0; t < GG_RMS_MAXV; ++t)
+        for (int e = 0; e < 8; ++e) dgam[t][e] = 0.f;
+    const long long nwaves = (long long)gridDim.x * 4;
+    for (long long r = (long long)blockIdx.x * 4 + wave; r < p.rows; r += nwaves) {
+        float xf[GG_RMS_MAXV][8], hf[GG_RMS_MAXV][8], vf[GG_RMS_MAXV][8], gf[GG_RMS_MAXV][8];
+        float ss = 0.f, uh = 0.f, uv = 0.f, vh = 0.f;
+#pragma unroll
+        for (int t = 0; t < GG_RMS_MAXV; ++t) {
+            if (t >= nv) break;
+            const int c = t * 512 + lane * 8;
+            for (int e = 0; e < 8; ++e) { xf[t][e] = 0.f; hf[t][e] = 0.f; vf[t][e] = 0.f; gf[t][e] = 0.f; }
+            if (c < p.C) {
+                u16x8 xv = *(const u16x8*)(p.x + r * p.C + c);
+                for (int e = 0; e < 8; ++e) { xf[t][e] = gg_bf2f(xv[e]); ss += xf[t][e] * xf[t][e]; }
+                if (MODE >= 1) {
+                    u16x8 gv = *(const u16x8*)(p.g + r * p.C + c);
+                    for (int e = 0; e < 8; ++e) {
+                        gf[t][e] = gg_bf2f(gv[e]);
+                        hf[t][e] = gf[t][e] * p.gamma[c + e];
+                        uh += xf[t][e] * hf[t][e];
+                    }
+                }
+                if (MODE == 2) {
+                    u16x8 vv = *(const u16x8*)(p.v + r * p.C + c);
+                    for (int e = 0; e < 8; ++e) {
+                        vf[t][e] = gg_bf2f(vv[e]);
+                        uv += xf[t][e] * vf[t][e];
+                        vh += vf[t][e] * hf[t][e];
+                    }
+                }
+            }
+        }
+        ss = gg_wave_sum(ss);
+        const float nrm = sqrtf(ss);
+        const bool clamped = nrm < p.eps;
+        const float n = clamped ? p.eps : nrm;
+        const float rn = s / n;                   // s / n
+        if (MODE >= 1) { uh = gg_wave_sum(uh) / n; }            // u.h  (u = x / n)
+        if (MODE == 2) { uv = gg_wave_sum(uv) / n; vh = gg_wave_sum(vh); }
+        if (clamped) { uh = 0.f; uv = 0.f; }      // y is linear in x below eps: the projection terms vanish
+#pragma unroll
+        for (int t = 0; t < GG_RMS_MAXV; ++t) {
+            if (t >= nv) break;
+            const int c = t * 512 + lane * 8;
+            if (c < p.C) {
+                u16x8 o0, o1;
+                for (int e = 0; e < 8; ++e) {
+                    const float u = xf[t][e] / n;
+                    if (MODE == 0) {
+                        o0[e] = gg_f2bf(xf[t][e] * rn * p.gamma[c + e]);
+                    } else if (MODE == 1) {
+                        o0[e] = gg_f2bf(rn * (hf[t][e] - u * uh));
+                        dgam[t][e] += rn * xf[t][e] * gf[t][e];
+                    } else {
+                        const float pv = vf[t][e] - u * uv;          // (P v)_c
+                        const float ph = hf[t][e] - u * uh;          // (P h)_c
+                        o1[e] = gg_f2bf(p.gamma[c + e] * rn * pv);
+                        dgam[t][e] += gf[t][e] * rn * pv;
+                        float gx = clamped ? 0.f : -(rn / n) * (u * (vh - uv * uh) + uh * pv + uv * ph);
+                        o0[e] = gg_f2bf(gx);
+                    }
+                }
+                *(u16x8*)(p.out0 + r * p.C + c) = o0;
+                if (MODE == 2) *(u16x8*)(p.out1 + r * p.C + c) = o1;
+            }
+        }
+    }
+    if (MODE >= 1 && p.dgamma_part) {
+#pragma unroll
+        for (int t = 0; t < GG_RMS_MAXV; ++t) {
+            if (t >= nv) break;
+            for (int e = 0; e < 8; ++e) red[wave][t * 512 + lane * 8 + e] = dgam[t][e];
+        }
+        gg_sync();
+        for (int c = threadIdx.x; c < p.C; c += 256)
+            p.dgamma_part[(long long)blockIdx.x * p.C + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    }
+}

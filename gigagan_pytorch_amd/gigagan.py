@@ -53,10 +53,14 @@ def gradient_penalty(images, outputs, grad_output_weights=None, weight=10, cente
         outputs = [outputs]
     if not exists(grad_output_weights):
         grad_output_weights = (1,) * len(outputs)
-    gradients, *_ = torch.autograd.grad(
-        outputs=outputs, inputs=images,
-        grad_outputs=[torch.ones_like(o) * w for o, w in zip(outputs, grad_output_weights)],
-        create_graph=True, retain_graph=True, only_inputs=True)
+    ops.inputs_only = True      # only d out / d images is wanted from this pass: skip parameter gradients
+    try:
+        gradients, *_ = torch.autograd.grad(
+            outputs=outputs, inputs=images,
+            grad_outputs=[torch.ones_like(o) * w for o, w in zip(outputs, grad_output_weights)],
+            create_graph=True, retain_graph=True, only_inputs=True)
+    finally:
+        ops.inputs_only = False
     gradients = gradients.float().flatten(1)
     return weight * ((gradients.norm(2, dim=1) - center) ** 2).mean()
 

@@ -549,3 +549,48 @@ def attn_bwd(q, k, v, k0, v0, o, lse, d_o, heads: int, alpha: float, beta: float
     L.check(rc, 'gg_attn_bwd')
     s = part.sum(dim=(0, 2))                 # (heads, 3, 64)
     return dq, dk, dv, s[:, 0] * alpha, s[:, 1], s[:, 2, 0]
+
+
+# --------------------------------------------------------------------------------------------------
+# ChannelRMSNorm passes
+# --------------------------------------------------------------------------------------------------
+RMS_EPS = 1e-12     # F.normalize's eps (gp.py:230)
+
+
+def rmsnorm_fwd(x: torch.Tensor, gamma: torch.Tensor) -> torch.Tensor:
+    """x (..., C) bf16 contiguous, gamma (C,) fp32 -> y bf16."""
+    L = _C.lib()
+    L.require(x, gamma)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and gamma.dtype == torch.float32 and gamma.is_contiguous()
+    Cc = x.shape[-1]
+    y = torch.empty_like(x)
+    rc = L.lib.gg_rmsnorm_fwd(ptr(x), ptr(gamma), ptr(y), x.numel() // Cc, Cc, RMS_EPS, L.stream(x))
+    L.check(rc, 'gg_rmsnorm_fwd')
+    return y
+
+
+def rmsnorm_bwd(x, g, gamma, want_dgamma: bool):
+    L = _C.lib()
+    L.require(x, g, gamma)
+    assert g.dtype == torch.bfloat16 and g.is_contiguous() and g.shape == x.shape
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    dx = torch.empty_like(x)
+    part = torch.empty((L.lib.gg_rmsnorm_blocks(rows), Cc), dtype=torch.float32, device=x.device) if want_dgamma else None
+    rc = L.lib.gg_rmsnorm_bwd(ptr(x), ptr(g), ptr(gamma), ptr(dx), ptr(part), rows, Cc, RMS_EPS, L.stream(x))
+    L.check(rc, 'gg_rmsnorm_bwd')
+    return dx, (part.sum(0) if part is not None else None)
+
+
+def rmsnorm_bwd2(x, g, v, gamma, want_dgamma: bool):
+    """second-order pass: (gx w.r.t. x, gg w.r.t. g, dgamma of this pass or None) for incoming v (gradient w.r.t. dx)."""
+    L = _C.lib()
+    L.require(x, g, v, gamma)
+    assert v.dtype == torch.bfloat16 and v.is_contiguous() and v.shape == x.shape
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    gx, gg = torch.empty_like(x), torch.empty_like(x)
+    part = torch.empty((L.lib.gg_rmsnorm_blocks(rows), Cc), dtype=torch.float32, device=x.device) if want_dgamma else None
+    rc = L.lib.gg_rmsnorm_bwd2(ptr(x), ptr(g), ptr(v), ptr(gamma), ptr(gx), ptr(gg), ptr(part), rows, Cc, RMS_EPS, L.stream(x))
+    L.check(rc, 'gg_rmsnorm_bwd2')
+    return gx, gg, (part.sum(0) if part is not None else None)

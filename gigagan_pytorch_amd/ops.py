@@ -25,6 +25,9 @@ from . import kernels as K
 ACT_DTYPE = torch.bfloat16
 LRELU_SLOPE = 0.2
 second_order = False   # set (by the trainer) while a graph that will be differentiated twice is being built
+inputs_only = False    # set while a backward pass is run only for gradients w.r.t. activations (the gradient penalty's
+                       # d out / d images): custom Functions then skip their parameter gradients, which autograd would
+                       # discard anyway but cannot prune inside a Function
 
 
 # --------------------------------------------------------------------------------------------------
@@ -165,7 +168,7 @@ class ConvFn(Function):
         x, w, in_scale, y = ctx.saved_tensors
         geom, alpha = ctx.geom, ctx.alpha
         dy = dy.contiguous()
-        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        want_db = ctx.has_bias and ctx.needs_input_grad[2] and not inputs_only
         db = None
         if ctx.act == 'lrelu' or want_db:
             dz, db = BiasActBwdFn.apply(dy, y if ctx.act == 'lrelu' else None, want_db)
@@ -186,7 +189,7 @@ class ConvFn(Function):
                 if ctx.needs_input_grad[3]:
                     ds = (x.float() * dxs.float()).sum(dim=(1, 2))
                 dx = (dxs.float() * in_scale[:, None, None, :]).to(dxs.dtype)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not inputs_only:
             dw = WgradFn.apply(x, dz, in_scale, geom, alpha, tuple(w.shape)).to(w.dtype)
         return dx, dw, db, ds, None, None, None, (dy if ctx.has_res and ctx.needs_input_grad[7] else None)
 
@@ -219,7 +222,7 @@ class DgradFn(Function):
         ddz = dw = None
         if ctx.needs_input_grad[0]:     # linear in dz: the adjoint of the adjoint is the forward conv
             ddz = ConvFn.apply(g, w, None, None, None, geom, alpha, None)
-        if ctx.needs_input_grad[1]:     # dL/dw[co][tap][ci] = alpha * sum_p dz[p][co] * g[p + tap][ci]
+        if ctx.needs_input_grad[1] and not inputs_only:     # dL/dw[co][tap][ci] = alpha * sum_p dz[p][co] * g[p + tap][ci]
             dw = WgradFn.apply(g, dz, None, geom, alpha, tuple(w.shape)).to(w.dtype)
         return ddz, dw, None, None, None, None
 
@@ -321,6 +324,45 @@ class ModMixFn(Function):
         O, N, act = ctx.cfg
         dY, da, dd, dnw = K.modmix_bwd(dy.contiguous(), y, Y, a, d, noise, O, N, act)
         return dY, (da if N > 1 else None), dd, None, dnw, None, None, None
+
+
+class RmsNormFn(Function):
+    """ChannelRMSNorm over the last (channel) axis of an NHWC bf16 tensor, one fused pass (gg_rmsnorm_kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma):
+        ctx.save_for_backward(x, gamma)
+        return K.rmsnorm_fwd(x, gamma)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma = ctx.saved_tensors
+        want_dgamma = ctx.needs_input_grad[1] and not inputs_only
+        dx, dgamma = RmsNormBwdFn.apply(x, g.contiguous(), gamma, want_dgamma)
+        return dx, (dgamma if want_dgamma else None)
+
+
+class RmsNormBwdFn(Function):
+    """(dx, dgamma) of RmsNormFn in one pass; differentiable once more (gradient penalty) through gg_rmsnorm bwd2.
+    The second-order pass ignores gradients flowing into `dgamma` (nothing in the GigaGAN losses produces them)."""
+
+    @staticmethod
+    def forward(ctx, x, g, gamma, want_dgamma):
+        dx, dgamma = K.rmsnorm_bwd(x, g, gamma, want_dgamma)
+        ctx.save_for_backward(x, g, gamma)
+        if dgamma is None:
+            dgamma = x.new_zeros((), dtype=torch.float32)
+        return dx, dgamma
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, v, v_dgamma):
+        x, g, gamma = ctx.saved_tensors
+        if v is None:
+            return None, None, None, None
+        want = ctx.needs_input_grad[2] and not inputs_only
+        gx, gg, dgamma = K.rmsnorm_bwd2(x, g, v.contiguous(), gamma, want)
+        return gx, gg, dgamma, None
 
 
 class FlashAttnFn(Function):
@@ -641,12 +683,14 @@ class HipOps:
 
     # -- norms / resampling ------------------------------------------------------------------------
     def channel_rmsnorm(self, x, gamma):
-        """F.normalize(x, dim=1) * sqrt(C) * gamma (gp.py:224-232), fp32 statistics."""
+        """F.normalize(x, dim=1) * sqrt(C) * gamma (gp.py:224-232), fp32 statistics, one fused pass over NHWC."""
         x = to_act(x)
-        xf = x.float()
         c = x.shape[1]
-        nrm = xf.norm(dim=1, keepdim=True).clamp(min=1e-12)
-        return (xf / nrm * (c ** 0.5) * gamma.float().view(1, c, 1, 1)).to(ACT_DTYPE)
+        if c % 8:
+            xf = x.float()
+            nrm = xf.norm(dim=1, keepdim=True).clamp(min=1e-12)
+            return (xf / nrm * (c ** 0.5) * gamma.float().view(1, c, 1, 1)).to(ACT_DTYPE)
+        return nchw(RmsNormFn.apply(nhwc(x), gamma.float().reshape(c).contiguous()))
 
     def upsample_blur(self, x):
         """nn.Upsample(x2, bilinear, align_corners=False) then the reflect-padded [1,2,1]^2/16 blur

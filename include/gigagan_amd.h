@@ -165,6 +165,17 @@ int gg_attn_bwd(const void* q, const void* k, const void* v, const void* k0, con
                 const void* d_o, float* dvec, void* dq, void* dk, void* dv, float* null_part, int32_t B, int32_t n, int32_t h,
                 float alpha, float beta, void* stream);
 
+/* ---- ChannelRMSNorm (gp.py:224-232): y = x / max(|x|_2, eps) * sqrt(C) * gamma over the channel axis of [rows][C] bf16
+ * (NHWC pixels as rows), fp32 statistics, C %% 8 == 0, C <= 2048. bwd: dx and per-workgroup partial sums of dgamma
+ * ([gg_rmsnorm_blocks(rows)][C] fp32, optional). bwd2 differentiates bwd for an incoming gradient v w.r.t. dx:
+ * gx (w.r.t. x), gg (w.r.t. g) and the partial sums of that pass's dgamma — gradient-penalty steps only. */
+int32_t gg_rmsnorm_blocks(int64_t rows);
+int gg_rmsnorm_fwd(const void* x, const float* gamma, void* y, int64_t rows, int32_t C, float eps, void* stream);
+int gg_rmsnorm_bwd(const void* x, const void* g, const float* gamma, void* dx, float* dgamma_part, int64_t rows, int32_t C,
+                   float eps, void* stream);
+int gg_rmsnorm_bwd2(const void* x, const void* g, const void* v, const float* gamma, void* gx, void* gg, float* dgamma_part,
+                    int64_t rows, int32_t C, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

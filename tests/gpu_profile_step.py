@@ -13,7 +13,7 @@ from gigagan_pytorch_amd.data import SyntheticImages   # noqa: E402
 from gigagan_pytorch_amd.gigagan import cycle   # noqa: E402
 
 dev = torch.device('cuda', 0)
-gan = bench.build_gan(256, dev)
+gan = bench.build_gan(256, dev, use_hip_graphs=False)
 it = cycle(SyntheticImages(32, 256, device=dev, seed=0))
 for _ in range(4):
     gan.train_step(it, 32)          # steps 1..4 (4 = GP step)
@@ -25,5 +25,10 @@ for label, nsteps in (('PLAIN step (D + G)', 1), ('GP step', None)):
         gan.train_step(it, 32)
         torch.cuda.synchronize()
     print('=' * 30, label, 'host step', gan._steps_host - 1)
-    print(prof.key_averages(group_by_input_shape=True).table(sort_by='self_cuda_time_total', row_limit=70,
-                                                             max_name_column_width=60, max_shapes_column_width=90))
+    evs = [e for e in prof.key_averages(group_by_input_shape=True) if not e.key.startswith('void ') and not e.key.startswith('gg_')
+           and e.self_device_time_total > 0]
+    evs.sort(key=lambda e: -e.self_device_time_total)
+    tot = sum(e.self_device_time_total for e in evs)
+    print(f'non-kernel-named rows: total self device time {tot/1e3:.1f} ms')
+    for e in evs[:60]:
+        print(f'{e.key[:28]:28s} calls {e.count:5d} self_dev {e.self_device_time_total/1e3:8.2f} ms  shapes {str(e.input_shapes)[:150]}')

@@ -377,3 +377,25 @@ def test_fused_attention_forward_backward_vs_reference(l2):
     assert rel_err(dq, g[0]) < 2e-2 and rel_err(dk, g[1]) < 2e-2 and rel_err(dv, g[2]) < 2e-2
     dk0 = dk0q + 2 * beta * dbias0[:, None] * k0.float()
     assert rel_err(dk0, g[3]) < 2e-2 and rel_err(dv0, g[4]) < 2e-2
+
+
+def test_channel_rmsnorm_first_and_second_order_vs_oracle():
+    torch.manual_seed(0)
+    H_, O_ = ops.HipOps(), OracleOps()
+    x0 = torch.randn(2, 24, 5, 5); gamma0 = torch.rand(24, 1, 1) + 0.5
+
+    def run(I):
+        x = bf(x0).float().requires_grad_(); gamma = gamma0.clone().requires_grad_()
+        y = I.channel_rmsnorm(x, gamma).float()
+        w = torch.linspace(-1, 1, y.numel()).view_as(y)
+        gx, = torch.autograd.grad((y * w).sum() + y.pow(2).sum(), x, create_graph=True)
+        gg = torch.autograd.grad(gx.float().pow(2).sum(), [x, gamma])
+        g1 = torch.autograd.grad((I.channel_rmsnorm(x, gamma).float() * w).sum(), [x, gamma])
+        return y, gx, gg, g1
+
+    yh, gxh, ggh, g1h = run(H_); yo, gxo, ggo, g1o = run(O_)
+    assert rel_err(yh, yo) < 6e-3 and rel_err(gxh, gxo) < 2e-2
+    for a, b in zip(g1h, g1o):
+        assert rel_err(a, b) < 2e-2
+    for a, b in zip(ggh, ggo):
+        assert rel_err(a, b) < 5e-2
