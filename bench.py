@@ -42,7 +42,7 @@ def build_gan(image_size, device, g_over=None, d_over=None, use_hip_graphs=None)
 
 def cpu_baseline(max_seconds=40.0):
     """The oracle (a fp32 PyTorch-CPU restatement of the reference, kind="port") timed on this box's host cores
-    on a bounded sample of the same workload: C2 model dims at 256x256, batch 2, one plain (non-GP) G+D step with
+    on a bounded sample of the same workload: C2 model dims at 256x256, batch 1, one plain (non-GP) G+D step with
     torch AdamW — the reference's own CPU throughput is nearly batch-independent."""
     from gigagan_pytorch_amd import ops
     from gigagan_pytorch_amd.generator import Generator
@@ -52,7 +52,7 @@ def cpu_baseline(max_seconds=40.0):
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     torch.manual_seed(0)
-    bs, S = 2, 256
+    bs, S = 1, 256
     with ops.use_impl(OracleOps()):
         G = Generator(image_size=S, **C2_G)
         D = Discriminator(image_size=S, **C2_D)
@@ -149,8 +149,19 @@ def main():
             tot_ms = sum(v['ms'] for v in agg.values())
             tot_fl = sum(v['flops'] for v in agg.values())
             achieved = a['flops'] / a['ms'] / 1e9
+            # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
+            # gfx950 correction + WRITE_SIZE, KiB -> bytes), when the summary for this kernel is present
+            traffic = None
+            pmc = ROOT / 'profiles' / 'r01_pmc_traffic.json'
+            if pmc.exists():
+                try:
+                    rec = json.loads(pmc.read_text())
+                    if rec.get('kernel') == name:
+                        traffic = rec.get('bytes_per_launch')
+                except Exception:
+                    traffic = None
             roofline = dict(bound='mfma', kernel=name, achieved=achieved, peak=MFMA_PEAK_TF, unit='TFLOP/s',
-                            frac=achieved / MFMA_PEAK_TF, traffic=None,
+                            frac=achieved / MFMA_PEAK_TF, traffic=traffic,
                             avg_launch_us=a['ms'] / a['launches'] * 1e3, launches_per_step=a['launches'] / 4,
                             all_gemm_kernels=dict(tflops=tot_fl / tot_ms / 1e9, ms_per_step=tot_ms / 4,
                                                   frac_of_step=tot_ms / 4 / ms_per_step),
