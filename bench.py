@@ -42,7 +42,7 @@ def build_gan(image_size, device, g_over=None, d_over=None, use_hip_graphs=None)
 
 def cpu_baseline(max_seconds=40.0):
     """The oracle (a fp32 PyTorch-CPU restatement of the reference, kind="port") timed on this box's host cores
-    on a bounded sample of the same workload: C2 model dims at 256x256, batch 1, one plain (non-GP) G+D step with
+    on a bounded sample of the same workload: C2 model dims at 256x256, batch 2, one plain (non-GP) G+D step with
     torch AdamW — the reference's own CPU throughput is nearly batch-independent."""
     from gigagan_pytorch_amd import ops
     from gigagan_pytorch_amd.generator import Generator
@@ -52,7 +52,7 @@ def cpu_baseline(max_seconds=40.0):
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     torch.manual_seed(0)
-    bs, S = 1, 256
+    bs, S = 2, 256
     with ops.use_impl(OracleOps()):
         G = Generator(image_size=S, **C2_G)
         D = Discriminator(image_size=S, **C2_D)
@@ -103,6 +103,7 @@ def main():
     steps = (args.steps + 3) // 4 * 4
     warmup = args.warmup
     gan = build_gan(args.image_size, dev, use_hip_graphs=False if args.no_graphs else None)
+    torch.manual_seed(1 + rank)          # identical initial weights (seed 0 in build_gan), per-rank latent / noise streams
     dl = SyntheticImages(args.batch, args.image_size, device=dev, seed=rank)
     it = cycle(dl)
 
@@ -114,7 +115,9 @@ def main():
     # warm-up starts at the trainer's step 1; keep the timed region aligned to whole GP cycles
     for _ in range(warmup):
         gan.train_step(it, args.batch)
-    while (gan._steps_host - 1) % 4 != 0:   # align so that the K timed steps contain exactly K/4 GP steps
+    # align so that the K timed steps contain exactly K/4 GP steps; with hipGraphs on, also make sure one whole
+    # 4-step cycle has run untimed (the three step kinds are captured on first use). Extra steps count as warm-up.
+    while (gan._steps_host - 1) % 4 != 0 or (gan.use_hip_graphs and gan._steps_host < 5):
         gan.train_step(it, args.batch)
         warmup += 1
     barrier()

@@ -367,7 +367,10 @@ class GigaGAN(nn.Module):
                 torch.cuda.synchronize(self._device)
                 graph = torch.cuda.CUDAGraph()
                 ops.pack_cache_clear()        # the graph must contain its own weight packing launches ...
-                with torch.cuda.graph(graph):
+                # with a process group alive, its watchdog thread polls events concurrently: only this thread's (and the
+                # autograd thread's stream-ordered) calls must be capture-safe, so do not police other threads
+                mode = 'thread_local' if gdist.is_distributed() else 'global'
+                with torch.cuda.graph(graph, capture_error_mode=mode):
                     outs = fn()
                 ops.pack_cache_clear()        # ... and nothing outside may keep tensors of its private pool
                 entry = self._graphs[key] = (graph, outs)
