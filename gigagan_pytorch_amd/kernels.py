@@ -10,17 +10,12 @@ from . import _C
 from ._C import GemmDesc, ROWK, KROW, ptr
 
 _ACTS = {None: 0, 'none': 0, 'lrelu': 1, 'gelu': 2, 'silu': 3}
-_ws_cache: dict = {}
-
-
 def _workspace(nbytes: int, like: torch.Tensor) -> torch.Tensor:
-    """Per-device scratch owned by the caller side (PyTorch allocator); grows monotonically."""
-    key = (like.device.type, like.device.index)
-    ws = _ws_cache.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=like.device)
-        _ws_cache[key] = ws
-    return ws
+    """split-K scratch for ONE launch, owned by the caller side (PyTorch's stream-ordered caching allocator). It is
+    deliberately not cached across launches: a hipGraph bakes the pointer in, and a cached buffer that is later
+    re-allocated (a bigger request while another step kind is being captured) would leave earlier graphs writing
+    to freed memory. Inside a capture the allocation comes from that graph's private pool."""
+    return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=like.device)
 
 
 class GemmProfiler:
