@@ -142,6 +142,7 @@ static const GgTileModel kTileModels[] = {
     {3, 128, 32, 32, 2.00, 1536, 1.5},
     {4, 256, 256, 64, 2.25, 256, 3.0},
     {5, 256, 128, 64, 1.45, 256, 3.0},
+    {6, 128, 128, 64, 1.50, 512, 2.5},    // 8 waves, 72 KB LDS: 2 workgroups per CU (small-M layers: no split-K needed)
 };
 
 static double gg_plan_cost(const gg_gemm_desc* d, const GgTileModel& tm, int sk, int* k_per_split) {
@@ -162,7 +163,7 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     const int v1_tile = d->N <= 32 ? 3 : (d->N <= 64 ? 2 : 1);
     int forced = d->force_tile;
     if (forced >= 4 && !gg_v2_eligible(d)) forced = 0;
-    if (forced < 0 || forced > 5) forced = 0;
+    if (forced < 0 || forced > 6) forced = 0;
     double best = 1e30;
     pl.tile = v1_tile; pl.splitk = 1;
     for (const GgTileModel& tm : kTileModels) {
@@ -172,6 +173,9 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
             if (tm.tile <= 3 && tm.tile != v1_tile) continue;
             if (tm.tile >= 4 && (!v2ok || !pol)) continue;
             if (tm.tile == 4 && d->N < 192) continue;
+            // the small 8-wave tile is for row-major launches whose grid the 256-row tiles cannot fill; weight
+            // gradients measured better on 256x256 + split-K at every size except the 4x4-resolution layers
+            if (tm.tile == 6 && (d->M > 32768 || d->a_layout == GG_KROW)) continue;
             if (pol >= 2 && v2ok && tm.tile <= 3) continue;
         }
         const int ktiles = (d->K + tm.bk - 1) / tm.bk;
@@ -315,6 +319,7 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     dim3 grid2((unsigned)(pl.blocks_mn * d->batch * pl.splitk), 1, 1);
     if (pl.tile == 4) gg_launch_gemm2_tile<256, 256, 2, 4>(p, akrow, bkrow, aconv, grid2, s);
     else if (pl.tile == 5) gg_launch_gemm2_tile<256, 128, 2, 4>(p, akrow, bkrow, aconv, grid2, s);
+    else if (pl.tile == 6) gg_launch_gemm2_tile<128, 128, 2, 4>(p, akrow, bkrow, aconv, grid2, s);
     else if (pl.tile == 1) gg_launch_gemm_tile<128, 128, 2, 2>(p, akrow, bkrow, aconv, grid, s);
     else if (pl.tile == 2) gg_launch_gemm_tile<128, 64, 2, 2>(p, akrow, bkrow, aconv, grid, s);
     else gg_launch_gemm_tile<128, 32, 4, 1>(p, akrow, bkrow, aconv, grid, s);

@@ -78,15 +78,32 @@ GG_DEVICE u16x8 gga_pack8(const f32x16& v, int c) {
     return f;
 }
 
-// stage a 64-token x 64-d tile (tokens t0 .. t0+63 of one (batch, head)) into LDS, row-major and/or transpose-read form
-// (256 threads: thread -> token t / 4... 8 threads per token, 16 bytes each); optionally the squared norms of the rows
-GG_DEVICE void gga_stage_tile(const bf16_t* base, long long row_stride, int t0, bf16_t (*rowk)[GGA_KP], char* tr, float* sq) {
+// A 64-token x 64-d tile (tokens t0 .. t0+63 of one (batch, head)) is staged in two halves: global -> registers
+// (issued one tile ahead, so the HBM/L2 latency overlaps the MFMAs of the current tile) and registers -> LDS in
+// row-major and/or transpose-read form (256 threads: 8 threads per token, 16 bytes each, two passes); optionally the
+// squared norms of the rows.
+struct GgaTileRegs {
+    u16x8 v[2];
+};
+
+GG_DEVICE GgaTileRegs gga_tile_load(const bf16_t* base, long long row_stride, int t0) {
+    GgaTileRegs r;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int v = t + 256 * it;
+        r.v[it] = *(const u16x8*)(base + (long long)(t0 + (v >> 3)) * row_stride + (v & 7) * 8);
+    }
+    return r;
+}
+
+GG_DEVICE void gga_tile_store(const GgaTileRegs& r, bf16_t (*rowk)[GGA_KP], char* tr, float* sq) {
     const int t = threadIdx.x;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int v = t + 256 * it;
         const int row = v >> 3, c8 = v & 7;
-        u16x8 x = *(const u16x8*)(base + (long long)(t0 + row) * row_stride + c8 * 8);
+        const u16x8 x = r.v[it];
         if (rowk) *(u16x8*)&rowk[row][c8 * 8] = x;
         if (tr) *(u16x8*)(tr + row * GGA_TP + c8 * 16) = x;
         if (sq) {
@@ -148,11 +165,16 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_fwd_kernel(GgAttnParams p) {
             for (int r = 0; r < 16; ++r) ot[db][r] = gg_bf2f(v0[db * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi]);
     }
 
+    GgaTileRegs rk = gga_tile_load(kb, rs, 0), rv = gga_tile_load(vb, rs, 0);
     for (int j0 = 0; j0 < p.n; j0 += 64) {
         gg_sync();
-        gga_stage_tile(kb, rs, j0, sK, nullptr, sKsq);
-        gga_stage_tile(vb, rs, j0, nullptr, sV, nullptr);
+        gga_tile_store(rk, sK, nullptr, sKsq);
+        gga_tile_store(rv, nullptr, sV, nullptr);
         gg_sync();
+        if (j0 + 64 < p.n) {
+            rk = gga_tile_load(kb, rs, j0 + 64);
+            rv = gga_tile_load(vb, rs, j0 + 64);
+        }
 
         f32x16 st[2];
 #pragma unroll
@@ -297,11 +319,16 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dq_kernel(GgAttnParams p) {
         if (lane == 0) sRed[wave][2][0] = s0;
     }
 
+    GgaTileRegs rk = gga_tile_load(p.k + boff, rs, 0), rv = gga_tile_load(p.v + boff, rs, 0);
     for (int j0 = 0; j0 < p.n; j0 += 64) {
         gg_sync();
-        gga_stage_tile(p.k + boff, rs, j0, sK, sKt, sKsq);
-        gga_stage_tile(p.v + boff, rs, j0, sV, nullptr, nullptr);
+        gga_tile_store(rk, sK, sKt, sKsq);
+        gga_tile_store(rv, sV, nullptr, nullptr);
         gg_sync();
+        if (j0 + 64 < p.n) {
+            rk = gga_tile_load(p.k + boff, rs, j0 + 64);
+            rv = gga_tile_load(p.v + boff, rs, j0 + 64);
+        }
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
             f32x16 st, dp;
@@ -383,15 +410,29 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dkv_kernel(GgAttnParams p) {
         for (int r = 0; r < 16; ++r) { dkt[db][r] = 0.f; dvt[db][r] = 0.f; }
     float dbias = 0.f;
 
+    GgaTileRegs rq = gga_tile_load(p.q + boff, rs, 0), rdo = gga_tile_load(p.d_o + boff, rs, 0);
+    float r_lse = 0.f, r_d = 0.f;
+    if (threadIdx.x < 64) {
+        r_lse = p.lse[(long long)bh * p.n + threadIdx.x];
+        r_d = p.dvec[(long long)bh * p.n + threadIdx.x];
+    }
     for (int i0 = 0; i0 < p.n; i0 += 64) {
         gg_sync();
-        gga_stage_tile(p.q + boff, rs, i0, sQ, sQt, nullptr);
-        gga_stage_tile(p.d_o + boff, rs, i0, sDO, sDOt, nullptr);
+        gga_tile_store(rq, sQ, sQt, nullptr);
+        gga_tile_store(rdo, sDO, sDOt, nullptr);
         if (threadIdx.x < 64) {
-            sLse[threadIdx.x] = p.lse[(long long)bh * p.n + i0 + threadIdx.x];
-            sD[threadIdx.x] = p.dvec[(long long)bh * p.n + i0 + threadIdx.x];
+            sLse[threadIdx.x] = r_lse;
+            sD[threadIdx.x] = r_d;
         }
         gg_sync();
+        if (i0 + 64 < p.n) {
+            rq = gga_tile_load(p.q + boff, rs, i0 + 64);
+            rdo = gga_tile_load(p.d_o + boff, rs, i0 + 64);
+            if (threadIdx.x < 64) {
+                r_lse = p.lse[(long long)bh * p.n + i0 + 64 + threadIdx.x];
+                r_d = p.dvec[(long long)bh * p.n + i0 + 64 + threadIdx.x];
+            }
+        }
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib) {
             f32x16 s, dp;

@@ -55,8 +55,8 @@ def _kernel_key(d: GemmDesc, L) -> str:
     tile, sk = C.c_int32(0), C.c_int32(0)
     L.lib.gg_gemm_plan(C.byref(d), C.byref(tile), C.byref(sk))
     if tile.value >= 4:
-        bn = {4: 256, 5: 128}[tile.value]
-        name = (f'gg_gemm2_kernel<256,{bn},2,4,A_KROW={int(d.a_layout == KROW)},B_KROW={int(d.b_layout == KROW)},'
+        bm, bn = {4: (256, 256), 5: (256, 128), 6: (128, 128)}[tile.value]
+        name = (f'gg_gemm2_kernel<{bm},{bn},2,4,A_KROW={int(d.a_layout == KROW)},B_KROW={int(d.b_layout == KROW)},'
                 f'A_CONV={int(bool(d.a_conv))}>')
     else:
         bn = {1: 128, 2: 64, 3: 32}[tile.value]

@@ -41,13 +41,15 @@ class Conv2d(nn.Conv2d):
     act = None
     out_scale = 1.0     # y = out_scale * (conv + bias): lets a following "(a + b) * c" merge be folded into its producers
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """`residual` (same shape as the output) is added in the kernel's epilogue: conv(x) + bias + residual."""
         k = self.kernel_size[0]
         if self.stride[0] != 1:
             assert k == 1 and self.padding[0] == 0 and self.stride[0] == 2
         else:
             assert self.padding[0] == k // 2
-        return ops.impl.conv2d(x, self.weight, self.bias, act=self.act, stride=self.stride[0], scale=self.out_scale)
+        return ops.impl.conv2d(x, self.weight, self.bias, act=self.act, stride=self.stride[0], scale=self.out_scale,
+                               residual=residual)
 
 
 class Linear(nn.Linear):
@@ -254,14 +256,14 @@ class SelfAttention(nn.Module):
         self.null_kv = nn.Parameter(torch.randn(2, heads, dim_head))
         self.to_out = Conv2d(dim_inner, dim, 1, bias=False)
 
-    def forward(self, fmap):
+    def forward(self, fmap, residual=None):
         b, _, x, y = fmap.shape
         h = self.heads
         fmap = self.norm(fmap)
         q, v = self.to_q(fmap), self.to_v(fmap)
         k = self.to_k(fmap) if exists(self.to_k) else q
         out = ops.impl.self_attention(q, k, v, self.null_kv, heads=h, scale=self.scale, l2=not self.dot_product)
-        return self.to_out(out)
+        return self.to_out(out, residual=residual)
 
 
 class CrossAttention(nn.Module):
@@ -297,6 +299,12 @@ def FeedForward(dim, mult=4, channel_first=False):
     return nn.Sequential(RMSNorm(dim), Linear(dim, dim_hidden), Act(F.gelu), Linear(dim_hidden, dim))
 
 
+def _ff_residual(ff, x):
+    """ff(x) + x for the channel-first FeedForward (norm, 1x1, gelu, 1x1) with the skip added in the last 1x1's epilogue."""
+    norm, conv_in, act, conv_out = ff
+    return conv_out(act(conv_in(norm(x))), residual=x)
+
+
 class SelfAttentionBlock(nn.Module):
     def __init__(self, dim, dim_head=64, heads=8, ff_mult=4, dot_product=False):
         super().__init__()
@@ -304,8 +312,8 @@ class SelfAttentionBlock(nn.Module):
         self.ff = FeedForward(dim=dim, mult=ff_mult, channel_first=True)
 
     def forward(self, x):
-        x = self.attn(x) + x
-        x = self.ff(x) + x
+        x = self.attn(x, residual=x)       # attn(x) + x, the skip added in to_out's epilogue (gp.py:757-758)
+        x = _ff_residual(self.ff, x)
         return x
 
 
@@ -317,7 +325,7 @@ class CrossAttentionBlock(nn.Module):
 
     def forward(self, x, context, mask=None):
         x = self.attn(x, context=context, mask=mask) + x
-        x = self.ff(x) + x
+        x = _ff_residual(self.ff, x)
         return x
 
 

@@ -550,7 +550,7 @@ class HipOps:
         return to_act(x)
 
     # -- convolution -------------------------------------------------------------------------------
-    def conv2d(self, x, weight, bias=None, act=None, stride=1, scale=1.0):
+    def conv2d(self, x, weight, bias=None, act=None, stride=1, scale=1.0, residual=None):
         """scale * (conv(x, w) + bias) [-> leaky relu]: stride-1 'same' conv (odd square kernel) — the reference's
         nn.Conv2d(…, padding=k//2) call sites — or the stride-2 1x1 residual conv (gp.py:1612), whose pixel
         sub-sampling is part of the kernel's gather."""
@@ -562,8 +562,13 @@ class HipOps:
         if ip != i:
             xh = F.pad(xh, (0, ip - i))
         geom = (k, stride, k // 2 if stride == 1 else 0, 'oihw')
+        res = None
+        if residual is not None:
+            if o % 8:        # ragged channel count: add outside the kernel
+                return self.conv2d(x, weight, bias, act, stride, scale) + residual.to(ACT_DTYPE)
+            res = nhwc(to_act(residual))
         y = ConvFn.apply(xh, weight, None if bias is None else bias.float().contiguous(), None, act, geom, float(scale),
-                         None)
+                         res)
         if y.shape[-1] != o:
             y = y[..., :o]
         return nchw(y)

@@ -70,7 +70,7 @@ typedef struct gg_gemm_desc {
     const float* noise; const float* noise_w;
     int32_t act; float act_slope;
     int32_t force_splitk; /* 0 = heuristic */
-    int32_t force_tile;   /* 0 = heuristic; 1: 128x128, 2: 128x64, 3: 128x32 (4 waves); 4: 256x256, 5: 256x128 (8 waves) */
+    int32_t force_tile;   /* 0 = heuristic; 1: 128x128, 2: 128x64, 3: 128x32 (4 waves); 4: 256x256, 5: 256x128, 6: 128x128 (8 waves) */
     int32_t conv_stride;  /* >= 1 */
     int32_t conv_pad;     /* >= 0 */
     float bias_scale;     /* multiplies bias (set 1.0f) */
@@ -80,7 +80,7 @@ typedef struct gg_gemm_desc {
 
 size_t gg_gemm_workspace_bytes(const gg_gemm_desc* d);
 /* reports the launch plan the library will use for `d`: tile (1: 128x128, 2: 128x64, 3: 128x32, 4: 256x256,
- * 5: 256x128) and the split-K factor; used by bench.py to attribute measured time to kernel instantiations. */
+ * 5: 256x128, 6: 128x128 with 8 waves) and the split-K factor; used by bench.py to attribute measured time to kernel instantiations. */
 int gg_gemm_plan(const gg_gemm_desc* d, int32_t* tile, int32_t* splitk);
 int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -63,7 +63,7 @@ def main():
         insc = (torch.rand(n, ci, device=dev) + 0.5) if scaled else None
         flops = 2.0 * n * R * R * ci * co * ks * ks
         ref_f = ref_w = None
-        for tile in (1, 2, 4, 5):
+        for tile in (1, 2, 4, 5, 6):
             if tile == 2 and co > 64:
                 continue
             try:

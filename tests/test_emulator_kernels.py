@@ -178,7 +178,7 @@ def test_fused_adamw_and_ema_match_torch():
 
 # ---- 8-wave large-tile kernel (gg_gemm2.h) and the generalised conv geometry ---------------------------------
 
-@pytest.mark.parametrize('tile', [4, 5])
+@pytest.mark.parametrize('tile', [4, 5, 6])
 def test_gemm2_dense_all_layouts(tile):
     torch.manual_seed(0)
     M, N, Kd, batch = 264, 136, 136, 2
@@ -197,7 +197,8 @@ def test_gemm2_dense_all_layouts(tile):
     assert rel_err(out, F.leaky_relu(ref * 0.5 + bias, 0.2)) < 1e-5
 
 
-@pytest.mark.parametrize('cfg', [(2, 12, 12, 64, 136, 3, 4), (1, 9, 7, 128, 128, 3, 5), (3, 8, 8, 64, 104, 1, 5)])
+@pytest.mark.parametrize('cfg', [(2, 12, 12, 64, 136, 3, 4), (1, 9, 7, 128, 128, 3, 5), (3, 8, 8, 64, 104, 1, 5),
+                                 (2, 8, 8, 64, 128, 3, 6)])
 def test_gemm2_conv_forward_dgrad_wgrad(cfg):
     n, H, W, Ci, Co, ks, tile = cfg
     torch.manual_seed(0)
@@ -237,7 +238,7 @@ def test_gemm2_conv_in_scale_virtual_channels_and_epilogue():
     y = F.leaky_relu(y, 0.2) + 0.5 * res.float()
     assert rel_err(outs[1], y) < 1e-5
     # bf16 output: the LDS-staged row-contiguous store path of the 8-wave kernel (residual added on the way out)
-    for t in (4, 5):
+    for t in (4, 5, 6):
         ob = K.conv2d_nhwc(x, w, ksize=3, cv=2 * C, in_scale=insc, out_scale=osc, noise=nz, noise_w=nw, act='lrelu',
                            residual=res, res_scale=0.5, force_tile=t)
         assert ob.dtype == torch.bfloat16 and rel_err(ob, y) < 4e-3
