@@ -135,44 +135,47 @@ def main():
     value = args.batch * world * steps / dt
 
     roofline = None
-    if rank == 0 and not args.no_profile_cycle:
-        # one extra GP cycle with per-launch HIP events around the contraction kernel (same stream)
+    if not args.no_profile_cycle:
+        # one extra GP cycle, executed eagerly on EVERY rank (the steps contain the gradient all-reduce, so all ranks
+        # must take part); rank 0 brackets each contraction launch with HIP events on the launch stream
         graphs_were_on, gan.use_hip_graphs = gan.use_hip_graphs, False   # HIP events cannot be recorded inside a replay
-        K.profiler = K.GemmProfiler()
+        if rank == 0:
+            K.profiler = K.GemmProfiler()
         for _ in range(4):
             gan.train_step(it, args.batch)
-        agg = K.profiler.summary()
-        shapes = K.profiler.shape_summary()
-        K.profiler = None
+        agg = shapes = None
+        if rank == 0:
+            agg = K.profiler.summary()
+            shapes = K.profiler.shape_summary()
+            K.profiler = None
         gan.use_hip_graphs = graphs_were_on
-        Path(ROOT / 'gpurun_out').mkdir(exist_ok=True)
-        (ROOT / 'gpurun_out' / 'bench_gemm_shapes.json').write_text(json.dumps(shapes, indent=1))
-        if agg:
+        if rank == 0 and agg:
+            Path(ROOT / 'gpurun_out').mkdir(exist_ok=True)
+            (ROOT / 'gpurun_out' / 'bench_gemm_shapes.json').write_text(json.dumps(shapes, indent=1))
+            (ROOT / 'gpurun_out' / 'bench_gemm_breakdown.json').write_text(json.dumps(agg, indent=1))
             name, a = max(agg.items(), key=lambda kv: kv[1]['ms'])
             tot_ms = sum(v['ms'] for v in agg.values())
             tot_fl = sum(v['flops'] for v in agg.values())
             achieved = a['flops'] / a['ms'] / 1e9
             # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
             # gfx950 correction + WRITE_SIZE, KiB -> bytes), when the summary for this kernel is present
-            traffic = None
+            traffic = traffic_shape = None
             pmc = ROOT / 'profiles' / 'r01_pmc_traffic.json'
             if pmc.exists():
                 try:
                     rec = json.loads(pmc.read_text())
                     if rec.get('kernel') == name:
-                        traffic = rec.get('bytes_per_launch')
+                        traffic, traffic_shape = rec.get('bytes_per_launch'), rec.get('shape')
                 except Exception:
                     traffic = None
             roofline = dict(bound='mfma', kernel=name, achieved=achieved, peak=MFMA_PEAK_TF, unit='TFLOP/s',
-                            frac=achieved / MFMA_PEAK_TF, traffic=traffic,
+                            frac=achieved / MFMA_PEAK_TF, traffic=traffic, traffic_shape=traffic_shape,
                             avg_launch_us=a['ms'] / a['launches'] * 1e3, launches_per_step=a['launches'] / 4,
                             all_gemm_kernels=dict(tflops=tot_fl / tot_ms / 1e9, ms_per_step=tot_ms / 4,
                                                   frac_of_step=tot_ms / 4 / ms_per_step),
                             step=dict(achieved=value / world * GF_PER_IMG / 1e3, peak=MFMA_PEAK_TF,
                                       frac=value / world * GF_PER_IMG / 1e3 / MFMA_PEAK_TF,
                                       note='whole-step algorithmic-minimum 1192.1 GF/img vs dense bf16 MFMA peak'))
-            Path(ROOT / 'gpurun_out').mkdir(exist_ok=True)
-            (ROOT / 'gpurun_out' / 'bench_gemm_breakdown.json').write_text(json.dumps(agg, indent=1))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -63,3 +63,45 @@ def test_data_parallel_equals_large_batch_gradient():
     for f, x, y in zip(full, a, b):
         if f is not None:
             assert torch.allclose(f, (x + y) / 2, rtol=1e-3, atol=1e-5)
+
+
+def _train_worker(rank, world, port, ret, tmp):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    sys.path.insert(0, str(root)); sys.path.insert(0, str(root / 'tests'))
+    torch.set_num_threads(2)
+    from gigagan_pytorch_amd import _C, GigaGAN, distributed as gdist
+    from gigagan_pytorch_amd.data import SyntheticImages
+    from gigagan_pytorch_amd.gigagan import cycle
+    from helpers import SMALL_G, SMALL_D
+    _C.bind(root / 'tests' / 'emu' / 'libgigagan_amd_emu.so')
+    gdist.init_from_env('cpu')
+    torch.manual_seed(0)                     # identical initial replicas (and a broadcast on top)
+    gan = GigaGAN(generator=dict(SMALL_G), discriminator=dict(SMALL_D), apply_gradient_penalty_every=2, device='cpu',
+                  model_folder=f'{tmp}/m{rank}', results_folder=f'{tmp}/r{rank}')
+    torch.manual_seed(10 + rank)             # per-rank latents / noise / data
+    it = cycle(SyntheticImages(2, 32, seed=rank))
+    d0 = gan.D_opt.flat_p.clone()
+    for _ in range(2):
+        gan.train_step(it, 2)
+    flat = torch.cat([gan.D_opt.flat_p, gan.G_opt.flat_p])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    same = all(torch.equal(gathered[0], g) for g in gathered)
+    moved = not torch.equal(d0, gan.D_opt.flat_p)
+    ret[rank] = bool(same and moved and torch.isfinite(flat).all())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_keeps_replicas_identical(tmp_path):
+    """the whole trainer on 2 gloo ranks (emulator build): different data and noise per rank, summed flat gradients,
+    grad_scale = 1/world in the fused AdamW -> bit-identical replicas after plain and gradient-penalty steps."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_train_worker, args=(world, port, ret, str(tmp_path)), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
