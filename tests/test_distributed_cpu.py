@@ -75,14 +75,14 @@ def _train_worker(rank, world, port, ret, tmp):
     from gigagan_pytorch_amd import _C, GigaGAN, distributed as gdist
     from gigagan_pytorch_amd.data import SyntheticImages
     from gigagan_pytorch_amd.gigagan import cycle
-    from helpers import SMALL_G, SMALL_D
+    from helpers import TINY_G, TINY_D
     _C.bind(root / 'tests' / 'emu' / 'libgigagan_amd_emu.so')
     gdist.init_from_env('cpu')
     torch.manual_seed(0)                     # identical initial replicas (and a broadcast on top)
-    gan = GigaGAN(generator=dict(SMALL_G), discriminator=dict(SMALL_D), apply_gradient_penalty_every=2, device='cpu',
+    gan = GigaGAN(generator=dict(TINY_G), discriminator=dict(TINY_D), apply_gradient_penalty_every=2, device='cpu',
                   model_folder=f'{tmp}/m{rank}', results_folder=f'{tmp}/r{rank}')
     torch.manual_seed(10 + rank)             # per-rank latents / noise / data
-    it = cycle(SyntheticImages(2, 32, seed=rank))
+    it = cycle(SyntheticImages(2, 16, seed=rank))
     d0 = gan.D_opt.flat_p.clone()
     for _ in range(2):
         gan.train_step(it, 2)

@@ -400,3 +400,25 @@ def test_channel_rmsnorm_first_and_second_order_vs_oracle():
         assert rel_err(a, b) < 2e-2
     for a, b in zip(ggh, ggo):
         assert rel_err(a, b) < 5e-2
+
+
+@pytest.mark.parametrize('dot', [True, False])
+def test_self_attention_module_on_fused_kernels_vs_oracle(dot):
+    """SelfAttention (norm -> 1x1 projections -> fused attention with null kv -> 1x1 + skip) on the kernel path vs the
+    same module on the oracle, outputs and all parameter / input gradients."""
+    from gigagan_pytorch_amd.modules import SelfAttention
+    torch.manual_seed(0)
+    attn = SelfAttention(16, dim_head=64, heads=1, dot_product=dot)
+    x0 = torch.randn(1, 16, 16, 16)
+
+    def run(I):
+        with ops.use_impl(I):
+            x = x0.clone().requires_grad_()
+            y = attn(x, residual=x).float()
+            g = torch.autograd.grad((y * torch.linspace(-1, 1, y.numel()).view_as(y)).sum(), [x, *attn.parameters()])
+        return y, g
+
+    yh, gh = run(ops.HipOps()); yo, go = run(OracleOps(bf16_operands=True))
+    assert rel_err(yh, yo) < 2e-2
+    for a, b in zip(gh, go):
+        assert rel_err(a, b) < 6e-2

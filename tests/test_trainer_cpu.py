@@ -4,17 +4,17 @@ import torch
 from gigagan_pytorch_amd import GigaGAN
 from gigagan_pytorch_amd.data import SyntheticImages
 from gigagan_pytorch_amd.gigagan import cycle
-from helpers import SMALL_G, SMALL_D
+from helpers import TINY_G, TINY_D
 
 
 def test_train_steps_update_both_models_and_skip_unused_params(tmp_path):
     torch.manual_seed(0)
-    gan = GigaGAN(generator=dict(SMALL_G), discriminator=dict(SMALL_D), apply_gradient_penalty_every=2, device='cpu',
+    gan = GigaGAN(generator=dict(TINY_G), discriminator=dict(TINY_D), apply_gradient_penalty_every=2, device='cpu',
                   model_folder=str(tmp_path / 'm'), results_folder=str(tmp_path / 'r'))
     unused = [p.detach().clone() for p in gan.D.unused_parameters()]
     assert len(unused) > 0
     g0 = gan.G_opt.flat_p.clone(); d0 = gan.D_opt.flat_p.clone()
-    it = cycle(SyntheticImages(2, 32))
+    it = cycle(SyntheticImages(2, 16))
     d1, g1 = gan.train_step(it, 2)          # step 1: plain
     d2, g2 = gan.train_step(it, 2)          # step 2: gradient penalty (double backward)
     vals = [float(v) for v in (*d1, *g1, *d2, *g2) if v is not None]
@@ -33,4 +33,4 @@ def test_train_steps_update_both_models_and_skip_unused_params(tmp_path):
     gan.load(ck)
     assert gan.G_opt.flat_p.abs().sum() > 0 and gan._steps_host == 3
     img = gan.generate(batch_size=2)
-    assert img.shape == (2, 3, 32, 32)
+    assert img.shape == (2, 3, 16, 16)
