@@ -267,7 +267,9 @@ class Discriminator(nn.Module):
         return next(self.parameters()).device
 
     def forward(self, images, rgbs, texts=None, text_encodings=None, text_embeds=None, real_images=None,
-                return_multiscale_outputs=True, calc_aux_loss=True):
+                return_multiscale_outputs=True, calc_aux_loss=True, aux_rows=None):
+        """`aux_rows=(a, b)` (an extension over the reference signature) restricts the auxiliary reconstruction loss to
+        samples a..b of the batch — used when fake and real images share one forward pass."""
         if not self.unconditional:
             assert (exists(texts) ^ exists(text_encodings)) ^ exists(text_embeds), \
                 'either texts as List[str] is passed in, or clip text_encodings as Tensor'
@@ -333,7 +335,10 @@ class Discriminator(nn.Module):
 
             if exists(recon_decoder) and calc_aux_loss:
                 # reference behaviour (Appendix B.5): first `batch` rows of the post-downsample tensor
-                aux_recon_losses.append(recon_decoder(x[:batch], images))
+                if aux_rows is None:
+                    aux_recon_losses.append(recon_decoder(x[:batch], images))
+                else:
+                    aux_recon_losses.append(recon_decoder(x[aux_rows[0]:aux_rows[1]], images[aux_rows[0]:aux_rows[1]]))
 
         assert self.unconditional or len([*conv_mods]) == 0, 'convolutions were incorrectly modulated'
 

@@ -47,8 +47,9 @@ def num_to_groups(num, divisor):
 
 # ---- losses (gp.py:120-171) ------------------------------------------------------------------------------
 
-def gradient_penalty(images, outputs, grad_output_weights=None, weight=10, center=0.):
-    """R1-style penalty on d(sum_i w_i * out_i)/d images via double backward (gp.py:120-155)."""
+def gradient_penalty(images, outputs, grad_output_weights=None, weight=10, center=0., per_sample=False):
+    """R1-style penalty on d(sum_i w_i * out_i)/d images via double backward (gp.py:120-155). `per_sample=True`
+    returns the un-averaged weight * (|grad_i| - center)^2 of every sample."""
     if not isinstance(outputs, (list, tuple)):
         outputs = [outputs]
     if not exists(grad_output_weights):
@@ -62,7 +63,8 @@ def gradient_penalty(images, outputs, grad_output_weights=None, weight=10, cente
     finally:
         ops.inputs_only = False
     gradients = gradients.float().flatten(1)
-    return weight * ((gradients.norm(2, dim=1) - center) ** 2).mean()
+    pen = weight * ((gradients.norm(2, dim=1) - center) ** 2)
+    return pen if per_sample else pen.mean()
 
 
 def generator_hinge_loss(fake):
@@ -215,6 +217,7 @@ class GigaGAN(nn.Module):
         # hipGraph replay of the forward+backward of each step kind (plain D, gradient-penalty D, G): the step is
         # ~8k small launches, i.e. host-bound when issued eagerly. Unconditional, tensor-only steps qualify; the
         # optimizer, the gradient all-reduce and the EMA stay outside the graphs.
+        self.merge_discriminator_passes = True   # D(fake) and D(real) of a D-step share one forward/backward pass
         if use_hip_graphs is None:
             use_hip_graphs = self._device.type == 'cuda'
         self.use_hip_graphs = bool(use_hip_graphs) and self._device.type == 'cuda'
@@ -391,11 +394,13 @@ class GigaGAN(nn.Module):
         # the reference marks the images as requiring grad in every step (gp.py:2269, :2307); the gradient w.r.t. the
         # input images is only consumed by the gradient penalty, so plain steps skip that part of the backward
         real_images = real_images.to(dev, non_blocking=True).detach()
-        if apply_gradient_penalty:
-            real_images.requires_grad_()
-        real_images_rgbs = self.D.real_images_to_rgbs(real_images)
-        if exists(self.diff_augment):
-            real_images, real_images_rgbs = self.diff_augment(real_images, real_images_rgbs)
+        merged = self.merge_discriminator_passes and self.unconditional and not exists(self.diff_augment)
+        if not merged:
+            if apply_gradient_penalty:
+                real_images.requires_grad_()
+            real_images_rgbs = self.D.real_images_to_rgbs(real_images)
+            if exists(self.diff_augment):
+                real_images, real_images_rgbs = self.diff_augment(real_images, real_images_rgbs)
         batch_size = real_images.shape[0]
 
         G_kwargs, maybe_text_kwargs = self.generate_kwargs(dl_iter, batch_size)
@@ -408,18 +413,37 @@ class GigaGAN(nn.Module):
                 images, rgbs = self.diff_augment(images, rgbs)
         images = images.detach()
         rgbs = [rgb.detach() for rgb in rgbs]
-        if apply_gradient_penalty:
-            images.requires_grad_()
-            for rgb in rgbs:
-                rgb.requires_grad_()
 
         ops.second_order = bool(apply_gradient_penalty)    # these graphs are differentiated twice
         try:
-            fake_logits, fake_ms_logits, _ = self.D(images, rgbs, **maybe_text_kwargs,
-                                                    return_multiscale_outputs=calc_multiscale_loss, calc_aux_loss=False)
-            real_logits, real_ms_logits, aux_recon_losses = self.D(real_images, real_images_rgbs, **maybe_text_kwargs,
-                                                                   return_multiscale_outputs=calc_multiscale_loss,
-                                                                   calc_aux_loss=True)
+            if merged:
+                # D(fake) and D(real) as ONE pass over the concatenated batch (samples are independent in D: no batch
+                # statistics anywhere). Twice the rows per launch and half the launches; the gradient penalty of both
+                # halves comes out of a single double backward (d sum_i out_i / d x_j = 0 for i != j).
+                b = batch_size
+                x_all = torch.cat((images.to(real_images.dtype), real_images), dim=0)
+                if apply_gradient_penalty:
+                    x_all.requires_grad_()
+                real_rgbs = {t.shape[-1]: t for t in self.D.real_images_to_rgbs(x_all[b:])}
+                fake_rgbs = {t.shape[-1]: t for t in rgbs}
+                rgbs_all = [torch.cat((fake_rgbs[r].to(real_rgbs[r].dtype), real_rgbs[r]), dim=0)
+                            for r in self.D.multiscale_input_resolutions]
+                logits_all, ms_all, aux_recon_losses = self.D(x_all, rgbs_all, return_multiscale_outputs=calc_multiscale_loss,
+                                                              calc_aux_loss=True, aux_rows=(b, 2 * b))
+                fake_logits, real_logits = logits_all[:, :b], logits_all[:, b:]
+                ms_split = [m.reshape(-1, 2 * b, *m.shape[1:]) for m in ms_all]          # '(s b) ... -> s b ...'
+                fake_ms_logits = [m[:, :b] for m in ms_split]
+                real_ms_logits = [m[:, b:] for m in ms_split]
+            else:
+                if apply_gradient_penalty:
+                    images.requires_grad_()
+                    for rgb in rgbs:
+                        rgb.requires_grad_()
+                fake_logits, fake_ms_logits, _ = self.D(images, rgbs, **maybe_text_kwargs,
+                                                        return_multiscale_outputs=calc_multiscale_loss, calc_aux_loss=False)
+                real_logits, real_ms_logits, aux_recon_losses = self.D(real_images, real_images_rgbs, **maybe_text_kwargs,
+                                                                       return_multiscale_outputs=calc_multiscale_loss,
+                                                                       calc_aux_loss=True)
         finally:
             ops.second_order = False
 
@@ -437,11 +461,16 @@ class GigaGAN(nn.Module):
         gp_detached = zero
         if apply_gradient_penalty:
             w = self.multiscale_divergence_loss_weight
-            real_gp = gradient_penalty(real_images, outputs=[real_logits, *real_ms_logits],
-                                       grad_output_weights=[1., *(w,) * len(real_ms_logits)])
-            fake_gp = gradient_penalty(images, outputs=[fake_logits, *fake_ms_logits],
-                                       grad_output_weights=[1., *(w,) * len(fake_ms_logits)])
-            gp_loss = real_gp + fake_gp
+            if merged:
+                per_sample = gradient_penalty(x_all, outputs=[logits_all, *ms_all],
+                                              grad_output_weights=[1., *(w,) * len(ms_all)], per_sample=True)
+                gp_loss = per_sample[b:].mean() + per_sample[:b].mean()           # real_gp + fake_gp
+            else:
+                real_gp = gradient_penalty(real_images, outputs=[real_logits, *real_ms_logits],
+                                           grad_output_weights=[1., *(w,) * len(real_ms_logits)])
+                fake_gp = gradient_penalty(images, outputs=[fake_logits, *fake_ms_logits],
+                                           grad_output_weights=[1., *(w,) * len(fake_ms_logits)])
+                gp_loss = real_gp + fake_gp
             gp_detached = torch.nan_to_num(gp_loss.detach(), nan=0.)
 
         total_loss = divergence + gp_loss

@@ -34,3 +34,27 @@ def test_train_steps_update_both_models_and_skip_unused_params(tmp_path):
     assert gan.G_opt.flat_p.abs().sum() > 0 and gan._steps_host == 3
     img = gan.generate(batch_size=2)
     assert img.shape == (2, 3, 16, 16)
+
+
+def test_merged_discriminator_pass_equals_separate_passes(tmp_path):
+    """D(fake) and D(real) as one concatenated pass (incl. the single-double-backward gradient penalty) gives the same
+    losses and the same discriminator gradients as the reference's two passes — fp32 oracle ops, same RNG stream."""
+    from gigagan_pytorch_amd import ops
+    from oracle.torch_ops import OracleOps
+
+    def run(merged, gp):
+        torch.manual_seed(0)
+        gan = GigaGAN(generator=dict(TINY_G), discriminator=dict(TINY_D), device='cpu', create_ema_generator_at_init=False,
+                      model_folder=str(tmp_path / f'm{merged}{gp}'), results_folder=str(tmp_path / f'r{merged}{gp}'))
+        gan.merge_discriminator_passes = merged
+        real = torch.rand(2, 3, 16, 16, generator=torch.Generator().manual_seed(3))
+        torch.manual_seed(1)
+        gan.D_opt.zero_grad()
+        with ops.use_impl(OracleOps()):
+            out = gan._d_micro(real, None, None, 1, gp, True)
+        return [float(o) for o in out], gan.D_opt.flat_g.clone()
+
+    for gp in (False, True):
+        la, ga = run(False, gp); lb, gb = run(True, gp)
+        assert all(abs(a - b) <= 1e-4 * max(1., abs(a)) for a, b in zip(la, lb)), (la, lb)
+        assert ((ga - gb).norm() / ga.norm()).item() < 1e-4
