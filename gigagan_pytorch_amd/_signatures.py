@@ -43,3 +43,5 @@ def declare(L):
     L.gg_rmsnorm_bwd.argtypes = [_P, _P, _P, _P, _P, C.c_int64, _I, _F, _P]
     L.gg_rmsnorm_bwd2.restype = C.c_int
     L.gg_rmsnorm_bwd2.argtypes = [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _I, _F, _P]
+    L.gg_attn_bwd2.restype = C.c_int
+    L.gg_attn_bwd2.argtypes = [_P] * 20 + [_I, _I, _I, _F, _F, _P]

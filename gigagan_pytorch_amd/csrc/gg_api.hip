@@ -6,6 +6,7 @@
 #include "gg_elementwise.h"
 #include "gg_modconv.h"
 #include "gg_attention.h"
+#include "gg_attention2.h"
 #include "../../include/gigagan_amd.h"
 
 #include <stdio.h>
@@ -604,4 +605,33 @@ extern "C" int gg_rmsnorm_bwd2(const void* x, const void* g, const void* v, cons
                                float* dgamma_part, int64_t rows, int32_t C, float eps, void* stream) {
     if (!g || !v || !gg) return gg_fail(-1, "gg_rmsnorm_bwd2: null pointer");
     return gg_rms_launch(2, x, g, v, gamma, gx, gg, dgamma_part, rows, C, gg_rmsnorm_blocks(rows), eps, stream);
+}
+
+extern "C" int gg_attn_bwd2(const void* q, const void* k, const void* v, const void* k0, const void* v0, const void* d_o,
+                            const void* aq, const void* ak, const void* av, const void* ak0, const void* av0,
+                            const float* lse, const float* dvec, float* mu, float* gi, void* gq, void* gk, void* gv,
+                            void* gdo, float* null_part, int32_t B, int32_t n, int32_t h, float alpha, float beta,
+                            void* stream) {
+    if (!q || !k || !v || !k0 || !v0 || !d_o || !aq || !ak || !av || !ak0 || !av0 || !lse || !dvec || !mu || !gi || !gq ||
+        !gk || !gv || !gdo || !null_part)
+        return gg_fail(-1, "gg_attn_bwd2: null pointer");
+    if (B <= 0 || h <= 0 || n <= 0 || (n % 128)) return gg_fail(-2, "gg_attn_bwd2: need n %% 128 == 0 tokens (got %d)", n);
+    if ((long long)B * h > 65535) return gg_fail(-2, "gg_attn_bwd2: B*h exceeds grid.y");
+    GgAttn2Params p;
+    memset(&p, 0, sizeof(p));
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.k0 = (const bf16_t*)k0; p.v0 = (const bf16_t*)v0;
+    p.d_o = (const bf16_t*)d_o; p.aq = (const bf16_t*)aq; p.ak = (const bf16_t*)ak; p.av = (const bf16_t*)av;
+    p.ak0 = (const bf16_t*)ak0; p.av0 = (const bf16_t*)av0; p.lse = lse; p.dvec = dvec; p.mu = mu; p.gi = gi;
+    p.gq = (bf16_t*)gq; p.gk = (bf16_t*)gk; p.gv = (bf16_t*)gv; p.gdo = (bf16_t*)gdo; p.null_part = null_part;
+    p.B = B; p.n = n; p.h = h; p.alpha = alpha; p.beta = beta;
+    dim3 grid((unsigned)(n / 128), (unsigned)(B * h));
+    hipStream_t s = (hipStream_t)stream;
+    GG_LAUNCH(gg_attn_bwd2_q_kernel<true>, grid, dim3(256), s, p);
+    int rc = gg_check_launch();
+    if (rc) return rc;
+    GG_LAUNCH(gg_attn_bwd2_q_kernel<false>, grid, dim3(256), s, p);
+    rc = gg_check_launch();
+    if (rc) return rc;
+    GG_LAUNCH(gg_attn_bwd2_kv_kernel, grid, dim3(256), s, p);
+    return gg_check_launch();
 }

@@ -528,7 +528,7 @@ def attn_fwd(q, k, v, k0, v0, heads: int, alpha: float, beta: float):
     return o, lse
 
 
-def attn_bwd(q, k, v, k0, v0, o, lse, d_o, heads: int, alpha: float, beta: float):
+def attn_bwd(q, k, v, k0, v0, o, lse, d_o, heads: int, alpha: float, beta: float, return_dvec: bool = False):
     """returns (dq, dk, dv bf16 like q; dk0_q (heads, 64) fp32 = alpha * sum dS_i0 q_i; dv0 (heads, 64) fp32;
     dbias0 (heads,) fp32 = sum dS_i0)."""
     L = _C.lib()
@@ -543,7 +543,32 @@ def attn_bwd(q, k, v, k0, v0, o, lse, d_o, heads: int, alpha: float, beta: float
                            ptr(dv), ptr(part), B, n, heads, alpha, beta, L.stream(q))
     L.check(rc, 'gg_attn_bwd')
     s = part.sum(dim=(0, 2))                 # (heads, 3, 64)
+    if return_dvec:
+        return dq, dk, dv, s[:, 0] * alpha, s[:, 1], s[:, 2, 0], dvec
     return dq, dk, dv, s[:, 0] * alpha, s[:, 1], s[:, 2, 0]
+
+
+def attn_bwd2(q, k, v, k0, v0, d_o, lse, dvec, aq, ak, av, ak0, av0, heads: int, alpha: float, beta: float):
+    """second-order pass: incoming gradients (aq, ak, av like q; ak0, av0 (heads, 64) bf16) w.r.t. attn_bwd's outputs ->
+    (gq, gk, gv, gdo bf16 like q; gk0, gv0 (heads, 64) fp32)."""
+    L = _C.lib()
+    L.require(q, k, v, k0, v0, d_o, lse, dvec, aq, ak, av, ak0, av0)
+    B, n, hd = q.shape
+    for t in (d_o, aq, ak, av):
+        assert t.dtype == torch.bfloat16 and t.is_contiguous() and t.shape == q.shape
+    for t in (ak0, av0):
+        assert t.dtype == torch.bfloat16 and t.is_contiguous() and t.shape == (heads, 64)
+    gq, gk, gv, gdo = (torch.empty_like(q) for _ in range(4))
+    mu, gi = torch.empty_like(lse), torch.empty_like(lse)
+    nblk = n // 128
+    part = torch.empty((B, heads, nblk, 3, 64), dtype=torch.float32, device=q.device)
+    rc = L.lib.gg_attn_bwd2(ptr(q), ptr(k), ptr(v), ptr(k0), ptr(v0), ptr(d_o), ptr(aq), ptr(ak), ptr(av), ptr(ak0), ptr(av0),
+                            ptr(lse), ptr(dvec), ptr(mu), ptr(gi), ptr(gq), ptr(gk), ptr(gv), ptr(gdo), ptr(part), B, n, heads,
+                            alpha, beta, L.stream(q))
+    L.check(rc, 'gg_attn_bwd2')
+    s = part.sum(dim=(0, 2))                 # (heads, 3, 64)
+    gk0 = alpha * s[:, 0] + 2.0 * beta * (s[:, 2, 0:1] * k0.float() + s[:, 2, 1:2] * ak0.float())
+    return gq, gk, gv, gdo, gk0, s[:, 1]
 
 
 # --------------------------------------------------------------------------------------------------

@@ -367,25 +367,57 @@ class RmsNormBwdFn(Function):
 
 class FlashAttnFn(Function):
     """fused self-attention over [B][n][heads*64] projections with the learned null key / value (gg_attention.h):
-    forward saves only o and the per-query log-sum-exp; backward = two kernels (dq; dk/dv) that recompute P.
-    First order only: graphs that are differentiated twice (gradient penalty) use the unfused Functions."""
+    forward saves only o and the per-query log-sum-exp; backward = two kernels (dq; dk/dv) that recompute P. When the
+    backward itself is recorded (gradient penalty, `create_graph=True`) it runs as FlashAttnBwdFn, whose own backward is
+    the fused second-order pass (gg_attention2.h)."""
 
     @staticmethod
     def forward(ctx, q, k, v, k0, v0, heads, alpha, beta):
         k0b, v0b = k0.to(ACT_DTYPE).contiguous(), v0.to(ACT_DTYPE).contiguous()
         o, lse = K.attn_fwd(q, k, v, k0b, v0b, heads, alpha, beta)
         ctx.cfg = (heads, alpha, beta)
-        ctx.save_for_backward(q, k, v, k0b, v0b, o, lse)
+        ctx.save_for_backward(q, k, v, k0, v0, o, lse)
         return o
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, d_o):
-        q, k, v, k0b, v0b, o, lse = ctx.saved_tensors
+        q, k, v, k0, v0, o, lse = ctx.saved_tensors
         heads, alpha, beta = ctx.cfg
-        dq, dk, dv, dk0q, dv0, dbias0 = K.attn_bwd(q, k, v, k0b, v0b, o, lse, d_o.contiguous(), heads, alpha, beta)
+        if torch.is_grad_enabled():       # this backward is being differentiated: keep it on the autograd tape
+            dq, dk, dv, dk0, dv0 = FlashAttnBwdFn.apply(q, k, v, k0, v0, o, lse, d_o.contiguous(), heads, alpha, beta)
+        else:
+            k0b, v0b = k0.to(ACT_DTYPE).contiguous(), v0.to(ACT_DTYPE).contiguous()
+            dq, dk, dv, dk0q, dv0, dbias0 = K.attn_bwd(q, k, v, k0b, v0b, o, lse, d_o.contiguous(), heads, alpha, beta)
+            dk0 = dk0q + (2.0 * beta) * dbias0[:, None] * k0b.float()
+        return dq, dk, dv, dk0.to(k0.dtype), dv0.to(v0.dtype), None, None, None
+
+
+class FlashAttnBwdFn(Function):
+    """(dq, dk, dv, dk0, dv0) of FlashAttnFn as a differentiable function of (q, k, v, k0, v0, dO). `o` and `lse` are the
+    forward's saved outputs; the second-order pass returns TOTAL derivatives w.r.t. q, k, v, k0, v0 (it differentiates
+    through P and D = dO.O itself), so no gradient is routed back through them."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, k0, v0, o, lse, d_o, heads, alpha, beta):
+        k0b, v0b = k0.to(ACT_DTYPE).contiguous(), v0.to(ACT_DTYPE).contiguous()
+        dq, dk, dv, dk0q, dv0, dbias0, dvec = K.attn_bwd(q, k, v, k0b, v0b, o, lse, d_o, heads, alpha, beta, return_dvec=True)
         dk0 = dk0q + (2.0 * beta) * dbias0[:, None] * k0b.float()
-        return dq, dk, dv, dk0, dv0, None, None, None
+        ctx.cfg = (heads, alpha, beta)
+        ctx.save_for_backward(q, k, v, k0b, v0b, lse, dvec, d_o)
+        return dq, dk, dv, dk0, dv0
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, a_q, a_k, a_v, a_k0, a_v0):
+        q, k, v, k0b, v0b, lse, dvec, d_o = ctx.saved_tensors
+        heads, alpha, beta = ctx.cfg
+
+        def like(t, ref):
+            return torch.zeros_like(ref) if t is None else t.to(ACT_DTYPE).contiguous()
+
+        gq, gk, gv, gdo, gk0, gv0 = K.attn_bwd2(q, k, v, k0b, v0b, d_o, lse, dvec, like(a_q, q), like(a_k, q), like(a_v, q),
+                                                like(a_k0, k0b), like(a_v0, v0b), heads, alpha, beta)
+        return gq, gk, gv, gk0, gv0, None, None, gdo, None, None, None
 
 
 class GemmFn(Function):
@@ -678,7 +710,7 @@ class HipOps:
         """SelfAttention.forward after the projections (gp.py:562-592); q, k, v logical (b, heads*d, x, y)."""
         b, c, x, y = q.shape
         n = x * y
-        if c == heads * 64 and n % 128 == 0 and not second_order:
+        if c == heads * 64 and n % 128 == 0:
             qh, kh, vh = (nhwc(to_act(t)).view(b, n, c) for t in (q, k, v))
             alpha, beta = (2.0 * scale, -scale) if l2 else (scale, 0.0)
             o = FlashAttnFn.apply(qh, kh, vh, null_kv[0], null_kv[1], heads, alpha, beta)

@@ -176,6 +176,18 @@ int gg_rmsnorm_bwd(const void* x, const void* g, const float* gamma, void* dx, f
 int gg_rmsnorm_bwd2(const void* x, const void* g, const void* v, const float* gamma, void* gx, void* gg, float* dgamma_part,
                     int64_t rows, int32_t C, float eps, void* stream);
 
+/* second-order pass of the fused attention (gradient-penalty steps differentiate gg_attn_bwd; reference:
+ * torch.autograd.grad(create_graph=True) through SelfAttention, gp.py:120-155 and :538-594). aq/ak/av ([B][n][h*64] bf16)
+ * and ak0/av0 ([h][64] bf16) are the incoming gradients w.r.t. gg_attn_bwd's dq/dk/dv/dk0/dv0; lse and dvec are the
+ * forward's log-sum-exp and gg_attn_bwd's dvec. Returns gq/gk/gv/gdo = d<A, (dq,dk,dv,dk0,dv0)> / d(q, k, v, dO) and the
+ * null token's partial sums null_part [B*h * n/128][3][64]: [0] sum_i (R_i0 q_i + dS_i0 A_q,i) (times alpha),
+ * [1] sum_i Pd_i0 dO_i (= gv0), [2][0] = sum_i R_i0, [2][1] = sum_i dS_i0, so that
+ * gk0 = alpha*[0] + 2*beta*([2][0]*k0 + [2][1]*ak0). mu, gi: [B*h][n] fp32 scratch. */
+int gg_attn_bwd2(const void* q, const void* k, const void* v, const void* k0, const void* v0, const void* d_o, const void* aq,
+                 const void* ak, const void* av, const void* ak0, const void* av0, const float* lse, const float* dvec,
+                 float* mu, float* gi, void* gq, void* gk, void* gv, void* gdo, float* null_part, int32_t B, int32_t n,
+                 int32_t h, float alpha, float beta, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

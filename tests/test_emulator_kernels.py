@@ -422,3 +422,54 @@ def test_self_attention_module_on_fused_kernels_vs_oracle(dot):
     assert rel_err(yh, yo) < 2e-2
     for a, b in zip(gh, go):
         assert rel_err(a, b) < 6e-2
+
+
+@pytest.mark.parametrize('l2', [False, True])
+def test_fused_attention_second_order_vs_autograd(l2):
+    """gg_attn_bwd2 (gradient of <A, first-backward outputs>) vs double backward of plain fp32 tensor algebra."""
+    torch.manual_seed(0)
+    B, n, h = 1, 128, 2
+    scale = 64 ** -0.5
+    mk = lambda *s, m=1.0: bf(torch.randn(*s) * m)
+    q, v, k0, v0, d_o = mk(B, n, h * 64, m=0.7), mk(B, n, h * 64), mk(h, 64, m=0.7), mk(h, 64), mk(B, n, h * 64)
+    k = mk(B, n, h * 64, m=0.7)
+    aq, ak, av, ak0, av0 = mk(B, n, h * 64), mk(B, n, h * 64), mk(B, n, h * 64), mk(h, 64), mk(h, 64)
+    alpha, beta = (2 * scale, -scale) if l2 else (scale, 0.)
+
+    def fwd(q, k, v, k0, v0):
+        qh, kh, vh = (t.view(B, n, h, 64).permute(0, 2, 1, 3) for t in (q, k, v))
+        kk = torch.cat((k0[None, :, None, :].expand(B, -1, -1, -1), kh), 2)
+        vv = torch.cat((v0[None, :, None, :].expand(B, -1, -1, -1), vh), 2)
+        x = alpha * qh @ kk.transpose(-1, -2) + beta * (kk * kk).sum(-1)[:, :, None, :]
+        return (x.softmax(-1) @ vv).permute(0, 2, 1, 3).reshape(B, n, h * 64)
+
+    ins = [t.float().requires_grad_() for t in (q, k, v, k0, v0)]
+    dof = d_o.float().requires_grad_()
+    first = torch.autograd.grad(fwd(*ins), ins, dof, create_graph=True)
+    F_ = sum((a.float() * g).sum() for a, g in zip((aq, ak, av, ak0, av0), first))
+    ref = torch.autograd.grad(F_, [*ins, dof])
+
+    o, lse = K.attn_fwd(q, k, v, k0, v0, h, alpha, beta)
+    *_, dvec = K.attn_bwd(q, k, v, k0, v0, o, lse, d_o, h, alpha, beta, return_dvec=True)
+    gq, gk, gv, gdo, gk0, gv0 = K.attn_bwd2(q, k, v, k0, v0, d_o, lse, dvec, aq, ak, av, ak0, av0, h, alpha, beta)
+    for name, a, b_ in zip(('gq', 'gk', 'gv', 'gk0', 'gv0', 'gdo'), (gq, gk, gv, gk0, gv0, gdo), ref):
+        assert rel_err(a, b_) < 4e-2, (name, rel_err(a, b_))
+
+
+@pytest.mark.parametrize('l2', [False, True])
+def test_self_attention_op_double_backward_on_fused_kernels(l2):
+    """gradient-penalty pattern through HipOps.self_attention: FlashAttnFn -> FlashAttnBwdFn -> fused second-order pass,
+    against the oracle's plain autograd (null key/value parameters included)."""
+    def run(I):
+        torch.manual_seed(0)
+        q = (torch.randn(1, 64, 16, 8) * 0.5).requires_grad_(); v = torch.randn(1, 64, 16, 8).requires_grad_()
+        k = q if l2 else (torch.randn(1, 64, 16, 8) * 0.5).requires_grad_()
+        null_kv = (torch.randn(2, 1, 64) * 0.5).requires_grad_()
+        out = I.self_attention(q, k, v, null_kv, heads=1, scale=0.125, l2=l2).float()
+        gq, = torch.autograd.grad((out * torch.linspace(-1, 1, out.numel()).view_as(out)).sum(), q, create_graph=True)
+        leaves = [q, v, null_kv] if l2 else [q, k, v, null_kv]
+        return torch.autograd.grad(gq.float().pow(2).sum(), leaves)
+
+    gh = run(ops.HipOps()); go = run(OracleOps(bf16_operands=True))
+    for a, b in zip(gh, go):
+        assert rel_err(a, b) < 6e-2

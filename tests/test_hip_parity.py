@@ -159,6 +159,40 @@ def test_fused_attention_vs_cpu_reference(cfg):
     assert rel_err(dk0, g[3]) < 2e-2 and rel_err(dv0.cpu(), g[4]) < 2e-2
 
 
+@pytest.mark.parametrize('cfg', [(2, 256, 4, True), (1, 1024, 2, False)])
+def test_fused_attention_second_order_vs_cpu_autograd(cfg):
+    """gg_attn_bwd2 on the GPU vs double backward of fp32 tensor algebra on the same bf16 inputs."""
+    B, n, h, l2 = cfg
+    torch.manual_seed(0)
+    scale = 64 ** -0.5
+    mk = lambda *s, m=1.0: bf(torch.randn(*s) * m)
+    q, v, k0, v0, d_o = mk(B, n, h * 64, m=0.7), mk(B, n, h * 64), mk(h, 64, m=0.7), mk(h, 64), mk(B, n, h * 64)
+    k = q.clone() if l2 else mk(B, n, h * 64, m=0.7)
+    aq, ak, av, ak0, av0 = mk(B, n, h * 64), mk(B, n, h * 64), mk(B, n, h * 64), mk(h, 64), mk(h, 64)
+    alpha, beta = (2 * scale, -scale) if l2 else (scale, 0.)
+
+    def fwd(q, k, v, k0, v0):
+        qh, kh, vh = (t.view(B, n, h, 64).permute(0, 2, 1, 3) for t in (q, k, v))
+        kk = torch.cat((k0[None, :, None, :].expand(B, -1, -1, -1), kh), 2)
+        vv = torch.cat((v0[None, :, None, :].expand(B, -1, -1, -1), vh), 2)
+        x = alpha * qh @ kk.transpose(-1, -2) + beta * (kk * kk).sum(-1)[:, :, None, :]
+        return (x.softmax(-1) @ vv).permute(0, 2, 1, 3).reshape(B, n, h * 64)
+
+    ins = [t.float().requires_grad_() for t in (q, k, v, k0, v0)]
+    dof = d_o.float().requires_grad_()
+    first = torch.autograd.grad(fwd(*ins), ins, dof, create_graph=True)
+    F_ = sum((a.float() * g).sum() for a, g in zip((aq, ak, av, ak0, av0), first))
+    ref = torch.autograd.grad(F_, [*ins, dof])
+    d = dev()
+    qd, kd, vd, k0d, v0d, dod, aqd, akd, avd, ak0d, av0d = (t.to(d) for t in (q, k, v, k0, v0, d_o, aq, ak, av, ak0, av0))
+    o, lse = K.attn_fwd(qd, kd, vd, k0d, v0d, h, alpha, beta)
+    *_, dvec = K.attn_bwd(qd, kd, vd, k0d, v0d, o, lse, dod, h, alpha, beta, return_dvec=True)
+    outs = K.attn_bwd2(qd, kd, vd, k0d, v0d, dod, lse, dvec, aqd, akd, avd, ak0d, av0d, h, alpha, beta)
+    gq, gk, gv, gdo, gk0, gv0 = (t.cpu() for t in outs)
+    for name, a, b_ in zip(('gq', 'gk', 'gv', 'gk0', 'gv0', 'gdo'), (gq, gk, gv, gk0, gv0, gdo), ref):
+        assert rel_err(a, b_) < 2e-2, (name, rel_err(a, b_))
+
+
 def test_ops_match_reference_golden_fixture():
     fx = torch.load(GOLD / 'ops_small.pt', weights_only=False)
     H_ = ops.HipOps()
