@@ -83,8 +83,14 @@ GG_HOST_DEVICE float gg_bf2f(bf16_t h) {
     return x.f;
 }
 
-// round-to-nearest-even fp32 -> bf16 (NaN kept quiet), identical to torch's .to(torch.bfloat16)
+// round-to-nearest-even fp32 -> bf16 (NaN kept quiet), identical to torch's .to(torch.bfloat16). The device pass uses
+// the gfx950 converter (v_cvt_pk_bf16_f32: same rounding, one instruction per PAIR of values instead of ~6 integer
+// ops per value — the softmax / epilogue / elementwise kernels are VALU-bound on exactly this); the host pass and the
+// emulator keep the integer formulation.
 GG_HOST_DEVICE bf16_t gg_f2bf(float f) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GG_HOST_EMULATION)
+    return __builtin_bit_cast(bf16_t, (__bf16)f);
+#endif
     union { unsigned int u; float f; } x;
     x.f = f;
     if ((x.u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((x.u >> 16) | 0x40u);
