@@ -7,6 +7,7 @@
 #include "gg_modconv.h"
 #include "gg_attention.h"
 #include "gg_attention2.h"
+#include "gg_weights.h"
 #include "../../include/gigagan_amd.h"
 
 #include <stdio.h>
@@ -383,6 +384,28 @@ extern "C" int gg_ema_flat_f32(float* ema, const float* p, int64_t n, float one_
     if (n <= 0 || (n % 4)) return gg_fail(-2, "gg_ema: n must be a positive multiple of 4");
     if ((((uintptr_t)ema) | ((uintptr_t)p)) & 15) return gg_fail(-3, "gg_ema: buffers must be 16-byte aligned");
     GG_LAUNCH(gg_ema_kernel, dim3(gg_grid_for(n / 4)), dim3(256), (hipStream_t)stream, ema, p, (long long)n, one_minus_beta);
+    return gg_check_launch();
+}
+
+static_assert(sizeof(gg_pack_entry) == sizeof(GgPackEntry), "gg_pack_entry must mirror GgPackEntry");
+
+extern "C" int gg_pack_weights(const gg_pack_entry* table, const int64_t* header, int32_t max_blocks, void* stream) {
+    if (!table || !header) return gg_fail(-1, "gg_pack_weights: null pointer");
+    if ((((uintptr_t)table) | ((uintptr_t)header)) & 7) return gg_fail(-3, "gg_pack_weights: table/header must be 8-byte aligned");
+    if (max_blocks <= 0) max_blocks = 2048;
+    GG_LAUNCH(gg_pack_weights_kernel, dim3((unsigned)max_blocks), dim3(256), (hipStream_t)stream,
+              (const GgPackEntry*)table, (const long long*)header);
+    return gg_check_launch();
+}
+
+extern "C" int gg_wgrad_finish(const float* g, float* dst, int32_t O, int32_t I, int32_t T, int32_t C8, int32_t O8,
+                               float alpha, int32_t accumulate, void* stream) {
+    if (!g || !dst) return gg_fail(-1, "gg_wgrad_finish: null pointer");
+    if (O <= 0 || I <= 0 || T <= 0 || C8 < I || O8 < O) return gg_fail(-2, "gg_wgrad_finish: bad extents");
+    GgWgradFinishParams p;
+    p.g = g; p.dst = dst; p.O = O; p.I = I; p.T = T; p.C8 = C8; p.O8 = O8; p.accumulate = accumulate; p.alpha = alpha;
+    GG_LAUNCH(gg_wgrad_finish_kernel, dim3((unsigned)((O + 31) / 32), (unsigned)((I + 31) / 32)), dim3(256),
+              (hipStream_t)stream, p);
     return gg_check_launch();
 }
 

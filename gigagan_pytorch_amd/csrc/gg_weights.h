@@ -1,0 +1,97 @@
+// gg_weights.h — the two passes that sit between the fp32 master parameters (reference layout (O, I, kh, kw), flat
+// AdamW buffers) and the GEMM kernels' operand layouts.
+//
+//  gg_pack_weights_kernel: ONE launch re-packs every registered conv weight of a model into its bf16 GEMM operand(s)
+//      kind 0 ('fwd'): dst[o][t][i8]        = src[o][i][t]            (forward B operand, [co][kh][kw][ci])
+//      kind 1 ('bwd'): dst[i][T-1-t][o8]    = src[o][i][t]            (data-gradient B operand: flipped, in/out swapped)
+//    channel counts zero-padded to multiples of 8. It replaces the per-weight permute / flip / pad / cast chain the
+//    reference gets from cuDNN's internal filter transforms (gp.py:402-409, :1608-1621 F.conv2d call sites) - ~1200
+//    tiny launches per step - by a table walk. The table and its header live in device memory, so a captured hipGraph
+//    sees entries registered after capture. HBM-bound: 4 B read + 2 B written per weight element and kind.
+//
+//  gg_wgrad_finish_kernel: dst[o][i][t] (+)= alpha * g[(t*C8 + i)*O8 + o] - the weight-gradient GEMM's fp32 output
+//    ([tap][ci][co], what the MFMA kernel produces with pixels as the reduction) scattered into the parameter layout
+//    through an LDS transpose, scaled, and accumulated straight into the flat gradient buffer (.grad view) when asked.
+#pragma once
+#include "gg_device.h"
+
+struct GgPackEntry {
+    const float* src;       // (O, I, T) fp32, contiguous
+    bf16_t* dst;            // kind 0: (O8, T, I8) ; kind 1: (I8, T, O8)
+    long long first_item;   // prefix sum of work items over the table
+    int O, I, T, O8, I8, kind;
+};
+
+// header[0] = number of entries, header[1] = total work items (one item = 8 output channels x all taps)
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_pack_weights_kernel(const GgPackEntry* table, const long long* header) {
+    const int n = (int)header[0];
+    const long long total = header[1];
+    for (long long item = (long long)blockIdx.x * 256 + threadIdx.x; item < total; item += (long long)gridDim.x * 256) {
+        int lo = 0, hi = n - 1;                       // last entry with first_item <= item
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (table[mid].first_item <= item) lo = mid; else hi = mid - 1;
+        }
+        const GgPackEntry e = table[lo];
+        const long long local = item - e.first_item;
+        const int T = e.T;
+        if (e.kind == 0) {
+            const int chunks = e.I8 >> 3;
+            const int o = (int)(local / chunks), i0 = (int)(local % chunks) * 8;
+            const float* s = e.src + ((long long)o * e.I + i0) * T;
+            bf16_t* d = e.dst + (long long)o * T * e.I8 + i0;
+            const int valid = (o < e.O) ? (e.I - i0 < 8 ? e.I - i0 : 8) : 0;
+            for (int t = 0; t < T; ++t) {
+                u16x8 v;
+                for (int j = 0; j < 8; ++j) v[j] = gg_f2bf(j < valid ? s[(long long)j * T + t] : 0.f);
+                *(u16x8*)(d + (long long)t * e.I8) = v;
+            }
+        } else {
+            const int i = (int)(local % e.I8), o0 = (int)(local / e.I8) * 8;
+            const float* s = e.src + ((long long)o0 * e.I + i) * T;
+            bf16_t* d = e.dst + (long long)i * T * e.O8 + o0;
+            const int valid = (i < e.I) ? (e.O - o0 < 8 ? e.O - o0 : 8) : 0;
+            const long long ostride = (long long)e.I * T;
+            for (int t = 0; t < T; ++t) {
+                u16x8 v;
+                for (int j = 0; j < 8; ++j) v[j] = gg_f2bf(j < valid ? s[j * ostride + t] : 0.f);
+                *(u16x8*)(d + (long long)(T - 1 - t) * e.O8) = v;
+            }
+        }
+    }
+}
+
+#define GG_WF_TG 9        // taps staged per pass (a 3x3 kernel in one pass)
+
+struct GgWgradFinishParams {
+    const float* g;       // (T*C8, O8) fp32
+    float* dst;           // (O, I, T) fp32
+    int O, I, T, C8, O8, accumulate;
+    float alpha;
+};
+
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_wgrad_finish_kernel(GgWgradFinishParams p) {
+    GG_SHARED float tile[32][32 * GG_WF_TG + 1];
+    const int o0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+    for (int t0 = 0; t0 < p.T; t0 += GG_WF_TG) {
+        const int tg = p.T - t0 < GG_WF_TG ? p.T - t0 : GG_WF_TG;
+        for (int idx = threadIdx.x; idx < 1024 * tg; idx += 256) {
+            const int ol = idx & 31, il = (idx >> 5) & 31, tl = idx >> 10;
+            float v = 0.f;
+            if (o0 + ol < p.O && i0 + il < p.I) v = p.g[((long long)(t0 + tl) * p.C8 + i0 + il) * p.O8 + o0 + ol];
+            tile[ol][il * tg + tl] = v;
+        }
+        gg_sync();
+        const int cols = 32 * tg;
+        for (int idx = threadIdx.x; idx < 32 * cols; idx += 256) {
+            const int ol = idx / cols, col = idx - ol * cols;
+            const int il = col / tg, tl = col - il * tg;
+            if (o0 + ol < p.O && i0 + il < p.I) {
+                float* d = p.dst + ((long long)(o0 + ol) * p.I + i0 + il) * p.T + t0 + tl;
+                const float v = p.alpha * tile[ol][col];
+                *d = p.accumulate ? *d + v : v;
+            }
+        }
+        gg_sync();
+    }
+}

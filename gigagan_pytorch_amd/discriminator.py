@@ -306,7 +306,7 @@ class Discriminator(nn.Module):
                 excitations.append(squeeze_excite(x))
             excite = excitations.pop(0) if excitations else None
             if exists(excite):
-                x = x * tile_batch(excite, x.shape[0]).to(x.dtype)
+                x = ops.impl.channel_scale(x, tile_batch(excite, x.shape[0]))
 
             batch_prev_stage = x.shape[0]
             if resolution in self.multiscale_input_resolutions:

@@ -184,7 +184,7 @@ class Generator(BaseGenerator):
                 excitations.append(squeeze_excite(x))
             excite = excitations.pop(0) if excitations else None
             if exists(excite):
-                x = x * excite.to(x.dtype)
+                x = ops.impl.channel_scale(x, excite)
 
             h, w = x.shape[-2:]
             # noise draws: same order, shape and device as the reference's Noise modules (gp.py:938)

@@ -101,6 +101,15 @@ class DiffAugment(nn.Module):
         return images, rgbs
 
 
+def _backward(loss):
+    """loss.backward() with conv weight gradients accumulated directly into the flat gradient buffers (ops.grad_sink)."""
+    ops.grad_sink = True
+    try:
+        loss.backward()
+    finally:
+        ops.grad_sink = False
+
+
 class GigaGAN(nn.Module):
     def __init__(
         self,
@@ -483,7 +492,7 @@ class GigaGAN(nn.Module):
                 aux_detached = aux_loss.detach()
             total_loss = total_loss + aux_loss * self.discr_aux_recon_loss_weight
 
-        (total_loss / grad_accum_every).backward()
+        _backward(total_loss / grad_accum_every)
         return divergence.detach(), ms_detached, gp_detached, aux_detached
 
     def train_discriminator_step(self, dl_iter, grad_accum_every=1, apply_gradient_penalty=False,
@@ -544,7 +553,7 @@ class GigaGAN(nn.Module):
                                          calc_aux_loss=False)
                 matching_loss = aux_matching_loss(real_logits, fake_logits)
                 total_matching_aware_loss = matching_loss.detach() / grad_accum_every
-                (matching_loss * self.matching_awareness_loss_weight / grad_accum_every).backward()
+                _backward(matching_loss * self.matching_awareness_loss_weight / grad_accum_every)
 
         works = gdist.all_reduce_flat_grads(self.D_opt.flat_g)
         gdist.wait_all(works)
@@ -573,7 +582,7 @@ class GigaGAN(nn.Module):
                 ms_div = ms_div + generator_hinge_loss(ms)
             ms_detached = ms_div.detach()
             total_loss = total_loss + ms_div * self.multiscale_divergence_loss_weight
-        (total_loss / grad_accum_every).backward()
+        _backward(total_loss / grad_accum_every)
         return divergence.detach(), ms_detached
 
     def train_generator_step(self, batch_size=None, dl_iter=None, grad_accum_every=1, calc_multiscale_loss=True):

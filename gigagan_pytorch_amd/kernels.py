@@ -614,3 +614,70 @@ def rmsnorm_bwd2(x, g, v, gamma, want_dgamma: bool):
     rc = L.lib.gg_rmsnorm_bwd2(ptr(x), ptr(g), ptr(v), ptr(gamma), ptr(gx), ptr(gg), ptr(part), rows, Cc, RMS_EPS, L.stream(x))
     L.check(rc, 'gg_rmsnorm_bwd2')
     return gx, gg, (part.sum(0) if part is not None else None)
+
+
+# --------------------------------------------------------------------------------------------------
+# weights: fp32 parameter layout <-> GEMM operand layouts (gg_weights.h)
+# --------------------------------------------------------------------------------------------------
+
+def wgrad_finish(g: torch.Tensor, O: int, I: int, T: int, alpha: float = 1.0, out: torch.Tensor | None = None,
+                 accumulate: bool = False) -> torch.Tensor:
+    """g: (T*C8, O8) fp32 from conv2d_wgrad_nhwc -> (O, I, T) fp32 = alpha * g transposed; with `out` (+ accumulate)
+    the result is written / added in place (e.g. into a parameter's .grad view of the flat gradient buffer)."""
+    L = _C.lib()
+    L.require(g, out)
+    assert g.dtype == torch.float32 and g.is_contiguous() and g.dim() == 2 and g.shape[0] % T == 0
+    c8, o8 = g.shape[0] // T, g.shape[1]
+    if out is None:
+        assert not accumulate
+        out = torch.empty((O, I, T), dtype=torch.float32, device=g.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == O * I * T
+    rc = L.lib.gg_wgrad_finish(ptr(g), ptr(out), O, I, T, c8, o8, float(alpha), int(accumulate), L.stream(g))
+    L.check(rc, 'gg_wgrad_finish')
+    return out
+
+
+class PackEntry(C.Structure):       # mirrors gg_pack_entry
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('first_item', C.c_int64), ('O', C.c_int32), ('I', C.c_int32),
+                ('T', C.c_int32), ('O8', C.c_int32), ('I8', C.c_int32), ('kind', C.c_int32)]
+
+
+class PackTable:
+    """The device-resident work table of gg_pack_weights for one model: every (weight, kind) registered here is
+    re-packed by ONE launch of `refresh()`. Table and header are fixed device buffers that are only appended to, so
+    graph-captured refresh launches follow later registrations."""
+    KINDS = {'fwd': 0, 'bwd': 1}
+
+    def __init__(self, device, capacity: int = 2048):
+        self.device = torch.device(device)
+        self.capacity = capacity
+        self.table = torch.zeros(capacity * C.sizeof(PackEntry) // 8, dtype=torch.int64, device=self.device)
+        self.header = torch.zeros(2, dtype=torch.int64, device=self.device)
+        self.n = 0
+        self.items = 0
+        self.keep = []          # (src, dst) tensors kept alive
+
+    def register(self, src: torch.Tensor, O: int, I: int, T: int, kind: str) -> torch.Tensor:
+        """src: fp32 contiguous storage of (O, I, T); returns the persistent bf16 operand (rows, T*cols8)."""
+        assert src.dtype == torch.float32 and src.is_contiguous() and src.numel() == O * I * T
+        assert self.n < self.capacity, 'PackTable capacity exceeded'
+        o8, i8 = (O + 7) // 8 * 8, (I + 7) // 8 * 8
+        k = self.KINDS[kind]
+        dst = torch.empty((o8, T * i8) if k == 0 else (i8, T * o8), dtype=torch.bfloat16, device=self.device)
+        e = PackEntry(src.data_ptr(), dst.data_ptr(), self.items, O, I, T, o8, i8, k)
+        words = torch.frombuffer(bytearray(bytes(e)), dtype=torch.int64)
+        w = words.numel()
+        self.table[self.n * w:(self.n + 1) * w].copy_(words)
+        self.n += 1
+        self.items += o8 * i8 // 8
+        self.header.copy_(torch.tensor([self.n, self.items], dtype=torch.int64))
+        self.keep.append((src, dst))
+        return dst
+
+    def refresh(self):
+        if self.n == 0:
+            return
+        L = _C.lib()
+        L.require(self.table)
+        rc = L.lib.gg_pack_weights(ptr(self.table), ptr(self.header), 4 if L.is_emulator else 0, L.stream(self.table))
+        L.check(rc, 'gg_pack_weights')

@@ -16,6 +16,8 @@ from __future__ import annotations
 import math
 from contextlib import contextmanager
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -85,6 +87,41 @@ def bump_weight_epoch():
 pack_cache_clear = bump_weight_epoch
 
 
+_DEBUG_NO_TABLE = bool(os.environ.get('GG_DEBUG_NO_PACK_TABLE'))
+_DEBUG_NO_SINK = bool(os.environ.get('GG_DEBUG_NO_GRAD_SINK'))
+
+
+def _table_pack(w, kind: str):
+    """parameters owned by a FlatAdamW: persistent operands, all re-packed by one gg_pack_weights launch the first time
+    any of them is used after the weight epoch moved. None -> caller falls back to the per-weight path."""
+    tab = w._gg_pack_table
+    slot = w.__dict__.get('_gg_tpacks')
+    ent = slot.get(kind) if slot else None
+    if ent is None or ent[1] != w.data_ptr():
+        if w.device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            return None                     # table appends are host->device copies: not while a graph is being captured
+        shp = tuple(w.shape)
+        if len(shp) == 5:
+            assert shp[0] == 1 or shp[1] % 8 == 0, 'stacked kernel banks need O % 8 == 0'
+            shp = (shp[0] * shp[1],) + shp[2:]
+        if kind == 's2d':                   # (O, 4C, 1, 1) over channels (c, s1, s2) == (O, C, 2*2) taps
+            O, I, T, tk = shp[0], shp[1] // 4, 4, 'fwd'
+        else:
+            O, I, T, tk = shp[0], shp[1], shp[2] * shp[3], kind
+        src = w.detach()
+        if not src.is_contiguous():
+            return None
+        dst = tab.register(src, O, I, T, tk)
+        if slot is None:
+            slot = w.__dict__.setdefault('_gg_tpacks', {})
+        ent = slot[kind] = (dst, w.data_ptr())
+        tab.epoch = -1
+    if tab.epoch != _weight_epoch:
+        tab.refresh()
+        tab.epoch = _weight_epoch
+    return ent[0]
+
+
 def _pad_oi(w: torch.Tensor, o_to: int, i_to: int) -> torch.Tensor:
     o, i = w.shape[0], w.shape[1]
     if o_to != o or i_to != i:
@@ -99,6 +136,10 @@ def packed_weight(w: torch.Tensor, kind: str) -> torch.Tensor:
          's2d'  -> w is the reference's (O, 4C, 1, 1) over channels (c, s1, s2): (O8, 4*C8) [co][s1][s2][c]
        channel counts are zero-padded to multiples of 8 (the kernels' 16-byte vectors)."""
     cacheable = isinstance(w, torch.nn.Parameter)
+    if cacheable and getattr(w, '_gg_pack_table', None) is not None and not _DEBUG_NO_TABLE:
+        out = _table_pack(w, kind)
+        if out is not None:
+            return out
     if cacheable:       # the cache lives on the Parameter object itself: (epoch, {kind: packed})
         slot = getattr(w, '_gg_packed', None)
         if slot is not None and slot[0] == _weight_epoch and kind in slot[1]:
@@ -141,6 +182,21 @@ def packed_weight(w: torch.Tensor, kind: str) -> torch.Tensor:
 
 def _geom_k(geom):
     return geom[0]
+
+
+# With `grad_sink` on (the trainer's .backward() calls), a conv's weight gradient is accumulated by the finish kernel
+# straight into the parameter's fp32 .grad (the flat gradient buffer) and autograd is handed None: no separate
+# transpose / scale / AccumulateGrad passes. Only when no graph of the backward is being recorded.
+grad_sink = False
+
+
+def _grad_sink_of(w):
+    if not grad_sink or _DEBUG_NO_SINK or torch.is_grad_enabled() or not isinstance(w, torch.nn.Parameter):
+        return None
+    g = w.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != w.shape:
+        return None
+    return g
 
 
 class ConvFn(Function):
@@ -190,7 +246,11 @@ class ConvFn(Function):
                     ds = (x.float() * dxs.float()).sum(dim=(1, 2))
                 dx = (dxs.float() * in_scale[:, None, None, :]).to(dxs.dtype)
         if ctx.needs_input_grad[1] and not inputs_only:
-            dw = WgradFn.apply(x, dz, in_scale, geom, alpha, tuple(w.shape)).to(w.dtype)
+            sink = _grad_sink_of(w)
+            if sink is not None:
+                WgradFn.compute(x, dz, in_scale, geom, alpha, tuple(w.shape), sink)
+            else:
+                dw = WgradFn.apply(x, dz, in_scale, geom, alpha, tuple(w.shape)).to(w.dtype)
         return dx, dw, db, ds, None, None, None, (dy if ctx.has_res and ctx.needs_input_grad[7] else None)
 
 
@@ -223,7 +283,11 @@ class DgradFn(Function):
         if ctx.needs_input_grad[0]:     # linear in dz: the adjoint of the adjoint is the forward conv
             ddz = ConvFn.apply(g, w, None, None, None, geom, alpha, None)
         if ctx.needs_input_grad[1] and not inputs_only:     # dL/dw[co][tap][ci] = alpha * sum_p dz[p][co] * g[p + tap][ci]
-            dw = WgradFn.apply(g, dz, None, geom, alpha, tuple(w.shape)).to(w.dtype)
+            sink = _grad_sink_of(w)
+            if sink is not None:
+                WgradFn.compute(g, dz, None, geom, alpha, tuple(w.shape), sink)
+            else:
+                dw = WgradFn.apply(g, dz, None, geom, alpha, tuple(w.shape)).to(w.dtype)
         return ddz, dw, None, None, None, None
 
 
@@ -258,22 +322,26 @@ class WgradFn(Function):
     @staticmethod
     def forward(ctx, x, dy, in_scale, geom, alpha, wshape):
         ksize, stride, pad, wkind = geom
-        g = K.conv2d_wgrad_nhwc(x, dy, ksize=ksize, stride=stride, pad=pad, in_scale=in_scale)  # (k*k*C8, O8) fp32
-        c8, o8 = x.shape[-1], dy.shape[-1]
         ctx.geom, ctx.alpha, ctx.wshape = geom, alpha, wshape
         ctx.save_for_backward(x, dy, in_scale)
-        g = g.view(ksize, ksize, c8, o8)
-        if wkind == 's2d':
-            o, c = wshape[0], wshape[1] // 4
-            g = g[:, :, :c, :o].permute(3, 2, 0, 1).reshape(wshape)        # (O, C, s1, s2) -> (O, 4C, 1, 1)
-        elif len(wshape) == 5:   # kernel bank (N, O, I, k, k) stacked along output channels
-            n, o, i = wshape[0], wshape[1], wshape[2]
-            g = g[:, :, :i, :n * o].permute(3, 2, 0, 1).reshape(wshape)
+        return WgradFn.compute(x, dy, in_scale, geom, alpha, wshape, None)
+
+    @staticmethod
+    def compute(x, dy, in_scale, geom, alpha, wshape, sink):
+        """the GEMM ([tap][ci][co] fp32, pixels reduced) + the transpose/scale pass into the parameter layout; with
+        `sink` (a parameter's fp32 .grad) the result is accumulated there instead of being returned."""
+        ksize, stride, pad, wkind = geom
+        g = K.conv2d_wgrad_nhwc(x, dy, ksize=ksize, stride=stride, pad=pad, in_scale=in_scale)  # (k*k*C8, O8) fp32
+        if wkind == 's2d':              # (O, C, s1, s2) == (O, 4C, 1, 1)
+            O, I = wshape[0], wshape[1] // 4
+        elif len(wshape) == 5:          # kernel bank (N, O, I, k, k) stacked along output channels
+            O, I = wshape[0] * wshape[1], wshape[2]
         else:
-            g = g[:, :, :wshape[1], :wshape[0]].permute(3, 2, 0, 1)
-        if alpha != 1.0:
-            g = g * alpha
-        return g.contiguous()
+            O, I = wshape[0], wshape[1]
+        if sink is not None:
+            K.wgrad_finish(g, O, I, ksize * ksize, alpha, out=sink, accumulate=True)
+            return None
+        return K.wgrad_finish(g, O, I, ksize * ksize, alpha).view(wshape)
 
     @staticmethod
     def backward(ctx, ddw):
@@ -618,6 +686,17 @@ class HipOps:
 
     def linear(self, x, weight, bias=None, act=None):
         return matmul_nt(x, weight, None if bias is None else bias.float().contiguous(), act)
+
+    # -- skip-layer excitation multiply (gp.py:1023-1024, :1812-1813) ----------------------------
+    def channel_scale(self, x, s):
+        """x (b, C, H, W) * s (b, C, 1, 1): one bf16 pass forward, and ONE backward pass for both dx = g*s and
+        ds = sum over pixels of g*x (gg_modulate_fwd / _bwd). Graphs that are differentiated twice keep the tensor-algebra
+        form."""
+        x = to_act(x)
+        b, C = x.shape[0], x.shape[1]
+        if second_order or C % 8 or not (torch.is_grad_enabled() and (x.requires_grad or s.requires_grad)):
+            return x * s.reshape(b, C, 1, 1).to(x.dtype)
+        return nchw(ModulateFn.apply(nhwc(x), s.reshape(b, C).float().contiguous()))
 
     # -- adaptive / modulated conv (gp.py:315-409) -----------------------------------------------
     def modconv2d(self, x, weights, mod, kernel_mod=None, demod=True, eps=1e-8, noise=None, noise_weight=None,

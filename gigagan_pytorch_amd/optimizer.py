@@ -71,6 +71,13 @@ class FlatAdamW(torch.optim.Optimizer):
             st['exp_avg'] = self.flat_m[off:off + n].view(p.shape)
             st['exp_avg_sq'] = self.flat_v[off:off + n].view(p.shape)
         self.flags = flags.to(device)
+        # conv weights: persistent bf16 GEMM operands, re-packed by one launch per epoch (ops._table_pack)
+        from .kernels import PackTable
+        self.pack_table = PackTable(device, capacity=3 * len(self._all) + 16)
+        self.pack_table.epoch = -1
+        for p in self._all:
+            if p.ndim >= 4:
+                p._gg_pack_table = self.pack_table
 
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()

@@ -104,6 +104,27 @@ int gg_adamw_flat_f32(float* p, const float* g, float* m, float* v, const uint8_
 /* ema += (1 - beta) * (p - ema) over flat fp32 buffers (ema_pytorch update, gp.py:2603); n %% 4 == 0. */
 int gg_ema_flat_f32(float* ema, const float* p, int64_t n, float one_minus_beta, void* stream);
 
+/* One work-table entry of gg_pack_weights: a conv weight (O, I, T = kh*kw) in the reference's fp32 parameter layout
+ * (gp.py:352 `weights`, nn.Conv2d.weight) and the bf16 GEMM operand it is packed into. */
+typedef struct gg_pack_entry {
+    const float* src;     /* (O, I, T) fp32 contiguous (device) */
+    uint16_t* dst;        /* kind 0: (O8, T, I8) [co][tap][ci] ; kind 1: (I8, T, O8) [ci][T-1-tap][co] ; bf16 (device) */
+    int64_t first_item;   /* prefix sum over the table of items = kind 0: O8*I8/8, kind 1: I8*O8/8 */
+    int32_t O, I, T, O8, I8, kind;   /* O8, I8 = O, I rounded up to multiples of 8 (zero filled) */
+} gg_pack_entry;
+
+/* Re-pack every registered weight of a model in one launch (replaces the filter transforms behind the reference's
+ * F.conv2d / nn.Conv2d calls, gp.py:402-409, :1608-1621, and their transposes in autograd's conv backward).
+ * `table` (device) holds header[0] entries, header[1] (device) is the total item count: both are read on the device,
+ * so a captured graph follows later registrations. max_blocks <= 0 picks a default grid. */
+int gg_pack_weights(const gg_pack_entry* table, const int64_t* header, int32_t max_blocks, void* stream);
+
+/* dst[o][i][t] (+)= alpha * g[(t*C8 + i)*O8 + o]: the weight-gradient GEMM output ([tap][ci][co] fp32) moved into the
+ * parameter layout (O, I, T), optionally accumulated in place - `dst` may be the parameter's .grad inside the flat
+ * gradient buffer (what autograd's AccumulateGrad does after conv2d_weight backward in the reference). */
+int gg_wgrad_finish(const float* g, float* dst, int32_t O, int32_t I, int32_t T, int32_t C8, int32_t O8, float alpha,
+                    int32_t accumulate, void* stream);
+
 /* Row softmax over materialised attention logits (replaces sim*scale, masked_fill, softmax and the dtype casts
  * of gp.py:584-588 / :643-649 with one pass):
  *   S[r][j] = softmax_j(alpha * x[r][j] + bias[r / rows_per_batch][j]) for j < n_valid, 0 for n_valid <= j < ld.

@@ -15,6 +15,9 @@ REFERENCE = Path('/root/reference')
 
 
 def pytest_configure(config):
+    if os.environ.get('GG_TEST_POISON'):    # torch.empty() returns NaN-filled memory: reads of never-written elements surface
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        torch.utils.deterministic.fill_uninitialized_memory = True
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 

@@ -30,5 +30,14 @@ for label, nsteps in (('PLAIN step (D + G)', 1), ('GP step', None)):
     evs.sort(key=lambda e: -e.self_device_time_total)
     tot = sum(e.self_device_time_total for e in evs)
     print(f'non-kernel-named rows: total self device time {tot/1e3:.1f} ms')
-    for e in evs[:60]:
+    import collections
+    by_name = collections.Counter(); by_calls = collections.Counter()
+    for e in evs:
+        by_name[e.key] += e.self_device_time_total; by_calls[e.key] += e.count
+    print('-- aggregated by name')
+    for k, t in by_name.most_common(40):
+        print(f'{k[:36]:36s} calls {by_calls[k]:5d} self_dev {t/1e3:8.2f} ms')
+    print('-- aten / memcpy rows by shape')
+    aten = [e for e in evs if e.key.startswith('aten::') or e.key.startswith('Mem')]
+    for e in aten[:70]:
         print(f'{e.key[:28]:28s} calls {e.count:5d} self_dev {e.self_device_time_total/1e3:8.2f} ms  shapes {str(e.input_shapes)[:150]}')

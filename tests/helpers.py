@@ -22,3 +22,73 @@ TINY_G = dict(image_size=16, dim_capacity=8, dim_max=32, dim_latent=32, style_ne
               self_attn_dim_head=16)
 TINY_D = dict(image_size=16, dim_capacity=8, dim_max=32, unconditional=True, num_skip_layers_excite=1,
               attn_resolutions=(8,), attn_heads=2, attn_dim_head=16, multiscale_input_resolutions=(8,))
+
+
+def check_pack_table_and_wgrad_finish(shape, device):
+    """gg_pack_weights (one launch, table on the device) equals the permute/flip/pad/cast chain, follows entries
+    registered later, and gg_wgrad_finish equals the transpose (+ in-place accumulate) of the GEMM's [tap][ci][co]."""
+    import torch.nn.functional as F
+    from gigagan_pytorch_amd import kernels as K
+    O, I, T = shape
+    k = int(round(T ** 0.5))
+    torch.manual_seed(0)
+    tab = K.PackTable(device, capacity=8)
+    w1 = torch.randn(O, I, k, k).to(device)
+    w2 = torch.randn(I + 5, O + 1, k, k).to(device)
+    f1 = tab.register(w1.view(O, I, T), O, I, T, 'fwd')
+    b1 = tab.register(w1.view(O, I, T), O, I, T, 'bwd')
+    tab.refresh()
+    f2 = tab.register(w2.view(I + 5, O + 1, T), I + 5, O + 1, T, 'fwd')     # appended after a first launch
+    w1.mul_(2.0)                                                            # the table reads the live parameter
+    tab.refresh()
+    r8 = lambda n: (n + 7) // 8 * 8
+
+    def ref(w, kind):
+        w = w.cpu()
+        wp = F.pad(w, (0, 0, 0, 0, 0, r8(w.shape[1]) - w.shape[1], 0, r8(w.shape[0]) - w.shape[0]))
+        if kind == 'fwd':
+            return wp.permute(0, 2, 3, 1).reshape(wp.shape[0], -1).to(torch.bfloat16)
+        return wp.flip(2, 3).permute(1, 2, 3, 0).reshape(wp.shape[1], -1).to(torch.bfloat16)
+    assert torch.equal(f1.cpu(), ref(w1, 'fwd')) and torch.equal(b1.cpu(), ref(w1, 'bwd')) and torch.equal(f2.cpu(), ref(w2, 'fwd'))
+    c8, o8 = r8(I), r8(O)
+    g = torch.randn(T * c8, o8)
+    want = (g.view(T, c8, o8)[:, :I, :O].permute(2, 1, 0) * 0.5).contiguous()
+    got = K.wgrad_finish(g.to(device), O, I, T, 0.5)
+    assert torch.equal(got.cpu(), want)
+    acc = torch.ones(O, I, T, device=device)
+    K.wgrad_finish(g.to(device), O, I, T, 0.5, out=acc, accumulate=True)
+    assert torch.allclose(acc.cpu(), want + 1.0)
+
+
+def check_flat_optimizer_packs_and_grad_sink(device):
+    """parameters owned by FlatAdamW: conv weights come from the persistent pack table (fresh after every step), and
+    with ops.grad_sink the weight gradients land in the flat gradient buffer exactly as autograd's accumulation."""
+    from gigagan_pytorch_amd import ops
+    from gigagan_pytorch_amd.modules import Conv2d, Downsample
+    from gigagan_pytorch_amd.optimizer import FlatAdamW
+    torch.manual_seed(0)
+    net = torch.nn.ModuleList([Conv2d(8, 16, 3, padding=1), Conv2d(16, 16, 1), Downsample(16)]).to(device)
+    opt = FlatAdamW(list(net.parameters()), lr=1e-2)
+    x = torch.randn(2, 8, 8, 8).to(device)
+
+    def loss():
+        h = net[1](net[0](x))
+        return (net[2](h) ** 2).mean() + h.mean()
+    with ops.use_impl(ops.HipOps()):
+        for it in range(2):
+            opt.zero_grad()
+            loss().backward()
+            ref = opt.flat_g.clone()
+            opt.zero_grad()
+            ops.grad_sink = True
+            try:
+                loss().backward()
+            finally:
+                ops.grad_sink = False
+            assert opt.flat_g.abs().sum() > 0 and rel_err(opt.flat_g, ref) < 1e-6
+            w = net[0].weight
+            packed = w._gg_tpacks['fwd'][0]
+            opt.step()
+            fresh = ops.packed_weight(w, 'fwd')
+            assert fresh.data_ptr() == packed.data_ptr()
+            assert torch.equal(fresh, w.detach().permute(0, 2, 3, 1).reshape(16, -1).to(torch.bfloat16))

@@ -473,3 +473,14 @@ def test_self_attention_op_double_backward_on_fused_kernels(l2):
     gh = run(ops.HipOps()); go = run(OracleOps(bf16_operands=True))
     for a, b in zip(gh, go):
         assert rel_err(a, b) < 6e-2
+
+
+@pytest.mark.parametrize('shape', [(16, 24, 9), (3, 40, 49), (35, 3, 1), (64, 16, 4)])
+def test_weight_pack_table_and_wgrad_finish(shape):
+    from helpers import check_pack_table_and_wgrad_finish
+    check_pack_table_and_wgrad_finish(shape, 'cpu')
+
+
+def test_flat_optimizer_packs_and_grad_sink_match_autograd():
+    from helpers import check_flat_optimizer_packs_and_grad_sink
+    check_flat_optimizer_packs_and_grad_sink('cpu')

@@ -305,3 +305,67 @@ def test_config2_shapes_linearity_and_adjointness():
         rhs2 = (wg.double() * wh.t().double()).sum()
         assert abs(lhs - rhs) / abs(lhs) < 1e-3 and abs(lhs - rhs2) / abs(lhs) < 1e-3
         del c1, c2, c12, cz1, cz2, dg
+
+
+@pytest.mark.parametrize('shape', [(16, 24, 9), (3, 40, 49), (35, 3, 1), (512, 512, 9), (64, 16, 4)])
+def test_weight_pack_table_and_wgrad_finish(shape):
+    from helpers import check_pack_table_and_wgrad_finish
+    check_pack_table_and_wgrad_finish(shape, dev())
+
+
+def test_flat_optimizer_packs_and_grad_sink_match_autograd():
+    from helpers import check_flat_optimizer_packs_and_grad_sink
+    check_flat_optimizer_packs_and_grad_sink(dev())
+
+
+def test_trained_generator_matches_oracle_after_optimizer_steps(tmp_path):
+    """two trainer steps (plain + gradient penalty, eager) on the GPU, then the updated generator against the CPU
+    oracle on the same weights: the packed operands follow the optimizer, nothing is stale or non-finite."""
+    torch.manual_seed(0)
+    gan = GigaGAN(generator=dict(C1_G), discriminator=dict(C1_D), apply_gradient_penalty_every=2, device=dev(),
+                  use_hip_graphs=False, model_folder=str(tmp_path / 'm'), results_folder=str(tmp_path / 'r'))
+    it = cycle(SyntheticImages(2, C1_G['image_size'], device=dev()))
+    for _ in range(2):
+        d, g = gan.train_step(it, 2)
+        vals = [float(v) for v in (*d, *g) if v is not None]
+        assert all(v == v and abs(v) != float('inf') for v in vals), vals
+    assert torch.isfinite(gan.G_opt.flat_p).all() and torch.isfinite(gan.D_opt.flat_p).all()
+    z = torch.randn(2, 64, device=dev())
+    gan.G.eval()
+    with torch.no_grad():
+        torch.manual_seed(1)
+        img = gan.G(noise=z).float().cpu()
+        Gc = Generator(**C1_G)
+        Gc.load_state_dict({k: v.detach().cpu() for k, v in gan.G.state_dict().items()})
+        with ops.use_impl(OracleOps()):
+            torch.manual_seed(1)
+            ref = Gc(noise=z.cpu()).float()
+    assert rel_err(img, ref) < 5e-2
+
+
+def test_hipgraph_replays_keep_gradients_and_weights_sane(tmp_path):
+    """the trainer with hipGraph capture + replays (plain and gradient-penalty steps interleaved): every replay must
+    leave finite, plausibly sized flat gradients (garbage from a stale buffer shows up as 1e30+ or NaN), and the
+    trained generator still matches the CPU oracle on its own weights."""
+    torch.manual_seed(0)
+    gan = GigaGAN(generator=dict(C1_G), discriminator=dict(C1_D), apply_gradient_penalty_every=2, device=dev(),
+                  use_hip_graphs=True, model_folder=str(tmp_path / 'm'), results_folder=str(tmp_path / 'r'))
+    it = cycle(SyntheticImages(2, C1_G['image_size'], device=dev()))
+    for step in range(5):
+        d, g = gan.train_step(it, 2)
+        for name, opt in (('D', gan.D_opt), ('G', gan.G_opt)):
+            gmax = float(opt.flat_g.abs().max())
+            assert gmax == gmax and gmax < 1e6, (step, name, gmax)
+            assert torch.isfinite(opt.flat_p).all(), (step, name)
+    assert gan.use_hip_graphs and len(gan._graphs) >= 3          # capture was not refused
+    z = torch.randn(2, 64, device=dev())
+    gan.G.eval()
+    with torch.no_grad():
+        torch.manual_seed(1)
+        img = gan.G(noise=z).float().cpu()
+        Gc = Generator(**C1_G)
+        Gc.load_state_dict({k: v.detach().cpu() for k, v in gan.G.state_dict().items()})
+        with ops.use_impl(OracleOps()):
+            torch.manual_seed(1)
+            ref = Gc(noise=z.cpu()).float()
+    assert rel_err(img, ref) < 5e-2
