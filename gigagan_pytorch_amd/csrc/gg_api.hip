@@ -317,6 +317,11 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
 
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)pl.blocks_mn, 1, (unsigned)(d->batch * pl.splitk));
+    if (pl.tile <= 3 && pl.splitk > 1 && pl.blocks_mn <= 64) {
+        p.xcd_slices = 1;
+        const long long groups = ((long long)d->batch * pl.splitk + 7) / 8;
+        grid = dim3((unsigned)(8 * pl.blocks_mn * groups), 1, 1);
+    }
     bool akrow = d->a_layout == GG_KROW, bkrow = d->b_layout == GG_KROW, aconv = d->a_conv != 0;
     dim3 grid2((unsigned)(pl.blocks_mn * d->batch * pl.splitk), 1, 1);
     if (pl.tile == 4) gg_launch_gemm2_tile<256, 256, 2, 4>(p, akrow, bkrow, aconv, grid2, s);

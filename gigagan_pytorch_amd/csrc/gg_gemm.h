@@ -72,6 +72,10 @@ struct GgGemmParams {
     // of an [img][d2s_oh*d2s][d2s_ow*d2s][d2s_c] tensor. d2s == 0: plain [m][ldc] store.
     int d2s, d2s_t, d2s_c, d2s_oh, d2s_ow;
     float* partial;  // [batch][splitk][M][N] fp32
+    // 4-wave kernel, split-K launches with few output tiles (narrow weight gradients): 1-D grid in which all tiles of
+    // one k-slice land on the same XCD (block b -> XCD b % 8), so the slice of x / dy they all stream is fetched from
+    // HBM once and shared through that XCD's L2. 0: (tiles, 1, batch*splitk) grid.
+    int xcd_slices;
 };
 
 GG_DEVICE float gg_apply_act(float v, int act, float slope) {
@@ -385,9 +389,16 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_gemm_kernel(GgGemmParams p) {
     const int wm = wave / WN, wn = wave % WN;
 
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    int bx = blockIdx.x, bz = blockIdx.z;
+    if (p.xcd_slices) {
+        const int blocks_mn = ((p.M + BM - 1) / BM) * tiles_n;
+        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+        bx = q % blocks_mn;
+        bz = (q / blocks_mn) * 8 + xcd;
+        if (bz >= p.batch * p.splitk) return;
+    }
+    const int tile_m = bx / tiles_n, tile_n = bx % tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int bz = blockIdx.z;
     const int b = bz / p.splitk, ks = bz % p.splitk;
     const int kbeg = ks * p.k_per_split;
     int kend = kbeg + p.k_per_split;

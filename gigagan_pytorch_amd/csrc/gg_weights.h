@@ -22,11 +22,22 @@ struct GgPackEntry {
     int O, I, T, O8, I8, kind;
 };
 
-// header[0] = number of entries, header[1] = total work items (one item = 8 output channels x all taps)
+// Work items (one workgroup each; `first_item` is their prefix sum, computed by the host with the same formulas):
+//   T <= 16: kind 0: one output row o x 256 input channels      -> O8 * ceil(I8 / 256) items
+//            kind 1: 64 output channels x 16 input channels     -> ceil(O8 / 64) * ceil(I8 / 16) items
+//            both stream contiguous fp32 runs in, transpose through LDS, and write contiguous bf16 rows out
+//   T  > 16: 256 eight-channel units per item, one per thread (strided scalar gathers; 7x7 stems only)
+#define GG_PK_TMAX 16
+#define GG_PK_P0 264      // kind 0 LDS pitch (bf16): 256 + 8
+#define GG_PK_P1 66       // kind 1 LDS pitch (bf16): 64 + 2 -> 33-word row shift, conflict-free transposed writes
+
+// header[0] = number of entries, header[1] = total work items
 GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_pack_weights_kernel(const GgPackEntry* table, const long long* header) {
+    GG_SHARED __attribute__((aligned(16))) bf16_t lds[16 * GG_PK_TMAX * GG_PK_P1];
     const int n = (int)header[0];
     const long long total = header[1];
-    for (long long item = (long long)blockIdx.x * 256 + threadIdx.x; item < total; item += (long long)gridDim.x * 256) {
+    const int tid = threadIdx.x;
+    for (long long item = blockIdx.x; item < total; item += gridDim.x) {
         int lo = 0, hi = n - 1;                       // last entry with first_item <= item
         while (lo < hi) {
             int mid = (lo + hi + 1) >> 1;
@@ -35,28 +46,76 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_pack_weights_kernel(const GgPackEntry* t
         const GgPackEntry e = table[lo];
         const long long local = item - e.first_item;
         const int T = e.T;
+        if (T > GG_PK_TMAX) {
+            const long long unit = local * 256 + tid;
+            if (e.kind == 0) {
+                const int chunks = e.I8 >> 3;
+                if (unit >= (long long)e.O8 * chunks) continue;
+                const int o = (int)(unit / chunks), i0 = (int)(unit % chunks) * 8;
+                const float* s = e.src + ((long long)o * e.I + i0) * T;
+                bf16_t* d = e.dst + (long long)o * T * e.I8 + i0;
+                const int valid = (o < e.O) ? (e.I - i0 < 8 ? e.I - i0 : 8) : 0;
+                for (int t = 0; t < T; ++t) {
+                    u16x8 v;
+                    for (int j = 0; j < 8; ++j) v[j] = gg_f2bf(j < valid ? s[(long long)j * T + t] : 0.f);
+                    *(u16x8*)(d + (long long)t * e.I8) = v;
+                }
+            } else {
+                if (unit >= (long long)e.I8 * (e.O8 >> 3)) continue;
+                const int i = (int)(unit % e.I8), o0 = (int)(unit / e.I8) * 8;
+                const float* s = e.src + ((long long)o0 * e.I + i) * T;
+                bf16_t* d = e.dst + (long long)i * T * e.O8 + o0;
+                const int valid = (i < e.I) ? (e.O - o0 < 8 ? e.O - o0 : 8) : 0;
+                const long long ostride = (long long)e.I * T;
+                for (int t = 0; t < T; ++t) {
+                    u16x8 v;
+                    for (int j = 0; j < 8; ++j) v[j] = gg_f2bf(j < valid ? s[j * ostride + t] : 0.f);
+                    *(u16x8*)(d + (long long)(T - 1 - t) * e.O8) = v;
+                }
+            }
+            continue;
+        }
         if (e.kind == 0) {
-            const int chunks = e.I8 >> 3;
-            const int o = (int)(local / chunks), i0 = (int)(local % chunks) * 8;
+            const int chunks = (e.I8 + 255) >> 8;
+            const int o = (int)(local / chunks), i0 = (int)(local % chunks) * 256;
+            const int nI8 = e.I8 - i0 < 256 ? e.I8 - i0 : 256;
+            int nI = (o < e.O) ? e.I - i0 : 0;
+            nI = nI < 0 ? 0 : (nI > 256 ? 256 : nI);
             const float* s = e.src + ((long long)o * e.I + i0) * T;
+            for (int idx = tid; idx < nI8 * T; idx += 256) {
+                const int il = idx / T, t = idx - il * T;
+                lds[t * GG_PK_P0 + il] = gg_f2bf(il < nI ? s[idx] : 0.f);
+            }
+            gg_sync();
+            const int cpr = nI8 >> 3;
             bf16_t* d = e.dst + (long long)o * T * e.I8 + i0;
-            const int valid = (o < e.O) ? (e.I - i0 < 8 ? e.I - i0 : 8) : 0;
-            for (int t = 0; t < T; ++t) {
-                u16x8 v;
-                for (int j = 0; j < 8; ++j) v[j] = gg_f2bf(j < valid ? s[(long long)j * T + t] : 0.f);
-                *(u16x8*)(d + (long long)t * e.I8) = v;
+            for (int c = tid; c < T * cpr; c += 256) {
+                const int t = c / cpr, j = c - t * cpr;
+                *(u16x8*)(d + (long long)t * e.I8 + 8 * j) = *(const u16x8*)&lds[t * GG_PK_P0 + 8 * j];
             }
+            gg_sync();
         } else {
-            const int i = (int)(local % e.I8), o0 = (int)(local / e.I8) * 8;
-            const float* s = e.src + ((long long)o0 * e.I + i) * T;
-            bf16_t* d = e.dst + (long long)i * T * e.O8 + o0;
-            const int valid = (i < e.I) ? (e.O - o0 < 8 ? e.O - o0 : 8) : 0;
-            const long long ostride = (long long)e.I * T;
-            for (int t = 0; t < T; ++t) {
-                u16x8 v;
-                for (int j = 0; j < 8; ++j) v[j] = gg_f2bf(j < valid ? s[j * ostride + t] : 0.f);
-                *(u16x8*)(d + (long long)(T - 1 - t) * e.O8) = v;
+            const int ibs = (e.I8 + 15) >> 4;
+            const int o0 = (int)(local / ibs) * 64, i0 = (int)(local % ibs) * 16;
+            int nI = e.I - i0;
+            nI = nI < 0 ? 0 : (nI > 16 ? 16 : nI);
+            const int run = 16 * T;
+            for (int idx = tid; idx < 64 * run; idx += 256) {
+                const int ol = idx / run, r = idx - ol * run;
+                const int il = r / T, t = r - il * T;
+                float v = 0.f;
+                if (o0 + ol < e.O && il < nI) v = e.src[((long long)(o0 + ol) * e.I + i0) * T + r];
+                lds[(il * T + (T - 1 - t)) * GG_PK_P1 + ol] = gg_f2bf(v);
             }
+            gg_sync();
+            const int nI8 = e.I8 - i0 < 16 ? e.I8 - i0 : 16;
+            bf16_t* d = e.dst + (long long)i0 * T * e.O8 + o0;
+            for (int idx = tid; idx < nI8 * T * 32; idx += 256) {
+                const int w = idx & 31, row = idx >> 5;
+                if (o0 + 2 * w < e.O8)
+                    *(unsigned int*)(d + (long long)row * e.O8 + 2 * w) = *(const unsigned int*)&lds[row * GG_PK_P1 + 2 * w];
+            }
+            gg_sync();
         }
     }
 }

@@ -656,6 +656,7 @@ class PackTable:
         self.n = 0
         self.items = 0
         self.keep = []          # (src, dst) tensors kept alive
+        self.dirty = True
 
     def register(self, src: torch.Tensor, O: int, I: int, T: int, kind: str) -> torch.Tensor:
         """src: fp32 contiguous storage of (O, I, T); returns the persistent bf16 operand (rows, T*cols8)."""
@@ -669,7 +670,10 @@ class PackTable:
         w = words.numel()
         self.table[self.n * w:(self.n + 1) * w].copy_(words)
         self.n += 1
-        self.items += o8 * i8 // 8
+        if T <= 16:     # work items per entry: the formulas of gg_weights.h
+            self.items += o8 * ((i8 + 255) // 256) if k == 0 else ((o8 + 63) // 64) * ((i8 + 15) // 16)
+        else:
+            self.items += (o8 * i8 // 8 + 255) // 256
         self.header.copy_(torch.tensor([self.n, self.items], dtype=torch.int64))
         self.keep.append((src, dst))
         return dst
@@ -679,5 +683,5 @@ class PackTable:
             return
         L = _C.lib()
         L.require(self.table)
-        rc = L.lib.gg_pack_weights(ptr(self.table), ptr(self.header), 4 if L.is_emulator else 0, L.stream(self.table))
+        rc = L.lib.gg_pack_weights(ptr(self.table), ptr(self.header), 2 if L.is_emulator else 0, L.stream(self.table))
         L.check(rc, 'gg_pack_weights')

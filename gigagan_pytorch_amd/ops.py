@@ -17,6 +17,7 @@ import math
 from contextlib import contextmanager
 
 import os
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -78,13 +79,22 @@ def flip_transpose(w: torch.Tensor) -> torch.Tensor:
 _weight_epoch = 0
 
 
-def bump_weight_epoch():
-    """invalidate every cached pack (optimizer step, state-dict load, start/end of a hipGraph capture)."""
+_pack_tables = weakref.WeakSet()     # every FlatAdamW's PackTable (persistent operands, refreshed by one launch)
+
+
+def pack_cache_clear():
+    """drop the per-parameter cached packs (start/end of a hipGraph capture: a graph must contain its own packing
+    launches and nothing outside may keep tensors of its private pool). The persistent pack tables are not affected."""
     global _weight_epoch
     _weight_epoch += 1
 
 
-pack_cache_clear = bump_weight_epoch
+def bump_weight_epoch():
+    """parameters were modified behind the optimizers' back (state-dict load, broadcast, manual edits): drop the cached
+    packs and have every pack table re-packed on its next use."""
+    pack_cache_clear()
+    for tab in _pack_tables:
+        tab.dirty = True
 
 
 _DEBUG_NO_TABLE = bool(os.environ.get('GG_DEBUG_NO_PACK_TABLE'))
@@ -92,8 +102,9 @@ _DEBUG_NO_SINK = bool(os.environ.get('GG_DEBUG_NO_GRAD_SINK'))
 
 
 def _table_pack(w, kind: str):
-    """parameters owned by a FlatAdamW: persistent operands, all re-packed by one gg_pack_weights launch the first time
-    any of them is used after the weight epoch moved. None -> caller falls back to the per-weight path."""
+    """parameters owned by a FlatAdamW: persistent operands, all re-packed by ONE gg_pack_weights launch right after
+    each optimizer step (FlatAdamW.step) or, when something else touched the weights (`bump_weight_epoch`), on the next
+    use. None -> caller falls back to the per-weight path."""
     tab = w._gg_pack_table
     slot = w.__dict__.get('_gg_tpacks')
     ent = slot.get(kind) if slot else None
@@ -115,10 +126,10 @@ def _table_pack(w, kind: str):
         if slot is None:
             slot = w.__dict__.setdefault('_gg_tpacks', {})
         ent = slot[kind] = (dst, w.data_ptr())
-        tab.epoch = -1
-    if tab.epoch != _weight_epoch:
+        tab.dirty = True
+    if tab.dirty:
         tab.refresh()
-        tab.epoch = _weight_epoch
+        tab.dirty = False
     return ent[0]
 
 

@@ -74,7 +74,9 @@ class FlatAdamW(torch.optim.Optimizer):
         # conv weights: persistent bf16 GEMM operands, re-packed by one launch per epoch (ops._table_pack)
         from .kernels import PackTable
         self.pack_table = PackTable(device, capacity=3 * len(self._all) + 16)
-        self.pack_table.epoch = -1
+        self.pack_table.dirty = True
+        from . import ops
+        ops._pack_tables.add(self.pack_table)
         for p in self._all:
             if p.ndim >= 4:
                 p._gg_pack_table = self.pack_table
@@ -100,7 +102,9 @@ class FlatAdamW(torch.optim.Optimizer):
                                      1. - b1 ** t, math.sqrt(1. - b2 ** t), grad_scale, L.stream(self.flat_p))
         L.check(rc, 'gg_adamw_flat_f32')
         from . import ops
-        ops.bump_weight_epoch()      # packed bf16 copies of the parameters are stale now
+        ops.pack_cache_clear()       # per-parameter cached packs are stale now ...
+        self.pack_table.refresh()    # ... and the persistent GEMM operands of this model are re-packed right here
+        self.pack_table.dirty = False
         self._steps_dirty = True
 
     def state_dict(self):

@@ -109,7 +109,8 @@ int gg_ema_flat_f32(float* ema, const float* p, int64_t n, float one_minus_beta,
 typedef struct gg_pack_entry {
     const float* src;     /* (O, I, T) fp32 contiguous (device) */
     uint16_t* dst;        /* kind 0: (O8, T, I8) [co][tap][ci] ; kind 1: (I8, T, O8) [ci][T-1-tap][co] ; bf16 (device) */
-    int64_t first_item;   /* prefix sum over the table of items = kind 0: O8*I8/8, kind 1: I8*O8/8 */
+    int64_t first_item;   /* prefix sum over the table of work items per entry. T <= 16: kind 0: O8*ceil(I8/256),
+                           * kind 1: ceil(O8/64)*ceil(I8/16); T > 16: ceil((O8*I8/8)/256) */
     int32_t O, I, T, O8, I8, kind;   /* O8, I8 = O, I rounded up to multiples of 8 (zero filled) */
 } gg_pack_entry;
 
