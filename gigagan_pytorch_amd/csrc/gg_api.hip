@@ -183,11 +183,14 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
         const int ktiles = (d->K + tm.bk - 1) / tm.bk;
         int max_sk = ktiles / (tm.bk == 64 ? 4 : 8);   // keep >= 256 reduction elements per split
         if (max_sk < 1) max_sk = 1;
-        if (max_sk > 256) max_sk = 256;
+        // the 4-wave tiles may split much further: a narrow weight gradient (M*N of a few thousand, K = millions of
+        // pixels) needs thousands of workgroups in flight to pull HBM bandwidth; its partials stay small
+        const int sk_cap = tm.tile <= 3 ? 4096 : 256;
+        if (max_sk > sk_cap) max_sk = sk_cap;
         if ((long long)d->batch * max_sk > 65535) max_sk = (int)(65535 / d->batch);
         int lo = 1, hi = max_sk;
         if (d->force_splitk > 0) { lo = hi = d->force_splitk < ktiles ? d->force_splitk : ktiles; }
-        for (int sk = lo; sk <= hi; ++sk) {
+        for (int sk = lo; sk <= hi; sk += (sk < 256 ? 1 : (sk < 1024 ? 64 : 256))) {
             const int per = (ktiles + sk - 1) / sk;
             if ((ktiles + per - 1) / per != sk && d->force_splitk <= 0) continue;   // split counts that leave empty slices
             double c = gg_plan_cost(d, tm, sk, nullptr);
@@ -334,8 +337,8 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     if (rc) return rc;
     if (pl.splitk > 1) {
         long long total = (long long)d->M * d->N * d->batch;
-        long long nb = (total + 255) / 256;
-        if (nb > 4096) nb = 4096;
+        long long nb = pl.splitk <= 8 ? (total + 255) / 256 : (total + 63) / 64;
+        if (nb > 8192) nb = 8192;
         GG_LAUNCH(gg_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), s, p);
         rc = gg_check_launch();
     }

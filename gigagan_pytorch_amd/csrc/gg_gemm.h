@@ -504,21 +504,62 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_gemm_kernel(GgGemmParams p) {
     }
 }
 
-// finishes a split-K launch: sums the fp32 partials and applies the epilogue
+// finishes a split-K launch: sums the fp32 partials and applies the epilogue. Few splits: one thread per output
+// element. Many splits (narrow weight gradients: a few thousand outputs, hundreds to thousands of slices): a wave per 64
+// consecutive outputs (256-byte coalesced rows of the partial buffer), the 4 waves of the workgroup interleave over the
+// slices and combine through LDS - the summation order is fixed, so the result is run-to-run deterministic.
 GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_splitk_reduce_kernel(GgGemmParams p) {
+    GG_SHARED float part[3][64];
     const long long per = (long long)p.M * p.N;
     const long long total = per * p.batch;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * 256) {
-        int b = (int)(idx / per);
-        long long rem = idx - (long long)b * per;
-        int m = (int)(rem / p.N), n = (int)(rem - (long long)m * p.N);
+    if (p.splitk <= 8) {
+        for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+             idx += (long long)gridDim.x * 256) {
+            int b = (int)(idx / per);
+            long long rem = idx - (long long)b * per;
+            int m = (int)(rem / p.N), n = (int)(rem - (long long)m * p.N);
+            float s = 0.f;
+            for (int ks = 0; ks < p.splitk; ++ks)
+                s += p.partial[((long long)(b * p.splitk + ks) * p.M + m) * p.N + n];
+            float v = gg_epilogue(p, s, m, n);
+            const long long off = p.d2s ? gg_d2s_offset(p, m, n) : (long long)b * p.c_bs + (long long)m * p.ldc + n;
+            if (p.c_f32) ((float*)p.Cout)[off] = v;
+            else ((bf16_t*)p.Cout)[off] = gg_f2bf(v);
+        }
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long long base = (long long)blockIdx.x * 64; base < total; base += (long long)gridDim.x * 64) {
+        const long long idx = base + lane;
+        const bool valid = idx < total;
+        int b = 0;
+        long long rem = 0;
         float s = 0.f;
-        for (int ks = 0; ks < p.splitk; ++ks)
-            s += p.partial[((long long)(b * p.splitk + ks) * p.M + m) * p.N + n];
-        float v = gg_epilogue(p, s, m, n);
-        const long long off = p.d2s ? gg_d2s_offset(p, m, n) : (long long)b * p.c_bs + (long long)m * p.ldc + n;
-        if (p.c_f32) ((float*)p.Cout)[off] = v;
-        else ((bf16_t*)p.Cout)[off] = gg_f2bf(v);
+        if (valid) {
+            b = (int)(idx / per);
+            rem = idx - (long long)b * per;
+            const float* src = p.partial + (long long)b * p.splitk * per + rem;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int ks = wave;
+            for (; ks + 12 < p.splitk; ks += 16) {
+                s0 += src[(long long)ks * per];
+                s1 += src[(long long)(ks + 4) * per];
+                s2 += src[(long long)(ks + 8) * per];
+                s3 += src[(long long)(ks + 12) * per];
+            }
+            for (; ks < p.splitk; ks += 4) s0 += src[(long long)ks * per];
+            s = (s0 + s1) + (s2 + s3);
+        }
+        if (wave) part[wave - 1][lane] = s;
+        gg_sync();
+        if (wave == 0 && valid) {
+            s += part[0][lane] + part[1][lane] + part[2][lane];
+            int m = (int)(rem / p.N), n = (int)(rem - (long long)m * p.N);
+            float v = gg_epilogue(p, s, m, n);
+            const long long off = p.d2s ? gg_d2s_offset(p, m, n) : (long long)b * p.c_bs + (long long)m * p.ldc + n;
+            if (p.c_f32) ((float*)p.Cout)[off] = v;
+            else ((bf16_t*)p.Cout)[off] = gg_f2bf(v);
+        }
+        gg_sync();
     }
 }

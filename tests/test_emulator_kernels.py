@@ -484,3 +484,18 @@ def test_weight_pack_table_and_wgrad_finish(shape):
 def test_flat_optimizer_packs_and_grad_sink_match_autograd():
     from helpers import check_flat_optimizer_packs_and_grad_sink
     check_flat_optimizer_packs_and_grad_sink('cpu')
+
+
+def test_many_way_splitk_reduce_and_xcd_slice_mapping():
+    """split counts above 8 take the wave-per-64-outputs reduce, and few-tile split-K launches of the 4-wave kernel use
+    the slice-major (XCD-aware) 1-D grid: same numbers as the unsplit launch."""
+    torch.manual_seed(0)
+    a = bf(torch.randn(1, 72, 32 * 40)); b = bf(torch.randn(1, 24, 32 * 40))
+    ref = torch.einsum('bmk,bnk->bmn', a.float(), b.float())
+    for sk in (3, 12, 40):
+        out = K.gemm(a, b, out_dtype=torch.float32, force_splitk=sk, force_tile=3)
+        assert rel_err(out, ref) < 1e-5
+    x = bf(torch.randn(2, 12, 12, 8)); dy = bf(torch.randn(2, 12, 12, 16))
+    want = K.conv2d_wgrad_nhwc(x, dy, ksize=3, force_splitk=1, force_tile=3)
+    got = K.conv2d_wgrad_nhwc(x, dy, ksize=3, force_splitk=9, force_tile=3)
+    assert rel_err(got, want) < 1e-5
