@@ -8,6 +8,7 @@
 #include "gg_attention.h"
 #include "gg_attention2.h"
 #include "gg_weights.h"
+#include "gg_dconv.h"
 #include "../../include/gigagan_amd.h"
 
 #include <stdio.h>
@@ -158,14 +159,64 @@ static double gg_plan_cost(const gg_gemm_desc* d, const GgTileModel& tm, int sk,
     return t;
 }
 
+// the direct convolution (gg_dconv.h, plan tile 9): narrow 3x3 / stride 1 / pad 1 layers on large feature maps.
+// GG_DCONV=0 disables it (A/B runs); force_tile 9 selects it wherever eligible, any other force_tile bypasses it.
+static int gg_dconv_policy() {
+    static int policy = -1;
+    if (policy < 0) {
+        const char* e = getenv("GG_DCONV");
+        policy = e ? atoi(e) : 1;
+        if (policy < 0) policy = 1;
+    }
+    return policy;
+}
+
+static bool gg_dconv_eligible(const gg_gemm_desc* d) {
+    if (!d->a_conv || d->a_layout != GG_ROWK || d->b_layout != GG_ROWK) return false;
+    if (d->R != 3 || d->S != 3 || d->conv_stride != 1 || d->conv_pad != 1) return false;
+    if (d->C != d->CV || !(d->C == 16 || d->C == 32 || d->C == 64)) return false;
+    if (d->N > 64 || (d->N & 7) || d->batch != 1 || d->d2s || d->c_is_f32) return false;
+    if ((d->W % GG_DC_TW) || (d->H % GG_DC_TH) || (d->ldc & 7) || d->K != 9 * d->C) return false;
+    if (d->M % (d->H * d->W)) return false;
+    return true;
+}
+
+static bool gg_use_dconv(const gg_gemm_desc* d) {
+    if (!gg_dconv_eligible(d)) return false;
+    if (d->force_tile == 9) return true;
+    if (d->force_tile != 0 || d->force_splitk > 1) return false;
+    // 64 -> 64 channels is MFMA/LDS-bound in this form (one 124 KB workgroup per CU): the implicit GEMM measured faster
+    return gg_dconv_policy() != 0 && d->M >= 65536 && (d->C <= 32 || d->N <= 32);
+}
+
+template <int C, int TN>
+static void gg_launch_dconv(const GgGemmParams& p, hipStream_t s) {
+    using L = GgDconvLds<C, TN>;
+    const int lds = (L::XO_ELEMS + L::W_ELEMS) * 2;
+    int per_cu = (160 * 1024) / lds;
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    const long long total = (long long)(p.M / (p.H * p.W)) * (p.W / GG_DC_TW) * (p.H / GG_DC_TH);
+    long long blocks = 256LL * per_cu;
+    if (blocks > total) blocks = total;
+    const bool full = p.bias || p.out_scale || p.noise || p.residual || p.act != GG_ACT_NONE;
+    if (full) GG_LAUNCH((gg_dconv_kernel<C, TN, true>), dim3((unsigned)blocks), dim3(256), s, p);
+    else GG_LAUNCH((gg_dconv_kernel<C, TN, false>), dim3((unsigned)blocks), dim3(256), s, p);
+}
+
 GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     GemmPlan pl;
+    if (gg_use_dconv(d)) {
+        pl.tile = 9; pl.bm = GG_DC_TH * GG_DC_TW; pl.bn = d->N <= 32 ? 32 : 64;
+        pl.splitk = 1; pl.k_per_split = d->K; pl.blocks_mn = d->M / pl.bm;
+        return pl;
+    }
     const bool v2ok = gg_v2_eligible(d) && d->N >= 96 && d->M >= 192;
     const int pol = gg_v2_policy();
     const int v1_tile = d->N <= 32 ? 3 : (d->N <= 64 ? 2 : 1);
     int forced = d->force_tile;
     if (forced >= 4 && !gg_v2_eligible(d)) forced = 0;
-    if (forced < 0 || forced > 6) forced = 0;
+    if (forced < 0 || forced > 6) forced = 0;      // (9 = direct convolution: handled above when eligible)
     double best = 1e30;
     pl.tile = v1_tile; pl.splitk = 1;
     for (const GgTileModel& tm : kTileModels) {
@@ -327,7 +378,13 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     }
     bool akrow = d->a_layout == GG_KROW, bkrow = d->b_layout == GG_KROW, aconv = d->a_conv != 0;
     dim3 grid2((unsigned)(pl.blocks_mn * d->batch * pl.splitk), 1, 1);
-    if (pl.tile == 4) gg_launch_gemm2_tile<256, 256, 2, 4>(p, akrow, bkrow, aconv, grid2, s);
+    if (pl.tile == 9) {
+        const bool wide = d->N > 32;
+        if (d->C == 16) { if (wide) gg_launch_dconv<16, 2>(p, s); else gg_launch_dconv<16, 1>(p, s); }
+        else if (d->C == 32) { if (wide) gg_launch_dconv<32, 2>(p, s); else gg_launch_dconv<32, 1>(p, s); }
+        else { if (wide) gg_launch_dconv<64, 2>(p, s); else gg_launch_dconv<64, 1>(p, s); }
+    }
+    else if (pl.tile == 4) gg_launch_gemm2_tile<256, 256, 2, 4>(p, akrow, bkrow, aconv, grid2, s);
     else if (pl.tile == 5) gg_launch_gemm2_tile<256, 128, 2, 4>(p, akrow, bkrow, aconv, grid2, s);
     else if (pl.tile == 6) gg_launch_gemm2_tile<128, 128, 2, 4>(p, akrow, bkrow, aconv, grid2, s);
     else if (pl.tile == 1) gg_launch_gemm_tile<128, 128, 2, 2>(p, akrow, bkrow, aconv, grid, s);

@@ -54,7 +54,9 @@ plan_log: list | None = None    # when a list: (tile, splitk) of every launch is
 def _kernel_key(d: GemmDesc, L) -> str:
     tile, sk = C.c_int32(0), C.c_int32(0)
     L.lib.gg_gemm_plan(C.byref(d), C.byref(tile), C.byref(sk))
-    if tile.value >= 4:
+    if tile.value == 9:
+        name = f'gg_dconv_kernel<C={d.C},TN={1 if d.N <= 32 else 2}>'
+    elif tile.value >= 4:
         bm, bn = {4: (256, 256), 5: (256, 128), 6: (128, 128)}[tile.value]
         name = (f'gg_gemm2_kernel<{bm},{bn},2,4,A_KROW={int(d.a_layout == KROW)},B_KROW={int(d.b_layout == KROW)},'
                 f'A_CONV={int(bool(d.a_conv))}>')

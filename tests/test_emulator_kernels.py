@@ -499,3 +499,24 @@ def test_many_way_splitk_reduce_and_xcd_slice_mapping():
     want = K.conv2d_wgrad_nhwc(x, dy, ksize=3, force_splitk=1, force_tile=3)
     got = K.conv2d_wgrad_nhwc(x, dy, ksize=3, force_splitk=9, force_tile=3)
     assert rel_err(got, want) < 1e-5
+
+
+@pytest.mark.parametrize('cfg', [(2, 16, 32, 16, 24), (1, 8, 64, 32, 32), (3, 16, 32, 64, 56), (1, 24, 32, 32, 64), (2, 8, 32, 64, 16)])
+def test_direct_conv_matches_implicit_gemm(cfg):
+    """gg_dconv (persistent workgroups, LDS halo tile, taps by pixel shift) == the implicit-GEMM kernel bit for bit
+    (same bf16 products, fp32 accumulation in the same k order per MFMA chain is not guaranteed -> compare at fp32
+    rounding), with the plain and the full epilogue (bias, leaky-relu, residual, alpha)."""
+    n, H, W, ci, co = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(n, H, W, ci)); w = bf(torch.randn(co, 9 * ci) * 0.1)
+    bias = torch.randn(co); res = bf(torch.randn(n, H, W, co))
+    ref = K.conv2d_nhwc(x, w, ksize=3, force_tile=1)
+    got = K.conv2d_nhwc(x, w, ksize=3, force_tile=9)
+    assert rel_err(got, ref) < 2e-3 and got.shape == ref.shape
+    ref = K.conv2d_nhwc(x, w, ksize=3, bias=bias, act='lrelu', alpha=0.5, bias_scale=0.5, residual=res, force_tile=1)
+    got = K.conv2d_nhwc(x, w, ksize=3, bias=bias, act='lrelu', alpha=0.5, bias_scale=0.5, residual=res, force_tile=9)
+    assert rel_err(got, ref) < 2e-3
+    exact = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().view(co, 3, 3, ci).permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    assert rel_err(K.conv2d_nhwc(x, w, ksize=3, force_tile=9), exact) < 4e-3
+    s_in = torch.rand(n, ci) + 0.5                 # per-sample style modulation applied while staging the tile
+    assert rel_err(K.conv2d_nhwc(x, w, ksize=3, in_scale=s_in, force_tile=9), K.conv2d_nhwc(x, w, ksize=3, in_scale=s_in, force_tile=1)) < 2e-3

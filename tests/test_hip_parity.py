@@ -369,3 +369,20 @@ def test_hipgraph_replays_keep_gradients_and_weights_sane(tmp_path):
             torch.manual_seed(1)
             ref = Gc(noise=z.cpu()).float()
     assert rel_err(img, ref) < 5e-2
+
+
+@pytest.mark.parametrize('cfg', [(4, 128, 128, 32, 32), (2, 256, 256, 64, 64), (3, 64, 96, 16, 24), (2, 128, 128, 64, 16)])
+def test_direct_conv_vs_implicit_gemm_and_cpu(cfg):
+    """gg_dconv (the narrow high-resolution layers) against the implicit-GEMM kernel on the same operands (bf16 store
+    rounding only) and against fp32 CPU math, plain and full epilogue."""
+    n, H, W, ci, co = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(n, H, W, ci)); w = bf(torch.randn(co, 9 * ci) * 0.1)
+    bias = torch.randn(co); res = bf(torch.randn(n, H, W, co))
+    xd, wd, bd, rd = x.to(dev()), w.to(dev()), bias.to(dev()), res.to(dev())
+    got = K.conv2d_nhwc(xd, wd, ksize=3, force_tile=9)
+    assert rel_err(got, K.conv2d_nhwc(xd, wd, ksize=3, force_tile=1)) < BF16_TOL
+    exact = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().view(co, 3, 3, ci).permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    assert rel_err(got.cpu(), exact) < BF16_TOL
+    kw = dict(ksize=3, bias=bd, act='lrelu', alpha=0.5, bias_scale=0.5, residual=rd)
+    assert rel_err(K.conv2d_nhwc(xd, wd, force_tile=9, **kw), K.conv2d_nhwc(xd, wd, force_tile=1, **kw)) < BF16_TOL
