@@ -423,8 +423,25 @@ def softmax_bwd2(S: torch.Tensor, dS: torch.Tensor, g_dx, g_dbias, alpha: float,
     return g_S, g_dS
 
 
-def bias_act_bwd(dy: torch.Tensor, y, want_db: bool, slope: float = 0.2):
-    """dz = dy * lrelu'(y) (dz is dy itself when y is None) and db = column sums of dz (fp32) in one pass."""
+def colsum_finish(part: torch.Tensor, n: int, alpha: float = 1.0, out: torch.Tensor | None = None,
+                  accumulate: bool = False) -> torch.Tensor:
+    """part (P, C) fp32 -> (n,) fp32 = alpha * column sums (first n columns); with `out` written / accumulated in place."""
+    L = _C.lib()
+    L.require(part, out)
+    assert part.dtype == torch.float32 and part.dim() == 2 and part.is_contiguous() and n <= part.shape[1]
+    if out is None:
+        assert not accumulate
+        out = torch.empty(n, dtype=torch.float32, device=part.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == n
+    rc = L.lib.gg_colsum_finish(ptr(part), ptr(out), part.shape[0], part.shape[1], n, float(alpha), int(accumulate),
+                                L.stream(part))
+    L.check(rc, 'gg_colsum_finish')
+    return out
+
+
+def bias_act_bwd(dy: torch.Tensor, y, want_db: bool, slope: float = 0.2, partials: bool = False):
+    """dz = dy * lrelu'(y) (dz is dy itself when y is None) and db = column sums of dz (fp32) in one pass; with
+    `partials` the per-workgroup partial sums (P, C) are returned for colsum_finish instead of db."""
     L = _C.lib()
     L.require(dy, y)
     assert dy.dtype == torch.bfloat16 and dy.is_contiguous()
@@ -438,7 +455,9 @@ def bias_act_bwd(dy: torch.Tensor, y, want_db: bool, slope: float = 0.2):
         part = torch.empty((L.lib.gg_bias_act_bwd_partials(rows, Cc), Cc), dtype=torch.float32, device=dy.device)
     rc = L.lib.gg_bias_act_bwd(ptr(dy), ptr(y), ptr(dz), ptr(part), rows, Cc, slope, L.stream(dy))
     L.check(rc, 'gg_bias_act_bwd')
-    return (dz if dz is not None else dy), (part.sum(0) if part is not None else None)
+    if partials:
+        return (dz if dz is not None else dy), part
+    return (dz if dz is not None else dy), (colsum_finish(part, Cc) if part is not None else None)
 
 
 # --------------------------------------------------------------------------------------------------

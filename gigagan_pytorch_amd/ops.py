@@ -224,7 +224,7 @@ class ConvFn(Function):
         y = K.conv2d_nhwc(x, wmat, ksize=ksize, stride=stride, pad=pad, in_scale=in_scale, bias=b8, bias_scale=alpha,
                           alpha=alpha, act=act, act_slope=LRELU_SLOPE, residual=residual)
         ctx.act, ctx.geom, ctx.alpha = act, geom, alpha
-        ctx.save_for_backward(x, w, in_scale, y if act else None)
+        ctx.save_for_backward(x, w, in_scale, y if act else None, bias)
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
         ctx.n_bias = bias.shape[0] if bias is not None else 0
@@ -232,12 +232,16 @@ class ConvFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, in_scale, y = ctx.saved_tensors
+        x, w, in_scale, y, bias = ctx.saved_tensors
         geom, alpha = ctx.geom, ctx.alpha
         dy = dy.contiguous()
         want_db = ctx.has_bias and ctx.needs_input_grad[2] and not inputs_only
         db = None
-        if ctx.act == 'lrelu' or want_db:
+        bsink = _grad_sink_of(bias) if want_db else None
+        if bsink is not None:       # bias gradient: partial column sums -> one finish launch into the flat .grad
+            dz, part = K.bias_act_bwd(dy, y if ctx.act == 'lrelu' else None, True, LRELU_SLOPE, partials=True)
+            K.colsum_finish(part, ctx.n_bias, alpha, out=bsink, accumulate=True)
+        elif ctx.act == 'lrelu' or want_db:
             dz, db = BiasActBwdFn.apply(dy, y if ctx.act == 'lrelu' else None, want_db)
             if want_db:
                 db = db[:ctx.n_bias]
@@ -308,18 +312,23 @@ class BiasActBwdFn(Function):
 
     @staticmethod
     def forward(ctx, dy, y, want_db):
+        ctx.set_materialize_grads(False)
         dz, db = K.bias_act_bwd(dy, y, want_db, LRELU_SLOPE)
         ctx.save_for_backward(y)
+        ctx.like = (dy.shape, dy.dtype)
         if db is None:
-            db = dy.new_zeros((), dtype=torch.float32)
+            db = dy.new_empty(0, dtype=torch.float32)      # placeholder (no launch); never differentiated
+            ctx.mark_non_differentiable(db)
         return dz, db
 
     @staticmethod
     def backward(ctx, g_dz, g_db):
         y, = ctx.saved_tensors
         g = g_dz
-        if g_db is not None and g_db.dim() == 1:
-            g = g_db.to(g_dz.dtype).view(1, 1, 1, -1) + (g if g is not None else 0)
+        if g_db is not None and g_db.numel() > 0:
+            shape, dtype = ctx.like
+            gb = g_db.to(dtype).view(1, 1, 1, -1)
+            g = gb + g if g is not None else gb.expand(shape)
         if g is None:
             return None, None, None
         if y is not None:
@@ -427,10 +436,12 @@ class RmsNormBwdFn(Function):
 
     @staticmethod
     def forward(ctx, x, g, gamma, want_dgamma):
+        ctx.set_materialize_grads(False)
         dx, dgamma = K.rmsnorm_bwd(x, g, gamma, want_dgamma)
         ctx.save_for_backward(x, g, gamma)
         if dgamma is None:
-            dgamma = x.new_zeros((), dtype=torch.float32)
+            dgamma = x.new_empty(0, dtype=torch.float32)     # placeholder (no launch)
+            ctx.mark_non_differentiable(dgamma)
         return dx, dgamma
 
     @staticmethod
@@ -584,11 +595,13 @@ class SoftmaxBwdFn(Function):
 
     @staticmethod
     def forward(ctx, S, dS, alpha, m_valid, want_dbias):
+        ctx.set_materialize_grads(False)
         dx, dbias = K.softmax_bwd(S, dS, alpha, m_valid, want_dbias)
         ctx.alpha, ctx.m_valid = alpha, m_valid
         ctx.save_for_backward(S, dS)
         if dbias is None:
-            dbias = S.new_zeros((), dtype=torch.float32)
+            dbias = S.new_empty(0, dtype=torch.float32)      # placeholder (no launch)
+            ctx.mark_non_differentiable(dbias)
         return dx, dbias
 
     @staticmethod

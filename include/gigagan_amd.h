@@ -127,6 +127,12 @@ int gg_pack_weights(const gg_pack_entry* table, const int64_t* header, int32_t m
 int gg_wgrad_finish(const float* g, float* dst, int32_t O, int32_t I, int32_t T, int32_t C8, int32_t O8, float alpha,
                     int32_t accumulate, void* stream);
 
+/* dst[c] (+)= alpha * sum_p part[p][c] for c < n: folds the [P][C] fp32 partial column sums written by
+ * gg_bias_act_bwd (nn.Conv2d bias gradient, gp.py:1608-1621 autograd) into the bias gradient, optionally in place
+ * into the parameter's .grad. */
+int gg_colsum_finish(const float* part, float* dst, int32_t P, int32_t C, int32_t n, float alpha, int32_t accumulate,
+                     void* stream);
+
 /* Row softmax over materialised attention logits (replaces sim*scale, masked_fill, softmax and the dtype casts
  * of gp.py:584-588 / :643-649 with one pass):
  *   S[r][j] = softmax_j(alpha * x[r][j] + bias[r / rows_per_batch][j]) for j < n_valid, 0 for n_valid <= j < ld.
