@@ -19,6 +19,10 @@ def declare(L):
     L.gg_wgrad_finish.argtypes = [_P, _P, _I, _I, _I, _I, _I, _F, _I, _P]
     L.gg_colsum_finish.restype = C.c_int
     L.gg_colsum_finish.argtypes = [_P, _P, _I, _I, _I, _F, _I, _P]
+    L.gg_modcoef_fwd.restype = C.c_int
+    L.gg_modcoef_fwd.argtypes = [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]
+    L.gg_modcoef_bwd.restype = C.c_int
+    L.gg_modcoef_bwd.argtypes = [_P] * 11 + [_I] * 7 + [_F, _P]
     L.gg_softmax_fwd.restype = C.c_int
     L.gg_softmax_fwd.argtypes = [_P, _P, _P, C.c_int64, _I, _I, _I, _F, _P]
     L.gg_softmax_bwd.restype = C.c_int

@@ -9,6 +9,7 @@
 #include "gg_attention2.h"
 #include "gg_weights.h"
 #include "gg_dconv.h"
+#include "gg_modcoef.h"
 #include "../../include/gigagan_amd.h"
 
 #include <stdio.h>
@@ -480,6 +481,49 @@ extern "C" int gg_colsum_finish(const float* part, float* dst, int32_t P, int32_
     if (P <= 0 || C <= 0 || n <= 0 || n > C) return gg_fail(-2, "gg_colsum_finish: bad extents");
     GG_LAUNCH(gg_colsum_finish_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), (hipStream_t)stream, part, dst, (int)P,
               (int)C, (int)n, alpha, (int)accumulate);
+    return gg_check_launch();
+}
+
+static int gg_modcoef_common(GgModCoefParams& p, const float* w, const float* kmod, int32_t b, int32_t N, int32_t O, int32_t I,
+                             int32_t T, int32_t Ip, int32_t Op, float eps) {
+    if (!w) return gg_fail(-1, "gg_modcoef: null weights");
+    if (b <= 0 || N <= 0 || O <= 0 || I <= 0 || T <= 0 || Ip < I || Op < O) return gg_fail(-2, "gg_modcoef: bad extents");
+    if (N > GG_MC_NMAX || I > GG_MC_IMAX || O > GG_MC_IMAX)
+        return gg_fail(-3, "gg_modcoef: supports N <= %d kernels and I, O <= %d channels", GG_MC_NMAX, GG_MC_IMAX);
+    if (N > 1 && !kmod) return gg_fail(-1, "gg_modcoef: kernel_mod is required for N > 1");
+    memset(&p, 0, sizeof(p));
+    p.w = w; p.kmod = kmod; p.b = b; p.N = N; p.O = O; p.I = I; p.T = T; p.Ip = Ip; p.Op = Op; p.eps = eps;
+    return 0;
+}
+
+extern "C" int gg_modcoef_fwd(const float* w, const float* mod, const float* kmod, float* s, float* a, float* d, int32_t b,
+                              int32_t N, int32_t O, int32_t I, int32_t T, int32_t Ip, int32_t Op, float eps, void* stream) {
+    GgModCoefParams p;
+    int rc = gg_modcoef_common(p, w, kmod, b, N, O, I, T, Ip, Op, eps);
+    if (rc) return rc;
+    if (!mod || !s || !a) return gg_fail(-1, "gg_modcoef_fwd: null pointer");
+    p.mod = mod; p.s = s; p.a = a; p.d = d;
+    const unsigned grid = d ? (unsigned)O : (unsigned)(b < 256 ? b : 256);
+    GG_LAUNCH(gg_modcoef_fwd_kernel, dim3(grid), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+extern "C" int gg_modcoef_bwd(const float* w, const float* kmod, const float* s, const float* d, const float* gs,
+                              const float* ga, const float* gd, float* gmod, float* gkmod, float* da_acc, float* gw,
+                              int32_t b, int32_t N, int32_t O, int32_t I, int32_t T, int32_t Ip, int32_t Op, float eps,
+                              void* stream) {
+    GgModCoefParams p;
+    int rc = gg_modcoef_common(p, w, kmod, b, N, O, I, T, Ip, Op, eps);
+    if (rc) return rc;
+    if (!s || !d || !gd || !gmod || !da_acc) return gg_fail(-1, "gg_modcoef_bwd: null pointer");
+    if (N > 1 && !gkmod) return gg_fail(-1, "gg_modcoef_bwd: gkmod is required for N > 1");
+    p.s = (float*)s; p.d = (float*)d; p.gs = gs; p.ga = ga; p.gd = gd; p.gmod = gmod; p.gkmod = gkmod; p.da_acc = da_acc; p.gw = gw;
+    if (gw || N > 1) {
+        GG_LAUNCH(gg_modcoef_bwd_w_kernel, dim3((unsigned)O), dim3(256), (hipStream_t)stream, p);
+        rc = gg_check_launch();
+        if (rc) return rc;
+    }
+    GG_LAUNCH(gg_modcoef_bwd_s_kernel, dim3((unsigned)I), dim3(256), (hipStream_t)stream, p);
     return gg_check_launch();
 }
 

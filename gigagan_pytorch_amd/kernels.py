@@ -706,3 +706,47 @@ class PackTable:
         L.require(self.table)
         rc = L.lib.gg_pack_weights(ptr(self.table), ptr(self.header), 2 if L.is_emulator else 0, L.stream(self.table))
         L.check(rc, 'gg_pack_weights')
+
+
+# --------------------------------------------------------------------------------------------------
+# adaptive-conv coefficients (gg_modcoef.h)
+# --------------------------------------------------------------------------------------------------
+
+MODCOEF_MAX_N, MODCOEF_MAX_C = 4, 1024
+
+
+def modcoef_fwd(w: torch.Tensor, mod: torch.Tensor, kmod, demod: bool, eps: float, Ip: int, Op: int):
+    """w (N, O, I, k, k) fp32, mod (b, I) fp32, kmod (b, N) fp32 or None -> s (b, Ip), a (b, N), d (b, Op) or None."""
+    L = _C.lib()
+    L.require(w, mod, kmod)
+    N, O, I = w.shape[:3]
+    T = w.shape[3] * w.shape[4]
+    b = mod.shape[0]
+    assert w.dtype == torch.float32 and w.is_contiguous() and mod.dtype == torch.float32 and mod.is_contiguous()
+    assert mod.shape == (b, I) and (kmod is None or (kmod.shape == (b, N) and kmod.dtype == torch.float32 and kmod.is_contiguous()))
+    s = torch.empty((b, Ip), dtype=torch.float32, device=w.device)
+    a = torch.empty((b, N), dtype=torch.float32, device=w.device)
+    d = torch.empty((b, Op), dtype=torch.float32, device=w.device) if demod else None
+    rc = L.lib.gg_modcoef_fwd(ptr(w), ptr(mod), ptr(kmod), ptr(s), ptr(a), ptr(d), b, N, O, I, T, Ip, Op, float(eps),
+                              L.stream(w))
+    L.check(rc, 'gg_modcoef_fwd')
+    return s, a, d
+
+
+def modcoef_bwd(w, kmod, s, d, gs, ga, gd, gw, eps: float):
+    """-> (gmod (b, I), gkmod (b, N) or None); adds the demodulation path's weight gradient into gw (w-shaped) if given."""
+    L = _C.lib()
+    L.require(w, kmod, s, d, gs, ga, gd, gw)
+    N, O, I = w.shape[:3]
+    T = w.shape[3] * w.shape[4]
+    b, Ip = s.shape
+    Op = d.shape[1]
+    for t in (gs, ga, gd, gw):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    gmod = torch.empty((b, I), dtype=torch.float32, device=w.device)
+    gkmod = torch.empty((b, N), dtype=torch.float32, device=w.device) if N > 1 else None
+    da_acc = torch.zeros((b, N), dtype=torch.float32, device=w.device)
+    rc = L.lib.gg_modcoef_bwd(ptr(w), ptr(kmod), ptr(s), ptr(d), ptr(gs), ptr(ga), ptr(gd), ptr(gmod), ptr(gkmod),
+                              ptr(da_acc), ptr(gw), b, N, O, I, T, Ip, Op, float(eps), L.stream(w))
+    L.check(rc, 'gg_modcoef_bwd')
+    return gmod, gkmod

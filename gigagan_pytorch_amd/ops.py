@@ -394,6 +394,41 @@ class ModulateFn(Function):
         return (dx if ctx.needs_input_grad[0] else None), (ds if ctx.needs_input_grad[1] else None)
 
 
+class ModCoefFn(Function):
+    """(s, a, d) of the adaptive convolution (gp.py:378-400) in ONE launch; backward in two (gg_modcoef.h). The
+    weights' gradient through the demodulation is accumulated into the flat gradient buffer when `grad_sink` is on."""
+
+    @staticmethod
+    def forward(ctx, mod, kmod, weights, eps, Ip, Op):
+        ctx.set_materialize_grads(False)
+        s, a, d = K.modcoef_fwd(weights.detach(), mod, kmod, True, eps, Ip, Op)
+        ctx.eps = eps
+        ctx.save_for_backward(kmod, weights, s, d)
+        return s, a, d
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gs, ga, gd):
+        kmod, weights, s, d = ctx.saved_tensors
+
+        def f32(t):
+            return None if t is None else t.float().contiguous()
+        gs, ga, gd = f32(gs), f32(ga), f32(gd)
+        gw = sink = None
+        if ctx.needs_input_grad[2] and not inputs_only and gd is not None:
+            sink = _grad_sink_of(weights)
+            gw = sink if sink is not None else torch.zeros_like(weights, dtype=torch.float32)
+        if gd is None:      # d was not used downstream: only the linear parts remain
+            gmod = None if gs is None else gs[:, :weights.shape[2]]
+            gk = None
+            if ga is not None and kmod is not None:
+                a = kmod.softmax(dim=-1)
+                gk = a * (ga - (a * ga).sum(-1, keepdim=True))
+            return gmod, gk, None, None, None, None
+        gmod, gk = K.modcoef_bwd(weights.detach(), kmod, s, d, gs, ga, gd, gw, ctx.eps)
+        return gmod, gk, (gw if (gw is not None and sink is None) else None), None, None, None
+
+
 class ModMixFn(Function):
     """y = act(d[b,o] * sum_n a[b,n] * Y[..., n*Os + o] + noise_w[o] * noise[b,p]) — the per-sample kernel mix,
     demodulation, noise and leaky-relu after the stacked conv — one bf16 pass forward, one backward."""
@@ -728,28 +763,41 @@ class HipOps:
         x = to_act(x)
         b, _, H, W = x.shape
         N, O, I, k, _ = weights.shape
-        s = mod.float() + 1.0                                           # (b, I)
-        if N > 1:
-            a = kernel_mod.float().softmax(dim=-1)                      # (b, N)
-        else:
-            a = torch.ones((b, 1), device=x.device, dtype=torch.float32)
-        d = None
-        if demod:
-            d = demod_coefficients(weights, s, a, eps)                  # (b, O) fp32
         Ip, Op = _round8(I), _round8(O)
-        xh = nhwc(x)
         needs_grad = torch.is_grad_enabled() and any(
             t is not None and t.requires_grad for t in (x, weights, mod, kernel_mod, noise_weight))
+        fused_coef = (demod and not second_order and N <= K.MODCOEF_MAX_N and max(I, O) <= K.MODCOEF_MAX_C
+                      and weights.dtype == torch.float32 and weights.is_contiguous())
+        s_padded = d_padded = False
+        if fused_coef:      # s, a, d in one launch (and two backward), padded to the kernels' channel multiples
+            km = kernel_mod.float().contiguous() if N > 1 else None
+            if needs_grad:
+                s, a, d = ModCoefFn.apply(mod.float().contiguous(), km, weights, eps, Ip, Op)
+            else:
+                s, a, d = K.modcoef_fwd(weights.detach(), mod.detach().float().contiguous(),
+                                        None if km is None else km.detach(), True, eps, Ip, Op)
+            s_padded = d_padded = True
+        else:
+            s = mod.float() + 1.0                                       # (b, I)
+            if N > 1:
+                a = kernel_mod.float().softmax(dim=-1)                  # (b, N)
+            else:
+                a = torch.ones((b, 1), device=x.device, dtype=torch.float32)
+            d = None
+            if demod:
+                d = demod_coefficients(weights, s, a, eps)              # (b, O) fp32
+        xh = nhwc(x)
         if Ip != I:
             xh = F.pad(xh, (0, Ip - I))
-            s = F.pad(s, (0, Ip - I))
+            if not s_padded:
+                s = F.pad(s, (0, Ip - I))
         if not needs_grad:
             wts = weights
             if Ip != I:
                 wts = F.pad(wts, (0, 0, 0, 0, 0, Ip - I))
             if Op != O:
                 wts = F.pad(wts, (0, 0, 0, 0, 0, 0, 0, Op - O))
-            y = fused_modconv_forward(xh, wts, s, a, d, noise, noise_weight, act, O, Op)
+            y = fused_modconv_forward(xh, wts, s, a, d, noise, noise_weight, act, O, Op, d_padded)
             return nchw(y[..., :O] if Op != O else y)
         # training path: modulate -> ONE conv with the N kernels stacked along output channels -> mix/demod/noise/act
         geom = (k, 1, k // 2, 'oihw')
@@ -759,7 +807,7 @@ class HipOps:
             if N == 1 and d is None and noise is None and act is None:
                 y = Y
             else:
-                d8 = None if d is None else (F.pad(d, (0, Op - O)) if Op != O else d).contiguous()
+                d8 = None if d is None else (F.pad(d, (0, Op - O)) if (Op != O and not d_padded) else d).contiguous()
                 nz = nw = None
                 if noise is not None:
                     nz = noise.reshape(b, H * W).float().contiguous()
@@ -875,7 +923,7 @@ def demod_coefficients(weights, s, a, eps):
     return sumsq.clamp(min=eps).rsqrt()
 
 
-def fused_modconv_forward(xh, wts, s, a, d, noise, noise_weight, act, O, Op):
+def fused_modconv_forward(xh, wts, s, a, d, noise, noise_weight, act, O, Op, d_padded=False):
     """no-grad path: the whole adaptive conv (kernel mix, modulation, demodulation, noise, leaky-relu) as
     ONE implicit-GEMM launch with the N kernels stacked along the reduction and batch folded into M."""
     b, H, W, Ip = xh.shape
@@ -884,7 +932,7 @@ def fused_modconv_forward(xh, wts, s, a, d, noise, noise_weight, act, O, Op):
     wk = wts.permute(1, 3, 4, 0, 2).reshape(Op, k * k * N * Ip).to(ACT_DTYPE).contiguous()
     out_scale = None
     if d is not None:
-        out_scale = (F.pad(d, (0, Op - O)) if Op != O else d).contiguous()
+        out_scale = (F.pad(d, (0, Op - O)) if (Op != O and not d_padded) else d).contiguous()
     nz = nw = None
     if noise is not None:
         nz = noise.reshape(-1).float().contiguous()

@@ -127,6 +127,20 @@ int gg_pack_weights(const gg_pack_entry* table, const int64_t* header, int32_t m
 int gg_wgrad_finish(const float* g, float* dst, int32_t O, int32_t I, int32_t T, int32_t C8, int32_t O8, float alpha,
                     int32_t accumulate, void* stream);
 
+/* Per-sample coefficients of the adaptive convolution (AdaptiveConv2DMod.forward, gp.py:378-400) in one launch:
+ *   s[b,i] = mod[b,i] + 1 (zero for I <= i < Ip),  a[b,n] = softmax_n(kmod[b,:]) (1 when N == 1, kmod may be NULL),
+ *   d[b,o] = rsqrt(max(sum_{i,t} (sum_n a[b,n] w[n,o,i,t] s[b,i])^2, eps)) (zero for O <= o < Op; d NULL: skipped).
+ * w fp32 (N, O, I, T); mod (b, I), kmod (b, N), s (b, Ip), a (b, N), d (b, Op) fp32. N <= 4, I, O <= 1024. */
+int gg_modcoef_fwd(const float* w, const float* mod, const float* kmod, float* s, float* a, float* d, int32_t b,
+                   int32_t N, int32_t O, int32_t I, int32_t T, int32_t Ip, int32_t Op, float eps, void* stream);
+
+/* Backward of gg_modcoef_fwd (what autograd derives from gp.py:378-400): given gs (b, Ip) / ga (b, N) (either may be
+ * NULL) and gd (b, Op), writes gmod (b, I) and gkmod (b, N), and ADDS the weights' gradient through the demodulation
+ * into gw (N, O, I, T) when gw != NULL. da_acc (b, N) is caller-zeroed scratch. */
+int gg_modcoef_bwd(const float* w, const float* kmod, const float* s, const float* d, const float* gs, const float* ga,
+                   const float* gd, float* gmod, float* gkmod, float* da_acc, float* gw, int32_t b, int32_t N, int32_t O,
+                   int32_t I, int32_t T, int32_t Ip, int32_t Op, float eps, void* stream);
+
 /* dst[c] (+)= alpha * sum_p part[p][c] for c < n: folds the [P][C] fp32 partial column sums written by
  * gg_bias_act_bwd (nn.Conv2d bias gradient, gp.py:1608-1621 autograd) into the bias gradient, optionally in place
  * into the parameter's .grad. */

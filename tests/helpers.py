@@ -92,3 +92,35 @@ def check_flat_optimizer_packs_and_grad_sink(device):
             fresh = ops.packed_weight(w, 'fwd')
             assert fresh.data_ptr() == packed.data_ptr()
             assert torch.equal(fresh, w.detach().permute(0, 2, 3, 1).reshape(16, -1).to(torch.bfloat16))
+
+
+def check_modcoef(cfg, device):
+    """gg_modcoef (s, a, d in one launch; gradients w.r.t. mod, kernel_mod and the kernel bank in two) against the
+    tensor-algebra formulation of gp.py:378-400, values and gradients."""
+    from gigagan_pytorch_amd import kernels as K, ops
+    b, N, O, I, k = cfg
+    torch.manual_seed(0)
+    w = (torch.randn(N, O, I, k, k) * 0.2).to(device).requires_grad_()
+    mod = (torch.randn(b, I) * 0.5).to(device).requires_grad_()
+    kmod = torch.randn(b, N).to(device).requires_grad_() if N > 1 else None
+    r8 = lambda n: (n + 7) // 8 * 8
+    cs, ca, cd = torch.randn(b, r8(I)).to(device), torch.randn(b, N).to(device), torch.randn(b, r8(O)).to(device)
+
+    def reference():
+        s = mod + 1.0
+        a = kmod.softmax(-1) if N > 1 else torch.ones(b, 1, device=device)
+        d = ops.demod_coefficients(w, s, a, 1e-8)
+        return s, a, d
+    s0, a0, d0 = reference()
+    loss0 = (s0 * cs[:, :I]).sum() + (a0 * ca).sum() + (d0 * cd[:, :O]).sum()
+    g0 = torch.autograd.grad(loss0, [t for t in (mod, kmod, w) if t is not None])
+    s1, a1, d1 = ops.ModCoefFn.apply(mod, kmod, w, 1e-8, r8(I), r8(O))
+    assert torch.allclose(s1[:, :I], s0, atol=1e-6) and (s1[:, I:] == 0).all()
+    assert torch.allclose(a1, a0, atol=1e-6) and rel_err(d1[:, :O], d0) < 1e-5 and (d1[:, O:] == 0).all()
+    loss1 = (s1 * cs).sum() + (a1 * ca).sum() + (d1 * cd).sum()
+    g1 = torch.autograd.grad(loss1, [t for t in (mod, kmod, w) if t is not None])
+    for x, y in zip(g1, g0):
+        assert rel_err(x, y) < 2e-5, (x.shape, rel_err(x, y))
+    # forward-only entry (no-grad generator pass)
+    s2, a2, d2 = K.modcoef_fwd(w.detach(), mod.detach(), None if kmod is None else kmod.detach(), True, 1e-8, r8(I), r8(O))
+    assert torch.equal(s2, s1) and torch.equal(d2, d1)

@@ -520,3 +520,9 @@ def test_direct_conv_matches_implicit_gemm(cfg):
     assert rel_err(K.conv2d_nhwc(x, w, ksize=3, force_tile=9), exact) < 4e-3
     s_in = torch.rand(n, ci) + 0.5                 # per-sample style modulation applied while staging the tile
     assert rel_err(K.conv2d_nhwc(x, w, ksize=3, in_scale=s_in, force_tile=9), K.conv2d_nhwc(x, w, ksize=3, in_scale=s_in, force_tile=1)) < 2e-3
+
+
+@pytest.mark.parametrize('cfg', [(5, 2, 10, 12, 3), (18, 1, 8, 16, 1), (3, 4, 6, 20, 3)])
+def test_fused_adaptive_conv_coefficients_match_tensor_algebra(cfg):
+    from helpers import check_modcoef
+    check_modcoef(cfg, 'cpu')

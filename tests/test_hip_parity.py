@@ -386,3 +386,9 @@ def test_direct_conv_vs_implicit_gemm_and_cpu(cfg):
     assert rel_err(got.cpu(), exact) < BF16_TOL
     kw = dict(ksize=3, bias=bd, act='lrelu', alpha=0.5, bias_scale=0.5, residual=rd)
     assert rel_err(K.conv2d_nhwc(xd, wd, force_tile=9, **kw), K.conv2d_nhwc(xd, wd, force_tile=1, **kw)) < BF16_TOL
+
+
+@pytest.mark.parametrize('cfg', [(5, 2, 10, 12, 3), (32, 2, 512, 512, 3), (32, 2, 32, 64, 3), (32, 1, 3, 32, 1)])
+def test_fused_adaptive_conv_coefficients_match_tensor_algebra(cfg):
+    from helpers import check_modcoef
+    check_modcoef(cfg, dev())
