@@ -18,7 +18,7 @@ def declare(L):
     L.gg_wgrad_finish.restype = C.c_int
     L.gg_wgrad_finish.argtypes = [_P, _P, _I, _I, _I, _I, _I, _F, _I, _P]
     L.gg_colsum_finish.restype = C.c_int
-    L.gg_colsum_finish.argtypes = [_P, _P, _I, _I, _I, _F, _I, _P]
+    L.gg_colsum_finish.argtypes = [_P, _P, _I, _I, _I, _F, _P]
     L.gg_modcoef_fwd.restype = C.c_int
     L.gg_modcoef_fwd.argtypes = [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]
     L.gg_modcoef_bwd.restype = C.c_int

@@ -475,12 +475,13 @@ extern "C" int gg_wgrad_finish(const float* g, float* dst, int32_t O, int32_t I,
     return gg_check_launch();
 }
 
-extern "C" int gg_colsum_finish(const float* part, float* dst, int32_t P, int32_t C, int32_t n, float alpha,
-                                int32_t accumulate, void* stream) {
+extern "C" int gg_colsum_finish(const float* part, float* dst, int32_t P, int32_t C, int32_t n, float alpha, void* stream) {
     if (!part || !dst) return gg_fail(-1, "gg_colsum_finish: null pointer");
     if (P <= 0 || C <= 0 || n <= 0 || n > C) return gg_fail(-2, "gg_colsum_finish: bad extents");
-    GG_LAUNCH(gg_colsum_finish_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), (hipStream_t)stream, part, dst, (int)P,
-              (int)C, (int)n, alpha, (int)accumulate);
+    int groups = (P + 15) / 16;
+    if (groups > 32) groups = 32;
+    GG_LAUNCH(gg_colsum_finish_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)groups), dim3(256), (hipStream_t)stream, part,
+              dst, (int)P, (int)C, (int)n, alpha);
     return gg_check_launch();
 }
 

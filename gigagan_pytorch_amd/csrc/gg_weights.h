@@ -155,21 +155,19 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_wgrad_finish_kernel(GgWgradFinishParams 
     }
 }
 
-// dst[c] (+)= alpha * sum_p part[p][c], c < n: the per-workgroup partial column sums of gg_bias_act_bwd (or of any
+// dst[c] += alpha * sum_p part[p][c], c < n: the per-workgroup partial column sums of gg_bias_act_bwd (or of any
 // [P][C] fp32 partial buffer) folded, scaled and accumulated into a bias gradient in one launch - replaces the
-// sum / slice / scale / AccumulateGrad chain (4 launches per bias).
-GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_colsum_finish_kernel(const float* part, float* dst, int P, int C, int n, float alpha,
-                                                             int accumulate) {
+// sum / slice / scale / AccumulateGrad chain (4 launches per bias). grid (ceil(n/64), G): workgroup (x, y) folds the
+// partial rows y, y+G, ... (4 waves interleaved) of 64 channels and issues one atomic add per channel; dst holds the
+// running gradient (or zeros).
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_colsum_finish_kernel(const float* part, float* dst, int P, int C, int n, float alpha) {
     GG_SHARED float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
     if (c < n)
-        for (int q = wave; q < P; q += 4) s += part[(long long)q * C + c];
+        for (int q = blockIdx.y * 4 + wave; q < P; q += 4 * gridDim.y) s += part[(long long)q * C + c];
     red[wave][lane] = s;
     gg_sync();
-    if (wave == 0 && c < n) {
-        const float v = alpha * ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
-        dst[c] = accumulate ? dst[c] + v : v;
-    }
+    if (wave == 0 && c < n) gg_atomic_add(dst + c, alpha * ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])));
 }

@@ -425,16 +425,17 @@ def softmax_bwd2(S: torch.Tensor, dS: torch.Tensor, g_dx, g_dbias, alpha: float,
 
 def colsum_finish(part: torch.Tensor, n: int, alpha: float = 1.0, out: torch.Tensor | None = None,
                   accumulate: bool = False) -> torch.Tensor:
-    """part (P, C) fp32 -> (n,) fp32 = alpha * column sums (first n columns); with `out` written / accumulated in place."""
+    """part (P, C) fp32 -> (n,) fp32 = alpha * column sums (first n columns); with `out` (+ accumulate) added in place."""
     L = _C.lib()
     L.require(part, out)
     assert part.dtype == torch.float32 and part.dim() == 2 and part.is_contiguous() and n <= part.shape[1]
     if out is None:
         assert not accumulate
-        out = torch.empty(n, dtype=torch.float32, device=part.device)
+        out = torch.zeros(n, dtype=torch.float32, device=part.device)
+    elif not accumulate:
+        out.zero_()
     assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == n
-    rc = L.lib.gg_colsum_finish(ptr(part), ptr(out), part.shape[0], part.shape[1], n, float(alpha), int(accumulate),
-                                L.stream(part))
+    rc = L.lib.gg_colsum_finish(ptr(part), ptr(out), part.shape[0], part.shape[1], n, float(alpha), L.stream(part))
     L.check(rc, 'gg_colsum_finish')
     return out
 

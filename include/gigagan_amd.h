@@ -141,11 +141,10 @@ int gg_modcoef_bwd(const float* w, const float* kmod, const float* s, const floa
                    const float* gd, float* gmod, float* gkmod, float* da_acc, float* gw, int32_t b, int32_t N, int32_t O,
                    int32_t I, int32_t T, int32_t Ip, int32_t Op, float eps, void* stream);
 
-/* dst[c] (+)= alpha * sum_p part[p][c] for c < n: folds the [P][C] fp32 partial column sums written by
- * gg_bias_act_bwd (nn.Conv2d bias gradient, gp.py:1608-1621 autograd) into the bias gradient, optionally in place
- * into the parameter's .grad. */
-int gg_colsum_finish(const float* part, float* dst, int32_t P, int32_t C, int32_t n, float alpha, int32_t accumulate,
-                     void* stream);
+/* dst[c] += alpha * sum_p part[p][c] for c < n: folds the [P][C] fp32 partial column sums written by
+ * gg_bias_act_bwd (nn.Conv2d bias gradient, gp.py:1608-1621 autograd) into the bias gradient - `dst` is the
+ * parameter's .grad (running sum) or a zeroed buffer; fp32 atomics, one per channel and group of 16 partial rows. */
+int gg_colsum_finish(const float* part, float* dst, int32_t P, int32_t C, int32_t n, float alpha, void* stream);
 
 /* Row softmax over materialised attention logits (replaces sim*scale, masked_fill, softmax and the dtype casts
  * of gp.py:584-588 / :643-649 with one pass):
