@@ -870,15 +870,44 @@ class HipOps:
         return self_attention_unfused(self, q, k, v, null_kv, heads, scale, l2)
 
     # -- norms / resampling ------------------------------------------------------------------------
-    def channel_rmsnorm(self, x, gamma):
-        """F.normalize(x, dim=1) * sqrt(C) * gamma (gp.py:224-232), fp32 statistics, one fused pass over NHWC."""
+    def channel_rmsnorm(self, x, gamma, act=None):
+        """F.normalize(x, dim=1) * sqrt(C) * gamma (gp.py:224-232, unet.py:224-234), fp32 statistics, one fused pass
+        over NHWC; `act='silu'` is the unet Block's activation (unet.py:268-269)."""
         x = to_act(x)
         c = x.shape[1]
         if c % 8:
             xf = x.float()
             nrm = xf.norm(dim=1, keepdim=True).clamp(min=1e-12)
-            return (xf / nrm * (c ** 0.5) * gamma.float().view(1, c, 1, 1)).to(ACT_DTYPE)
-        return nchw(RmsNormFn.apply(nhwc(x), gamma.float().reshape(c).contiguous()))
+            y = (xf / nrm * (c ** 0.5) * gamma.float().view(1, c, 1, 1)).to(ACT_DTYPE)
+        else:
+            y = nchw(RmsNormFn.apply(nhwc(x), gamma.float().reshape(c).contiguous()))
+        if act == 'silu':
+            y = F.silu(y)
+        else:
+            assert act is None
+        return y
+
+    # -- unet pieces (unet_upsampler.py) -----------------------------------------------------------------
+    def maxpool_highfreq(self, x):
+        """(max_pool2d(x, 2), x - blur(x)): the unet Downsample's pooled map and the high-frequency map that rides the
+        skip connection (unet.py:134-160)."""
+        x = to_act(x)
+        hf = (x.float() - self.blur(x).float()).to(ACT_DTYPE)
+        return F.max_pool2d(x, kernel_size=2), hf
+
+    def linear_attention(self, q, k, v, *, heads, scale):
+        """LinearAttention core (unet.py:338-348): q softmax over the head features (times scale), k softmax over the
+        positions, context = k v^T (d x e per head), out = context^T q. q, k, v logical (b, heads*d, x, y); both
+        contractions on the batched MFMA GEMM, softmaxes in fp32."""
+        b, c, x, y = q.shape
+        n, d = x * y, c // heads
+        qf = q.reshape(b, heads, d, n).float().softmax(dim=2) * scale
+        kf = k.reshape(b, heads, d, n).float().softmax(dim=3)
+        q2, k2, v2 = (t.reshape(b * heads, d, n).transpose(1, 2).to(ACT_DTYPE).contiguous()      # (BH, n, d)
+                      for t in (qf, kf, v.reshape(b, heads, d, n)))
+        ctx = GemmFn.apply(k2, v2, False, False, (d, d, n), None, None, 1.0, False)               # (BH, d, e)
+        out = GemmFn.apply(q2, ctx, True, False, (n, d, d), None, None, 1.0, False)               # (BH, n, e)
+        return out.reshape(b, heads, n, d).permute(0, 1, 3, 2).reshape(b, c, x, y)
 
     def upsample_blur(self, x):
         """nn.Upsample(x2, bilinear, align_corners=False) then the reflect-padded [1,2,1]^2/16 blur

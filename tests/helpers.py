@@ -124,3 +124,10 @@ def check_modcoef(cfg, device):
     # forward-only entry (no-grad generator pass)
     s2, a2, d2 = K.modcoef_fwd(w.detach(), mod.detach(), None if kmod is None else kmod.detach(), True, 1e-8, r8(I), r8(O))
     assert torch.equal(s2, s1) and torch.equal(d2, d1)
+
+
+# UnetUpsampler (BASELINE config 5 at toy size): two no-downsample stages (8 -> 32), linear attention in the first stage,
+# full attention in the last two, high-frequency skip maps from the downsampling stages
+UNET_SMALL = dict(dim=8, image_size=32, input_image_size=8, style_network=dict(dim=16, depth=2), dim_mults=(1, 2, 4),
+                  full_attn=(False, True, True), self_attn_dim_head=8, self_attn_heads=2, cross_attn_dim_head=8,
+                  unconditional=True)
