@@ -615,13 +615,14 @@ class AttnProbsFn(Function):
     def backward(ctx, dattn):
         q, k, attn = ctx.saved_tensors
         alpha, m_valid, (n, mp, dh) = ctx.cfg
-        dx, dbias = SoftmaxBwdFn.apply(attn, dattn.contiguous(), alpha, m_valid, ctx.has_bias)
+        want_dbias = ctx.has_bias and ctx.needs_input_grad[2]      # key-padding masks are constants: no column sums
+        dx, dbias = SoftmaxBwdFn.apply(attn, dattn.contiguous(), alpha, m_valid, want_dbias)
         dq = dk = None
         if ctx.needs_input_grad[0]:   # dq(i,d) = sum_j dx(i,j) k(j,d)
             dq = GemmFn.apply(dx, k, True, False, (n, dh, mp), None, None, 1.0, False)
         if ctx.needs_input_grad[1]:   # dk(j,d) = sum_i dx(i,j) q(i,d)
             dk = GemmFn.apply(dx, q, False, False, (mp, dh, n), None, None, 1.0, False)
-        return dq, dk, (dbias if ctx.has_bias else None), None, None
+        return dq, dk, (dbias if want_dbias else None), None, None
 
 
 class SoftmaxBwdFn(Function):

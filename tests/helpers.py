@@ -131,3 +131,23 @@ def check_modcoef(cfg, device):
 UNET_SMALL = dict(dim=8, image_size=32, input_image_size=8, style_network=dict(dim=16, depth=2), dim_mults=(1, 2, 4),
                   full_attn=(False, True, True), self_attn_dim_head=8, self_attn_heads=2, cross_attn_dim_head=8,
                   unconditional=True)
+
+
+# text-conditional GigaGAN (BASELINE config 4 at toy size): CLIP is an external frozen encoder, the models are fed
+# pre-computed token encodings (b, tokens, clip_dim_latent) with zero rows as padding
+TEXT_ENC = dict(dim=16, depth=1, heads=2, dim_head=8)
+TEXT_CLIP_DIM = 24
+TEXT_G = dict(image_size=16, dim_capacity=8, dim_max=32, dim_latent=32, style_network=dict(dim=32, depth=2, dim_text_latent=16),
+              unconditional=False, self_attn_resolutions=(8,), cross_attn_resolutions=(8,), self_attn_heads=2,
+              self_attn_dim_head=16, cross_attn_heads=2, cross_attn_dim_head=16, num_skip_layers_excite=1)
+TEXT_D = dict(image_size=16, dim_capacity=8, dim_max=32, unconditional=False, attn_resolutions=(8,), attn_heads=2,
+              attn_dim_head=16, num_skip_layers_excite=1, multiscale_input_resolutions=(8,))
+
+
+def text_encodings(batch=2, tokens=7, seed=0):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    enc = torch.randn(batch, tokens, TEXT_CLIP_DIM, generator=g)
+    for i in range(batch):
+        enc[i, tokens - 2 - 2 * i:] = 0          # ragged lengths: zero rows are padding (gp.py:853)
+    return enc
