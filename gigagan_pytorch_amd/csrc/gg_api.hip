@@ -369,6 +369,9 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     p.noise = d->noise; p.noise_w = d->noise_w;
     p.act = d->act; p.act_slope = d->act_slope;
     p.partial = (float*)workspace;
+#ifdef GG2_PROBE
+    if (pl.tile > 3) p.xcd_slices = getenv("GG2_DBG") ? atoi(getenv("GG2_DBG")) : 0;   // probe builds: k-loop phase mask
+#endif
 
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)pl.blocks_mn, 1, (unsigned)(d->batch * pl.splitk));

@@ -427,15 +427,36 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_gemm2_kernel(GgGemmParams p) {
     gg_sync();
 
     const int frow = lane & 31, fk = (lane >> 5) * 8;
+#ifdef GG2_PROBE
+    // probe builds only (tests/probes/build_gemm2_probe.sh): phases of the k-loop can be switched off to time the others.
+    // bit 0: no LDS stores, bit 1: no global loads, bit 2: no LDS fragment reads, bit 3: no MFMAs. Results are garbage.
+    const int dbg = p.xcd_slices;
+    u16x8 pfa[TM], pfb[TN];
+    float psink = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) pfa[i] = (u16x8){0x3f80, 0x3f00, 0x3e80, 0x3f80, 0x3f00, 0x3e80, 0x3f80, 0x3f00};
+#pragma unroll
+    for (int j = 0; j < TN; ++j) pfb[j] = (u16x8){0x3f00, 0x3f80, 0x3f00, 0x3e80, 0x3f80, 0x3f00, 0x3e80, 0x3f80};
+#else
+    constexpr int dbg = 0;
+#endif
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         // tile kt+1 sits in the staging registers (its loads were issued one MFMA phase ago): park it in the
         // other LDS buffer (free since the barrier that ended iteration kt-1), then put tile kt+2 in flight
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
-        if (kt + 2 < nk) load_tiles(kbeg + (kt + 2) * GG2_BK);
+        if (kt + 1 < nk && !(dbg & 1)) store_tiles(buf ^ 1);
+        if (kt + 2 < nk && !(dbg & 2)) load_tiles(kbeg + (kt + 2) * GG2_BK);
 #pragma unroll
         for (int kk = 0; kk < GG2_BK / 16; ++kk) {
             u16x8 fa[TM], fb[TN];
+#ifdef GG2_PROBE
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = pfa[i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = pfb[j];
+            if (!(dbg & 4))
+#endif
+            {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 if (A_KROW) fa[i] = gg2_frag_krow<BM>(tileA(buf), wm * WTM + i * 32, kk, lane);
@@ -446,14 +467,28 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_gemm2_kernel(GgGemmParams p) {
                 if (B_KROW) fb[j] = gg2_frag_krow<BN>(tileB(buf), wn * WTN + j * 32, kk, lane);
                 else fb[j] = *(const u16x8*)&((const bf16_t(*)[GG2_PITCH])tileB(buf))[wn * WTN + j * 32 + frow][kk * 16 + fk];
             }
+            }
+#ifdef GG2_PROBE
+            if (dbg & 8) {      // keep the fragment reads alive without the matrix pipe
+#pragma unroll
+                for (int i = 0; i < TM; ++i) psink += gg_bf2f(fa[i][0]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) psink += gg_bf2f(fb[j][1]);
+            } else
+#endif
+            {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = gg_mfma_32x32x16_bf16(fb[j], fa[i], acc[i][j]);   // swapped: lane registers run along n
+            }
         }
         gg_sync();
     }
+#ifdef GG2_PROBE
+    acc[0][0][0] += psink;
+#endif
 
     // epilogue (same fragment ownership as gg_gemm_kernel): lane owns row m = ... + (lane & 31); register r holds
     // column n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5). The argument struct is copied from the kernarg segment HERE

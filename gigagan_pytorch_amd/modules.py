@@ -29,6 +29,8 @@ def tile_batch(t, batch):
     """reference `repeat(t, 'b ... -> (s b) ...')`: the multi-scale batch is scale-major (gp.py:365-366)."""
     if t.shape[0] == batch:
         return t
+    if t.dim() == 4:    # cat keeps channels_last storage; repeat() would hand back an NCHW tensor and every consumer
+        return torch.cat([t] * (batch // t.shape[0]), dim=0)        # (add, cat, conv) would fall onto strided kernels
     return t.repeat(batch // t.shape[0], *((1,) * (t.dim() - 1)))
 
 
@@ -184,7 +186,7 @@ class PixelShuffleUpsample(nn.Module):
 def SqueezeExcite(dim, dim_out, reduction=4, dim_min=32):
     dim_hidden = max(dim_out // reduction, dim_min)
     return nn.Sequential(
-        Placeholder(lambda x: x.float().mean(dim=(2, 3))),
+        Placeholder(lambda x: ops.impl.global_mean(x)),
         Linear(dim, dim_hidden),
         Act(F.silu),
         Linear(dim_hidden, dim_out),

@@ -680,6 +680,24 @@ def matmul_nt(x: torch.Tensor, w: torch.Tensor, bias=None, act=None, out_f32=Fal
     return out.reshape(*lead, n)
 
 
+class GlobalMeanFn(Function):
+    """(b, C, H, W) bf16 channels_last -> (b, C) fp32 mean over the pixels (SqueezeExcite's pool, gp.py:300) read straight
+    from the bf16 tensor; the backward hands autograd a bf16 channels_last gradient, so its accumulation into the main
+    path's gradient is a plain contiguous add (the stock mean backward materialises an fp32 NCHW expansion, casts it and
+    adds it through the strided kernel: five more passes over the activation)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape, ctx.dtype = x.shape, x.dtype
+        return x.mean(dim=(2, 3), dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        b, C, H, W = ctx.shape
+        gs = (g * (1.0 / (H * W))).to(ctx.dtype)
+        return gs[:, None, None, :].expand(b, H, W, C).contiguous().permute(0, 3, 1, 2)
+
+
 class ResampleFn(Function):
     """Separable banded linear resampling of an NHWC tensor (bilinear x2 + binomial blur, bilinear resize,
     and their adjoints), closed under differentiation: backward = the same kernel with the transposed
@@ -757,6 +775,13 @@ class HipOps:
         if second_order or C % 8 or not (torch.is_grad_enabled() and (x.requires_grad or s.requires_grad)):
             return x * s.reshape(b, C, 1, 1).to(x.dtype)
         return nchw(ModulateFn.apply(nhwc(x), s.reshape(b, C).float().contiguous()))
+
+    def global_mean(self, x):
+        """mean over the pixels in fp32 (the squeeze of SqueezeExcite, gp.py:300)."""
+        x = to_act(x)
+        if second_order or not (torch.is_grad_enabled() and x.requires_grad):
+            return x.mean(dim=(2, 3), dtype=torch.float32)
+        return GlobalMeanFn.apply(x)
 
     # -- adaptive / modulated conv (gp.py:315-409) -----------------------------------------------
     def modconv2d(self, x, weights, mod, kernel_mod=None, demod=True, eps=1e-8, noise=None, noise_weight=None,
