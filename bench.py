@@ -30,14 +30,49 @@ C2_G = dict(dim_capacity=8, dim_max=512, style_network=dict(dim=64, depth=4), nu
 C2_D = dict(dim_capacity=16, dim_max=512, num_skip_layers_excite=4, unconditional=True)
 
 
-def build_gan(image_size, device, g_over=None, d_over=None, use_hip_graphs=None):
+# secondary workloads (BASELINE configs 5 and 4; reference README.md:104-125 and :68-95): same trainer, eager launches
+C5_G = dict(style_network=dict(dim=64, depth=4), dim=32, input_image_size=64, unconditional=True)
+C5_D = dict(dim_capacity=16, dim_max=512, num_skip_layers_excite=4, multiscale_input_resolutions=(128,), unconditional=True)
+C4_TEXT = dict(dim=64, depth=4, clip_dim_latent=512)      # CLIP itself is external: pre-computed (b, 77, 512) encodings
+C4_G = dict(dim_capacity=8, dim_max=512, style_network=dict(dim=64, depth=4, dim_text_latent=64), num_skip_layers_excite=4,
+            unconditional=False)
+C4_D = dict(dim_capacity=16, dim_max=512, num_skip_layers_excite=4, unconditional=False)
+
+
+def build_gan(image_size, device, g_over=None, d_over=None, use_hip_graphs=None, workload='uncond'):
     from gigagan_pytorch_amd import GigaGAN
     torch.manual_seed(0)
+    kw = dict(amp=True, mixed_precision_type='bf16', apply_gradient_penalty_every=4, calc_multiscale_loss_every=1,
+              device=device, model_folder='/tmp/gg-bench-models', results_folder='/tmp/gg-bench-results',
+              use_hip_graphs=use_hip_graphs)
+    if workload == 'upsampler':
+        return GigaGAN(train_upsampler=True, generator=dict(C5_G, image_size=image_size),
+                       discriminator=dict(C5_D, image_size=image_size), **kw)
+    if workload == 'text':
+        return GigaGAN(generator=dict(C4_G, image_size=image_size, text_encoder=dict(C4_TEXT)),
+                       discriminator=dict(C4_D, image_size=image_size, text_encoder=dict(C4_TEXT)),
+                       generator_contrastive_loss_weight=0., **kw)
     g = dict(C2_G, image_size=image_size, **(g_over or {}))
     d = dict(C2_D, image_size=image_size, **(d_over or {}))
-    return GigaGAN(generator=g, discriminator=d, amp=True, mixed_precision_type='bf16', apply_gradient_penalty_every=4,
-                   calc_multiscale_loss_every=1, device=device, model_folder='/tmp/gg-bench-models',
-                   results_folder='/tmp/gg-bench-results', use_hip_graphs=use_hip_graphs)
+    return GigaGAN(generator=g, discriminator=d, **kw)
+
+
+class SyntheticTextImages:
+    """endless (images, token encodings) batches resident on the device: uniform images, normal (b, 77, 512) encodings with
+    ragged zero padding (what a frozen CLIP text tower hands the TextEncoder, gp.py:843-853)."""
+
+    def __init__(self, batch, image_size, device, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        self.batch_size = batch
+        self.images = torch.rand(batch, 3, image_size, image_size, generator=g).to(device)
+        enc = torch.randn(batch, 77, 512, generator=g)
+        for i in range(batch):
+            enc[i, 16 + (5 * i) % 60:] = 0
+        self.enc = enc.to(device)
+
+    def __iter__(self):
+        while True:
+            yield self.images, self.enc
 
 
 def cpu_baseline(max_seconds=40.0):
@@ -77,12 +112,59 @@ def cpu_baseline(max_seconds=40.0):
                 sample=f'fp32 CPU oracle, C2 dims 256x256, batch {bs}, one plain G+D step (no gradient penalty), {dt:.1f} s')
 
 
+def modconv_forward_roofline(gan, batch, dev):
+    """north-star sub-target: the style-modulated (demodulated 3x3) adaptive convolutions of ONE generator forward at the
+    bench batch, no-grad path (what the D-step runs): HIP events on the launch stream around every AdaptiveConv2DMod call
+    (coefficient kernel + fused implicit-GEMM launch, issued eagerly, so launch gaps of the tiny low-resolution layers
+    are inside the brackets), algorithmic flops 2*b*O*I*9*H*W per layer (171.5 GF at batch 32)."""
+    from gigagan_pytorch_amd import ops, kernels as K
+    rec = []
+    orig = ops.HipOps.modconv2d
+
+    def timed(self, x, weights, mod, kernel_mod=None, demod=True, **kw):
+        if not demod or weights.shape[-1] != 3:
+            return orig(self, x, weights, mod, kernel_mod, demod=demod, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n0 = len(K.profiler.records)
+        e0.record()
+        y = orig(self, x, weights, mod, kernel_mod, demod=demod, **kw)
+        e1.record()
+        b, _, H, W = x.shape
+        O, I = weights.shape[1], weights.shape[2]
+        rec.append((e0, e1, 2.0 * b * O * I * 9 * H * W, f'{I}->{O}@{H}x{W}', K.profiler.records[n0:]))
+        return y
+    ops.HipOps.modconv2d = timed
+    K.profiler = K.GemmProfiler()
+    try:
+        with torch.no_grad():
+            for _ in range(3):
+                rec.clear()
+                gan.G(noise=torch.randn(batch, gan.G.style_network_dim, device=dev))
+        torch.cuda.synchronize()
+    finally:
+        ops.HipOps.modconv2d = orig
+        K.profiler = None
+    layers, call_ms, kern_ms, fl = [], 0., 0., 0.
+    for e0, e1, f, name, launches in rec:
+        t_call = e0.elapsed_time(e1)
+        t_kern = sum(a.elapsed_time(b) for _, _, a, b in launches)     # the implicit-GEMM launch(es) alone
+        layers.append(dict(layer=name, call_us=t_call * 1e3, kernel_us=t_kern * 1e3, kernel_tflops=f / t_kern / 1e9))
+        call_ms, kern_ms, fl = call_ms + t_call, kern_ms + t_kern, fl + f
+    return dict(achieved=fl / kern_ms / 1e9, peak=MFMA_PEAK_TF, unit='TFLOP/s', frac=fl / kern_ms / 1e9 / MFMA_PEAK_TF,
+                kernel_ms=kern_ms, call_ms=call_ms, gflop=fl / 1e9, batch=batch, layers=layers,
+                note='the 15 demodulated 3x3 adaptive convs of one no-grad generator forward: `achieved` = algorithmic flops '
+                     '(2*b*O*I*9*H*W) / time of the fused implicit-GEMM launches (HIP events around each launch); call_ms '
+                     'brackets whole eager calls incl. the coefficient kernel and launch gaps')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=4)
-    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 32; 16 for the secondary workloads)')
+    ap.add_argument('--workload', choices=['uncond', 'upsampler', 'text'], default='uncond',
+                    help='uncond = the headline config 2/3; upsampler = config 5 (UnetUpsampler 64->256); text = config 4')
     ap.add_argument('--image-size', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile-cycle', action='store_true')
@@ -100,12 +182,16 @@ def main():
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
 
+    if args.batch is None:
+        args.batch = 32 if args.workload == 'uncond' else 16
     steps = (args.steps + 3) // 4 * 4
     warmup = args.warmup
-    gan = build_gan(args.image_size, dev, use_hip_graphs=False if args.no_graphs else None)
+    gan = build_gan(args.image_size, dev, use_hip_graphs=False if args.no_graphs else None, workload=args.workload)
     torch.manual_seed(1 + rank)          # identical initial weights (seed 0 in build_gan), per-rank latent / noise streams
-    dl = SyntheticImages(args.batch, args.image_size, device=dev, seed=rank)
-    it = cycle(dl)
+    if args.workload == 'text':
+        it = iter(SyntheticTextImages(args.batch, args.image_size, dev, seed=rank))
+    else:
+        it = cycle(SyntheticImages(args.batch, args.image_size, device=dev, seed=rank))
 
     def barrier():
         if world > 1:
@@ -177,17 +263,31 @@ def main():
                                       frac=value / world * GF_PER_IMG / 1e3 / MFMA_PEAK_TF,
                                       note='whole-step algorithmic-minimum 1192.1 GF/img vs dense bf16 MFMA peak'))
 
+    if rank == 0 and roofline is not None and args.workload == 'uncond':
+        try:
+            roofline['modconv_forward'] = modconv_forward_roofline(gan, args.batch, dev)
+        except Exception as e:    # noqa: BLE001 - a secondary measurement must not take the bench line down
+            roofline['modconv_forward'] = dict(error=f'{type(e).__name__}: {e}')
+
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'uncond':
         cpu = cpu_baseline()
 
     if rank == 0:
+        metric, what = {
+            'uncond': ('images/sec G+D step, uncond 256x256 bs32',
+                       f'Unconditional GigaGAN image_size={args.image_size} dim_max=512 (G cap 8, D cap 16)'),
+            'upsampler': ('images/sec G+D step, UnetUpsampler 64->256 bs16',
+                          f'UnetUpsampler dim=32 64->{args.image_size} (train_upsampler=True), D cap 16 dim_max=512'),
+            'text': ('images/sec G+D step, text-conditional 256x256 bs16',
+                     f'Text-conditional GigaGAN image_size={args.image_size} dim_max=512, TextEncoder dim 64 depth 4 on '
+                     'pre-computed (77, 512) token encodings, cross attention, matching-aware loss (no CLIP contrastive loss)'),
+        }[args.workload]
         line = dict(
-            metric='images/sec G+D step, uncond 256x256 bs32', value=value, unit='images/sec', n_gpus=world,
+            metric=metric, value=value, unit='images/sec', n_gpus=world,
             steps=steps, warmup=warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling='weak',
             vs_baseline=None, dtype='bf16', data='synthetic',
-            config=dict(workload=f'Unconditional GigaGAN image_size={args.image_size} dim_max=512 (G cap 8, D cap 16) '
-                                 f'bf16 bs={args.batch}/GPU, GP every 4th step', global_batch=args.batch * world,
+            config=dict(workload=f'{what} bf16 bs={args.batch}/GPU, GP every 4th step', global_batch=args.batch * world,
                         parallelism=f'dp{world}', hip_graphs=bool(gan.use_hip_graphs)),
             roofline=roofline, cpu_baseline=cpu,
             last_losses=dict(d=float(d_losses.divergence), g=float(g_losses.divergence)))

@@ -69,7 +69,7 @@ class Library:
         L.gg_gemm_plan.argtypes = [C.POINTER(GemmDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         self._declare_elementwise()
         self.is_emulator = bool(L.gg_is_emulator())
-        if L.gg_version() != 2:
+        if L.gg_version() != 3:
             raise RuntimeError(f'gigagan_pytorch_amd: ABI version mismatch in {path}')
 
     # filled in by _elementwise_signatures (kept separate so the table reads like the header)

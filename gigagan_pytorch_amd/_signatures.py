@@ -29,6 +29,8 @@ def declare(L):
     L.gg_softmax_bwd.argtypes = [_P, _P, _P, _P, C.c_int64, _I, _I, _I, _F, _P]
     L.gg_bias_act_bwd.restype = C.c_int
     L.gg_bias_act_bwd.argtypes = [_P, _P, _P, _P, C.c_int64, _I, _F, _P]
+    L.gg_gelu.restype = C.c_int
+    L.gg_gelu.argtypes = [_P, _P, _P, _P, _P, C.c_int64, _I, _P]
     L.gg_bias_act_bwd_partials.restype = C.c_int32
     L.gg_bias_act_bwd_partials.argtypes = [C.c_int64, _I]
     L.gg_softmax_bwd2.restype = C.c_int

@@ -583,6 +583,21 @@ extern "C" int gg_softmax_bwd2(const void* S, const void* dS, const void* g_dx, 
     return gg_check_launch();
 }
 
+extern "C" int gg_gelu(const void* x, const void* dy, const void* g, void* out0, void* out1, int64_t n, int32_t mode,
+                       void* stream) {
+    if (!x || !out0) return gg_fail(-1, "gg_gelu: null pointer");
+    if (mode < 0 || mode > 2) return gg_fail(-2, "gg_gelu: mode must be 0 (forward), 1 (backward) or 2 (second order)");
+    if ((mode >= 1 && !dy) || (mode == 2 && (!g || !out1))) return gg_fail(-1, "gg_gelu: missing operand for mode %d", mode);
+    if (n <= 0 || n % 8) return gg_fail(-3, "gg_gelu: n must be a positive multiple of 8");
+    GgGeluParams p;
+    p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.g = (const bf16_t*)g;
+    p.out0 = (bf16_t*)out0; p.out1 = (bf16_t*)out1; p.n8 = n / 8; p.mode = mode;
+    long long nb = (p.n8 + 256 * 4 - 1) / (256 * 4);     // ~4 vectors per thread
+    if (nb > 4096) nb = 4096;
+    GG_LAUNCH(gg_gelu_kernel, dim3((unsigned)nb), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
 static long long gg_bias_act_blocks(int64_t rows, int32_t C) {
     long long nb = (rows * (long long)(C / 8) + 4095) / 4096;   // ~16 vectors per thread
     if (nb > 1024) nb = 1024;

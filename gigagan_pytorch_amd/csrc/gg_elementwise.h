@@ -407,6 +407,52 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_bias_act_bwd_kernel(GgBiasActBwdParams p
     }
 }
 
+// ---- exact (erf) GELU of the attention feed-forward (nn.GELU, gp.py:731; unet.py:388) and its two derivatives --------
+// One pass each over contiguous bf16, fp32 math:
+//   mode 0: out0 = gelu(x)
+//   mode 1: out0 = dy * gelu'(x)                                     (backward)
+//   mode 2: out0 = g * gelu'(x) [d/d dy],  out1 = g * dy * gelu''(x) [d/d x]   (backward of the backward: the gradient
+//           penalty's double backward, for which autograd otherwise chains ~12 pointwise launches over the 4x-wide hidden)
+// gelu(x) = x Phi(x), gelu'(x) = Phi(x) + x phi(x), gelu''(x) = phi(x) (2 - x^2); phi = exp(-x^2/2)/sqrt(2 pi).
+struct GgGeluParams {
+    const bf16_t* x;
+    const bf16_t* dy;   // modes 1, 2
+    const bf16_t* g;    // mode 2
+    bf16_t* out0;
+    bf16_t* out1;       // mode 2
+    long long n8;       // number of 8-element vectors
+    int mode;
+};
+
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_gelu_kernel(GgGeluParams p) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < p.n8; v += stride) {
+        const u16x8 xv = *(const u16x8*)(p.x + v * 8);
+        u16x8 dv = xv, gv = xv, o0, o1 = xv;
+        if (p.mode >= 1) dv = *(const u16x8*)(p.dy + v * 8);
+        if (p.mode == 2) gv = *(const u16x8*)(p.g + v * 8);
+        for (int e = 0; e < 8; ++e) {
+            const float x = gg_bf2f(xv[e]);
+            const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+            if (p.mode == 0) {
+                o0[e] = gg_f2bf(x * cdf);
+            } else {
+                const float pdf = 0.3989422804014327f * gg_expf(-0.5f * x * x);
+                const float d1 = cdf + x * pdf;
+                if (p.mode == 1) {
+                    o0[e] = gg_f2bf(gg_bf2f(dv[e]) * d1);
+                } else {
+                    const float g = gg_bf2f(gv[e]);
+                    o0[e] = gg_f2bf(g * d1);
+                    o1[e] = gg_f2bf(g * gg_bf2f(dv[e]) * pdf * (2.f - x * x));
+                }
+            }
+        }
+        *(u16x8*)(p.out0 + v * 8) = o0;
+        if (p.mode == 2) *(u16x8*)(p.out1 + v * 8) = o1;
+    }
+}
+
 // ---- ChannelRMSNorm (gp.py:224-232): y = x / max(|x|, eps) * sqrt(C) * gamma over the channel axis ---------------
 // NHWC makes the reduction contiguous: one wavefront per pixel row, 8 channels (16 bytes) per lane per pass, fp32
 // statistics. Three passes exist because gradient-penalty steps differentiate the backward as well:

@@ -20,6 +20,7 @@ struct GgPackEntry {
     bf16_t* dst;            // kind 0: (O8, T, I8) ; kind 1: (I8, T, O8)
     long long first_item;   // prefix sum of work items over the table
     int O, I, T, O8, I8, kind;
+    int dst_row, dst_tap;   // kind 0: element pitch of a dst row / of a tap within it (0 = dense: T * I8, I8)
 };
 
 // Work items (one workgroup each; `first_item` is their prefix sum, computed by the host with the same formulas):
@@ -46,6 +47,8 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_pack_weights_kernel(const GgPackEntry* t
         const GgPackEntry e = table[lo];
         const long long local = item - e.first_item;
         const int T = e.T;
+        const long long drow = e.dst_row ? e.dst_row : (long long)T * e.I8;    // kind 0 destination pitches
+        const long long dtap = e.dst_tap ? e.dst_tap : e.I8;
         if (T > GG_PK_TMAX) {
             const long long unit = local * 256 + tid;
             if (e.kind == 0) {
@@ -53,12 +56,12 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_pack_weights_kernel(const GgPackEntry* t
                 if (unit >= (long long)e.O8 * chunks) continue;
                 const int o = (int)(unit / chunks), i0 = (int)(unit % chunks) * 8;
                 const float* s = e.src + ((long long)o * e.I + i0) * T;
-                bf16_t* d = e.dst + (long long)o * T * e.I8 + i0;
+                bf16_t* d = e.dst + (long long)o * drow + i0;
                 const int valid = (o < e.O) ? (e.I - i0 < 8 ? e.I - i0 : 8) : 0;
                 for (int t = 0; t < T; ++t) {
                     u16x8 v;
                     for (int j = 0; j < 8; ++j) v[j] = gg_f2bf(j < valid ? s[(long long)j * T + t] : 0.f);
-                    *(u16x8*)(d + (long long)t * e.I8) = v;
+                    *(u16x8*)(d + (long long)t * dtap) = v;
                 }
             } else {
                 if (unit >= (long long)e.I8 * (e.O8 >> 3)) continue;
@@ -88,10 +91,10 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_pack_weights_kernel(const GgPackEntry* t
             }
             gg_sync();
             const int cpr = nI8 >> 3;
-            bf16_t* d = e.dst + (long long)o * T * e.I8 + i0;
+            bf16_t* d = e.dst + (long long)o * drow + i0;
             for (int c = tid; c < T * cpr; c += 256) {
                 const int t = c / cpr, j = c - t * cpr;
-                *(u16x8*)(d + (long long)t * e.I8 + 8 * j) = *(const u16x8*)&lds[t * GG_PK_P0 + 8 * j];
+                *(u16x8*)(d + (long long)t * dtap + 8 * j) = *(const u16x8*)&lds[t * GG_PK_P0 + 8 * j];
             }
             gg_sync();
         } else {

@@ -326,7 +326,7 @@ class Discriminator(nn.Module):
                 if not self.unconditional:
                     pred_kwargs = dict(mod=next(conv_mods), kernel_mod=next(conv_mods))
                 if return_multiscale_outputs:
-                    multiscale_outputs.append(predictor(x[:batch_prev_stage], **pred_kwargs))
+                    multiscale_outputs.append(predictor(ops.impl.take_rows(x, batch_prev_stage), **pred_kwargs))
 
             if exists(downsample):
                 x = downsample(x, residual=residual, scale=self.residual_scale)   # merge fused into the conv epilogue

@@ -423,6 +423,21 @@ def softmax_bwd2(S: torch.Tensor, dS: torch.Tensor, g_dx, g_dbias, alpha: float,
     return g_S, g_dS
 
 
+def gelu(x: torch.Tensor, dy: torch.Tensor | None = None, g: torch.Tensor | None = None):
+    """exact GELU passes over contiguous bf16 tensors of equal shape (numel % 8 == 0): gelu(x) | dy * gelu'(x) (with dy) |
+    (g * gelu'(x), g * dy * gelu''(x)) (with dy and g)."""
+    L = _C.lib()
+    L.require(x, dy, g)
+    mode = 0 if dy is None else (1 if g is None else 2)
+    for t in (x, dy, g):
+        assert t is None or (t.dtype == torch.bfloat16 and t.is_contiguous() and t.shape == x.shape)
+    out0 = torch.empty_like(x)
+    out1 = torch.empty_like(x) if mode == 2 else None
+    rc = L.lib.gg_gelu(ptr(x), ptr(dy), ptr(g), ptr(out0), ptr(out1), x.numel(), mode, L.stream(x))
+    L.check(rc, 'gg_gelu')
+    return out0 if mode < 2 else (out0, out1)
+
+
 def colsum_finish(part: torch.Tensor, n: int, alpha: float = 1.0, out: torch.Tensor | None = None,
                   accumulate: bool = False) -> torch.Tensor:
     """part (P, C) fp32 -> (n,) fp32 = alpha * column sums (first n columns); with `out` (+ accumulate) added in place."""
@@ -661,7 +676,8 @@ def wgrad_finish(g: torch.Tensor, O: int, I: int, T: int, alpha: float = 1.0, ou
 
 class PackEntry(C.Structure):       # mirrors gg_pack_entry
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('first_item', C.c_int64), ('O', C.c_int32), ('I', C.c_int32),
-                ('T', C.c_int32), ('O8', C.c_int32), ('I8', C.c_int32), ('kind', C.c_int32)]
+                ('T', C.c_int32), ('O8', C.c_int32), ('I8', C.c_int32), ('kind', C.c_int32), ('dst_row', C.c_int32),
+                ('dst_tap', C.c_int32)]
 
 
 class PackTable:
@@ -680,14 +696,30 @@ class PackTable:
         self.keep = []          # (src, dst) tensors kept alive
         self.dirty = True
 
-    def register(self, src: torch.Tensor, O: int, I: int, T: int, kind: str) -> torch.Tensor:
-        """src: fp32 contiguous storage of (O, I, T); returns the persistent bf16 operand (rows, T*cols8)."""
+    def register_bank(self, src: torch.Tensor, N: int, O: int, I: int, T: int) -> torch.Tensor:
+        """src: fp32 contiguous (N, O, I, T) kernel bank -> persistent bf16 (O8, T*N*I8) laid out [co][tap][n][ci]: the
+        fused adaptive conv's B operand (the N kernels interleaved along the reduction), one table entry per kernel."""
+        assert src.dtype == torch.float32 and src.is_contiguous() and src.numel() == N * O * I * T
+        o8, i8 = (O + 7) // 8 * 8, (I + 7) // 8 * 8
+        dst = torch.zeros((o8, T * N * i8), dtype=torch.bfloat16, device=self.device)
+        for n in range(N):
+            self.register(src[n], O, I, T, 'fwd', into=(dst, n * i8, T * N * i8, N * i8))
+        return dst
+
+    def register(self, src: torch.Tensor, O: int, I: int, T: int, kind: str, into=None) -> torch.Tensor:
+        """src: fp32 contiguous storage of (O, I, T); returns the persistent bf16 operand (rows, T*cols8). `into` =
+        (tensor, element offset, row pitch, tap pitch) writes kind 'fwd' into a strided window of an existing operand."""
         assert src.dtype == torch.float32 and src.is_contiguous() and src.numel() == O * I * T
         assert self.n < self.capacity, 'PackTable capacity exceeded'
         o8, i8 = (O + 7) // 8 * 8, (I + 7) // 8 * 8
         k = self.KINDS[kind]
-        dst = torch.empty((o8, T * i8) if k == 0 else (i8, T * o8), dtype=torch.bfloat16, device=self.device)
-        e = PackEntry(src.data_ptr(), dst.data_ptr(), self.items, O, I, T, o8, i8, k)
+        if into is None:
+            dst = torch.empty((o8, T * i8) if k == 0 else (i8, T * o8), dtype=torch.bfloat16, device=self.device)
+            e = PackEntry(src.data_ptr(), dst.data_ptr(), self.items, O, I, T, o8, i8, k, 0, 0)
+        else:
+            assert k == 0
+            dst, off, row, tap = into
+            e = PackEntry(src.data_ptr(), dst.data_ptr() + 2 * off, self.items, O, I, T, o8, i8, k, row, tap)
         words = torch.frombuffer(bytearray(bytes(e)), dtype=torch.int64)
         w = words.numel()
         self.table[self.n * w:(self.n + 1) * w].copy_(words)

@@ -294,11 +294,15 @@ class CrossAttention(nn.Module):
         return self.to_out(out)
 
 
+def _gelu(x):
+    return ops.impl.gelu(x)
+
+
 def FeedForward(dim, mult=4, channel_first=False):
     dim_hidden = int(dim * mult)
     if channel_first:
-        return nn.Sequential(ChannelRMSNorm(dim), Conv2d(dim, dim_hidden, 1), Act(F.gelu), Conv2d(dim_hidden, dim, 1))
-    return nn.Sequential(RMSNorm(dim), Linear(dim, dim_hidden), Act(F.gelu), Linear(dim_hidden, dim))
+        return nn.Sequential(ChannelRMSNorm(dim), Conv2d(dim, dim_hidden, 1), Act(_gelu), Conv2d(dim_hidden, dim, 1))
+    return nn.Sequential(RMSNorm(dim), Linear(dim, dim_hidden), Act(_gelu), Linear(dim_hidden, dim))
 
 
 def _ff_residual(ff, x):

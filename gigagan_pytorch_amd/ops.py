@@ -112,6 +112,19 @@ def _table_pack(w, kind: str):
         if w.device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
             return None                     # table appends are host->device copies: not while a graph is being captured
         shp = tuple(w.shape)
+        if kind == 'modk':                  # (N, O, I, k, k) bank -> [co][tap][n][ci] (fused no-grad adaptive conv)
+            src = w.detach()
+            if len(shp) != 5 or not src.is_contiguous():
+                return None
+            dst = tab.register_bank(src, shp[0], shp[1], shp[2], shp[3] * shp[4])
+            if slot is None:
+                slot = w.__dict__.setdefault('_gg_tpacks', {})
+            ent = slot[kind] = (dst, w.data_ptr())
+            tab.dirty = True
+            if tab.dirty:
+                tab.refresh()
+                tab.dirty = False
+            return ent[0]
         if len(shp) == 5:
             assert shp[0] == 1 or shp[1] % 8 == 0, 'stacked kernel banks need O % 8 == 0'
             shp = (shp[0] * shp[1],) + shp[2:]
@@ -698,6 +711,61 @@ class GlobalMeanFn(Function):
         return gs[:, None, None, :].expand(b, H, W, C).contiguous().permute(0, 3, 1, 2)
 
 
+class GeluFn(Function):
+    """exact GELU on a dense bf16 buffer (any shape; the storage order is irrelevant to a pointwise op), one HIP pass;
+    backward and the backward of the backward are one pass each (gg_gelu modes 1 / 2)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return K.gelu(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        return GeluBwdFn.apply(x, dy.contiguous())
+
+
+class GeluBwdFn(Function):
+    @staticmethod
+    def forward(ctx, x, dy):
+        ctx.save_for_backward(x, dy)
+        return K.gelu(x, dy)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, dy = ctx.saved_tensors
+        g_dy, g_x = K.gelu(x, dy, g.contiguous())
+        return g_x, g_dy
+
+
+def _dense_view(x: torch.Tensor):
+    """the flat storage-order view of a dense tensor (contiguous in SOME dimension order), or None."""
+    if x.is_contiguous():
+        return x.view(-1)
+    if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last):
+        return x.permute(0, 2, 3, 1).reshape(-1)
+    return None
+
+
+class TakeRowsFn(Function):
+    """x[:n] along the batch axis (the discriminator's predictors see the stage's first rows only, gp.py:1789). The stock
+    slice backward fills an NCHW zeros tensor and copies into it, after which the accumulation with the main path's
+    channels_last gradient runs on the strided add kernel; here the gradient is built channels_last in one cat."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.rest = (x.shape[0] - n,) + tuple(x.shape[1:])
+        return x[:n]
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous(memory_format=torch.channels_last)
+        pad = torch.zeros(ctx.rest, dtype=g.dtype, device=g.device).contiguous(memory_format=torch.channels_last)
+        return torch.cat((g, pad), dim=0), None
+
+
 class ResampleFn(Function):
     """Separable banded linear resampling of an NHWC tensor (bilinear x2 + binomial blur, bilinear resize,
     and their adjoints), closed under differentiation: backward = the same kernel with the transposed
@@ -776,6 +844,27 @@ class HipOps:
             return x * s.reshape(b, C, 1, 1).to(x.dtype)
         return nchw(ModulateFn.apply(nhwc(x), s.reshape(b, C).float().contiguous()))
 
+    def gelu(self, x):
+        """nn.GELU() (exact) of the attention feed-forward, gp.py:731."""
+        if x.dtype != ACT_DTYPE:
+            x = x.to(ACT_DTYPE)
+        flat = _dense_view(x)
+        if flat is None or flat.numel() % 8:
+            return F.gelu(x)
+        y = GeluFn.apply(flat)
+        if x.is_contiguous():
+            return y.view(x.shape)
+        b, c, h, w = x.shape
+        return y.view(b, h, w, c).permute(0, 3, 1, 2)
+
+    def take_rows(self, x, n):
+        """x[:n] (batch rows) with a channels_last gradient."""
+        if n >= x.shape[0]:
+            return x
+        if second_order or x.dim() != 4 or not (torch.is_grad_enabled() and x.requires_grad):
+            return x[:n]
+        return TakeRowsFn.apply(x, n)
+
     def global_mean(self, x):
         """mean over the pixels in fp32 (the squeeze of SqueezeExcite, gp.py:300)."""
         x = to_act(x)
@@ -818,12 +907,17 @@ class HipOps:
             if not s_padded:
                 s = F.pad(s, (0, Ip - I))
         if not needs_grad:
+            wk = None       # parameters owned by a FlatAdamW: the [co][tap][n][ci] operand lives in the pack table
+            if (isinstance(weights, torch.nn.Parameter) and getattr(weights, '_gg_pack_table', None) is not None
+                    and not _DEBUG_NO_TABLE):
+                wk = _table_pack(weights, 'modk')
             wts = weights
-            if Ip != I:
-                wts = F.pad(wts, (0, 0, 0, 0, 0, Ip - I))
-            if Op != O:
-                wts = F.pad(wts, (0, 0, 0, 0, 0, 0, 0, Op - O))
-            y = fused_modconv_forward(xh, wts, s, a, d, noise, noise_weight, act, O, Op, d_padded)
+            if wk is None:
+                if Ip != I:
+                    wts = F.pad(wts, (0, 0, 0, 0, 0, Ip - I))
+                if Op != O:
+                    wts = F.pad(wts, (0, 0, 0, 0, 0, 0, 0, Op - O))
+            y = fused_modconv_forward(xh, wts, s, a, d, noise, noise_weight, act, O, Op, d_padded, wk=wk)
             return nchw(y[..., :O] if Op != O else y)
         # training path: modulate -> ONE conv with the N kernels stacked along output channels -> mix/demod/noise/act
         geom = (k, 1, k // 2, 'oihw')
@@ -978,13 +1072,15 @@ def demod_coefficients(weights, s, a, eps):
     return sumsq.clamp(min=eps).rsqrt()
 
 
-def fused_modconv_forward(xh, wts, s, a, d, noise, noise_weight, act, O, Op, d_padded=False):
+def fused_modconv_forward(xh, wts, s, a, d, noise, noise_weight, act, O, Op, d_padded=False, wk=None):
     """no-grad path: the whole adaptive conv (kernel mix, modulation, demodulation, noise, leaky-relu) as
-    ONE implicit-GEMM launch with the N kernels stacked along the reduction and batch folded into M."""
+    ONE implicit-GEMM launch with the N kernels stacked along the reduction and batch folded into M. `wk`: the
+    pre-packed (Op, k*k*N*Ip) [co][tap][n][ci] operand (pack table), else it is built from `wts` here."""
     b, H, W, Ip = xh.shape
     N, _, _, k, _ = wts.shape
     insc = (a[:, :, None] * s[:, None, :]).reshape(b, N * Ip).contiguous()
-    wk = wts.permute(1, 3, 4, 0, 2).reshape(Op, k * k * N * Ip).to(ACT_DTYPE).contiguous()
+    if wk is None:
+        wk = wts.permute(1, 3, 4, 0, 2).reshape(Op, k * k * N * Ip).to(ACT_DTYPE).contiguous()
     out_scale = None
     if d is not None:
         out_scale = (F.pad(d, (0, Op - O)) if (Op != O and not d_padded) else d).contiguous()

@@ -155,8 +155,12 @@ class Attention(nn.Module):
         return self.to_out(out, residual=residual)
 
 
+def _gelu(x):
+    return ops.impl.gelu(x)
+
+
 def FeedForward(dim, mult=4):
-    return nn.Sequential(RMSNorm(dim), Conv2d(dim, dim * mult, 1), Act(F.gelu), Conv2d(dim * mult, dim, 1))
+    return nn.Sequential(RMSNorm(dim), Conv2d(dim, dim * mult, 1), Act(_gelu), Conv2d(dim * mult, dim, 1))
 
 
 def _ff_residual(ff, x):

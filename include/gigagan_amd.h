@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 2
+#define GG_ABI_VERSION 3
 
 int gg_version(void);
 const char* gg_last_error(void);
@@ -113,6 +113,9 @@ typedef struct gg_pack_entry {
     int64_t first_item;   /* prefix sum over the table of work items per entry. T <= 16: kind 0: O8*ceil(I8/256),
                            * kind 1: ceil(O8/64)*ceil(I8/16); T > 16: ceil((O8*I8/8)/256) */
     int32_t O, I, T, O8, I8, kind;   /* O8, I8 = O, I rounded up to multiples of 8 (zero filled) */
+    int32_t dst_row, dst_tap;        /* kind 0 only: element pitch of a dst row / of a tap inside a row; 0 = dense (T*I8, I8).
+                                      * Lets the N kernels of an AdaptiveConv2DMod bank (gp.py:352) interleave along the
+                                      * reduction as [co][tap][n][ci]: entry n has dst + n*I8, dst_row = T*N*I8, dst_tap = N*I8 */
 } gg_pack_entry;
 
 /* Re-pack every registered weight of a model in one launch (replaces the filter transforms behind the reference's
@@ -169,6 +172,12 @@ int gg_softmax_bwd2(const void* S, const void* dS, const void* g_dx, const float
  * w's partial column sums of dz (fp32 [gg_bias_act_bwd_partials(rows, C)][C]; the caller adds the rows up).
  * dy / y / dz: bf16 [rows][C], C %% 8 == 0. */
 int32_t gg_bias_act_bwd_partials(int64_t rows, int32_t C);
+
+/* Exact (erf) GELU over n contiguous bf16 elements (n %% 8 == 0) - nn.GELU() of FeedForward, gp.py:731 / unet.py:388 -
+ * and its derivatives, one pass each: mode 0: out0 = gelu(x); mode 1: out0 = dy * gelu'(x) (autograd's gelu backward);
+ * mode 2: out0 = g * gelu'(x), out1 = g * dy * gelu''(x) (the backward of that backward, which the gradient penalty's
+ * double backward, gp.py:120-155, reaches through the discriminator's attention blocks). */
+int gg_gelu(const void* x, const void* dy, const void* g, void* out0, void* out1, int64_t n, int32_t mode, void* stream);
 int gg_bias_act_bwd(const void* dy, const void* y, void* dz, float* db, int64_t rows, int32_t C, float slope,
                     void* stream);
 

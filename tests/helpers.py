@@ -151,3 +151,64 @@ def text_encodings(batch=2, tokens=7, seed=0):
     for i in range(batch):
         enc[i, tokens - 2 - 2 * i:] = 0          # ragged lengths: zero rows are padding (gp.py:853)
     return enc
+
+
+def check_fused_modconv_uses_bank_operand_from_pack_table(device):
+    """no-grad adaptive conv with optimizer-owned parameters: the [co][tap][n][ci] operand comes from the pack table (one
+    strided entry per kernel of the bank), equals the permute/pad/cast chain, follows optimizer steps, and the fused launch
+    gives the same result as with the per-call pack."""
+    from gigagan_pytorch_amd import ops
+    from gigagan_pytorch_amd.modules import AdaptiveConv2DMod
+    from gigagan_pytorch_amd.optimizer import FlatAdamW
+    torch.manual_seed(0)
+    conv = AdaptiveConv2DMod(12, 24, 3, num_conv_kernels=2).to(device)      # ragged I: zero padded to 16
+    opt = FlatAdamW(list(conv.parameters()), lr=1e-2)
+    x = torch.randn(2, 12, 8, 8).to(device)
+    mod, kmod = (torch.randn(2, 12) * 0.3).to(device), torch.randn(2, 2).to(device)
+
+    def want_operand():
+        w = conv.weights.detach().cpu()
+        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 4))
+        return w.permute(1, 3, 4, 0, 2).reshape(24, -1).to(torch.bfloat16)
+    with ops.use_impl(ops.HipOps()), torch.no_grad():
+        y1 = conv(x, mod, kmod)
+        packed = conv.weights._gg_tpacks['modk'][0]
+        assert torch.equal(packed.cpu(), want_operand())
+        conv.weights._gg_pack_table, tab = None, conv.weights._gg_pack_table
+        y0 = conv(x, mod, kmod)                      # per-call pack
+        conv.weights._gg_pack_table = tab
+        assert torch.equal(y0, y1)
+    with ops.use_impl(ops.HipOps()):
+        opt.zero_grad()
+        conv(x, mod, kmod).float().square().mean().backward()
+        opt.step()
+        with torch.no_grad():
+            conv(x, mod, kmod)
+        assert conv.weights._gg_tpacks['modk'][0].data_ptr() == packed.data_ptr()
+        assert torch.equal(packed.cpu(), want_operand())
+
+
+def check_gelu_first_and_second_order(device):
+    """gg_gelu (forward, backward, backward of the backward) against torch's exact GELU under autograd, on a channels_last
+    activation and on a token tensor; values, first-order gradient, and the gradient-penalty style double backward."""
+    import torch.nn.functional as F
+    from gigagan_pytorch_amd import ops
+    torch.manual_seed(0)
+    H = ops.HipOps()
+    for shape, cl in (((2, 24, 6, 6), True), ((3, 7, 16), False)):
+        x0 = (torch.randn(shape) * 2).to(torch.bfloat16).to(device)
+        if cl:
+            x0 = x0.contiguous(memory_format=torch.channels_last)
+        c1, c2 = torch.randn(shape).to(device), torch.randn(shape).to(device)
+
+        def run(fn):
+            x = x0.clone().requires_grad_()
+            y = fn(x)
+            g, = torch.autograd.grad((y.float() * c1).sum(), x, create_graph=True)
+            gg, = torch.autograd.grad((g.float() * c2).sum(), x)
+            return y.detach(), g.detach(), gg.detach()
+        got = run(H.gelu)
+        want = run(lambda x: F.gelu(x.float()))
+        assert got[0].dtype == torch.bfloat16 and got[0].shape == x0.shape
+        for a, b, tol in zip(got, want, (4e-3, 8e-3, 2e-2)):
+            assert rel_err(a, b) < tol, (shape, rel_err(a, b))

@@ -481,6 +481,16 @@ def test_weight_pack_table_and_wgrad_finish(shape):
     check_pack_table_and_wgrad_finish(shape, 'cpu')
 
 
+def test_gelu_first_and_second_order():
+    from helpers import check_gelu_first_and_second_order
+    check_gelu_first_and_second_order('cpu')
+
+
+def test_fused_modconv_uses_bank_operand_from_pack_table():
+    from helpers import check_fused_modconv_uses_bank_operand_from_pack_table
+    check_fused_modconv_uses_bank_operand_from_pack_table('cpu')
+
+
 def test_flat_optimizer_packs_and_grad_sink_match_autograd():
     from helpers import check_flat_optimizer_packs_and_grad_sink
     check_flat_optimizer_packs_and_grad_sink('cpu')
