@@ -288,7 +288,7 @@ def main():
             steps=steps, warmup=warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling='weak',
             vs_baseline=None, dtype='bf16', data='synthetic',
             config=dict(workload=f'{what} bf16 bs={args.batch}/GPU, GP every 4th step', global_batch=args.batch * world,
-                        parallelism=f'dp{world}', hip_graphs=bool(gan.use_hip_graphs)),
+                        parallelism=f'dp{world}', hip_graphs=bool(gan._graphable(1))),
             roofline=roofline, cpu_baseline=cpu,
             last_losses=dict(d=float(d_losses.divergence), g=float(g_losses.divergence)))
         print(json.dumps(line), flush=True)

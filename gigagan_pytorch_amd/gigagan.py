@@ -334,10 +334,14 @@ class GigaGAN(nn.Module):
     def generate_kwargs(self, dl_iter, batch_size):
         maybe_text_kwargs = dict()
         if self.train_upsampler or not self.unconditional:
-            assert exists(dl_iter)
-            if self.unconditional:
+            static_src = getattr(self, '_static_G_src', None)
+            if not exists(dl_iter) and self.unconditional and exists(static_src):
+                real_images = static_src     # hipGraph replay: the loader batch was copied into this buffer beforehand
+            elif self.unconditional:
+                assert exists(dl_iter)
                 real_images = next(dl_iter)
             else:
+                assert exists(dl_iter)
                 result = next(dl_iter)
                 assert isinstance(result, (tuple, list)), \
                     'dataset should return a tuple of two items for text conditioned training, (images, texts)'
@@ -362,8 +366,19 @@ class GigaGAN(nn.Module):
 
     # -- hipGraph capture of one step kind ---------------------------------------------------------------------
     def _graphable(self, grad_accum_every):
-        return (self.use_hip_graphs and grad_accum_every == 1 and self.unconditional and not self.train_upsampler
-                and not exists(self.diff_augment))
+        return (self.use_hip_graphs and grad_accum_every == 1 and self.unconditional and not exists(self.diff_augment))
+
+    def _stage_upsampler_source(self, dl_iter):
+        """upsampler mode under hipGraphs: the generator's low-resolution conditioning comes from a loader batch of its own
+        (gp.py:2196, :2208-2212); copy it into the static buffer the captured step reads."""
+        if not self.train_upsampler:
+            return
+        src = next(dl_iter)
+        buf = self._graphs.get(('src', tuple(src.shape)))
+        if buf is None:
+            buf = self._graphs[('src', tuple(src.shape))] = torch.empty_like(src, device=self.device)
+        buf.copy_(src, non_blocking=True)
+        self._static_G_src = buf
 
     def _run_graphed(self, key, fn, static_inputs=()):
         """replay (capturing on first use) the hipGraph of `fn`, a closure over static input buffers that returns a
@@ -513,6 +528,7 @@ class GigaGAN(nn.Module):
             if static_real is None:
                 static_real = self._graphs[('in',) + key] = torch.empty_like(real, device=dev)
             static_real.copy_(real, non_blocking=True)
+            self._stage_upsampler_source(dl_iter)
 
             def fn():
                 self.D_opt.zero_grad()
@@ -599,6 +615,7 @@ class GigaGAN(nn.Module):
         try:
             if self._graphable(grad_accum_every):
                 key = ('G', int(batch_size), bool(calc_multiscale_loss))
+                self._stage_upsampler_source(dl_iter)
 
                 def fn():
                     self.G_opt.zero_grad()

@@ -212,6 +212,14 @@ def _upsampler_trainer_steps(tmp_path, dev):
     assert all(v == v and abs(v) < 1e9 for v in vals), vals
     assert float(d2.gradient_penalty) > 0 and float(d1.gradient_penalty) == 0
     assert not torch.equal(g0, gan.G_opt.flat_p) and not torch.equal(d0, gan.D_opt.flat_p)
+    if dev != 'cpu':                        # on the GPU the step kinds are hipGraphs by now: replay each of them again
+        assert gan.use_hip_graphs and len(gan._graphs) > 0
+        for _ in range(3):
+            dn, gn = gan.train_step(it, 2)
+            vals = [float(v) for v in (*dn, *gn) if v is not None]
+            assert all(v == v and abs(v) < 1e9 for v in vals), vals
+        assert torch.isfinite(gan.G_opt.flat_p).all() and torch.isfinite(gan.D_opt.flat_p).all()
+        assert gan.use_hip_graphs, 'a capture was refused: the upsampler step fell back to eager launches'
     lowres = torch.rand(2, 3, 8, 8, device=dev)
     img = gan.generate(lowres_image=lowres)
     assert img.shape == (2, 3, 16, 16) and torch.isfinite(img.float()).all()
