@@ -65,3 +65,44 @@ def test_invalid_multiscale_output_stages_are_refused_like_the_reference(referen
         reference.Discriminator(**cfg)
     with pytest.raises(AssertionError):
         Discriminator(**cfg)
+
+
+# ---- UnetUpsampler options (`init_dim != dim` is left out: the reference's own final_res_block then fails, unet.py:629) ----
+
+from helpers import UNET_SMALL, TEXT_ENC, TEXT_CLIP_DIM   # noqa: E402
+
+U_OPTS = [dict(num_conv_kernels=3), dict(skip_connect_scale=1.0), dict(attn_depths=(2, 1, 1), mid_attn_depth=2),
+          dict(full_attn=True), dict(full_attn=False), dict(self_attn_ff_mult=2), dict(channels=1), dict(image_size=64),
+          'text']
+
+
+@pytest.mark.parametrize('opt', U_OPTS, ids=lambda o: o if isinstance(o, str) else ','.join(f'{k}={v}' for k, v in o.items()))
+def test_unet_upsampler_option_matches_reference(reference, opt):
+    from torch import nn
+    from gigagan_pytorch_amd.unet_upsampler import UnetUpsampler
+
+    class PrecomputedClip(nn.Module):
+        dim_latent = TEXT_CLIP_DIM
+
+    torch.manual_seed(0)
+    kw = {}
+    if opt == 'text':       # text-conditional upsampler: cross attention in the last stages, tokens handed over directly
+        cfg = {**UNET_SMALL, 'unconditional': False, 'style_network': dict(dim=16, depth=2, dim_text_latent=16),
+               'cross_attn': (False, True, True)}
+        Ur = reference.UnetUpsampler(text_encoder=reference.TextEncoder(clip=PrecomputedClip(), **TEXT_ENC), **cfg)
+        U = UnetUpsampler(text_encoder=dict(clip_dim_latent=TEXT_CLIP_DIM, **TEXT_ENC), **cfg)
+        mask = torch.ones(2, 5, dtype=torch.bool)
+        mask[1, 3:] = False
+        kw = dict(global_text_tokens=torch.randn(2, 16), fine_text_tokens=torch.randn(2, 5, 16), text_mask=mask)
+    else:
+        cfg = {**UNET_SMALL, **opt}
+        Ur, U = reference.UnetUpsampler(**cfg), UnetUpsampler(**cfg)
+    assert list(U.state_dict().keys()) == list(Ur.state_dict().keys())
+    U.load_state_dict(Ur.state_dict())
+    x, z = torch.rand(2, cfg.get('channels', 3), 8, 8), torch.randn(2, 16)
+    with torch.no_grad():
+        img_r, rgbs_r = Ur(x, noise=z, return_all_rgbs=True, **kw)
+        with ops.use_impl(OracleOps()):
+            img, rgbs = U(x, noise=z, return_all_rgbs=True, **kw)
+    assert rel_err(img, img_r) < TOL
+    assert len(rgbs) == len(rgbs_r) and all(rel_err(a, b) < TOL for a, b in zip(rgbs, rgbs_r))
