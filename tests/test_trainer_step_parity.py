@@ -115,3 +115,50 @@ def test_text_conditional_training_steps_match_the_reference_trainer(reference, 
             assert abs(num(a) - num(b)) <= 1e-5 * max(1., abs(num(b))), (g_ours, g_ref)
         assert rel_err(_flat(gan.D.parameters()), _flat(ref_gan.unwrapped_D.parameters())) < 1e-6
         assert rel_err(_flat(gan.G.parameters()), _flat(ref_gan.unwrapped_G.parameters())) < 1e-6
+
+
+def test_training_loop_with_gradient_accumulation_matches_the_reference(reference, tmp_path, capsys):
+    """`GigaGAN.__call__(steps=, grad_accum_every=)` (gp.py:2665-2750) over a real DataLoader: three steps with two
+    micro-batches each (the second step with the gradient penalty) leave the same weights, step counter, log lines and
+    EMA generator output as the reference's loop."""
+    from torch.utils.data import DataLoader, Dataset
+
+    class Images(Dataset):
+        def __len__(self):
+            return 16
+
+        def __getitem__(self, i):
+            return torch.rand(3, 16, 16, generator=torch.Generator().manual_seed(i))
+
+    torch.manual_seed(0)
+    kw = dict(apply_gradient_penalty_every=2, log_steps_every=1)
+    ref_gan = reference.GigaGAN(generator=dict(TINY_G), discriminator=dict(TINY_D), model_folder=str(tmp_path / 'rm'),
+                                results_folder=str(tmp_path / 'rr'), **kw)
+    gan = GigaGAN(generator=dict(TINY_G), discriminator=dict(TINY_D), device='cpu', model_folder=str(tmp_path / 'm'),
+                  results_folder=str(tmp_path / 'r'), **kw)
+    gan.merge_discriminator_passes = False
+    gan.G.load_state_dict(ref_gan.unwrapped_G.state_dict())
+    gan.D.load_state_dict(ref_gan.unwrapped_D.state_dict())
+    gan.G_ema.load_state_dict(ref_gan.G_ema.state_dict())
+    ops.bump_weight_epoch()
+    ref_gan.set_dataloader(DataLoader(Images(), batch_size=2, shuffle=False))
+    gan.set_dataloader(DataLoader(Images(), batch_size=2, shuffle=False))
+    capsys.readouterr()
+    torch.manual_seed(5)
+    ref_gan(steps=3, grad_accum_every=2)
+    log_ref = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith('G:')]
+    with ops.use_impl(OracleOps()):
+        torch.manual_seed(5)
+        gan(steps=3, grad_accum_every=2)
+    log_ours = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith('G:')]
+    assert len(log_ref) == 3 and log_ours == log_ref
+    assert int(ref_gan.steps.item()) == gan._steps_host == 4
+    assert rel_err(_flat(gan.D.parameters()), _flat(ref_gan.unwrapped_D.parameters())) < 1e-6
+    assert rel_err(_flat(gan.G.parameters()), _flat(ref_gan.unwrapped_G.parameters())) < 1e-6
+    z = torch.randn(2, 32)
+    with ops.use_impl(OracleOps()):
+        torch.manual_seed(1)
+        ours = gan.generate(noise=z)
+    torch.manual_seed(1)
+    theirs = ref_gan.generate(noise=z)
+    assert rel_err(ours, theirs) < 1e-5
