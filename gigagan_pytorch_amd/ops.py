@@ -99,6 +99,7 @@ def bump_weight_epoch():
 
 _DEBUG_NO_TABLE = bool(os.environ.get('GG_DEBUG_NO_PACK_TABLE'))
 _DEBUG_NO_SINK = bool(os.environ.get('GG_DEBUG_NO_GRAD_SINK'))
+_NARROW_MODCONV = bool(os.environ.get('GG_MODCONV_NARROW'))    # experimental no-grad path for the narrow layers
 
 
 def _table_pack(w, kind: str):
@@ -906,6 +907,22 @@ class HipOps:
             xh = F.pad(xh, (0, Ip - I))
             if not s_padded:
                 s = F.pad(s, (0, Ip - I))
+        if (not needs_grad and _NARROW_MODCONV and k == 3 and N * Op <= 64 and Ip in (16, 32, 64) and Ip == I
+                and (Ip <= 32 or N * Op <= 32) and H % 8 == 0 and W % 32 == 0 and b * H * W >= 65536 and d is not None):
+            # EXPERIMENTAL (GG_MODCONV_NARROW=1, off by default, not yet measured on the GPU): the narrow high-resolution
+            # layers as direct convolution (style modulation applied on load, the N kernels stacked along the output
+            # channels: N*O <= 64) + the mix / demodulate / noise / activation pass, instead of the gather-bound
+            # implicit GEMM with the kernels stacked along the reduction
+            Y = K.conv2d_nhwc(xh, packed_weight(weights, 'fwd'), ksize=3,
+                              in_scale=(s if s_padded or Ip == I else F.pad(s, (0, Ip - I))).contiguous())
+            d8 = (F.pad(d, (0, Op - O)) if (Op != O and not d_padded) else d).contiguous()
+            nz = nw = None
+            if noise is not None:
+                nz = noise.reshape(b, H * W).float().contiguous()
+                nw = noise_weight.reshape(-1).float()
+                nw = (F.pad(nw, (0, Op - O)) if Op != O else nw).contiguous()
+            y = K.modmix_fwd(Y, a.contiguous(), d8, nz, nw, Op, N, act)
+            return nchw(y[..., :O] if Op != O else y)
         if not needs_grad:
             wk = None       # parameters owned by a FlatAdamW: the [co][tap][n][ci] operand lives in the pack table
             if (isinstance(weights, torch.nn.Parameter) and getattr(weights, '_gg_pack_table', None) is not None

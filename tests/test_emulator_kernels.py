@@ -536,3 +536,28 @@ def test_direct_conv_matches_implicit_gemm(cfg):
 def test_fused_adaptive_conv_coefficients_match_tensor_algebra(cfg):
     from helpers import check_modcoef
     check_modcoef(cfg, 'cpu')
+
+
+def test_experimental_narrow_modconv_path_matches_fused_launch():
+    """GG_MODCONV_NARROW (off by default): direct convolution with the modulation applied on load + the mix/demodulate pass
+    gives the fused single-launch result up to the bf16 rounding of the intermediate."""
+    from gigagan_pytorch_amd.modules import AdaptiveConv2DMod
+    torch.manual_seed(0)
+    I, O, b, H, W = 16, 16, 2, 128, 256
+    conv = AdaptiveConv2DMod(I, O, 3, num_conv_kernels=2)
+    x, mod, km = torch.randn(b, I, H, W), torch.randn(b, I) * 0.3, torch.randn(b, 2)
+    nz, nw = torch.randn(b, 1, H, W), torch.randn(O, 1, 1) * 0.1
+    try:
+        with torch.no_grad():
+            assert not ops._NARROW_MODCONV
+            K.plan_log = []
+            y0 = conv(x, mod, km, noise=nz, noise_weight=nw, act='lrelu')
+            assert [t for t, _ in K.plan_log] == [3]
+            ops._NARROW_MODCONV = True
+            K.plan_log = []
+            y1 = conv(x, mod, km, noise=nz, noise_weight=nw, act='lrelu')
+            assert [t for t, _ in K.plan_log] == [9]          # the direct-convolution kernel
+    finally:
+        ops._NARROW_MODCONV = False
+        K.plan_log = None
+    assert rel_err(y1, y0) < 8e-3
