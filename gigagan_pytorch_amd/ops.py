@@ -121,10 +121,8 @@ def _table_pack(w, kind: str):
             if slot is None:
                 slot = w.__dict__.setdefault('_gg_tpacks', {})
             ent = slot[kind] = (dst, w.data_ptr())
-            tab.dirty = True
-            if tab.dirty:
-                tab.refresh()
-                tab.dirty = False
+            tab.refresh()
+            tab.dirty = False
             return ent[0]
         if len(shp) == 5:
             assert shp[0] == 1 or shp[1] % 8 == 0, 'stacked kernel banks need O % 8 == 0'
@@ -913,8 +911,7 @@ class HipOps:
             # layers as direct convolution (style modulation applied on load, the N kernels stacked along the output
             # channels: N*O <= 64) + the mix / demodulate / noise / activation pass, instead of the gather-bound
             # implicit GEMM with the kernels stacked along the reduction
-            Y = K.conv2d_nhwc(xh, packed_weight(weights, 'fwd'), ksize=3,
-                              in_scale=(s if s_padded or Ip == I else F.pad(s, (0, Ip - I))).contiguous())
+            Y = K.conv2d_nhwc(xh, packed_weight(weights, 'fwd'), ksize=3, in_scale=s.contiguous())    # I == Ip here
             d8 = (F.pad(d, (0, Op - O)) if (Op != O and not d_padded) else d).contiguous()
             nz = nw = None
             if noise is not None:
