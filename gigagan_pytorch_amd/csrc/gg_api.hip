@@ -3,6 +3,7 @@
 #include "gg_device.h"
 #include "gg_gemm.h"
 #include "gg_gemm2.h"
+#include "gg_gemm3.h"
 #include "gg_elementwise.h"
 #include "gg_modconv.h"
 #include "gg_attention.h"
@@ -147,7 +148,13 @@ static const GgTileModel kTileModels[] = {
     {4, 256, 256, 64, 2.25, 256, 3.0},
     {5, 256, 128, 64, 1.45, 256, 3.0},
     {6, 128, 128, 64, 1.50, 512, 2.5},    // 8 waves, 72 KB LDS: 2 workgroups per CU (small-M layers: no split-K needed)
+    {7, 256, 256, 32, 1.10, 256, 3.0},    // EXPERIMENTAL LDS-DMA ring (gg_gemm3.h): force_tile = 7 only, never planned
 };
+
+// tile 7: dense row-major x row-major, whole 32-k stages, 16-byte aligned rows
+static bool gg_v3_eligible(const gg_gemm_desc* d) {
+    return !d->a_conv && d->a_layout == GG_ROWK && d->b_layout == GG_ROWK && d->K % 32 == 0 && d->K >= 32 && !d->d2s;
+}
 
 static double gg_plan_cost(const gg_gemm_desc* d, const GgTileModel& tm, int sk, int* k_per_split) {
     const long long blocks = (long long)((d->M + tm.bm - 1) / tm.bm) * ((d->N + tm.bn - 1) / tm.bn) * d->batch;
@@ -216,14 +223,16 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     const int pol = gg_v2_policy();
     const int v1_tile = d->N <= 32 ? 3 : (d->N <= 64 ? 2 : 1);
     int forced = d->force_tile;
-    if (forced >= 4 && !gg_v2_eligible(d)) forced = 0;
-    if (forced < 0 || forced > 6) forced = 0;      // (9 = direct convolution: handled above when eligible)
+    if (forced == 7 && !gg_v3_eligible(d)) forced = 0;
+    if (forced >= 4 && forced <= 6 && !gg_v2_eligible(d)) forced = 0;
+    if (forced < 0 || forced > 7) forced = 0;      // (9 = direct convolution: handled above when eligible)
     double best = 1e30;
     pl.tile = v1_tile; pl.splitk = 1;
     for (const GgTileModel& tm : kTileModels) {
         if (forced) {
             if (tm.tile != forced) continue;
         } else {
+            if (tm.tile == 7) continue;             // experimental: forced only
             if (tm.tile <= 3 && tm.tile != v1_tile) continue;
             if (tm.tile >= 4 && (!v2ok || !pol)) continue;
             if (tm.tile == 4 && d->N < 192) continue;
@@ -238,6 +247,7 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
         // the 4-wave tiles may split much further: a narrow weight gradient (M*N of a few thousand, K = millions of
         // pixels) needs thousands of workgroups in flight to pull HBM bandwidth; its partials stay small
         const int sk_cap = tm.tile <= 3 ? 4096 : 256;
+        if (tm.tile == 7) max_sk = ktiles / 8 > 0 ? ktiles / 8 : 1;
         if (max_sk > sk_cap) max_sk = sk_cap;
         if ((long long)d->batch * max_sk > 65535) max_sk = (int)(65535 / d->batch);
         int lo = 1, hi = max_sk;
@@ -387,6 +397,11 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
         if (d->C == 16) { if (wide) gg_launch_dconv<16, 2>(p, s); else gg_launch_dconv<16, 1>(p, s); }
         else if (d->C == 32) { if (wide) gg_launch_dconv<32, 2>(p, s); else gg_launch_dconv<32, 1>(p, s); }
         else { if (wide) gg_launch_dconv<64, 2>(p, s); else gg_launch_dconv<64, 1>(p, s); }
+    }
+    else if (pl.tile == 7) {
+        const bool full = p.bias || p.out_scale || p.noise || p.residual || p.act != GG_ACT_NONE;
+        if (full) GG_LAUNCH((gg_gemm3_kernel<true>), grid2, dim3(GG2_NT), s, p);
+        else GG_LAUNCH((gg_gemm3_kernel<false>), grid2, dim3(GG2_NT), s, p);
     }
     else if (pl.tile == 4) gg_launch_gemm2_tile<256, 256, 2, 4>(p, akrow, bkrow, aconv, grid2, s);
     else if (pl.tile == 5) gg_launch_gemm2_tile<256, 128, 2, 4>(p, akrow, bkrow, aconv, grid2, s);

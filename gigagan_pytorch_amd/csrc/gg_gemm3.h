@@ -1,0 +1,141 @@
+// gg_gemm3.h — EXPERIMENTAL k-loop for the 8-wave 256x256 tile (plan tile 7: only ever chosen by `force_tile = 7`, the
+// launch planner never selects it): the structure the phase probe of gg_gemm2.h calls for. Written after
+// this round's GPU budget was spent: index math and synchronisation ORDER are verified on the host emulator through the
+// normal C ABI (tests/test_emulator_kernels.py), the asynchronous behaviour (counted vmcnt across raw barriers, LDS-DMA
+// landing order) has not run on a GPU yet and must be race-screened before the planner may use it.
+//
+// What changes against gg_gemm2_kernel (dense row-major x row-major operands only, K % 32 == 0):
+//   * operand tiles go global -> LDS directly (`global_load_lds_dwordx4`, 1 KiB per wave instruction): no staging VGPRs,
+//     no ds_write pass (830 LDS cycles per 64-k tile in gg_gemm2), and loads stay in flight ACROSS barriers;
+//   * a ring of 4 stages of (256 + 256) rows x 32 k (32 KiB each): three stages = 96 KiB per CU in flight while the
+//     fourth is consumed (gg_gemm2 holds one 64 KiB tile in flight, issued as a burst);
+//   * waits are counted: a wave issues exactly 4 DMA instructions per stage, so `s_waitcnt vmcnt(8)` retires the stage
+//     about to be read while two younger stages keep streaming; barriers are raw `s_barrier` (no vmcnt(0) drain);
+//   * LDS rows are 64 bytes, unpadded (the DMA writes lane i at base + 16 i); bank conflicts are avoided by an XOR
+//     swizzle of the 16-byte chunk index with (row >> 2) & 3, applied to the GLOBAL source address of the DMA and to the
+//     ds_read_b128 address: the 16 lanes of every ds_read_b128 service group then hit 16 distinct 16-byte bank slots.
+// Accumulator ownership, XCD-aware tile order, split-K contract and epilogue are gg_gemm2's (shared code).
+#pragma once
+#include "gg_gemm2.h"
+
+#define GG3_BK 32
+#define GG3_NS 4
+#define GG3_ROWB 64                                  // bytes per LDS row (32 bf16)
+#define GG3_STAGE ((256 + 256) * GG3_ROWB)           // 32 KiB
+#define GG3_LDS 139264                               // max(ring = 4 * 32 KiB, gg_gemm2's epilogue staging: 8 * 128 * 136 B)
+
+template <bool FULL_EPI>
+GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_gemm3_kernel(GgGemmParams p) {
+    constexpr int BM = 256, BN = 256, WM = 2, WN = 4;
+    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    GG_SHARED __attribute__((aligned(16))) char smem[GG3_LDS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware flattened grid, as gg_gemm2_kernel
+    const int nwg = gridDim.x;
+    const int xq = nwg >> 3, xr = nwg & 7;
+    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+    const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + pos;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_mn = tiles_n * ((p.M + BM - 1) / BM);
+    const int bz = wg / tiles_mn, tile = wg - bz * tiles_mn;
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int b = bz / p.splitk, ks = bz % p.splitk;
+    const int kbeg = ks * p.k_per_split;
+    int kend = kbeg + p.k_per_split;
+    if (kend > p.K) kend = p.K;
+    const int nk = (kend > kbeg) ? (kend - kbeg) / GG3_BK : 0;          // whole stages only (K % 32 == 0)
+
+    const bf16_t* Ab = p.A + (long long)b * p.a_bs;
+    const bf16_t* Bb = p.B + (long long)b * p.b_bs;
+
+    // DMA plan of this lane: stage = 512 rows x 4 chunks of 16 B = 32 wave instructions of 64 chunks; wave w owns
+    // instructions 4w .. 4w+3. Chunk id -> stage row id / 4 (0..255: A rows, 256..511: B rows), LDS slot id % 4 of that
+    // row; the slot holds source chunk (slot ^ swizzle(row)). Rows beyond M / N are clamped to the last valid row: they
+    // only feed output rows / columns that are never stored.
+    const bf16_t* src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = (wave * 4 + i) * 64 + lane;
+        const int row = id >> 2, slot = id & 3;
+        const int chunk = slot ^ ((row >> 2) & 3);
+        if (row < BM) {
+            int r = m0 + row;
+            if (r > p.M - 1) r = p.M - 1;
+            src[i] = Ab + (long long)r * p.lda + chunk * 8;
+        } else {
+            int r = n0 + row - BM;
+            if (r > p.N - 1) r = p.N - 1;
+            src[i] = Bb + (long long)r * p.ldb + chunk * 8;
+        }
+    }
+    auto issue_stage = [&](int kt) {                    // the 4 DMA instructions of this wave for k-stage kt
+        char* base = smem + (kt % GG3_NS) * GG3_STAGE + wave * 4 * 1024;
+        const int k0 = kbeg + kt * GG3_BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gg_load_lds16(src[i] + k0, base + i * 1024);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int s = 0; s < GG3_NS - 1 && s < nk; ++s) issue_stage(s);
+
+    const int frow = lane & 31, hi = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt has landed once at most the two younger stages (4 instructions each) are outstanding
+        if (kt + 2 < nk) gg_wait_vm<8>();
+        else if (kt + 1 < nk) gg_wait_vm<4>();
+        else gg_wait_vm<0>();
+        gg_barrier_raw();       // every wave's share of stage kt is in LDS; every wave has finished reading stage kt-1
+        if (kt + GG3_NS - 1 < nk) issue_stage(kt + GG3_NS - 1);        // refills the slot that stage kt-1 occupied
+        const char* stA = smem + (kt % GG3_NS) * GG3_STAGE;
+        const char* stB = stA + BM * GG3_ROWB;
+#pragma unroll
+        for (int kk = 0; kk < GG3_BK / 16; ++kk) {
+            u16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wm * WTM + i * 32 + frow;
+                fa[i] = *(const u16x8*)(stA + r * GG3_ROWB + (((kk * 2 + hi) ^ ((r >> 2) & 3)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wn * WTN + j * 32 + frow;
+                fb[j] = *(const u16x8*)(stB + r * GG3_ROWB + (((kk * 2 + hi) ^ ((r >> 2) & 3)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = gg_mfma_32x32x16_bf16(fb[j], fa[i], acc[i][j]);
+        }
+    }
+    gg_barrier_raw();           // the ring is free: the epilogue stages through it
+
+    const GgGemmParams e = *gg_late_params(p);
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const int m_wave = m0 + wm * WTM, n_wave = n0 + wn * WTN;
+    const bool staged = e.splitk == 1 && !e.c_f32 && !e.d2s && (e.N & 3) == 0 && (e.ldc & 3) == 0 &&
+                        (!e.residual || (e.ldr & 3) == 0);
+    if (staged) {
+        constexpr int SP = WTN * 2 + 8;
+        static_assert(8 * WTM * SP <= GG3_LDS, "staging area must fit");
+        char* stage = smem + wave * (WTM * SP);
+        gg2_epilogue_step<0, TM, TN, FULL_EPI, true>(acc, e, b, bz, m_wave + (lane & 31), n_wave + 4 * (lane >> 5), stage, SP,
+                                                     lane, z4, z4);
+        gg_sync();
+        gg2_stage_writeback<WTM, WTN>(e, b, stage, SP, m_wave, n_wave, lane);
+    } else {
+        gg2_epilogue_step<0, TM, TN, FULL_EPI, false>(acc, e, b, bz, m_wave + (lane & 31), n_wave + 4 * (lane >> 5), nullptr, 0,
+                                                      lane, z4, z4);
+    }
+}

@@ -50,6 +50,14 @@ u16x4 gg_emu_lds_read_tr16(const bf16_t* p);
     gg_emu_launch(grid, block, [=]() { kernel(__VA_ARGS__); })
 
 static inline void gg_sync() { gg_emu_syncthreads(); }
+// LDS-DMA stand-ins: the copy happens at issue time (the emulator has no asynchrony: ordering bugs that only show with
+// loads in flight are NOT caught here, index math and slot rotation are)
+static inline void gg_load_lds16(const void* g, void* lds_wave_base) {
+    memcpy((char*)lds_wave_base + 16 * (threadIdx.x & 63u), g, 16);
+}
+template <int N>
+static inline void gg_wait_vm() {}
+static inline void gg_barrier_raw() { gg_emu_syncthreads(); }
 template <typename T>
 static inline const T* gg_late_params(const T& by_value) { return &by_value; }
 static inline f32x16 gg_mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c) {

@@ -561,3 +561,31 @@ def test_experimental_narrow_modconv_path_matches_fused_launch():
         ops._NARROW_MODCONV = False
         K.plan_log = None
     assert rel_err(y1, y0) < 8e-3
+
+
+@pytest.mark.parametrize('shape', [(256, 256, 64, 1, 0), (300, 520, 96, 1, 0), (257, 129, 256, 2, 0), (512, 256, 512, 1, 2)])
+def test_experimental_lds_ring_gemm_index_math(shape):
+    """gg_gemm3.h (force_tile 7, never planned): the LDS-DMA ring's chunk swizzle, slot rotation, clamped edge rows,
+    split-K and shared epilogue on the emulator — which executes the DMA at issue time, so this checks index math and
+    ordering of the code, not the asynchronous behaviour (tests/gpu_ring_gemm_probe.py is the GPU race screen)."""
+    M, N, Kd, batch, sk = shape
+    torch.manual_seed(0)
+    a = bf(torch.randn(batch, M, Kd)); b = bf(torch.randn(batch, N, Kd))
+    ref = torch.einsum('bmk,bnk->bmn', a.float(), b.float())
+    K.plan_log = []
+    try:
+        out = K.gemm(a, b, out_dtype=torch.float32, force_tile=7, force_splitk=sk)
+        assert [t for t, _ in K.plan_log] == [7]
+    finally:
+        K.plan_log = None
+    assert rel_err(out, ref) < 1e-5
+    if N % 8 == 0:
+        bias = torch.randn(N)
+        out = K.gemm(a, b, force_tile=7, bias=bias, act='lrelu', alpha=0.5)
+        assert rel_err(out, F.leaky_relu(ref * 0.5 + bias, 0.2)) < 4e-3
+    K.plan_log = []
+    try:
+        K.gemm(a, b, out_dtype=torch.float32)           # the planner itself never picks the experimental tile
+        assert all(t != 7 for t, _ in K.plan_log)
+    finally:
+        K.plan_log = None
