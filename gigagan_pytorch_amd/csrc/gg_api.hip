@@ -153,7 +153,10 @@ static const GgTileModel kTileModels[] = {
 
 // tile 7: dense row-major x row-major, whole 32-k stages, 16-byte aligned rows
 static bool gg_v3_eligible(const gg_gemm_desc* d) {
-    return !d->a_conv && d->a_layout == GG_ROWK && d->b_layout == GG_ROWK && d->K % 32 == 0 && d->K >= 32 && !d->d2s;
+    if (d->a_layout != GG_ROWK || d->b_layout != GG_ROWK || d->K % 32 || d->K < 32 || d->d2s) return false;
+    if (!d->a_conv) return true;
+    // conv gather: a 32-k stage lies inside one tap; padding taps load from the caller's zero page; no per-sample input scale
+    return d->CV % 32 == 0 && d->C % 8 == 0 && d->R * d->S <= 32 && d->zero_page != nullptr && d->in_scale == nullptr;
 }
 
 static double gg_plan_cost(const gg_gemm_desc* d, const GgTileModel& tm, int sk, int* k_per_split) {
@@ -379,6 +382,7 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     p.noise = d->noise; p.noise_w = d->noise_w;
     p.act = d->act; p.act_slope = d->act_slope;
     p.partial = (float*)workspace;
+    p.zero_page = (const bf16_t*)d->zero_page;
 #ifdef GG2_PROBE
     if (pl.tile > 3) p.xcd_slices = getenv("GG2_DBG") ? atoi(getenv("GG2_DBG")) : 0;   // probe builds: k-loop phase mask
 #endif
@@ -400,8 +404,13 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     }
     else if (pl.tile == 7) {
         const bool full = p.bias || p.out_scale || p.noise || p.residual || p.act != GG_ACT_NONE;
-        if (full) GG_LAUNCH((gg_gemm3_kernel<true>), grid2, dim3(GG2_NT), s, p);
-        else GG_LAUNCH((gg_gemm3_kernel<false>), grid2, dim3(GG2_NT), s, p);
+        if (aconv) {
+            if (full) GG_LAUNCH((gg_gemm3_kernel<true, true>), grid2, dim3(GG2_NT), s, p);
+            else GG_LAUNCH((gg_gemm3_kernel<true, false>), grid2, dim3(GG2_NT), s, p);
+        } else {
+            if (full) GG_LAUNCH((gg_gemm3_kernel<false, true>), grid2, dim3(GG2_NT), s, p);
+            else GG_LAUNCH((gg_gemm3_kernel<false, false>), grid2, dim3(GG2_NT), s, p);
+        }
     }
     else if (pl.tile == 4) gg_launch_gemm2_tile<256, 256, 2, 4>(p, akrow, bkrow, aconv, grid2, s);
     else if (pl.tile == 5) gg_launch_gemm2_tile<256, 128, 2, 4>(p, akrow, bkrow, aconv, grid2, s);

@@ -76,6 +76,7 @@ struct GgGemmParams {
     // one k-slice land on the same XCD (block b -> XCD b % 8), so the slice of x / dy they all stream is fetched from
     // HBM once and shared through that XCD's L2. 0: (tiles, 1, batch*splitk) grid.
     int xcd_slices;
+    const bf16_t* zero_page;   // experimental tile 7 (gg_gemm3.h): >= 16 bytes of zeros for the conv gather's padding taps
 };
 
 GG_DEVICE float gg_apply_act(float v, int act, float slope) {

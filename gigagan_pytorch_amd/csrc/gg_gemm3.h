@@ -4,7 +4,7 @@
 // normal C ABI (tests/test_emulator_kernels.py), the asynchronous behaviour (counted vmcnt across raw barriers, LDS-DMA
 // landing order) has not run on a GPU yet and must be race-screened before the planner may use it.
 //
-// What changes against gg_gemm2_kernel (dense row-major x row-major operands only, K % 32 == 0):
+// What changes against gg_gemm2_kernel (row-major x row-major operands, dense or conv gather, K % 32 == 0):
 //   * operand tiles go global -> LDS directly (`global_load_lds_dwordx4`, 1 KiB per wave instruction): no staging VGPRs,
 //     no ds_write pass (830 LDS cycles per 64-k tile in gg_gemm2), and loads stay in flight ACROSS barriers;
 //   * a ring of 4 stages of (256 + 256) rows x 32 k (32 KiB each): three stages = 96 KiB per CU in flight while the
@@ -24,7 +24,7 @@
 #define GG3_STAGE ((256 + 256) * GG3_ROWB)           // 32 KiB
 #define GG3_LDS 139264                               // max(ring = 4 * 32 KiB, gg_gemm2's epilogue staging: 8 * 128 * 136 B)
 
-template <bool FULL_EPI>
+template <bool A_CONV, bool FULL_EPI>
 GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_gemm3_kernel(GgGemmParams p) {
     constexpr int BM = 256, BN = 256, WM = 2, WN = 4;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
@@ -57,16 +57,38 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_gemm3_kernel(GgGemmParams p) {
     // instructions 4w .. 4w+3. Chunk id -> stage row id / 4 (0..255: A rows, 256..511: B rows), LDS slot id % 4 of that
     // row; the slot holds source chunk (slot ^ swizzle(row)). Rows beyond M / N are clamped to the last valid row: they
     // only feed output rows / columns that are never stored.
+    // Conv gather (A_CONV): the A rows are output pixels and k = (tap, cv), CV % 32 == 0, so a stage lies inside one tap:
+    // per A row the element offset of its window corner and a tap-validity bitmask are fixed, the tap offset is a scalar per
+    // stage; a padding tap loads the caller's zero page instead (same instruction count every stage, no LDS zero fill).
+    // Waves 0..3 own the A instructions (stage rows 0..255), waves 4..7 the B (weight) instructions.
     const bf16_t* src[4];
+    long long corner[4];
+    unsigned int tapmask[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int id = (wave * 4 + i) * 64 + lane;
         const int row = id >> 2, slot = id & 3;
         const int chunk = slot ^ ((row >> 2) & 3);
+        corner[i] = 0;
+        tapmask[i] = 0;
         if (row < BM) {
             int r = m0 + row;
             if (r > p.M - 1) r = p.M - 1;
-            src[i] = Ab + (long long)r * p.lda + chunk * 8;
+            if (A_CONV) {
+                const int hw = p.OH * p.OW;
+                const int img = r / hw, rem = r - img * hw;
+                const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+                corner[i] = (((long long)img * p.H + ih0) * p.W + iw0) * p.C + chunk * 8;
+                for (int kh = 0; kh < p.R; ++kh)
+                    for (int kw = 0; kw < p.S; ++kw) {
+                        const int ih = ih0 + kh, iw = iw0 + kw;
+                        if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) tapmask[i] |= 1u << (kh * p.S + kw);
+                    }
+                src[i] = p.A;
+            } else {
+                src[i] = Ab + (long long)r * p.lda + chunk * 8;
+            }
         } else {
             int r = n0 + row - BM;
             if (r > p.N - 1) r = p.N - 1;
@@ -76,8 +98,19 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_gemm3_kernel(GgGemmParams p) {
     auto issue_stage = [&](int kt) {                    // the 4 DMA instructions of this wave for k-stage kt
         char* base = smem + (kt % GG3_NS) * GG3_STAGE + wave * 4 * 1024;
         const int k0 = kbeg + kt * GG3_BK;
+        if (A_CONV && wave < 4) {
+            const int tap = k0 / p.CV, cv0 = k0 - tap * p.CV;
+            const int kh = tap / p.S, kw = tap - kh * p.S;
+            const long long off = ((long long)kh * p.W + kw) * p.C + ((p.CV == p.C) ? cv0 : cv0 % p.C);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) gg_load_lds16(src[i] + k0, base + i * 1024);
+            for (int i = 0; i < 4; ++i) {
+                const bf16_t* g = ((tapmask[i] >> tap) & 1u) ? p.A + corner[i] + off : p.zero_page;
+                gg_load_lds16(g, base + i * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gg_load_lds16(src[i] + k0, base + i * 1024);
+        }
     };
 
     f32x16 acc[TM][TN];

@@ -150,6 +150,17 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=True, out_d
     return out
 
 
+_zero_pages: dict = {}
+
+
+def _zero_page(device) -> torch.Tensor:
+    """256 bytes of zeros per device, kept for the process lifetime (gg_gemm_desc.zero_page)."""
+    z = _zero_pages.get(device)
+    if z is None:
+        z = _zero_pages[device] = torch.zeros(128, dtype=torch.bfloat16, device=device)
+    return z
+
+
 def _conv_out(size: int, ksize: int, stride: int, pad: int) -> int:
     return (size + 2 * pad - ksize) // stride + 1
 
@@ -184,6 +195,8 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, *, ksize: int, stride: int = 1
         keep.append(in_scale)
     d.C_out, d.ldc, d.c_is_f32 = ptr(out), cout, int(out_dtype == torch.float32)
     d.force_splitk, d.force_tile = force_splitk, force_tile
+    if force_tile == 7:     # experimental LDS-DMA tile: padding taps read a page of zeros
+        d.zero_page = ptr(_zero_page(x.device))
     if residual is not None:
         assert residual.shape == out.shape
     _epilogue(d, alpha, bias, out_scale, OH * OW if out_scale is not None else 0, noise, noise_w, act,

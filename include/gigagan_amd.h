@@ -77,6 +77,9 @@ typedef struct gg_gemm_desc {
     float bias_scale;     /* multiplies bias (set 1.0f) */
     const void* residual; int32_t ldr; float res_scale;   /* bf16 [M][ldr], optional */
     int32_t d2s, d2s_taps, d2s_c, d2s_oh, d2s_ow;
+    const void* zero_page;   /* optional: >= 16 bytes of zeros on the device. Only the experimental LDS-DMA tile (force_tile 7)
+                              * reads it: padding taps of its conv gather load from here, so every stage issues the same
+                              * number of loads and nothing has to be zero-filled in LDS */
 } gg_gemm_desc;
 
 size_t gg_gemm_workspace_bytes(const gg_gemm_desc* d);

@@ -589,3 +589,28 @@ def test_experimental_lds_ring_gemm_index_math(shape):
         assert all(t != 7 for t, _ in K.plan_log)
     finally:
         K.plan_log = None
+
+
+@pytest.mark.parametrize('cfg', [(2, 12, 12, 64, 136, 3, 0), (1, 9, 7, 32, 128, 3, 0), (2, 8, 8, 96, 64, 3, 3), (3, 8, 8, 64, 104, 1, 0)])
+def test_experimental_lds_ring_conv_gather_index_math(cfg):
+    """conv gather of gg_gemm3.h (force_tile 7): per-row window corners and tap masks, padding taps served from the zero
+    page, stacked-stage tap decode, split-K; forward and (same kernel, flipped weights) data gradient."""
+    n, H, W, Ci, Co, ks, sk = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(n, Ci, H, W)); w = bf(torch.randn(Co, Ci, ks, ks) * 0.1); dy = bf(torch.randn(n, Co, H, W))
+    xf, wf = x.float().requires_grad_(), w.float()
+    ref = F.conv2d(xf, wf, padding=ks // 2)
+    ref.backward(dy.float())
+    xh, dyh = x.permute(0, 2, 3, 1).contiguous(), dy.permute(0, 2, 3, 1).contiguous()
+    wh = w.permute(0, 2, 3, 1).reshape(Co, -1).contiguous()
+    K.plan_log = []
+    try:
+        out = K.conv2d_nhwc(xh, wh, ksize=ks, out_dtype=torch.float32, force_tile=7, force_splitk=sk)
+        assert [t for t, _ in K.plan_log] == [7]
+    finally:
+        K.plan_log = None
+    assert rel_err(out.permute(0, 3, 1, 2), ref) < 1e-5
+    if Co % 32 == 0:       # the data gradient's reduction is over Co: a stage must lie inside one tap
+        wT = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Ci, -1).contiguous()
+        dx = K.conv2d_nhwc(dyh, wT, ksize=ks, out_dtype=torch.float32, force_tile=7)
+        assert rel_err(dx.permute(0, 3, 1, 2), xf.grad) < 1e-5
