@@ -153,7 +153,14 @@ static const GgTileModel kTileModels[] = {
 
 // tile 7: dense row-major x row-major, whole 32-k stages, 16-byte aligned rows
 static bool gg_v3_eligible(const gg_gemm_desc* d) {
-    if (d->a_layout != GG_ROWK || d->b_layout != GG_ROWK || d->K % 32 || d->K < 32 || d->d2s) return false;
+    if (d->K % 32 || d->K < 32 || d->d2s) return false;
+    if (d->a_layout == GG_KROW && d->b_layout == GG_KROW) {     // weight gradients: plain epilogue, whole 8-column groups
+        const bool full = d->bias || d->out_scale || d->noise || d->residual || d->act != GG_ACT_NONE;
+        if (full || (d->M & 7) || (d->N & 7) || d->M < 8 || d->N < 8) return false;
+        if (!d->a_conv) return true;
+        return d->CV % 8 == 0 && d->C % 8 == 0 && d->zero_page != nullptr && d->in_scale == nullptr;
+    }
+    if (d->a_layout != GG_ROWK || d->b_layout != GG_ROWK) return false;
     if (!d->a_conv) return true;
     // conv gather: a 32-k stage lies inside one tap; padding taps load from the caller's zero page; no per-sample input scale
     return d->CV % 32 == 0 && d->C % 8 == 0 && d->R * d->S <= 32 && d->zero_page != nullptr && d->in_scale == nullptr;
@@ -404,7 +411,10 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     }
     else if (pl.tile == 7) {
         const bool full = p.bias || p.out_scale || p.noise || p.residual || p.act != GG_ACT_NONE;
-        if (aconv) {
+        if (akrow) {
+            if (aconv) GG_LAUNCH((gg_gemm3k_kernel<true>), grid2, dim3(GG2_NT), s, p);
+            else GG_LAUNCH((gg_gemm3k_kernel<false>), grid2, dim3(GG2_NT), s, p);
+        } else if (aconv) {
             if (full) GG_LAUNCH((gg_gemm3_kernel<true, true>), grid2, dim3(GG2_NT), s, p);
             else GG_LAUNCH((gg_gemm3_kernel<true, false>), grid2, dim3(GG2_NT), s, p);
         } else {

@@ -172,3 +172,146 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_gemm3_kernel(GgGemmParams p) {
                                                       lane, z4, z4);
     }
 }
+
+// ---- reduction-major x reduction-major (weight gradients): out[m][n] = sum_k A[k][m] * B[k][n] -------------------------
+// Stage = 32 k-rows x 256 columns per operand, rows kept as they sit in HBM (512 bytes, unpadded: DMA destination is
+// linear); the k-contiguous MFMA fragments come from ds_read_b64_tr_b16 as in gg_gemm2 (gg2_frag_krow). The four k-rows a
+// transpose read touches must fall on different 64-byte bank quarters: LDS chunk position pos of k-row r holds source
+// chunk pos ^ ((r & 3) << 2). A_CONV: column = (tap, cv) of the im2col matrix, k-row = output pixel; out-of-image taps
+// load the zero page. Plain epilogue only (what the step uses: fp32 split-K partials / fp32 outputs).
+#define GG3K_ROWB 512
+
+GG_DEVICE u16x8 gg3_frag_krow(const char* tile, int col0, int kk, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const int col = col0 + (g & 1) * 16 + 4 * (i & 3);
+    const int row = kk * 16 + (g >> 1) * 8 + (i >> 2);
+    const int phys = ((col >> 3) ^ ((row & 3) << 2)) * 16 + (col & 7) * 2;         // rows row and row + 4 share row & 3
+    u16x4 a = gg_lds_read_tr16((const bf16_t*)(tile + row * GG3K_ROWB + phys));
+    u16x4 b = gg_lds_read_tr16((const bf16_t*)(tile + (row + 4) * GG3K_ROWB + phys));
+    u16x8 f = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return f;
+}
+
+template <bool A_CONV>
+GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_gemm3k_kernel(GgGemmParams p) {
+    constexpr int BM = 256, BN = 256, WM = 2, WN = 4;
+    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    GG_SHARED __attribute__((aligned(16))) char smem[GG3_LDS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int nwg = gridDim.x;
+    const int xq = nwg >> 3, xr = nwg & 7;
+    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+    const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + pos;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_mn = tiles_n * ((p.M + BM - 1) / BM);
+    const int bz = wg / tiles_mn, tile = wg - bz * tiles_mn;
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int b = bz / p.splitk, ks = bz % p.splitk;
+    const int kbeg = ks * p.k_per_split;
+    int kend = kbeg + p.k_per_split;
+    if (kend > p.K) kend = p.K;
+    const int nk = (kend > kbeg) ? (kend - kbeg) / GG3_BK : 0;
+
+    const bf16_t* Ab = p.A + (long long)b * p.a_bs;
+    const bf16_t* Bb = p.B + (long long)b * p.b_bs;
+
+    // DMA plan: per operand 32 k-rows x 32 chunks = 16 wave instructions; waves 0..3 own A's, waves 4..7 B's. Chunk id ->
+    // k-row id / 32, LDS position id % 32, source chunk = position ^ swizzle(k-row). Columns beyond M / N are clamped to the
+    // last valid 8-column group (they only feed outputs that are never stored).
+    int krow[4], colv[4];                       // this lane's k-row inside a stage and first column of its chunk
+    int ckh[4], ckw[4], cci[4];                 // A_CONV: the column's tap and physical channel
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = ((wave & 3) * 4 + i) * 64 + lane;
+        krow[i] = id >> 5;
+        const int chunk = (id & 31) ^ ((krow[i] & 3) << 2);
+        const bool isA = wave < 4;
+        const int lim = isA ? p.M : p.N;
+        int c = (isA ? m0 : n0) + chunk * 8;
+        if (c > lim - 8) c = lim - 8 > 0 ? lim - 8 : 0;
+        colv[i] = c;
+        ckh[i] = ckw[i] = cci[i] = 0;
+        if (A_CONV && isA) {
+            const int tap = c / p.CV, cv = c - tap * p.CV;
+            ckh[i] = tap / p.S;
+            ckw[i] = tap - ckh[i] * p.S;
+            cci[i] = (p.CV == p.C) ? cv : cv % p.C;
+        }
+    }
+    const int hw = p.OH * p.OW;
+    auto issue_stage = [&](int kt) {
+        char* base = smem + (kt % GG3_NS) * GG3_STAGE + wave * 4 * 1024;       // A: bytes 0..16383 of the stage, B: the rest
+        const int k0 = kbeg + kt * GG3_BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + krow[i];
+            const bf16_t* g;
+            if (wave >= 4) {
+                g = Bb + (long long)k * p.ldb + colv[i];
+            } else if (!A_CONV) {
+                g = Ab + (long long)k * p.lda + colv[i];
+            } else {
+                const int img = k / hw, rem = k - img * hw;
+                const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                const int ih = oh * p.stride - p.pad + ckh[i], iw = ow * p.stride - p.pad + ckw[i];
+                const bool in = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+                g = in ? p.A + (((long long)img * p.H + ih) * p.W + iw) * p.C + cci[i] : p.zero_page;
+            }
+            gg_load_lds16(g, base + i * 1024);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int s = 0; s < GG3_NS - 1 && s < nk; ++s) issue_stage(s);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 2 < nk) gg_wait_vm<8>();
+        else if (kt + 1 < nk) gg_wait_vm<4>();
+        else gg_wait_vm<0>();
+        gg_barrier_raw();
+        if (kt + GG3_NS - 1 < nk) issue_stage(kt + GG3_NS - 1);
+        const char* stA = smem + (kt % GG3_NS) * GG3_STAGE;
+        const char* stB = stA + 32 * GG3K_ROWB;
+#pragma unroll
+        for (int kk = 0; kk < GG3_BK / 16; ++kk) {
+            u16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = gg3_frag_krow(stA, wm * WTM + i * 32, kk, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = gg3_frag_krow(stB, wn * WTN + j * 32, kk, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = gg_mfma_32x32x16_bf16(fb[j], fa[i], acc[i][j]);
+        }
+    }
+    gg_barrier_raw();
+
+    const GgGemmParams e = *gg_late_params(p);
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const int m_wave = m0 + wm * WTM, n_wave = n0 + wn * WTN;
+    const bool staged = e.splitk == 1 && !e.c_f32 && !e.d2s && (e.N & 3) == 0 && (e.ldc & 3) == 0 && !e.residual;
+    if (staged) {
+        constexpr int SP = WTN * 2 + 8;
+        char* stage = smem + wave * (WTM * SP);
+        gg2_epilogue_step<0, TM, TN, false, true>(acc, e, b, bz, m_wave + (lane & 31), n_wave + 4 * (lane >> 5), stage, SP, lane,
+                                                  z4, z4);
+        gg_sync();
+        gg2_stage_writeback<WTM, WTN>(e, b, stage, SP, m_wave, n_wave, lane);
+    } else {
+        gg2_epilogue_step<0, TM, TN, false, false>(acc, e, b, bz, m_wave + (lane & 31), n_wave + 4 * (lane >> 5), nullptr, 0, lane,
+                                                   z4, z4);
+    }
+}

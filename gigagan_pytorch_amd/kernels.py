@@ -232,6 +232,8 @@ def conv2d_wgrad_nhwc(x: torch.Tensor, dy: torch.Tensor, *, ksize: int, stride: 
     d.alpha = 1.0
     d.bias_scale = 1.0
     d.force_splitk, d.force_tile = force_splitk, force_tile
+    if force_tile == 7:
+        d.zero_page = ptr(_zero_page(x.device))
     _run_gemm(d, x)
     return out
 

@@ -63,6 +63,24 @@ def main():
         print(f'{name:9s} M={n*R*R:7d} N={co:4d} K={9*ci:5d}  ring {t7*1e3:8.1f} us {flops/t7/1e9:7.1f} TF   planned '
               f'{t0*1e3:8.1f} us {flops/t0/1e9:7.1f} TF   worst rel err over 20 runs {worst:.2e} {"ok" if ok else "MISMATCH"}',
               flush=True)
+    # weight gradients (reduction-major operands, transpose reads): same screen
+    for name, n, R, ci, co in [('D3.conv2', 256, 32, 256, 256), ('D4.conv2', 512, 16, 512, 512), ('D5.conv', 1024, 8, 512, 512),
+                               ('D2.conv2', 128, 64, 128, 128)]:
+        x = torch.randn(n, R, R, ci, device=dev).to(torch.bfloat16)
+        dy = torch.randn(n, R, R, co, device=dev).to(torch.bfloat16)
+        ref = K.conv2d_wgrad_nhwc(x, dy, ksize=3, force_tile=1)
+        worst = 0.
+        for rep in range(20):
+            out = K.conv2d_wgrad_nhwc(x, dy, ksize=3, force_tile=7)
+            worst = max(worst, ((out - ref).norm() / ref.norm()).item())
+        flops = 2.0 * n * R * R * ci * co * 9
+        t7 = time_ms(lambda: K.conv2d_wgrad_nhwc(x, dy, ksize=3, force_tile=7))
+        t0 = time_ms(lambda: K.conv2d_wgrad_nhwc(x, dy, ksize=3))
+        ok = worst < 1e-5
+        bad += not ok
+        print(f'wgrad {name:9s} pixels={n*R*R:7d} {ci}->{co}  ring {t7*1e3:8.1f} us {flops/t7/1e9:7.1f} TF   planned '
+              f'{t0*1e3:8.1f} us {flops/t0/1e9:7.1f} TF   worst rel err over 20 runs {worst:.2e} {"ok" if ok else "MISMATCH"}',
+              flush=True)
     print('RACE SCREEN', 'PASSED' if not bad else f'FAILED ({bad} shapes)')
 
 

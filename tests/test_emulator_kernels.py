@@ -614,3 +614,25 @@ def test_experimental_lds_ring_conv_gather_index_math(cfg):
         wT = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Ci, -1).contiguous()
         dx = K.conv2d_nhwc(dyh, wT, ksize=ks, out_dtype=torch.float32, force_tile=7)
         assert rel_err(dx.permute(0, 3, 1, 2), xf.grad) < 1e-5
+
+
+@pytest.mark.parametrize('cfg', [(2, 8, 8, 64, 136, 3, 0), (2, 8, 8, 96, 64, 3, 2), (2, 4, 4, 64, 104, 1, 0), (2, 16, 8, 16, 40, 3, 0)])
+def test_experimental_lds_ring_weight_gradient_index_math(cfg):
+    """reduction-major variant of gg_gemm3.h (force_tile 7): rows staged as they sit in HBM, quarter-XOR swizzle on the DMA
+    source and the ds_read_b64_tr_b16 address, im2col column decode with zero-page padding taps, split-K; dense too."""
+    n, H, W, Ci, Co, ks, sk = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(n, H, W, Ci)); dy = bf(torch.randn(n, H, W, Co))
+    wf = torch.zeros(Co, Ci, ks, ks, requires_grad=True)
+    F.conv2d(x.float().permute(0, 3, 1, 2), wf, padding=ks // 2).backward(dy.float().permute(0, 3, 1, 2))
+    ref = wf.grad.permute(2, 3, 1, 0).reshape(-1, Co)
+    K.plan_log = []
+    try:
+        g = K.conv2d_wgrad_nhwc(x, dy, ksize=ks, force_tile=7, force_splitk=sk)
+        assert [t for t, _ in K.plan_log] == [7]
+    finally:
+        K.plan_log = None
+    assert rel_err(g[:, :Co], ref) < 1e-5
+    a, b = bf(torch.randn(96, 264)), bf(torch.randn(96, 136))          # dense (K, M) x (K, N)
+    out = K.gemm(a, b, trans_a=True, trans_b=False, out_dtype=torch.float32, force_tile=7)
+    assert rel_err(out[0], a.float().t() @ b.float()) < 1e-5
