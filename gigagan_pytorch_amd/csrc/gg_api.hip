@@ -152,6 +152,15 @@ static const GgTileModel kTileModels[] = {
 };
 
 // tile 7: dense row-major x row-major, whole 32-k stages, 16-byte aligned rows
+static int gg_v3_policy() {   // GG_GEMM_V3=1 lets the planner choose the experimental tile 7 (default: never)
+    static int policy = -1;
+    if (policy < 0) {
+        const char* e = getenv("GG_GEMM_V3");
+        policy = e ? (atoi(e) > 0 ? 1 : 0) : 0;
+    }
+    return policy;
+}
+
 static bool gg_v3_eligible(const gg_gemm_desc* d) {
     if (d->K % 32 || d->K < 32 || d->d2s) return false;
     if (d->a_layout == GG_KROW && d->b_layout == GG_KROW) {     // weight gradients: plain epilogue, whole 8-column groups
@@ -242,7 +251,8 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
         if (forced) {
             if (tm.tile != forced) continue;
         } else {
-            if (tm.tile == 7) continue;             // experimental: forced only
+            // experimental LDS-DMA ring: forced, or offered to the cost model when GG_GEMM_V3=1 (next round's A/B switch)
+            if (tm.tile == 7 && !(gg_v3_policy() && gg_v3_eligible(d) && d->N >= 192 && d->M >= 192)) continue;
             if (tm.tile <= 3 && tm.tile != v1_tile) continue;
             if (tm.tile >= 4 && (!v2ok || !pol)) continue;
             if (tm.tile == 4 && d->N < 192) continue;

@@ -151,6 +151,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=True, out_d
 
 
 _zero_pages: dict = {}
+_V3_POLICY = bool(int(__import__('os').environ.get('GG_GEMM_V3', '0') or 0))   # experimental tile 7 offered to the planner
 
 
 def _zero_page(device) -> torch.Tensor:
@@ -195,7 +196,7 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, *, ksize: int, stride: int = 1
         keep.append(in_scale)
     d.C_out, d.ldc, d.c_is_f32 = ptr(out), cout, int(out_dtype == torch.float32)
     d.force_splitk, d.force_tile = force_splitk, force_tile
-    if force_tile == 7:     # experimental LDS-DMA tile: padding taps read a page of zeros
+    if force_tile == 7 or _V3_POLICY:     # experimental LDS-DMA tile: padding taps read a page of zeros
         d.zero_page = ptr(_zero_page(x.device))
     if residual is not None:
         assert residual.shape == out.shape
@@ -232,7 +233,7 @@ def conv2d_wgrad_nhwc(x: torch.Tensor, dy: torch.Tensor, *, ksize: int, stride: 
     d.alpha = 1.0
     d.bias_scale = 1.0
     d.force_splitk, d.force_tile = force_splitk, force_tile
-    if force_tile == 7:
+    if force_tile == 7 or _V3_POLICY:
         d.zero_page = ptr(_zero_page(x.device))
     _run_gemm(d, x)
     return out
