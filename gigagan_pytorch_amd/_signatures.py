@@ -17,6 +17,8 @@ def declare(L):
     L.gg_pack_weights.argtypes = [_P, _P, _I, _P]
     L.gg_wgrad_finish.restype = C.c_int
     L.gg_wgrad_finish.argtypes = [_P, _P, _I, _I, _I, _I, _I, _F, _I, _P]
+    L.gg_wgrad_finish_splits.restype = C.c_int
+    L.gg_wgrad_finish_splits.argtypes = [_P, _P, _I, _I, _I, _I, _I, _F, _I, _I, C.c_int64, _P]
     L.gg_colsum_finish.restype = C.c_int
     L.gg_colsum_finish.argtypes = [_P, _P, _I, _I, _I, _F, _P]
     L.gg_modcoef_fwd.restype = C.c_int

@@ -440,7 +440,7 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     else gg_launch_gemm_tile<128, 32, 4, 1>(p, akrow, bkrow, aconv, grid, s);
     rc = gg_check_launch();
     if (rc) return rc;
-    if (pl.splitk > 1) {
+    if (pl.splitk > 1 && !(d->no_reduce && d->batch == 1)) {
         long long total = (long long)d->M * d->N * d->batch;
         long long nb = pl.splitk <= 8 ? (total + 255) / 256 : (total + 63) / 64;
         if (nb > 8192) nb = 8192;
@@ -511,12 +511,22 @@ extern "C" int gg_pack_weights(const gg_pack_entry* table, const int64_t* header
     return gg_check_launch();
 }
 
+extern "C" int gg_wgrad_finish_splits(const float* g, float* dst, int32_t O, int32_t I, int32_t T, int32_t C8, int32_t O8,
+                                      float alpha, int32_t accumulate, int32_t splits, int64_t split_stride, void* stream);
+
 extern "C" int gg_wgrad_finish(const float* g, float* dst, int32_t O, int32_t I, int32_t T, int32_t C8, int32_t O8,
                                float alpha, int32_t accumulate, void* stream) {
+    return gg_wgrad_finish_splits(g, dst, O, I, T, C8, O8, alpha, accumulate, 1, 0, stream);
+}
+
+extern "C" int gg_wgrad_finish_splits(const float* g, float* dst, int32_t O, int32_t I, int32_t T, int32_t C8, int32_t O8,
+                                      float alpha, int32_t accumulate, int32_t splits, int64_t split_stride, void* stream) {
     if (!g || !dst) return gg_fail(-1, "gg_wgrad_finish: null pointer");
     if (O <= 0 || I <= 0 || T <= 0 || C8 < I || O8 < O) return gg_fail(-2, "gg_wgrad_finish: bad extents");
+    if (splits < 1 || (splits > 1 && split_stride < (int64_t)T * C8 * O8)) return gg_fail(-3, "gg_wgrad_finish: bad split layout");
     GgWgradFinishParams p;
     p.g = g; p.dst = dst; p.O = O; p.I = I; p.T = T; p.C8 = C8; p.O8 = O8; p.accumulate = accumulate; p.alpha = alpha;
+    p.splits = splits; p.split_stride = split_stride;
     GG_LAUNCH(gg_wgrad_finish_kernel, dim3((unsigned)((O + 31) / 32), (unsigned)((I + 31) / 32)), dim3(256),
               (hipStream_t)stream, p);
     return gg_check_launch();

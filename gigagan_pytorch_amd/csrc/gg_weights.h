@@ -130,6 +130,8 @@ struct GgWgradFinishParams {
     float* dst;           // (O, I, T) fp32
     int O, I, T, C8, O8, accumulate;
     float alpha;
+    int splits;               // >= 1 slices of g, `split_stride` elements apart, summed while reading (split-K partials)
+    long long split_stride;
 };
 
 GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_wgrad_finish_kernel(GgWgradFinishParams p) {
@@ -140,7 +142,10 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_wgrad_finish_kernel(GgWgradFinishParams 
         for (int idx = threadIdx.x; idx < 1024 * tg; idx += 256) {
             const int ol = idx & 31, il = (idx >> 5) & 31, tl = idx >> 10;
             float v = 0.f;
-            if (o0 + ol < p.O && i0 + il < p.I) v = p.g[((long long)(t0 + tl) * p.C8 + i0 + il) * p.O8 + o0 + ol];
+            if (o0 + ol < p.O && i0 + il < p.I) {
+                const float* g = p.g + ((long long)(t0 + tl) * p.C8 + i0 + il) * p.O8 + o0 + ol;
+                for (int sp = 0; sp < p.splits; ++sp) v += g[sp * p.split_stride];
+            }
             tile[ol][il * tg + tl] = v;
         }
         gg_sync();

@@ -99,6 +99,7 @@ def bump_weight_epoch():
 
 _DEBUG_NO_TABLE = bool(os.environ.get('GG_DEBUG_NO_PACK_TABLE'))
 _DEBUG_NO_SINK = bool(os.environ.get('GG_DEBUG_NO_GRAD_SINK'))
+_WGRAD_FUSED = bool(os.environ.get('GG_WGRAD_FUSED'))          # experimental: no separate split-K reduce for weight gradients
 _NARROW_MODCONV = bool(os.environ.get('GG_MODCONV_NARROW'))    # experimental no-grad path for the narrow layers
 
 
@@ -363,7 +364,12 @@ class WgradFn(Function):
         """the GEMM ([tap][ci][co] fp32, pixels reduced) + the transpose/scale pass into the parameter layout; with
         `sink` (a parameter's fp32 .grad) the result is accumulated there instead of being returned."""
         ksize, stride, pad, wkind = geom
-        g = K.conv2d_wgrad_nhwc(x, dy, ksize=ksize, stride=stride, pad=pad, in_scale=in_scale)  # (k*k*C8, O8) fp32
+        if _WGRAD_FUSED:     # EXPERIMENTAL (GG_WGRAD_FUSED=1, unmeasured): split-K partials folded by the finish pass itself
+            g, _ = K.conv2d_wgrad_nhwc(x, dy, ksize=ksize, stride=stride, pad=pad, in_scale=in_scale, keep_partials=True)
+            if g.shape[0] == 1:
+                g = g[0]
+        else:
+            g = K.conv2d_wgrad_nhwc(x, dy, ksize=ksize, stride=stride, pad=pad, in_scale=in_scale)  # (k*k*C8, O8) fp32
         if wkind == 's2d':              # (O, C, s1, s2) == (O, 4C, 1, 1)
             O, I = wshape[0], wshape[1] // 4
         elif len(wshape) == 5:          # kernel bank (N, O, I, k, k) stacked along output channels

@@ -636,3 +636,33 @@ def test_experimental_lds_ring_weight_gradient_index_math(cfg):
     a, b = bf(torch.randn(96, 264)), bf(torch.randn(96, 136))          # dense (K, M) x (K, N)
     out = K.gemm(a, b, trans_a=True, trans_b=False, out_dtype=torch.float32, force_tile=7)
     assert rel_err(out[0], a.float().t() @ b.float()) < 1e-5
+
+
+def test_experimental_fused_splitk_fold_in_wgrad_finish():
+    """GG_WGRAD_FUSED (off by default): the weight-gradient GEMM keeps its split-K partials (`no_reduce`) and
+    gg_wgrad_finish_splits sums them while transposing into the parameter layout - same gradient as reduce + finish."""
+    torch.manual_seed(0)
+    x, dy = bf(torch.randn(2, 32, 32, 16)), bf(torch.randn(2, 32, 32, 24))
+    K.plan_log = []
+    try:
+        parts, sk = K.conv2d_wgrad_nhwc(x, dy, ksize=3, keep_partials=True)
+        assert K.plan_log[0][1] == sk and sk > 1 and parts.shape == (sk, 144, 24)
+    finally:
+        K.plan_log = None
+    g = K.conv2d_wgrad_nhwc(x, dy, ksize=3)
+    assert rel_err(parts.sum(0), g) < 1e-6
+    want = K.wgrad_finish(g, 24, 16, 9, 0.5)
+    assert rel_err(K.wgrad_finish(parts, 24, 16, 9, 0.5), want) < 1e-6
+    acc = torch.ones(24, 16, 9)
+    K.wgrad_finish(parts, 24, 16, 9, 0.5, out=acc, accumulate=True)
+    assert rel_err(acc, want + 1.0) < 1e-6
+    # through the autograd op, flag on vs off
+    w = torch.randn(24, 16, 3, 3, requires_grad=True)
+    geom = (3, 1, 1, 'oihw')
+    try:
+        ops._WGRAD_FUSED = True
+        a = ops.WgradFn.compute(x, dy, None, geom, 1.0, tuple(w.shape), None)
+    finally:
+        ops._WGRAD_FUSED = False
+    b = ops.WgradFn.compute(x, dy, None, geom, 1.0, tuple(w.shape), None)
+    assert rel_err(a, b) < 1e-6
