@@ -152,11 +152,11 @@ static const GgTileModel kTileModels[] = {
 };
 
 // tile 7: dense row-major x row-major, whole 32-k stages, 16-byte aligned rows
-static int gg_v3_policy() {   // GG_GEMM_V3=1 lets the planner choose the experimental tile 7 (default: never)
+static int gg_v3_policy() {   // GG_GEMM_V3=1 lets the planner choose the experimental tile 7, =2 forces it (default 0: never)
     static int policy = -1;
     if (policy < 0) {
         const char* e = getenv("GG_GEMM_V3");
-        policy = e ? (atoi(e) > 0 ? 1 : 0) : 0;
+        policy = e ? (atoi(e) > 0 ? atoi(e) : 0) : 0;      // 2: use it wherever eligible (integration tests on small shapes)
     }
     return policy;
 }
@@ -242,6 +242,7 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     const int pol = gg_v2_policy();
     const int v1_tile = d->N <= 32 ? 3 : (d->N <= 64 ? 2 : 1);
     int forced = d->force_tile;
+    if (forced == 0 && gg_v3_policy() >= 2 && gg_v3_eligible(d)) forced = 7;
     if (forced == 7 && !gg_v3_eligible(d)) forced = 0;
     if (forced >= 4 && forced <= 6 && !gg_v2_eligible(d)) forced = 0;
     if (forced < 0 || forced > 7) forced = 0;      // (9 = direct convolution: handled above when eligible)
