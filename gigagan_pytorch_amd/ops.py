@@ -1092,6 +1092,9 @@ def demod_coefficients(weights, s, a, eps):
     return sumsq.clamp(min=eps).rsqrt()
 
 
+_PREMOD_MODCONV = bool(os.environ.get('GG_MODCONV_PREMOD'))     # experimental no-grad path for the low/mid-resolution layers
+
+
 def fused_modconv_forward(xh, wts, s, a, d, noise, noise_weight, act, O, Op, d_padded=False, wk=None):
     """no-grad path: the whole adaptive conv (kernel mix, modulation, demodulation, noise, leaky-relu) as
     ONE implicit-GEMM launch with the N kernels stacked along the reduction and batch folded into M. `wk`: the
@@ -1109,6 +1112,14 @@ def fused_modconv_forward(xh, wts, s, a, d, noise, noise_weight, act, O, Op, d_p
         nz = noise.reshape(-1).float().contiguous()
         nw = noise_weight.reshape(-1).float()
         nw = (F.pad(nw, (0, Op - O)) if Op != O else nw).contiguous()
+    if _PREMOD_MODCONV and k == 3 and b * H * W <= 131072:
+        # EXPERIMENTAL (GG_MODCONV_PREMOD=1, off by default, unmeasured): the per-sample scale a_n * s applied to the
+        # activation by one pointwise pass per kernel of the bank (channels laid out (n, ci) like the packed reduction),
+        # so the convolution is the plain gather of the discriminator's layers - the in-gather scale costs two extra loads
+        # and a wait per staged vector. Worth it where the activation is small next to the weights (<= 64x64).
+        x2 = torch.cat([K.modulate(xh, insc[:, n * Ip:(n + 1) * Ip].contiguous()) for n in range(N)], dim=-1) if N > 1 \
+            else K.modulate(xh, insc)
+        return K.conv2d_nhwc(x2, wk, ksize=k, out_scale=out_scale, noise=nz, noise_w=nw, act=act, act_slope=LRELU_SLOPE)
     return K.conv2d_nhwc(xh, wk, ksize=k, cv=N * Ip, in_scale=insc, out_scale=out_scale, noise=nz, noise_w=nw,
                          act=act, act_slope=LRELU_SLOPE)
 

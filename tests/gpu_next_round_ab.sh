@@ -7,12 +7,12 @@ mkdir -p gpurun_out
 {
   echo "== ring GEMM race screen + timing (gg_gemm3.h, force_tile 7)"
   timeout 120 python tests/gpu_ring_gemm_probe.py 2>&1 | grep -v amdgpu.ids
-  for cfg in "" "GG_WGRAD_FUSED=1" "GG_MODCONV_NARROW=1" "GG_GEMM_V3=1" "GG_GEMM_V3=1 GG_WGRAD_FUSED=1 GG_MODCONV_NARROW=1"; do
+  for cfg in "" "GG_WGRAD_FUSED=1" "GG_MODCONV_NARROW=1 GG_MODCONV_PREMOD=1" "GG_GEMM_V3=1" "GG_GEMM_V3=1 GG_WGRAD_FUSED=1 GG_MODCONV_NARROW=1 GG_MODCONV_PREMOD=1"; do
     echo "== bench.py [$cfg]"
     env $cfg timeout 150 python bench.py --no-cpu-baseline --no-profile-cycle 2>&1 | grep '^{' | cut -c1-260
   done
   echo "== modulated-conv forward roofline with and without the narrow direct path"
-  for cfg in "" "GG_MODCONV_NARROW=1"; do
+  for cfg in "" "GG_MODCONV_NARROW=1" "GG_MODCONV_PREMOD=1" "GG_MODCONV_NARROW=1 GG_MODCONV_PREMOD=1"; do
     env $cfg timeout 150 python bench.py --no-cpu-baseline --steps 4 2>&1 | grep '^{' | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); m = d['roofline']['modconv_forward']

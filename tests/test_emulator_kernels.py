@@ -666,3 +666,26 @@ def test_experimental_fused_splitk_fold_in_wgrad_finish():
         ops._WGRAD_FUSED = False
     b = ops.WgradFn.compute(x, dy, None, geom, 1.0, tuple(w.shape), None)
     assert rel_err(a, b) < 1e-6
+
+
+def test_experimental_premodulated_modconv_path_matches_fused_launch():
+    """GG_MODCONV_PREMOD (off by default): activation scaled per kernel of the bank by a pointwise pass, then the plain conv
+    gather over (n, ci) channels - the same numbers as the in-gather scaling (both round the scaled activation to bf16)."""
+    from gigagan_pytorch_amd.modules import AdaptiveConv2DMod
+    torch.manual_seed(0)
+    conv = AdaptiveConv2DMod(64, 72, 3, num_conv_kernels=2)
+    x, mod, km = torch.randn(2, 64, 8, 8), torch.randn(2, 64) * 0.3, torch.randn(2, 2)
+    nz, nw = torch.randn(2, 1, 8, 8), torch.randn(72, 1, 1) * 0.1
+    calls, orig = [], K.modulate
+    try:
+        K.modulate = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        with torch.no_grad():
+            y0 = conv(x, mod, km, noise=nz, noise_weight=nw, act='lrelu')
+            assert not calls
+            ops._PREMOD_MODCONV = True
+            y1 = conv(x, mod, km, noise=nz, noise_weight=nw, act='lrelu')
+            assert len(calls) == 2                      # one pointwise pass per kernel of the bank
+    finally:
+        ops._PREMOD_MODCONV = False
+        K.modulate = orig
+    assert rel_err(y1, y0) < 1e-3                       # both round x * (a_n s) to bf16 before the MFMAs
