@@ -75,41 +75,67 @@ class SyntheticTextImages:
             yield self.images, self.enc
 
 
-def cpu_baseline(max_seconds=40.0):
-    """The oracle (a fp32 PyTorch-CPU restatement of the reference, kind="port") timed on this box's host cores
-    on a bounded sample of the same workload: C2 model dims at 256x256, batch 2, one plain (non-GP) G+D step with
-    torch AdamW — the reference's own CPU throughput is nearly batch-independent."""
-    from gigagan_pytorch_amd import ops
-    from gigagan_pytorch_amd.generator import Generator
-    from gigagan_pytorch_amd.discriminator import Discriminator
-    from gigagan_pytorch_amd.gigagan import discriminator_hinge_loss, generator_hinge_loss
+def cpu_baseline(budget_s=45.0):
+    """SURVEY.md §8(d) protocol on a bounded sample: OUR trainer (gigagan.py) on the fp32 CPU oracle (kind="port": the
+    reference itself cannot travel to the GPU box; the port/reference ratio measured in the build container is committed in
+    profiles/r02_cpu_baseline_calibration.json and copied into the record), config-2 dims at 256x256, fp32, batch 2, same
+    synthetic uniform images: ONE plain G+D step and ONE gradient-penalty G+D step, both through
+    train_discriminator_step / train_generator_step incl. the optimizer updates; cycle mean = (3 plain + 1 GP) / 4, what a
+    4-step cycle costs. Thread count: best of a 3-point sweep on one discriminator forward. The reference's CPU throughput
+    is nearly batch-independent (0.166 / 0.225 img/s at batch 1 / 2 on 8 cores)."""
+    from gigagan_pytorch_amd import GigaGAN, ops
+    from gigagan_pytorch_amd.data import SyntheticImages
+    from gigagan_pytorch_amd.gigagan import cycle
     from oracle.torch_ops import OracleOps
+    from oracle.cpu_trainer import install_cpu_adamw
+    t_start = time.time()
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    torch.manual_seed(0)
     bs, S = 2, 256
+    torch.manual_seed(0)
     with ops.use_impl(OracleOps()):
-        G = Generator(image_size=S, **C2_G)
-        D = Discriminator(image_size=S, **C2_D)
-        g_opt = torch.optim.AdamW(G.parameters(), lr=2e-4, betas=(0.5, 0.9))
-        d_opt = torch.optim.AdamW(D.parameters(), lr=2e-4, betas=(0.5, 0.9))
-        real = torch.rand(bs, 3, S, S)
-        t0 = time.time()
-        # D step
-        with torch.no_grad():
-            img, rgbs = G(noise=torch.randn(bs, 64), return_all_rgbs=True)
-        fl, fms, _ = D(img, rgbs, calc_aux_loss=False)
-        rl, rms, aux = D(real, D.real_images_to_rgbs(real), calc_aux_loss=True)
-        loss = discriminator_hinge_loss(rl, fl) + 0.1 * sum(discriminator_hinge_loss(a, b) for a, b in zip(rms, fms)) + sum(aux)
-        d_opt.zero_grad(); loss.backward(); d_opt.step()
-        # G step
-        img, rgbs = G(noise=torch.randn(bs, 64), return_all_rgbs=True)
-        l, ms, _ = D(img, rgbs, calc_aux_loss=False)
-        loss = generator_hinge_loss(l) + 0.1 * sum(generator_hinge_loss(m) for m in ms)
-        g_opt.zero_grad(); loss.backward(); g_opt.step()
-        dt = time.time() - t0
-    return dict(value=bs / dt, unit='images/sec', cores=cores, kind='port',
-                sample=f'fp32 CPU oracle, C2 dims 256x256, batch {bs}, one plain G+D step (no gradient penalty), {dt:.1f} s')
+        gan = GigaGAN(generator=dict(C2_G, image_size=S), discriminator=dict(C2_D, image_size=S), device='cpu',
+                      apply_gradient_penalty_every=4, create_ema_generator_at_init=False, use_hip_graphs=False,
+                      model_folder='/tmp/gg-bench-cpu-models', results_folder='/tmp/gg-bench-cpu-results')
+        install_cpu_adamw(gan.G_opt)
+        install_cpu_adamw(gan.D_opt)
+        it = cycle(SyntheticImages(bs, S, device='cpu'))
+        real = next(it)
+        sweep = {}
+        for n in sorted({min(cores, c) for c in (8, 32, 96)}):
+            torch.set_num_threads(n)
+            with torch.no_grad():
+                gan.D(real, gan.D.real_images_to_rgbs(real), calc_aux_loss=False)       # warm the allocator at this width
+                t0 = time.time()
+                gan.D(real, gan.D.real_images_to_rgbs(real), calc_aux_loss=False)
+            sweep[n] = time.time() - t0
+        threads = min(sweep, key=sweep.get)
+        torch.set_num_threads(threads)
+        times = {}
+        for name, gp in (('plain', False), ('gp', True)):
+            if name == 'gp' and time.time() - t_start + 3.5 * times['plain'] > budget_s * 2:
+                break           # a slow box: report the plain step alone rather than blow the bench's wall time
+            t0 = time.time()
+            gan.train_discriminator_step(dl_iter=it, apply_gradient_penalty=gp)
+            gan.train_generator_step(batch_size=bs, dl_iter=it)
+            times[name] = time.time() - t0
+    if 'gp' in times:
+        per_step = (3 * times['plain'] + times['gp']) / 4
+        what = f"plain step {times['plain']:.1f} s + gradient-penalty step {times['gp']:.1f} s, cycle mean (3 plain + 1 GP) / 4"
+    else:
+        per_step = times['plain']
+        what = f"plain step {times['plain']:.1f} s only (gradient-penalty step skipped: time budget)"
+    rec = dict(value=bs / per_step, unit='images/sec', cores=threads, kind='port',
+               sample=f'our trainer on the fp32 CPU oracle, config-2 dims 256x256, batch {bs}: {what}; {threads} threads = best of '
+                      f'the sweep {({k: round(v, 2) for k, v in sweep.items()})} (seconds per D forward) on a {cores}-core host')
+    cal = ROOT / 'profiles' / 'r02_cpu_baseline_calibration.json'
+    if cal.exists():
+        try:
+            c = json.loads(cal.read_text())
+            rec['port_vs_reference'] = c.get('port_vs_reference')
+            rec['calibration'] = c.get('note')
+        except Exception:
+            pass
+    return rec
 
 
 def modconv_forward_roofline(gan, batch, dev):
@@ -160,8 +186,8 @@ def modconv_forward_roofline(gan, batch, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=8)
-    ap.add_argument('--warmup', type=int, default=4)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 32; 16 for the secondary workloads)')
     ap.add_argument('--workload', choices=['uncond', 'upsampler', 'text'], default='uncond',
                     help='uncond = the headline config 2/3; upsampler = config 5 (UnetUpsampler 64->256); text = config 4')
@@ -169,6 +195,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile-cycle', action='store_true')
     ap.add_argument('--no-graphs', action='store_true', help='issue every launch eagerly instead of replaying hipGraphs')
+    ap.add_argument('--no-restore', action='store_true',
+                    help='let the trajectory run on (it diverges on synthetic uniform images, here as in the reference)')
     args = ap.parse_args()
 
     from gigagan_pytorch_amd import distributed as gdist, kernels as K
@@ -198,24 +226,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The trajectory diverges within ~10 steps on synthetic uniform "images" (the reference does too: G loss 59k at step 3,
+    # SURVEY.md §7.3; at config 2 the step-1 gradient penalty alone is 4.4e4, tests/golden/c2_step1.pt) and then runs on
+    # inf/NaN operands, which a power-limited matrix pipe multiplies faster than real data. The timed region therefore
+    # restarts from the initial weights / Adam moments at the start of every 4-step gradient-penalty cycle: three in-place
+    # device copies and one weight-pack launch per model (~1 ms per cycle), INSIDE the timed region - extra work, nothing
+    # skipped; every step still runs its full forward / backward / optimizer / EMA update. `--no-restore` switches it off.
+    snap = None if args.no_restore else gan.state_snapshot()
+
+    def run_steps(n):
+        out = None
+        for _ in range(n):
+            if snap is not None and (gan._steps_host - 1) % 4 == 0:
+                gan.state_restore(snap)
+            out = gan.train_step(it, args.batch)
+        return out
+
     # warm-up starts at the trainer's step 1; keep the timed region aligned to whole GP cycles
-    for _ in range(warmup):
-        gan.train_step(it, args.batch)
+    run_steps(warmup)
     # align so that the K timed steps contain exactly K/4 GP steps; with hipGraphs on, also make sure one whole
     # 4-step cycle has run untimed (the three step kinds are captured on first use). Extra steps count as warm-up.
     while (gan._steps_host - 1) % 4 != 0 or (gan.use_hip_graphs and gan._steps_host < 5):
-        gan.train_step(it, args.batch)
+        run_steps(1)
         warmup += 1
     barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        d_losses, g_losses = gan.train_step(it, args.batch)
+    d_losses, g_losses = run_steps(steps)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    finite = bool(torch.isfinite(gan.G_opt.flat_p).all() and torch.isfinite(gan.D_opt.flat_p).all()
+                  and torch.isfinite(gan.G_opt.flat_g).all() and torch.isfinite(gan.D_opt.flat_g).all())
+    loss_vals = [float(v) for v in (*d_losses, *g_losses) if v is not None]
+    finite = finite and all(v == v and abs(v) != float('inf') for v in loss_vals)
 
     ms_per_step = dt / steps * 1e3
     value = args.batch * world * steps / dt
@@ -227,8 +273,7 @@ def main():
         graphs_were_on, gan.use_hip_graphs = gan.use_hip_graphs, False   # HIP events cannot be recorded inside a replay
         if rank == 0:
             K.profiler = K.GemmProfiler()
-        for _ in range(4):
-            gan.train_step(it, args.batch)
+        run_steps(4)
         agg = shapes = None
         if rank == 0:
             agg = K.profiler.summary()
@@ -290,7 +335,9 @@ def main():
             config=dict(workload=f'{what} bf16 bs={args.batch}/GPU, GP every 4th step', global_batch=args.batch * world,
                         parallelism=f'dp{world}', hip_graphs=bool(gan._graphable(1))),
             roofline=roofline, cpu_baseline=cpu,
-            last_losses=dict(d=float(d_losses.divergence), g=float(g_losses.divergence)))
+            finite=finite, state_restored_every_cycle=snap is not None,
+            last_losses=dict(d=float(d_losses.divergence), g=float(g_losses.divergence),
+                             gp=float(d_losses.gradient_penalty), msd=float(d_losses.multiscale_divergence)))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

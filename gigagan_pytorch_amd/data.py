@@ -1,5 +1,7 @@
-"""Datasets (reference data.py:48-113). The benchmarked path uses synthetic batches already resident in HBM;
-these are host-side conveniences with the reference's names and item formats."""
+"""Datasets and the input pipeline (reference data.py:48-113; the reference hands its DataLoader to `accelerator.prepare`,
+gp.py:2150-2159, which shards it across ranks). The benchmarked path uses synthetic batches already resident in HBM; real
+data goes folder -> worker processes -> pinned host batches -> a copy stream (`DevicePrefetcher`), so the 25 MB fp32 batch of
+config 2 crosses PCIe while the previous step computes."""
 from __future__ import annotations
 
 from pathlib import Path
@@ -22,17 +24,22 @@ def collate_tensors_or_str(data):
 class ImageDataset(Dataset):
     """folder of images -> float tensors in [0,1], resized + center-cropped to image_size (data.py:48-85)."""
 
-    def __init__(self, folder, image_size, channels=3, convert_image_to=None, exts=('jpg', 'jpeg', 'png', 'tiff')):
+    def __init__(self, folder, image_size, exts=('jpg', 'jpeg', 'png', 'tiff'), augment_horizontal_flip=False,
+                 convert_image_to=None, channels=3):
         super().__init__()
         folder = Path(folder)
         assert folder.is_dir(), f'{folder} must be a folder containing images'
         self.paths = [p for ext in exts for p in folder.glob(f'**/*.{ext}')]
         assert len(self.paths) > 0, 'your folder contains no images'
         self.image_size = image_size
+        self.augment_horizontal_flip = augment_horizontal_flip       # T.RandomHorizontalFlip(), data.py:66
         self.mode = convert_image_to or {1: 'L', 3: 'RGB', 4: 'RGBA'}[channels]
 
     def get_dataloader(self, *args, **kwargs):
+        """reference data.py:76-77: shuffled, ragged last batch dropped (every step then has one shape: one hipGraph)."""
         kwargs.setdefault('collate_fn', collate_tensors_or_str)
+        kwargs.setdefault('shuffle', 'sampler' not in kwargs)
+        kwargs.setdefault('drop_last', True)
         return DataLoader(self, *args, **kwargs)
 
     def __len__(self):
@@ -51,6 +58,8 @@ class ImageDataset(Dataset):
         arr = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy())
         if arr.dim() == 2:
             arr = arr[..., None]
+        if self.augment_horizontal_flip and torch.rand(()) < 0.5:
+            arr = arr.flip(1)
         return arr.permute(2, 0, 1).float() / 255.
 
 
@@ -87,3 +96,82 @@ class SyntheticImages:
 
     def __iter__(self):
         return iter(self.batches)
+
+
+def shard_dataloader(dl, rank: int, world: int, seed: int = 0):
+    """what `accelerator.prepare(dl)` does for the reference (gp.py:2150-2159): every rank iterates a disjoint shard. A torch
+    DataLoader over a map-style dataset is rebuilt around a DistributedSampler (same batch size / workers / collate); anything
+    else (an iterable of ready batches) is returned unchanged - the caller owns the sharding then."""
+    if world <= 1 or not isinstance(dl, DataLoader) or not hasattr(dl.dataset, '__len__') or dl.batch_size is None:
+        return dl
+    from torch.utils.data.distributed import DistributedSampler
+    shuffle = not isinstance(dl.sampler, torch.utils.data.SequentialSampler)
+    sampler = DistributedSampler(dl.dataset, num_replicas=world, rank=rank, shuffle=shuffle, seed=seed, drop_last=True)
+    return DataLoader(dl.dataset, batch_size=dl.batch_size, sampler=sampler, num_workers=dl.num_workers,
+                      collate_fn=dl.collate_fn, pin_memory=dl.pin_memory, drop_last=True,
+                      persistent_workers=getattr(dl, 'persistent_workers', False) and dl.num_workers > 0)
+
+
+def _record_stream(item, stream):
+    if torch.is_tensor(item):
+        if item.is_cuda:
+            item.record_stream(stream)
+    elif isinstance(item, (tuple, list)):
+        for x in item:
+            _record_stream(x, stream)
+
+
+class DevicePrefetcher:
+    """wraps an iterable of host batches (tensors, or tuples / lists holding tensors next to captions): the NEXT batch is pinned
+    and copied to the device on a side stream while the current one is consumed; `__next__` makes the compute stream wait on
+    that copy's event, never on the host. Keeps `batch_size` for the trainer (gp.py:2668)."""
+
+    def __init__(self, loader, device, depth: int = 2):
+        self.loader, self.device, self.depth = loader, torch.device(device), max(1, depth)
+        self.batch_size = getattr(loader, 'batch_size', None)
+
+    def _to_device(self, item, stream):
+        if torch.is_tensor(item):
+            if self.device.type != 'cuda':
+                return item.to(self.device)
+            if not item.is_pinned():
+                item = item.pin_memory()
+            with torch.cuda.stream(stream):
+                return item.to(self.device, non_blocking=True)
+        if isinstance(item, (tuple, list)):
+            return type(item)(self._to_device(x, stream) for x in item)
+        return item
+
+    def __iter__(self):
+        from collections import deque
+        cuda = self.device.type == 'cuda'
+        stream = torch.cuda.Stream(self.device) if cuda else None
+        queue = deque()
+        it = iter(self.loader)
+
+        def push():
+            try:
+                host = next(it)
+            except StopIteration:
+                return False
+            dev = self._to_device(host, stream)
+            ev = None
+            if cuda:
+                ev = torch.cuda.Event()
+                ev.record(stream)
+            queue.append((dev, ev, host))      # the pinned source stays alive until the copy has been consumed
+            return True
+
+        while len(queue) < self.depth and push():
+            pass
+        while queue:
+            dev, ev, _host = queue.popleft()
+            if ev is not None:
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                _record_stream(dev, cur)     # allocated on the copy stream, consumed on the compute stream
+            push()
+            yield dev
+
+    def __len__(self):
+        return len(self.loader)

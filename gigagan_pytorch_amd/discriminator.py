@@ -252,6 +252,26 @@ class Discriminator(nn.Module):
             res //= 2
         return out
 
+    def multiscale_parameters(self):
+        """parameters that only receive a gradient when the multi-scale outputs are requested (the predictors and the text
+        conditioning that modulates them): with `calc_multiscale_loss_every > 1` their grads stay None in the other steps."""
+        out = []
+        for layer in self.layers:
+            if layer[5] is not None:
+                out.extend(layer[5].parameters())
+        t2c = getattr(self, 'text_to_conv_conditioning', None)
+        if t2c is not None:
+            out.extend(t2c.parameters())
+        return out
+
+    def aux_parameters(self):
+        """the auxiliary reconstruction decoders: trained only through D(real) with a positive aux loss weight (gp.py:2327-2335)."""
+        out = []
+        for layer in self.layers:
+            if layer[6] is not None:
+                out.extend(layer[6].parameters())
+        return out
+
     def resize_image_to(self, images, resolution):
         return ops.impl.resize_bilinear(images, resolution)
 

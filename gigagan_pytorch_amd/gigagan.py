@@ -259,6 +259,7 @@ class GigaGAN(nn.Module):
             _load_into(self.D, pkg['D'], strict)
             if self.has_ema_generator and 'G_ema' in pkg:
                 _load_into(self.G_ema, pkg['G_ema'], False)
+                self.G_ema.sync_host_counters()      # `step` / `initted` travelled in the package: resume the schedule there
         if 'steps' in pkg:
             self._steps_host = int(pkg['steps'])
             self.steps.fill_(self._steps_host)
@@ -269,6 +270,40 @@ class GigaGAN(nn.Module):
             self.D_opt.load_state_dict(pkg['D_opt'])
         except Exception as e:   # reference behaviour: optimizer state is best-effort
             self.print(f'unable to load optimizers {e} - optimizer states will be reset')
+
+    # -- in-memory training state (bench.py keeps its timed region on finite operands with it) -----------------------
+    def state_snapshot(self):
+        """clones of the flat parameter / moment buffers of both optimizers (+ the EMA copy) and the host-side counters."""
+        snap = dict(steps=self._steps_host)
+        for name, opt in (('G', self.G_opt), ('D', self.D_opt)):
+            snap[name] = (opt.flat_p.clone(), opt.flat_m.clone(), opt.flat_v.clone(), opt.step_count)
+        if self.has_ema_generator and getattr(self.G_ema, '_flat', None) is not None:
+            snap['ema'] = (self.G_ema._flat.clone(), self.G_ema._step_host, self.G_ema._initted_host)
+        return snap
+
+    @torch.no_grad()
+    def state_restore(self, snap, restore_step_counter=False):
+        """copy a snapshot back IN PLACE (captured hipGraphs keep pointing at the same buffers) and re-pack the bf16 GEMM
+        operands of both models: three device copies per model plus one pack launch each."""
+        for name, opt in (('G', self.G_opt), ('D', self.D_opt)):
+            p, m, v, t = snap[name]
+            opt.flat_p.copy_(p)
+            opt.flat_m.copy_(m)
+            opt.flat_v.copy_(v)
+            opt.step_count = t
+            opt._steps_dirty = True
+            ops.pack_cache_clear()
+            opt.pack_table.refresh()
+            opt.pack_table.dirty = False
+        if 'ema' in snap and self.has_ema_generator:
+            flat, st, ini = snap['ema']
+            self.G_ema._flat.copy_(flat)
+            self.G_ema._step_host, self.G_ema._initted_host = st, ini
+            self.G_ema.step.fill_(st)
+            self.G_ema.initted.fill_(bool(ini))
+        if restore_step_counter:
+            self._steps_host = int(snap['steps'])
+            self.steps.fill_(self._steps_host)
 
     # -- process topology ----------------------------------------------------------------------------------
     @property
@@ -310,10 +345,19 @@ class GigaGAN(nn.Module):
     def resize_image_to(self, images, resolution):
         return ops.impl.resize_bilinear(images, resolution)
 
-    def set_dataloader(self, dl):
+    def set_dataloader(self, dl, prefetch_to_device=None):
+        """reference gp.py:2150-2159 (`accelerator.prepare(dl)`): under data parallelism every rank gets a disjoint shard of a
+        torch DataLoader (DistributedSampler); on a GPU the batches are pinned and copied on a side stream one step ahead."""
         assert not exists(self.train_dl), 'training dataloader has already been set'
+        from .data import shard_dataloader, DevicePrefetcher
+        batch_size = dl.batch_size
+        dl = shard_dataloader(dl, gdist.rank(), gdist.world_size())
+        if prefetch_to_device is None:
+            prefetch_to_device = self._device.type == 'cuda' and isinstance(dl, torch.utils.data.DataLoader)
+        if prefetch_to_device:
+            dl = DevicePrefetcher(dl, self._device)
         self.train_dl = dl
-        self.train_dl_batch_size = dl.batch_size
+        self.train_dl_batch_size = batch_size
 
     @torch.inference_mode()
     def generate(self, *args, **kwargs):
@@ -573,7 +617,13 @@ class GigaGAN(nn.Module):
 
         works = gdist.all_reduce_flat_grads(self.D_opt.flat_g)
         gdist.wait_all(works)
-        self.D_opt.step(grad_scale=1. / gdist.world_size())
+        # parameters whose gradient is None in the reference this step are skipped entirely (no decay, no moment update)
+        skip = []
+        if not calc_multiscale_loss:
+            skip += self.D.multiscale_parameters()
+        if self.discr_aux_recon_loss_weight <= 0.:
+            skip += self.D.aux_parameters()
+        self.D_opt.step(grad_scale=1. / gdist.world_size(), skip=skip)
 
         return TrainDiscrLosses(total_divergence, total_multiscale_divergence, 0., total_matching_aware_loss,
                                 total_gp_loss, total_aux_loss)
@@ -728,6 +778,8 @@ def _load_into(module, state, strict):
     if strict and (missing or unexpected):
         raise RuntimeError(f'state dict mismatch: missing {missing[:5]} unexpected {unexpected[:5]}')
     for k, v in state.items():
+        if k.startswith('online_model.'):       # ema_pytorch's alias of the live generator: it loads its own package entry
+            continue
         if k in own and own[k].shape == v.shape:
             own[k].copy_(v)
 

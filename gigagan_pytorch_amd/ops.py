@@ -103,6 +103,21 @@ _WGRAD_FUSED = bool(os.environ.get('GG_WGRAD_FUSED'))          # experimental: n
 _NARROW_MODCONV = bool(os.environ.get('GG_MODCONV_NARROW'))    # experimental no-grad path for the narrow layers
 
 
+def _refresh_table(tab):
+    """one gg_pack_weights launch re-packs every operand of the table from the live parameters; afterwards every registered
+    parameter's recorded version is current (a state-dict load bumps them all: one re-pack, not one per parameter)."""
+    tab.refresh()
+    tab.dirty = False
+    for ref in list(getattr(tab, 'owners', {}).values()):
+        w = ref()
+        slot = None if w is None else w.__dict__.get('_gg_tpacks')
+        if slot:
+            v = w._version
+            for k, ent in slot.items():
+                if ent[2] != v:
+                    slot[k] = (ent[0], ent[1], v)
+
+
 def _table_pack(w, kind: str):
     """parameters owned by a FlatAdamW: persistent operands, all re-packed by ONE gg_pack_weights launch right after
     each optimizer step (FlatAdamW.step) or, when something else touched the weights (`bump_weight_epoch`), on the next
@@ -110,6 +125,11 @@ def _table_pack(w, kind: str):
     tab = w._gg_pack_table
     slot = w.__dict__.get('_gg_tpacks')
     ent = slot.get(kind) if slot else None
+    if ent is not None and ent[1] == w.data_ptr() and ent[2] != w._version:
+        # the parameter was written in place behind the optimizer's back (nn.Module.load_state_dict, a manual edit, another
+        # optimizer): its version counter moved, so the persistent operands are stale -> re-pack the table before use
+        slot[kind] = ent = (ent[0], ent[1], w._version)
+        tab.dirty = True
     if ent is None or ent[1] != w.data_ptr():
         if w.device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
             return None                     # table appends are host->device copies: not while a graph is being captured
@@ -121,9 +141,9 @@ def _table_pack(w, kind: str):
             dst = tab.register_bank(src, shp[0], shp[1], shp[2], shp[3] * shp[4])
             if slot is None:
                 slot = w.__dict__.setdefault('_gg_tpacks', {})
-            ent = slot[kind] = (dst, w.data_ptr())
-            tab.refresh()
-            tab.dirty = False
+            ent = slot[kind] = (dst, w.data_ptr(), w._version)
+            _owners(tab)[id(w)] = weakref.ref(w)
+            _refresh_table(tab)
             return ent[0]
         if len(shp) == 5:
             assert shp[0] == 1 or shp[1] % 8 == 0, 'stacked kernel banks need O % 8 == 0'
@@ -138,12 +158,19 @@ def _table_pack(w, kind: str):
         dst = tab.register(src, O, I, T, tk)
         if slot is None:
             slot = w.__dict__.setdefault('_gg_tpacks', {})
-        ent = slot[kind] = (dst, w.data_ptr())
+        ent = slot[kind] = (dst, w.data_ptr(), w._version)
+        _owners(tab)[id(w)] = weakref.ref(w)
         tab.dirty = True
     if tab.dirty:
-        tab.refresh()
-        tab.dirty = False
+        _refresh_table(tab)
     return ent[0]
+
+
+def _owners(tab):
+    o = getattr(tab, 'owners', None)
+    if o is None:
+        o = tab.owners = {}          # id -> weak reference (tensors compare element-wise: no sets of them)
+    return o
 
 
 def _pad_oi(w: torch.Tensor, o_to: int, i_to: int) -> torch.Tensor:
@@ -164,9 +191,9 @@ def packed_weight(w: torch.Tensor, kind: str) -> torch.Tensor:
         out = _table_pack(w, kind)
         if out is not None:
             return out
-    if cacheable:       # the cache lives on the Parameter object itself: (epoch, {kind: packed})
+    if cacheable:       # the cache lives on the Parameter object itself: (epoch, {kind: packed}, tensor version)
         slot = getattr(w, '_gg_packed', None)
-        if slot is not None and slot[0] == _weight_epoch and kind in slot[1]:
+        if slot is not None and slot[0] == _weight_epoch and slot[2] == w._version and kind in slot[1]:
             return slot[1][kind]
     with torch.no_grad():
         wd = w.detach()
@@ -190,8 +217,8 @@ def packed_weight(w: torch.Tensor, kind: str) -> torch.Tensor:
                 raise ValueError(kind)
     if cacheable:
         slot = getattr(w, '_gg_packed', None)
-        if slot is None or slot[0] != _weight_epoch:
-            slot = (_weight_epoch, {})
+        if slot is None or slot[0] != _weight_epoch or slot[2] != w._version:
+            slot = (_weight_epoch, {}, w._version)
             w._gg_packed = slot
         slot[1][kind] = out
     return out

@@ -71,6 +71,8 @@ class FlatAdamW(torch.optim.Optimizer):
             st['exp_avg'] = self.flat_m[off:off + n].view(p.shape)
             st['exp_avg_sq'] = self.flat_v[off:off + n].view(p.shape)
         self.flags = flags.to(device)
+        self._flags_host = flags
+        self._flag_variants = {}
         # conv weights: persistent bf16 GEMM operands, re-packed by one launch per epoch (ops._table_pack)
         from .kernels import PackTable
         self.pack_table = PackTable(device, capacity=3 * len(self._all) + 16)
@@ -87,8 +89,23 @@ class FlatAdamW(torch.optim.Optimizer):
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + off * 4:
                 p.grad = self.flat_g[off:off + p.numel()].view(p.shape)
 
+    def flags_without(self, params):
+        """the per-256-block flag table with `params` switched off for one step (their gradient is None in the reference:
+        torch optimizers then skip them entirely - no moment update, no weight decay). Cached per parameter set."""
+        key = frozenset(id(p) for p in params)
+        if not key:
+            return self.flags
+        fl = self._flag_variants.get(key)
+        if fl is None:
+            host = self._flags_host.clone()
+            for p, off in zip(self._all, self.offsets):
+                if id(p) in key:
+                    host[off // ALIGN:(off + p.numel() + ALIGN - 1) // ALIGN] &= 0xFE
+            fl = self._flag_variants[key] = host.to(self.flags.device)
+        return fl
+
     @torch.no_grad()
-    def step(self, grad_scale: float = 1.0):
+    def step(self, grad_scale: float = 1.0, skip=()):
         g = self.param_groups[0]
         lr, (b1, b2), eps = g['lr'], g['betas'], g['eps']
         self.step_count += 1
@@ -98,7 +115,7 @@ class FlatAdamW(torch.optim.Optimizer):
             raise RuntimeError('FlatAdamW: parameters are on the CPU; the fused optimizer runs on the GPU only')
         L.require(self.flat_p)
         rc = L.lib.gg_adamw_flat_f32(ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), ptr(self.flat_v),
-                                     ptr(self.flags), self.total, lr, b1, b2, eps, self.wd,
+                                     ptr(self.flags_without(skip)), self.total, lr, b1, b2, eps, self.wd,
                                      1. - b1 ** t, math.sqrt(1. - b2 ** t), grad_scale, L.stream(self.flat_p))
         L.check(rc, 'gg_adamw_flat_f32')
         from . import ops
