@@ -31,10 +31,29 @@ def rel(a, b):
     return ((a.float() - b.float()).norm() / b.float().norm().clamp(min=1e-12)).item()
 
 
+def pmc_shapes():
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(0)
+    b = 32
+    for name, n, R, ci, co in [('D4.conv2', 8 * b, 16, 512, 512), ('D3.conv2', 4 * b, 32, 256, 256), ('D5.conv', 16 * b, 8, 512, 512)]:
+        x = torch.randn(n, R, R, ci, device=dev).to(torch.bfloat16)
+        w = (torch.randn(co, 9 * ci, device=dev) * 0.05).to(torch.bfloat16)
+        dy = torch.randn(n, R, R, co, device=dev).to(torch.bfloat16)
+        for _ in range(3):
+            K.conv2d_nhwc(x, w, ksize=3)
+            K.conv2d_wgrad_nhwc(x, dy, ksize=3)
+        torch.cuda.synchronize()
+        print(name, 'done', flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--quick', action='store_true')
+    ap.add_argument('--pmc-shapes', action='store_true',
+                    help='a handful of launches of the dominant layers with the planned tiles (for rocprofv3 --pmc passes)')
     args = ap.parse_args()
+    if args.pmc_shapes:
+        return pmc_shapes()
     dev = torch.device('cuda', 0)
     torch.manual_seed(0)
     b = 32

@@ -1,0 +1,186 @@
+"""-m gpu: the HBM-bound passes that so far were only compared on the CPU emulator — fused AdamW / EMA (reference optimizer.py:10-34,
+gp.py:2603), softmax / RMSNorm second-order passes (what the gradient penalty's double backward runs, gp.py:120-155), the
+resampling stencil and its adjoint (gp.py:246-261, :1683-1687), the squeeze-excite pool (gp.py:297-307) — each on the MI355X
+against fp32 torch math of the same op at model-sized shapes. Expectations are stated per test."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gigagan_pytorch_amd import kernels as K, ops
+from oracle.torch_ops import OracleOps
+from helpers import rel_err, bf
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device('cuda', 0)
+
+
+def test_fused_adamw_matches_torch_adamw_on_the_gpu():
+    """gg_adamw_flat_f32 vs torch.optim.AdamW (fp32, same hyper-parameters as the trainer: lr 2e-4, betas (0.5, 0.9), weight
+    decay 1e-2 on ndim >= 2 only) over 5 steps on ~3 M parameters. Same formula, different operation order (the kernel folds
+    the bias corrections into two scalars): parameters agree to 2e-7 relative L2 and 1e-6 max-abs on O(1) values, moments to
+    1e-6; inactive / skipped parameters stay bit-identical."""
+    from gigagan_pytorch_amd.optimizer import FlatAdamW
+    torch.manual_seed(0)
+    d = dev()
+    shapes = [(512, 512, 3, 3), (512,), (1024, 257), (3, 64, 7, 7), (77,)]
+    ps = [torch.nn.Parameter(torch.randn(*s, device=d)) for s in shapes]
+    frozen = torch.nn.Parameter(torch.randn(33, 9, device=d))
+    extra = torch.nn.Parameter(torch.randn(300, 5, device=d))        # skipped in one step (its gradient is None there)
+    rs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    fo = FlatAdamW([*ps, frozen, extra], lr=2e-4, betas=(0.5, 0.9), inactive=[frozen])
+    to = torch.optim.AdamW([{'params': [r for r in rs if r.ndim >= 2]}, {'params': [r for r in rs if r.ndim < 2], 'weight_decay': 0.}],
+                           lr=2e-4, betas=(0.5, 0.9), weight_decay=1e-2)
+    frozen0 = frozen.detach().clone()
+    for step in range(5):
+        fo.zero_grad()
+        for p, r in zip(ps, rs):
+            g = torch.randn_like(p) * (10.0 ** (step - 2))
+            p.grad.add_(g)
+            r.grad = g.clone()
+        frozen.grad.add_(1.0)
+        extra.grad.add_(1.0)
+        before = extra.detach().clone()
+        fo.step(skip=[extra] if step == 2 else [])
+        to.step()
+        assert torch.equal(extra.detach(), before) == (step == 2)      # no decay, no moment-driven move when skipped
+    for p, r in zip(ps, rs):
+        assert rel_err(p, r) < 2e-7 and float((p - r).abs().max()) < 1e-6, (p.shape, rel_err(p, r))
+        assert rel_err(fo.state[p]['exp_avg'], to.state[r]['exp_avg']) < 1e-6
+        assert rel_err(fo.state[p]['exp_avg_sq'], to.state[r]['exp_avg_sq']) < 1e-6
+    assert torch.equal(frozen.detach(), frozen0)
+    # data-parallel mean folded into the update: grad_scale = 1 / world
+    fo.zero_grad()
+    for p, r in zip(ps, rs):
+        g = torch.randn_like(p)
+        p.grad.add_(4 * g)
+        r.grad = g.clone()
+    fo.step(grad_scale=0.25)
+    to.step()
+    for p, r in zip(ps, rs):
+        assert rel_err(p, r) < 2e-7
+
+
+def test_fused_ema_matches_lerp_on_the_gpu():
+    """gg_ema_flat_f32: ema += (1 - decay) * (p - ema) over a flat buffer; against torch.lerp_ in fp32: <= 1 ulp apart."""
+    from gigagan_pytorch_amd import _C
+    from gigagan_pytorch_amd._C import ptr
+    torch.manual_seed(0)
+    d = dev()
+    n = 3_000_064
+    ema, p = torch.randn(n, device=d), torch.randn(n, device=d)
+    ref = ema.clone()
+    L = _C.lib()
+    for decay in (0.798, 0.995):
+        L.check(L.lib.gg_ema_flat_f32(ptr(ema), ptr(p), n, 1. - decay, L.stream(ema)), 'gg_ema_flat_f32')
+        ref.lerp_(p, 1. - decay)
+    assert float((ema - ref).abs().max()) < 5e-7 and rel_err(ema, ref) < 1e-7
+
+
+def test_softmax_passes_first_and_second_order_at_attention_shapes():
+    """gg_softmax_fwd/_bwd/_bwd2 at the discriminator's 32x32 attention width (1025 keys incl. the null key, padded to 1032)
+    against fp32 tensor algebra on the same bf16 inputs: bf16 outputs, 4e-3 relative L2."""
+    torch.manual_seed(0)
+    d = dev()
+    nb, n, m, ld = 16, 1024, 1025, 1032
+    x = torch.randn(nb, n, ld, device=d)
+    bias = torch.randn(nb, ld, device=d) * 0.3
+    alpha = 0.25
+    S = K.softmax_fwd(x, bias, alpha, m)
+    ref = (alpha * x[..., :m] + bias[:, None, :m]).softmax(-1)
+    assert rel_err(S[..., :m], ref) < 4e-3 and float(S[..., m:].float().abs().max()) == 0
+    dS, g_dx = bf(torch.randn(nb, n, ld, device=d)), bf(torch.randn(nb, n, ld, device=d))
+    g_db = torch.randn(nb, ld, device=d)
+    Sf, dSf = S.float()[..., :m], dS.float()[..., :m]
+    r = (Sf * dSf).sum(-1, keepdim=True)
+    dx, dbias = K.softmax_bwd(S, dS, alpha, m, True)
+    u = Sf * (dSf - r)
+    assert rel_err(dx[..., :m], alpha * u) < 4e-3 and rel_err(dbias[:, :m], u.sum(1)) < 1e-3
+    gt = alpha * g_dx.float()[..., :m] + g_db[:, None, :m]
+    gs = (gt * Sf).sum(-1, keepdim=True)
+    g_S, g_dS = K.softmax_bwd2(S, dS, g_dx, g_db, alpha, m)
+    assert rel_err(g_S[..., :m], gt * (dSf - r) - dSf * gs) < 4e-3 and rel_err(g_dS[..., :m], Sf * (gt - gs)) < 4e-3
+    assert float(g_S[..., m:].float().abs().max()) == 0 and float(g_dS[..., m:].float().abs().max()) == 0
+
+
+@pytest.mark.parametrize('cfg', [(4, 256, 32, 32), (2, 512, 16, 16), (2, 64, 64, 64)])
+def test_channel_rmsnorm_first_and_second_order_vs_fp32_autograd(cfg):
+    """ChannelRMSNorm (gp.py:224-232) forward, backward and the backward of the backward at model widths against fp32 autograd
+    of the oracle on the same bf16 input: 6e-3 forward, 2e-2 first order, 5e-2 second order (bf16 intermediates)."""
+    b, c, h, w = cfg
+    torch.manual_seed(0)
+    H_, O_ = ops.HipOps(), OracleOps()
+    x0 = bf(torch.randn(b, c, h, w)).float()
+    gamma0 = torch.rand(c, 1, 1) + 0.5
+    wgt = torch.randn(b, c, h, w)
+
+    def run(I, d):
+        x = x0.to(d).requires_grad_()
+        gamma = gamma0.to(d).requires_grad_()
+        y = I.channel_rmsnorm(x, gamma).float()
+        gx, = torch.autograd.grad((y * wgt.to(d)).sum(), x, create_graph=True)
+        gg = torch.autograd.grad(gx.float().pow(2).sum(), [x, gamma])
+        g1 = torch.autograd.grad((I.channel_rmsnorm(x, gamma).float() * wgt.to(d)).sum(), [x, gamma])
+        return [t.detach().float().cpu() for t in (y, gx, *gg, *g1)]
+
+    yh, gxh, ggxh, gggh, g1xh, g1gh = run(H_, dev())
+    yo, gxo, ggxo, gggo, g1xo, g1go = run(O_, torch.device('cpu'))
+    assert rel_err(yh, yo) < 6e-3 and rel_err(gxh, gxo) < 2e-2
+    assert rel_err(g1xh, g1xo) < 2e-2 and rel_err(g1gh, g1go) < 2e-2
+    assert rel_err(ggxh, ggxo) < 5e-2 and rel_err(gggh, gggo) < 5e-2
+
+
+@pytest.mark.parametrize('cfg', [(4, 64, 32, 32), (2, 8, 128, 128), (3, 24, 20, 12)])
+def test_resample_stencil_forward_backward_and_adjoint(cfg):
+    """gg_resample_nhwc_bf16: bilinear x2 + binomial blur and bilinear resize against F.interpolate / the oracle's blur on the
+    same bf16 input (4e-3: bf16 output rounding), their backward against fp32 autograd (1e-2), and the adjoint identity
+    <R x, y> = <x, R^T y> evaluated in fp64 on the kernel's own outputs (2e-3: two bf16-rounded outputs)."""
+    b, c, h, w = cfg
+    torch.manual_seed(0)
+    d = dev()
+    H_, O_ = ops.HipOps(), OracleOps()
+    x0 = bf(torch.randn(b, c, h, w)).float()
+    for name, fn_h, fn_o in (('upsample_blur', lambda t: H_.upsample_blur(t), lambda t: O_.upsample_blur(t)),
+                             ('resize', lambda t: H_.resize_bilinear(t, (h // 2, w // 2)),
+                              lambda t: F.interpolate(t, (h // 2, w // 2), mode='bilinear'))):
+        xh = x0.to(d).requires_grad_()
+        xo = x0.clone().requires_grad_()
+        yh, yo = fn_h(xh), fn_o(xo)
+        assert rel_err(yh.float().cpu(), yo) < 4e-3, name
+        g = bf(torch.randn_like(yo)).float()
+        gh, = torch.autograd.grad(yh.float(), xh, g.to(d))
+        go, = torch.autograd.grad(yo, xo, g)
+        assert rel_err(gh.float().cpu(), go) < 1e-2, name
+        xp = bf(torch.rand(b, c, h, w)).float().to(d).requires_grad_()      # positive operands: no cancellation in <.,.>
+        yp = fn_h(xp)
+        gp_ = bf(torch.rand(*yp.shape)).float().to(d)
+        gxp, = torch.autograd.grad(yp.float(), xp, gp_)
+        lhs = (yp.detach().double() * gp_.double()).sum()
+        rhs = (gxp.double() * xp.detach().double()).sum()
+        assert abs(lhs - rhs) / abs(lhs) < 2e-3, (name, float(lhs), float(rhs))
+
+
+def test_squeeze_excite_pool_and_channel_scale_vs_fp32():
+    """SqueezeExcite's global mean (gp.py:300) and the excitation multiply (gp.py:1023-1024, :1812-1813) with their gradients
+    at the generator's 64x64 / 128-channel stage, against fp32 math on the same bf16 input."""
+    torch.manual_seed(0)
+    d = dev()
+    H_ = ops.HipOps()
+    x0 = bf(torch.randn(8, 128, 64, 64)).float()
+    s0 = torch.rand(8, 128) + 0.5
+    xh, sh = x0.to(d).requires_grad_(), s0.to(d).requires_grad_()
+    xo, so = x0.clone().requires_grad_(), s0.clone().requires_grad_()
+    mh, mo = H_.global_mean(xh), xo.mean(dim=(2, 3))
+    assert rel_err(mh.cpu(), mo) < 1e-5
+    yh = H_.channel_scale(xh, sh)
+    yo = xo * so[:, :, None, None]
+    assert rel_err(yh.float().cpu(), yo) < 4e-3
+    g = bf(torch.randn_like(yo)).float()
+    gm = torch.randn_like(mo)
+    ghx, ghs = torch.autograd.grad([yh.float(), mh], [xh, sh], [g.to(d), gm.to(d)])
+    gox, gos = torch.autograd.grad([yo, mo], [xo, so], [g, gm])
+    assert rel_err(ghx.float().cpu(), gox) < 1e-2 and rel_err(ghs.cpu(), gos) < 1e-3
