@@ -81,6 +81,20 @@ def aux_matching_loss(real, fake):
     return (F.softplus(-real.float()) + F.softplus(-fake.float())).mean()
 
 
+def aux_clip_loss(clip, images, texts=None, text_embeds=None):
+    """CLIP contrastive loss of the generator (gp.py:174-188): images (and caption embeddings) are gathered over the
+    data-parallel ranks with a differentiable all-gather (reference distributed.py:47-68; here RCCL's all_gather with the
+    local slice as its backward), then the frozen CLIP adapter scores every caption against every image. `clip` is the
+    injected adapter (`OpenClipAdapter`, open_clip.py:17-158): `embed_texts(texts) -> (embeds, encodings)` and
+    `contrastive_loss(images=, text_embeds=)`; CLIP's own arithmetic is third-party and stays outside this package."""
+    assert exists(texts) ^ exists(text_embeds)
+    images, batch_sizes = gdist.all_gather(images, 0, None)
+    if exists(texts):
+        text_embeds, _ = clip.embed_texts(texts)
+        text_embeds, _ = gdist.all_gather(text_embeds, 0, batch_sizes)
+    return clip.contrastive_loss(images=images, text_embeds=text_embeds)
+
+
 class DiffAugment(nn.Module):
     """random horizontal flip of image + rgbs (gp.py:193-220)."""
 
@@ -628,14 +642,19 @@ class GigaGAN(nn.Module):
         return TrainDiscrLosses(total_divergence, total_multiscale_divergence, 0., total_matching_aware_loss,
                                 total_gp_loss, total_aux_loss)
 
-    def _g_micro(self, batch_size, dl_iter, grad_accum_every, calc_multiscale_loss):
-        """forward + backward of ONE generator micro-batch (gp.py:2516-2580)."""
+    def _g_micro(self, batch_size, dl_iter, grad_accum_every, calc_multiscale_loss, collect=None):
+        """forward + backward of ONE generator micro-batch (gp.py:2516-2580). `collect`: (images, texts) lists for the CLIP
+        contrastive loss, whose backward runs after all micro-batches (the graph is retained for it, gp.py:2576)."""
         dev = self.device
         zero = torch.zeros((), device=dev)
         G_kwargs, maybe_text_kwargs = self.generate_kwargs(dl_iter, batch_size)
         images, rgbs = self.G(**G_kwargs, **maybe_text_kwargs, return_all_rgbs=True)
         if exists(self.diff_augment):
             images, rgbs = self.diff_augment(images, rgbs)
+        if collect is not None:
+            assert 'texts' in maybe_text_kwargs, 'the CLIP contrastive loss embeds raw captions: the loader must yield (images, List[str])'
+            collect[0].append(images)
+            collect[1].extend(maybe_text_kwargs['texts'])
 
         logits, ms_logits, _ = self.D(images, rgbs, **maybe_text_kwargs,
                                       return_multiscale_outputs=calc_multiscale_loss, calc_aux_loss=False)
@@ -648,13 +667,26 @@ class GigaGAN(nn.Module):
                 ms_div = ms_div + generator_hinge_loss(ms)
             ms_detached = ms_div.detach()
             total_loss = total_loss + ms_div * self.multiscale_divergence_loss_weight
-        _backward(total_loss / grad_accum_every)
+        ops.grad_sink = True
+        try:
+            (total_loss / grad_accum_every).backward(retain_graph=collect is not None)
+        finally:
+            ops.grad_sink = False
         return divergence.detach(), ms_detached
+
+    def _contrastive_adapter(self):
+        """the frozen CLIP adapter the generator's text encoder carries (gp.py:2583-2585), when the contrastive loss is on."""
+        if not self.need_contrastive_loss:
+            return None
+        clip = getattr(getattr(self.G, 'text_encoder', None), 'clip', None)
+        return clip if (exists(clip) and hasattr(clip, 'contrastive_loss')) else None
 
     def train_generator_step(self, batch_size=None, dl_iter=None, grad_accum_every=1, calc_multiscale_loss=True):
         dev = self.device
         zero = torch.zeros((), device=dev)
         contrastive_loss = 0.
+        clip = self._contrastive_adapter()
+        collected = ([], []) if exists(clip) else None
 
         self.G.train()
         self.D.train()
@@ -679,16 +711,18 @@ class GigaGAN(nn.Module):
                 total_multiscale_divergence = zero.clone() if calc_multiscale_loss else None
                 self.G_opt.zero_grad()
                 for _ in range(grad_accum_every):
-                    d, ms = self._g_micro(batch_size, dl_iter, grad_accum_every, calc_multiscale_loss)
+                    d, ms = self._g_micro(batch_size, dl_iter, grad_accum_every, calc_multiscale_loss, collect=collected)
                     total_divergence += d / grad_accum_every
                     if calc_multiscale_loss:
                         total_multiscale_divergence += ms / grad_accum_every
+                if exists(clip):
+                    # gather every micro-batch's images and captions (over the ranks too) and score them with CLIP (gp.py:2578-2592)
+                    loss = aux_clip_loss(clip=clip, texts=collected[1], images=torch.cat(collected[0], dim=0).float())
+                    contrastive_loss = loss.detach()
+                    _backward(loss * self.generator_contrastive_loss_weight)
         finally:
             for p in self.D.parameters():
                 p.requires_grad_(True)
-
-        if self.need_contrastive_loss and exists(getattr(self.G.text_encoder, 'clip', None)):
-            raise NotImplementedError('CLIP contrastive loss needs the external CLIP adapter (SURVEY.md §8f rank 2)')
 
         works = gdist.all_reduce_flat_grads(self.G_opt.flat_g)
         gdist.wait_all(works)

@@ -69,7 +69,7 @@ def _kernel_key(d: GemmDesc, L) -> str:
 
 
 def _run_gemm(d: GemmDesc, like: torch.Tensor):
-    """launches the contraction; returns the split-K workspace (or None) so that `no_reduce` callers can fold the partials."""
+    """launches the contraction (the split-K workspace, if any, comes from the caching allocator for this one launch)."""
     L = _C.lib()
     need = L.lib.gg_gemm_workspace_bytes(C.byref(d))
     ws = _workspace(need, like) if need else None
@@ -209,7 +209,7 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, *, ksize: int, stride: int = 1
 
 
 def conv2d_wgrad_nhwc(x: torch.Tensor, dy: torch.Tensor, *, ksize: int, stride: int = 1, pad: int | None = None,
-                      cv: int | None = None, in_scale=None, force_splitk=0, force_tile=0, keep_partials=False):
+                      cv: int | None = None, in_scale=None, force_splitk=0, force_tile=0):
     """Weight gradient of conv2d_nhwc: returns fp32 (ksize*ksize*CV, Cout) = sum over output pixels of
     gather(x)[pixel][(tap, cv)] * dy[pixel][co]."""
     L = _C.lib()
@@ -237,17 +237,8 @@ def conv2d_wgrad_nhwc(x: torch.Tensor, dy: torch.Tensor, *, ksize: int, stride: 
     d.force_splitk, d.force_tile = force_splitk, force_tile
     if force_tile == 7 or _V3_POLICY:
         d.zero_page = ptr(_zero_page(x.device))
-    if not keep_partials:
-        _run_gemm(d, x)
-        return out
-    # the caller folds the split-K partials itself (wgrad_finish(..., splits=)): -> (fp32 [splits][k*k*cv][cout], splits)
-    d.no_reduce = 1
-    tile, sk = C.c_int32(0), C.c_int32(0)
-    _C.lib().lib.gg_gemm_plan(C.byref(d), C.byref(tile), C.byref(sk))
-    ws = _run_gemm(d, x)
-    if sk.value <= 1 or ws is None:
-        return out.unsqueeze(0), 1
-    return ws.view(torch.float32)[:sk.value * out.numel()].view(sk.value, *out.shape), sk.value
+    _run_gemm(d, x)
+    return out
 
 
 def conv2d_dgrad_d2s(dy: torch.Tensor, w: torch.Tensor, *, cell: int, taps: int, alpha=1.0, force_splitk=0,
@@ -687,27 +678,11 @@ def rmsnorm_bwd2(x, g, v, gamma, want_dgamma: bool):
 def wgrad_finish(g: torch.Tensor, O: int, I: int, T: int, alpha: float = 1.0, out: torch.Tensor | None = None,
                  accumulate: bool = False) -> torch.Tensor:
     """g: (T*C8, O8) fp32 from conv2d_wgrad_nhwc -> (O, I, T) fp32 = alpha * g transposed; with `out` (+ accumulate)
-    the result is written / added in place (e.g. into a parameter's .grad view of the flat gradient buffer). A 3-D g
-    (splits, T*C8, O8) - split-K partials kept by conv2d_wgrad_nhwc(keep_partials=True) - is summed over splits on the way."""
+    the result is written / added in place (e.g. into a parameter's .grad view of the flat gradient buffer)."""
     L = _C.lib()
     L.require(g, out)
-    splits = 1
-    if g.dim() == 3:
-        splits, g2 = g.shape[0], g[0]
-    else:
-        g2 = g
-    assert g.dtype == torch.float32 and g.is_contiguous() and g2.dim() == 2 and g2.shape[0] % T == 0
-    c8, o8 = g2.shape[0] // T, g2.shape[1]
-    if splits > 1:
-        if out is None:
-            assert not accumulate
-            out = torch.empty((O, I, T), dtype=torch.float32, device=g.device)
-        assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == O * I * T
-        rc = L.lib.gg_wgrad_finish_splits(ptr(g), ptr(out), O, I, T, c8, o8, float(alpha), int(accumulate), splits,
-                                          g2.numel(), L.stream(g))
-        L.check(rc, 'gg_wgrad_finish_splits')
-        return out
-    g = g2
+    assert g.dtype == torch.float32 and g.is_contiguous() and g.dim() == 2 and g.shape[0] % T == 0
+    c8, o8 = g.shape[0] // T, g.shape[1]
     if out is None:
         assert not accumulate
         out = torch.empty((O, I, T), dtype=torch.float32, device=g.device)

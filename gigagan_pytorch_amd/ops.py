@@ -99,8 +99,6 @@ def bump_weight_epoch():
 
 _DEBUG_NO_TABLE = bool(os.environ.get('GG_DEBUG_NO_PACK_TABLE'))
 _DEBUG_NO_SINK = bool(os.environ.get('GG_DEBUG_NO_GRAD_SINK'))
-_WGRAD_FUSED = bool(os.environ.get('GG_WGRAD_FUSED'))          # experimental: no separate split-K reduce for weight gradients
-_NARROW_MODCONV = bool(os.environ.get('GG_MODCONV_NARROW'))    # experimental no-grad path for the narrow layers
 
 
 def _refresh_table(tab):
@@ -391,12 +389,7 @@ class WgradFn(Function):
         """the GEMM ([tap][ci][co] fp32, pixels reduced) + the transpose/scale pass into the parameter layout; with
         `sink` (a parameter's fp32 .grad) the result is accumulated there instead of being returned."""
         ksize, stride, pad, wkind = geom
-        if _WGRAD_FUSED:     # EXPERIMENTAL (GG_WGRAD_FUSED=1, unmeasured): split-K partials folded by the finish pass itself
-            g, _ = K.conv2d_wgrad_nhwc(x, dy, ksize=ksize, stride=stride, pad=pad, in_scale=in_scale, keep_partials=True)
-            if g.shape[0] == 1:
-                g = g[0]
-        else:
-            g = K.conv2d_wgrad_nhwc(x, dy, ksize=ksize, stride=stride, pad=pad, in_scale=in_scale)  # (k*k*C8, O8) fp32
+        g = K.conv2d_wgrad_nhwc(x, dy, ksize=ksize, stride=stride, pad=pad, in_scale=in_scale)  # (k*k*C8, O8) fp32
         if wkind == 's2d':              # (O, C, s1, s2) == (O, 4C, 1, 1)
             O, I = wshape[0], wshape[1] // 4
         elif len(wshape) == 5:          # kernel bank (N, O, I, k, k) stacked along output channels
@@ -938,12 +931,12 @@ class HipOps:
             xh = F.pad(xh, (0, Ip - I))
             if not s_padded:
                 s = F.pad(s, (0, Ip - I))
-        if (not needs_grad and _NARROW_MODCONV and k == 3 and N * Op <= 64 and Ip in (16, 32, 64) and Ip == I
+        if (not needs_grad and k == 3 and N * Op <= 64 and Ip in (16, 32, 64) and Ip == I
                 and (Ip <= 32 or N * Op <= 32) and H % 8 == 0 and W % 32 == 0 and b * H * W >= 65536 and d is not None):
-            # EXPERIMENTAL (GG_MODCONV_NARROW=1, off by default, not yet measured on the GPU): the narrow high-resolution
-            # layers as direct convolution (style modulation applied on load, the N kernels stacked along the output
-            # channels: N*O <= 64) + the mix / demodulate / noise / activation pass, instead of the gather-bound
-            # implicit GEMM with the kernels stacked along the reduction
+            # the narrow high-resolution layers as direct convolution (style modulation applied on load, the N kernels stacked
+            # along the output channels: N*O <= 64) + the mix / demodulate / noise / activation pass, instead of the
+            # gather-bound implicit GEMM with the kernels stacked along the reduction. Measured (profiles/r02_modconv_ab.log):
+            # 32->32@128x128 127 -> 45 us, 32->16@256x256 417 -> 93 us, 16->16@256x256 242 -> 50 us
             Y = K.conv2d_nhwc(xh, packed_weight(weights, 'fwd'), ksize=3, in_scale=s.contiguous())    # I == Ip here
             d8 = (F.pad(d, (0, Op - O)) if (Op != O and not d_padded) else d).contiguous()
             nz = nw = None
@@ -1119,9 +1112,6 @@ def demod_coefficients(weights, s, a, eps):
     return sumsq.clamp(min=eps).rsqrt()
 
 
-_PREMOD_MODCONV = bool(os.environ.get('GG_MODCONV_PREMOD'))     # experimental no-grad path for the low/mid-resolution layers
-
-
 def fused_modconv_forward(xh, wts, s, a, d, noise, noise_weight, act, O, Op, d_padded=False, wk=None):
     """no-grad path: the whole adaptive conv (kernel mix, modulation, demodulation, noise, leaky-relu) as
     ONE implicit-GEMM launch with the N kernels stacked along the reduction and batch folded into M. `wk`: the
@@ -1139,11 +1129,12 @@ def fused_modconv_forward(xh, wts, s, a, d, noise, noise_weight, act, O, Op, d_p
         nz = noise.reshape(-1).float().contiguous()
         nw = noise_weight.reshape(-1).float()
         nw = (F.pad(nw, (0, Op - O)) if Op != O else nw).contiguous()
-    if _PREMOD_MODCONV and k == 3 and b * H * W <= 131072:
-        # EXPERIMENTAL (GG_MODCONV_PREMOD=1, off by default, unmeasured): the per-sample scale a_n * s applied to the
-        # activation by one pointwise pass per kernel of the bank (channels laid out (n, ci) like the packed reduction),
-        # so the convolution is the plain gather of the discriminator's layers - the in-gather scale costs two extra loads
-        # and a wait per staged vector. Worth it where the activation is small next to the weights (<= 64x64).
+    if k == 3 and b * H * W <= 131072:
+        # the per-sample scale a_n * s applied to the activation by one pointwise pass per kernel of the bank (channels laid
+        # out (n, ci) like the packed reduction), so the convolution is the plain gather of the discriminator's layers - the
+        # in-gather scale costs two extra loads and a wait per staged vector. Worth it where the activation is small next to
+        # the weights (<= 64x64). Measured (profiles/r02_modconv_ab.log): 8x8 90 -> 71 us, 16x16 138 -> 122 us, 32x32
+        # 137 -> 111 us, 64x64 154 -> 120 us / 96 -> 69 us
         x2 = torch.cat([K.modulate(xh, insc[:, n * Ip:(n + 1) * Ip].contiguous()) for n in range(N)], dim=-1) if N > 1 \
             else K.modulate(xh, insc)
         return K.conv2d_nhwc(x2, wk, ksize=k, out_scale=out_scale, noise=nz, noise_w=nw, act=act, act_slope=LRELU_SLOPE)

@@ -30,6 +30,32 @@ def _worker(rank, world, port, ret):
     out, sizes = gdist.all_gather(x)
     (out * torch.arange(4.)[:, None]).sum().backward()
     ok = ok and out.shape == (4, 3) and torch.equal(x.grad, torch.arange(4.)[rank * 2:(rank + 1) * 2, None].expand(2, 3))
+    # the generator's CLIP contrastive loss (gp.py:174-188): images and caption embeddings of every rank are gathered, each rank
+    # keeps the gradient of ITS images; equals the single-process loss / gradient on the concatenated batch
+    import torch.nn.functional as F
+    from gigagan_pytorch_amd.gigagan import aux_clip_loss
+
+    class Clip:
+        proj = torch.randn(3 * 2 * 2, 6, generator=torch.Generator().manual_seed(5))
+        table = F.normalize(torch.randn(16, 6, generator=torch.Generator().manual_seed(6)), dim=-1)
+
+        def embed_texts(self, texts):
+            return self.table[[int(t) for t in texts]], None
+
+        def contrastive_loss(self, images, text_embeds):
+            emb = F.normalize(F.adaptive_avg_pool2d(images, 2).flatten(1) @ self.proj, dim=-1)
+            sim = text_embeds @ emb.t() * 10.
+            labels = torch.arange(sim.shape[0])
+            return (F.cross_entropy(sim, labels) + F.cross_entropy(sim.t(), labels)) / 2
+
+    imgs_all = torch.rand(4, 3, 8, 8, generator=torch.Generator().manual_seed(3))
+    mine = imgs_all[rank * 2:(rank + 1) * 2].clone().requires_grad_()
+    loss = aux_clip_loss(Clip(), mine, texts=[str(2 * rank), str(2 * rank + 1)])
+    loss.backward()
+    full = imgs_all.clone().requires_grad_()
+    ref = Clip().contrastive_loss(full, Clip().embed_texts(['0', '1', '2', '3'])[0])
+    ref.backward()
+    ok = ok and torch.allclose(loss, ref, atol=1e-6) and torch.allclose(mine.grad, full.grad[rank * 2:(rank + 1) * 2], atol=1e-6)
     ret[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()

@@ -117,6 +117,73 @@ def test_text_conditional_training_steps_match_the_reference_trainer(reference, 
         assert rel_err(_flat(gan.G.parameters()), _flat(ref_gan.unwrapped_G.parameters())) < 1e-6
 
 
+def test_generator_contrastive_loss_matches_the_reference_trainer(reference, tmp_path):
+    """config 4's generator step with the CLIP contrastive loss on (gp.py:174-188, :2530-2592, weight 0.1): images of both
+    micro-batches and their captions go through the (stand-in, deterministic) frozen adapter's `contrastive_loss`; the reported
+    loss and the generator after the AdamW update equal the reference trainer's. CLIP's own arithmetic is third-party."""
+    import torch.nn.functional as F
+    from torch import nn
+    from helpers import TEXT_ENC, TEXT_CLIP_DIM, TEXT_G, TEXT_D, text_encodings
+
+    class StandInClip(nn.Module):
+        dim_latent = TEXT_CLIP_DIM
+
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(99)
+            self.register_buffer('img_proj', torch.randn(3 * 4 * 4, 12, generator=g))
+            self.register_buffer('txt_table', F.normalize(torch.randn(64, 12, generator=g), dim=-1))
+
+        def embed_texts(self, texts):
+            enc = torch.cat([text_encodings(batch=1, seed=int(t)) for t in texts])
+            for i, t in enumerate(texts):
+                enc[i, 3 + int(t) % 4:] = 0
+            return self.txt_table[[int(t) % 64 for t in texts]], enc
+
+        def embed_images(self, images):
+            feats = F.adaptive_avg_pool2d(images, 4).flatten(1) @ self.img_proj
+            return F.normalize(feats, dim=-1), None
+
+        def contrastive_loss(self, images, texts=None, text_embeds=None):        # the arithmetic of open_clip.py:139-158
+            if text_embeds is None:
+                text_embeds, _ = self.embed_texts(texts)
+            image_embeds, _ = self.embed_images(images)
+            sim = torch.einsum('i d, j d -> i j', text_embeds, image_embeds) * 14.3
+            labels = torch.arange(text_embeds.shape[0])
+            return (F.cross_entropy(sim, labels) + F.cross_entropy(sim.t(), labels)) / 2
+
+    torch.manual_seed(0)
+    ref_gan = reference.GigaGAN(
+        generator=reference.Generator(text_encoder=reference.TextEncoder(clip=StandInClip(), **TEXT_ENC), **TEXT_G),
+        discriminator=reference.Discriminator(text_encoder=reference.TextEncoder(clip=StandInClip(), **TEXT_ENC), **TEXT_D),
+        generator_contrastive_loss_weight=0.1, model_folder=str(tmp_path / 'rm'), results_folder=str(tmp_path / 'rr'))
+    te = dict(clip=StandInClip(), **TEXT_ENC)
+    gan = GigaGAN(generator=dict(text_encoder=dict(te), **TEXT_G), discriminator=dict(text_encoder=dict(te), **TEXT_D),
+                  generator_contrastive_loss_weight=0.1, device='cpu', create_ema_generator_at_init=False,
+                  model_folder=str(tmp_path / 'm'), results_folder=str(tmp_path / 'r'))
+    assert gan.need_contrastive_loss
+    gan.G.load_state_dict(ref_gan.unwrapped_G.state_dict())
+    gan.D.load_state_dict(ref_gan.unwrapped_D.state_dict())
+    ops.bump_weight_epoch()
+
+    def loader():
+        i = 0
+        while True:
+            yield torch.rand(2, 3, 16, 16, generator=torch.Generator().manual_seed(7 + i)), [str(2 * i), str(2 * i + 1)]
+            i += 1
+
+    it_ref, it_ours = loader(), loader()
+    torch.manual_seed(12)
+    g_ref = ref_gan.train_generator_step(batch_size=2, dl_iter=it_ref, grad_accum_every=2)
+    with ops.use_impl(OracleOps()):
+        torch.manual_seed(12)
+        g_ours = gan.train_generator_step(batch_size=2, dl_iter=it_ours, grad_accum_every=2)
+    assert float(g_ref.contrastive_loss) > 0
+    for a, b in zip(g_ours, g_ref):
+        assert abs(float(a) - float(b)) <= 1e-5 * max(1., abs(float(b))), (g_ours, g_ref)
+    assert rel_err(_flat(gan.G.parameters()), _flat(ref_gan.unwrapped_G.parameters())) < 1e-6
+
+
 def test_training_loop_with_gradient_accumulation_matches_the_reference(reference, tmp_path, capsys):
     """`GigaGAN.__call__(steps=, grad_accum_every=)` (gp.py:2665-2750) over a real DataLoader: three steps with two
     micro-batches each (the second step with the gradient penalty) leave the same weights, step counter, log lines and
