@@ -149,6 +149,7 @@ static const GgTileModel kTileModels[] = {
     {5, 256, 128, 64, 1.45, 256, 3.0},
     {6, 128, 128, 64, 1.50, 512, 2.5},    // 8 waves, 72 KB LDS: 2 workgroups per CU (small-M layers: no split-K needed)
     {7, 256, 256, 32, 1.10, 256, 3.0},    // EXPERIMENTAL LDS-DMA ring (gg_gemm3.h): force_tile = 7 only, never planned
+    {8, 256, 256, 32, 1.00, 256, 3.0},    // the same ring with the two wave rows staggered (ping-pong): force_tile = 8 only
 };
 
 // tile 7: dense row-major x row-major, whole 32-k stages, 16-byte aligned rows
@@ -243,9 +244,10 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     const int v1_tile = d->N <= 32 ? 3 : (d->N <= 64 ? 2 : 1);
     int forced = d->force_tile;
     if (forced == 0 && gg_v3_policy() >= 2 && gg_v3_eligible(d)) forced = 7;
-    if (forced == 7 && !gg_v3_eligible(d)) forced = 0;
+    if ((forced == 7 || forced == 8) && !gg_v3_eligible(d)) forced = 0;
+    if (forced == 8 && d->a_layout == GG_KROW) forced = 7;     // the weight-gradient ring has no staggered variant yet
     if (forced >= 4 && forced <= 6 && !gg_v2_eligible(d)) forced = 0;
-    if (forced < 0 || forced > 7) forced = 0;      // (9 = direct convolution: handled above when eligible)
+    if (forced < 0 || forced > 8) forced = 0;      // (9 = direct convolution: handled above when eligible)
     double best = 1e30;
     pl.tile = v1_tile; pl.splitk = 1;
     for (const GgTileModel& tm : kTileModels) {
@@ -253,6 +255,7 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
             if (tm.tile != forced) continue;
         } else {
             // experimental LDS-DMA ring: forced, or offered to the cost model when GG_GEMM_V3=1 (next round's A/B switch)
+            if (tm.tile == 8) continue;
             if (tm.tile == 7 && !(gg_v3_policy() && gg_v3_eligible(d) && d->N >= 192 && d->M >= 192)) continue;
             if (tm.tile <= 3 && tm.tile != v1_tile) continue;
             if (tm.tile >= 4 && (!v2ok || !pol)) continue;
@@ -268,7 +271,7 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
         // the 4-wave tiles may split much further: a narrow weight gradient (M*N of a few thousand, K = millions of
         // pixels) needs thousands of workgroups in flight to pull HBM bandwidth; its partials stay small
         const int sk_cap = tm.tile <= 3 ? 4096 : 256;
-        if (tm.tile == 7) max_sk = ktiles / 8 > 0 ? ktiles / 8 : 1;
+        if (tm.tile >= 7) max_sk = ktiles / 8 > 0 ? ktiles / 8 : 1;
         if (max_sk > sk_cap) max_sk = sk_cap;
         if ((long long)d->batch * max_sk > 65535) max_sk = (int)(65535 / d->batch);
         int lo = 1, hi = max_sk;
@@ -420,17 +423,27 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
         else if (d->C == 32) { if (wide) gg_launch_dconv<32, 2>(p, s); else gg_launch_dconv<32, 1>(p, s); }
         else { if (wide) gg_launch_dconv<64, 2>(p, s); else gg_launch_dconv<64, 1>(p, s); }
     }
+    else if (pl.tile == 8) {
+        const bool full = p.bias || p.out_scale || p.noise || p.residual || p.act != GG_ACT_NONE;
+        if (aconv) {
+            if (full) GG_LAUNCH((gg_gemm3_kernel<true, true, true>), grid2, dim3(GG2_NT), s, p);
+            else GG_LAUNCH((gg_gemm3_kernel<true, false, true>), grid2, dim3(GG2_NT), s, p);
+        } else {
+            if (full) GG_LAUNCH((gg_gemm3_kernel<false, true, true>), grid2, dim3(GG2_NT), s, p);
+            else GG_LAUNCH((gg_gemm3_kernel<false, false, true>), grid2, dim3(GG2_NT), s, p);
+        }
+    }
     else if (pl.tile == 7) {
         const bool full = p.bias || p.out_scale || p.noise || p.residual || p.act != GG_ACT_NONE;
         if (akrow) {
             if (aconv) GG_LAUNCH((gg_gemm3k_kernel<true>), grid2, dim3(GG2_NT), s, p);
             else GG_LAUNCH((gg_gemm3k_kernel<false>), grid2, dim3(GG2_NT), s, p);
         } else if (aconv) {
-            if (full) GG_LAUNCH((gg_gemm3_kernel<true, true>), grid2, dim3(GG2_NT), s, p);
-            else GG_LAUNCH((gg_gemm3_kernel<true, false>), grid2, dim3(GG2_NT), s, p);
+            if (full) GG_LAUNCH((gg_gemm3_kernel<true, true, false>), grid2, dim3(GG2_NT), s, p);
+            else GG_LAUNCH((gg_gemm3_kernel<true, false, false>), grid2, dim3(GG2_NT), s, p);
         } else {
-            if (full) GG_LAUNCH((gg_gemm3_kernel<false, true>), grid2, dim3(GG2_NT), s, p);
-            else GG_LAUNCH((gg_gemm3_kernel<false, false>), grid2, dim3(GG2_NT), s, p);
+            if (full) GG_LAUNCH((gg_gemm3_kernel<false, true, false>), grid2, dim3(GG2_NT), s, p);
+            else GG_LAUNCH((gg_gemm3_kernel<false, false, false>), grid2, dim3(GG2_NT), s, p);
         }
     }
     else if (pl.tile == 4) gg_launch_gemm2_tile<256, 256, 2, 4>(p, akrow, bkrow, aconv, grid2, s);

@@ -87,6 +87,9 @@ GG_DEVICE void gg_barrier_raw() {
     asm volatile("" ::: "memory");
 }
 
+template <int P>
+GG_DEVICE void gg_setprio() { __builtin_amdgcn_s_setprio(P); }    // wave issue priority (arbitration between the waves of a SIMD)
+
 GG_DEVICE float gg_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 GG_DEVICE float gg_shfl(float v, int src) { return __shfl(v, src, 64); }
 GG_DEVICE void gg_atomic_add(float* p, float v) { atomicAdd(p, v); }

@@ -24,7 +24,16 @@
 #define GG3_STAGE ((256 + 256) * GG3_ROWB)           // 32 KiB
 #define GG3_LDS 139264                               // max(ring = 4 * 32 KiB, gg_gemm2's epilogue staging: 8 * 128 * 136 B)
 
-template <bool A_CONV, bool FULL_EPI>
+// STAGGER: the two wave rows (waves 0-3 / 4-7: one wave of each per SIMD) run half a stage apart - while one half issues its 16
+// MFMAs of a stage (fragments already in registers, raised priority) the other half reads its fragments of the next stage from
+// LDS, issues its DMA share and waits for the share it needs next, so the matrix pipe of every SIMD always has one wave feeding
+// it (the ping-pong of the guide's 8-phase template). Two raw barriers per stage; the halves are offset by ONE barrier (the
+// second half executes an extra barrier before the loop, the first half one after it). Hazards, with R(s) / M(s) the barriers
+// ending a half's read / MFMA interval of stage s (physical barrier = first half's R(s) = second half's M(s-1)):
+//   RAW  a wave waits (counted vmcnt) for ITS share of stage s+1 before R(s); every wave's R(s) precedes every read of s+1.
+//   WAR  slot (s+3)%4 held stage s-1; the last reads of s-1 are issued before the second half's R(s-1) (lgkmcnt(0) precedes the
+//        barrier) = the first half's M(s-1), and no wave issues the DMA of stage s+3 before its read interval of stage s.
+template <bool A_CONV, bool FULL_EPI, bool STAGGER>
 GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_gemm3_kernel(GgGemmParams p) {
     constexpr int BM = 256, BN = 256, WM = 2, WN = 4;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
@@ -124,6 +133,48 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_gemm3_kernel(GgGemmParams p) {
     for (int s = 0; s < GG3_NS - 1 && s < nk; ++s) issue_stage(s);
 
     const int frow = lane & 31, hi = lane >> 5;
+    if (STAGGER) {
+        const int half = wave >> 2;
+        if (nk > 2) gg_wait_vm<8>(); else if (nk > 1) gg_wait_vm<4>(); else gg_wait_vm<0>();
+        gg_barrier_raw();                   // every wave's share of stage 0 has landed
+        if (half == 1) gg_barrier_raw();    // the second half runs one barrier behind
+        for (int kt = 0; kt < nk; ++kt) {
+            // ---- read interval: DMA of stage kt+3 into the slot stage kt-1 left, fragments of stage kt into registers
+            if (kt + GG3_NS - 1 < nk) issue_stage(kt + GG3_NS - 1);
+            const char* stA = smem + (kt % GG3_NS) * GG3_STAGE;
+            const char* stB = stA + BM * GG3_ROWB;
+            u16x8 fa[2][TM], fb[2][TN];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int r = wm * WTM + i * 32 + frow;
+                    fa[kk][i] = *(const u16x8*)(stA + r * GG3_ROWB + (((kk * 2 + hi) ^ ((r >> 2) & 3)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int r = wn * WTN + j * 32 + frow;
+                    fb[kk][j] = *(const u16x8*)(stB + r * GG3_ROWB + (((kk * 2 + hi) ^ ((r >> 2) & 3)) << 4));
+                }
+            }
+            // this wave's share of stage kt+1 must be in LDS before anybody reads it (shares kt+2, kt+3 may stay in flight)
+            if (kt + 3 < nk) gg_wait_vm<8>();
+            else if (kt + 2 < nk) gg_wait_vm<4>();
+            else gg_wait_vm<0>();
+            gg_barrier_raw();               // R(kt): lgkmcnt(0) first - the fragments are in registers, the slot may be refilled
+            // ---- MFMA interval
+            gg_setprio<1>();
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = gg_mfma_32x32x16_bf16(fb[kk][j], fa[kk][i], acc[i][j]);
+            gg_setprio<0>();
+            gg_barrier_raw();               // M(kt)
+        }
+        if (half == 0) gg_barrier_raw();    // pairs with the second half's last M
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         // stage kt has landed once at most the two younger stages (4 instructions each) are outstanding
         if (kt + 2 < nk) gg_wait_vm<8>();

@@ -198,7 +198,7 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, *, ksize: int, stride: int = 1
         keep.append(in_scale)
     d.C_out, d.ldc, d.c_is_f32 = ptr(out), cout, int(out_dtype == torch.float32)
     d.force_splitk, d.force_tile = force_splitk, force_tile
-    if force_tile == 7 or _V3_POLICY:     # experimental LDS-DMA tile: padding taps read a page of zeros
+    if force_tile in (7, 8) or _V3_POLICY:     # experimental LDS-DMA tiles: padding taps read a page of zeros
         d.zero_page = ptr(_zero_page(x.device))
     if residual is not None:
         assert residual.shape == out.shape
@@ -235,7 +235,7 @@ def conv2d_wgrad_nhwc(x: torch.Tensor, dy: torch.Tensor, *, ksize: int, stride: 
     d.alpha = 1.0
     d.bias_scale = 1.0
     d.force_splitk, d.force_tile = force_splitk, force_tile
-    if force_tile == 7 or _V3_POLICY:
+    if force_tile in (7, 8) or _V3_POLICY:
         d.zero_page = ptr(_zero_page(x.device))
     _run_gemm(d, x)
     return out

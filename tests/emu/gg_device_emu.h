@@ -49,15 +49,24 @@ u16x4 gg_emu_lds_read_tr16(const bf16_t* p);
 #define GG_LAUNCH(kernel, grid, block, stream, ...) \
     gg_emu_launch(grid, block, [=]() { kernel(__VA_ARGS__); })
 
-static inline void gg_sync() { gg_emu_syncthreads(); }
-// LDS-DMA stand-ins: the copy happens at issue time (the emulator has no asynchrony: ordering bugs that only show with
-// loads in flight are NOT caught here, index math and slot rotation are)
+// LDS-DMA stand-ins. Two landing models bracket what the hardware may do (the emulator itself is sequential):
+//   early (default)      the 16 bytes land at issue time: a slot that is refilled before its last reader ran (WAR) shows up
+//                        whenever the refilling wave runs before the reading wave inside a barrier interval (fibers run in
+//                        thread order; GG_EMU_REVERSE=1 runs them in the opposite order to catch the other direction);
+//   late (GG_EMU_DMA=late)  a transfer lands only when its issuing thread executes the counted wait that retires it
+//                        (gg_wait_vm<N>: all but the N newest), a __syncthreads (which drains vmcnt on the hardware) or the
+//                        kernel end: a missing or mis-counted wait before a read (RAW) then reads stale LDS bytes.
+void gg_emu_dma_issue(const void* g, void* dst);
+void gg_emu_dma_wait(int keep_newest);
+static inline void gg_sync() { gg_emu_dma_wait(0); gg_emu_syncthreads(); }
 static inline void gg_load_lds16(const void* g, void* lds_wave_base) {
-    memcpy((char*)lds_wave_base + 16 * (threadIdx.x & 63u), g, 16);
+    gg_emu_dma_issue(g, (char*)lds_wave_base + 16 * (threadIdx.x & 63u));
 }
 template <int N>
-static inline void gg_wait_vm() {}
+static inline void gg_wait_vm() { gg_emu_dma_wait(N); }
 static inline void gg_barrier_raw() { gg_emu_syncthreads(); }
+template <int P>
+static inline void gg_setprio() {}
 template <typename T>
 static inline const T* gg_late_params(const T& by_value) { return &by_value; }
 static inline f32x16 gg_mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c) {

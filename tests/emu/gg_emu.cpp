@@ -4,6 +4,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include <deque>
+#include <utility>
 
 gg_emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 
@@ -34,11 +36,22 @@ int g_nthreads = 0;
 int g_block_arrived = 0;
 unsigned g_block_gen = 0;
 const std::function<void()>* g_body = nullptr;
+std::vector<std::deque<std::pair<const void*, void*>>> g_dma;     // per thread: LDS-DMA transfers issued and not yet landed
+bool g_dma_late = false, g_reverse = false;
 
 void yield_to_sched() { swapcontext(&g_fibers[g_cur].ctx, &g_sched); }
 
+void dma_flush(int t, size_t keep) {
+    auto& q = g_dma[t];
+    while (q.size() > keep) {
+        memcpy(q.front().second, q.front().first, 16);
+        q.pop_front();
+    }
+}
+
 void fiber_entry() {
     (*g_body)();
+    dma_flush(g_cur, 0);
     g_fibers[g_cur].done = true;
     swapcontext(&g_fibers[g_cur].ctx, &g_sched);
 }
@@ -57,6 +70,15 @@ void wave_sync() {
 }
 
 }  // namespace
+
+void gg_emu_dma_issue(const void* g, void* dst) {
+    if (!g_dma_late) { memcpy(dst, g, 16); return; }
+    g_dma[g_cur].push_back({g, dst});
+}
+
+void gg_emu_dma_wait(int keep_newest) {
+    if (g_dma_late) dma_flush(g_cur, (size_t)keep_newest);
+}
 
 void gg_emu_syncthreads() {
     unsigned my_gen = g_block_gen;
@@ -136,11 +158,16 @@ void gg_emu_launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     blockDim = block;
     g_body = &body;
     g_nthreads = nthreads;
+    const char* dm = getenv("GG_EMU_DMA");
+    g_dma_late = dm && dm[0] == 'l';
+    const char* rv = getenv("GG_EMU_REVERSE");
+    g_reverse = rv && rv[0] == '1';
     for (unsigned bz = 0; bz < grid.z; ++bz)
         for (unsigned by = 0; by < grid.y; ++by)
             for (unsigned bx = 0; bx < grid.x; ++bx) {
                 g_fibers.assign(nthreads, Fiber());
                 g_waves.assign((nthreads + 63) / 64, WaveState());
+                g_dma.assign(nthreads, {});
                 g_block_arrived = 0;
                 g_block_gen = 0;
                 for (int t = 0; t < nthreads; ++t) {
@@ -158,7 +185,8 @@ void gg_emu_launch(dim3 grid, dim3 block, const std::function<void()>& body) {
                 int remaining = nthreads;
                 while (remaining > 0) {
                     int progressed = 0;
-                    for (int t = 0; t < nthreads; ++t) {
+                    for (int tt = 0; tt < nthreads; ++tt) {
+                        const int t = g_reverse ? nthreads - 1 - tt : tt;
                         Fiber& f = g_fibers[t];
                         if (f.done) continue;
                         g_cur = t;

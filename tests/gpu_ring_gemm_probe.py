@@ -39,12 +39,16 @@ def main():
             out = K.gemm(a, b, out_dtype=torch.float32, force_tile=7)
             worst = max(worst, ((out - ref).norm() / ref.norm()).item())
         flops = 2.0 * M * N * Kd
+        for rep in range(20):                                               # the staggered (ping-pong) variant
+            out = K.gemm(a, b, out_dtype=torch.float32, force_tile=8)
+            worst = max(worst, ((out - ref).norm() / ref.norm()).item())
         t7 = time_ms(lambda: K.gemm(a, b, force_tile=7))
+        t8 = time_ms(lambda: K.gemm(a, b, force_tile=8))
         t4 = time_ms(lambda: K.gemm(a, b, force_tile=4)) if N >= 192 else float('nan')
         ok = worst < 1e-5
         bad += not ok
-        print(f'M={M:6d} N={N:5d} K={Kd:5d}  ring {t7*1e3:8.1f} us {flops/t7/1e9:7.1f} TF   tile4 {t4*1e3:8.1f} us '
-              f'{flops/t4/1e9:7.1f} TF   worst rel err over 20 runs {worst:.2e} {"ok" if ok else "MISMATCH"}', flush=True)
+        print(f'M={M:6d} N={N:5d} K={Kd:5d}  ring {t7*1e3:8.1f} us {flops/t7/1e9:7.1f} TF   staggered {t8*1e3:8.1f} us {flops/t8/1e9:7.1f} TF   '
+              f'tile4 {t4*1e3:8.1f} us {flops/t4/1e9:7.1f} TF   worst rel err over 40 runs {worst:.2e} {"ok" if ok else "MISMATCH"}', flush=True)
     # conv gather (forward / data gradient of the discriminator's 3x3 layers), same screen against the planned kernel
     for name, n, R, ci, co in [('D3.conv2', 256, 32, 256, 256), ('D4.conv2', 512, 16, 512, 512), ('D5.conv', 1024, 8, 512, 512),
                                ('D2.conv2', 128, 64, 128, 128), ('edge', 3, 20, 32, 40)]:
@@ -56,11 +60,15 @@ def main():
             out = K.conv2d_nhwc(x, w, ksize=3, out_dtype=torch.float32, force_tile=7)
             worst = max(worst, ((out - ref).norm() / ref.norm()).item())
         flops = 2.0 * n * R * R * ci * co * 9
+        for rep in range(20):
+            out = K.conv2d_nhwc(x, w, ksize=3, out_dtype=torch.float32, force_tile=8)
+            worst = max(worst, ((out - ref).norm() / ref.norm()).item())
         t7 = time_ms(lambda: K.conv2d_nhwc(x, w, ksize=3, force_tile=7))
+        t8 = time_ms(lambda: K.conv2d_nhwc(x, w, ksize=3, force_tile=8))
         t0 = time_ms(lambda: K.conv2d_nhwc(x, w, ksize=3))
         ok = worst < 1e-5
         bad += not ok
-        print(f'{name:9s} M={n*R*R:7d} N={co:4d} K={9*ci:5d}  ring {t7*1e3:8.1f} us {flops/t7/1e9:7.1f} TF   planned '
+        print(f'{name:9s} M={n*R*R:7d} N={co:4d} K={9*ci:5d}  ring {t7*1e3:8.1f} us {flops/t7/1e9:7.1f} TF   staggered {t8*1e3:8.1f} us {flops/t8/1e9:7.1f} TF   planned '
               f'{t0*1e3:8.1f} us {flops/t0/1e9:7.1f} TF   worst rel err over 20 runs {worst:.2e} {"ok" if ok else "MISMATCH"}',
               flush=True)
     # weight gradients (reduction-major operands, transpose reads): same screen

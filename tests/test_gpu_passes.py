@@ -22,7 +22,7 @@ def dev():
 def test_fused_adamw_matches_torch_adamw_on_the_gpu():
     """gg_adamw_flat_f32 vs torch.optim.AdamW (fp32, same hyper-parameters as the trainer: lr 2e-4, betas (0.5, 0.9), weight
     decay 1e-2 on ndim >= 2 only) over 5 steps on ~3 M parameters. Same formula, different operation order (the kernel folds
-    the bias corrections into two scalars): parameters agree to 2e-7 relative L2 and 1e-6 max-abs on O(1) values, moments to
+    the bias corrections into two scalars): parameters agree to 2e-7 relative L2 and 4e-6 max-abs (a few fp32 ulps of values up to ~5), moments to
     1e-6; inactive / skipped parameters stay bit-identical."""
     from gigagan_pytorch_amd.optimizer import FlatAdamW
     torch.manual_seed(0)
@@ -49,7 +49,7 @@ def test_fused_adamw_matches_torch_adamw_on_the_gpu():
         to.step()
         assert torch.equal(extra.detach(), before) == (step == 2)      # no decay, no moment-driven move when skipped
     for p, r in zip(ps, rs):
-        assert rel_err(p, r) < 2e-7 and float((p - r).abs().max()) < 1e-6, (p.shape, rel_err(p, r))
+        assert rel_err(p, r) < 2e-7 and float((p - r).abs().max()) < 4e-6, (p.shape, rel_err(p, r))
         assert rel_err(fo.state[p]['exp_avg'], to.state[r]['exp_avg']) < 1e-6
         assert rel_err(fo.state[p]['exp_avg_sq'], to.state[r]['exp_avg_sq']) < 1e-6
     assert torch.equal(frozen.detach(), frozen0)
