@@ -48,6 +48,15 @@ class GemmDesc(C.Structure):
     ]
 
 
+class PlanEntry(C.Structure):        # mirrors gg_plan_entry
+    FIELDS = ('M', 'N', 'K', 'batch', 'a_layout', 'b_layout', 'a_conv', 'H', 'W', 'C', 'CV', 'R', 'conv_stride', 'conv_pad',
+              'c_is_f32', 'd2s', 'epi', 'scaled', 'tile', 'splitk')
+    _fields_ = [(f, C.c_int32) for f in FIELDS]
+
+
+PLAN_TABLE = _HERE / 'plans' / 'gfx950.json'
+
+
 class Library:
     """One loaded libgigagan_amd.so with typed entry points."""
 
@@ -71,8 +80,26 @@ class Library:
         L.gg_gemm_plan.argtypes = [C.POINTER(GemmDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         self._declare_elementwise()
         self.is_emulator = bool(L.gg_is_emulator())
-        if L.gg_version() != 3:
+        if L.gg_version() != 4:
             raise RuntimeError(f'gigagan_pytorch_amd: ABI version mismatch in {path}')
+        L.gg_gemm_plan_table.restype = C.c_int
+        L.gg_gemm_plan_table.argtypes = [C.POINTER(PlanEntry), C.c_int32]
+        self.plan_entries = 0
+        if not self.is_emulator and PLAN_TABLE.exists() and not os.environ.get('GG_NO_PLAN_TABLE'):
+            self.load_plan_table(PLAN_TABLE)
+
+    def load_plan_table(self, path_or_entries):
+        """install the tuning cache: measured-best (tile, split-K) per exact problem geometry (tests/gpu_plan_sweep.py)."""
+        import json
+        entries = path_or_entries
+        if not isinstance(entries, (list, tuple)):
+            entries = json.loads(Path(path_or_entries).read_text())['entries']
+        arr = (PlanEntry * max(len(entries), 1))()
+        for i, e in enumerate(entries):
+            for f in PlanEntry.FIELDS:
+                setattr(arr[i], f, int(e[f]))
+        self.check(self.lib.gg_gemm_plan_table(arr, len(entries)), 'gg_gemm_plan_table')
+        self.plan_entries = len(entries)
 
     # filled in by _elementwise_signatures (kept separate so the table reads like the header)
     def _declare_elementwise(self):

@@ -17,6 +17,8 @@
 #include <stdarg.h>
 #include <string.h>
 #include <stdlib.h>
+#include <unordered_map>
+#include <string>
 
 static thread_local char g_err[512] = "";
 
@@ -232,8 +234,50 @@ static void gg_launch_dconv(const GgGemmParams& p, hipStream_t s) {
     else GG_LAUNCH((gg_dconv_kernel<C, TN, false>), dim3((unsigned)blocks), dim3(256), s, p);
 }
 
+// ---- tuning cache: measured-best (tile, split-K) per exact geometry (gg_gemm_plan_table) ----------------------------------
+struct GgPlanChoice { int tile, splitk; };
+static std::unordered_map<std::string, GgPlanChoice> g_plan_table;
+
+static std::string gg_plan_key(const int32_t* f) { return std::string((const char*)f, 18 * sizeof(int32_t)); }
+
+static std::string gg_plan_key_of(const gg_gemm_desc* d) {
+    const bool full = d->bias || d->out_scale || d->noise || d->residual || d->act != GG_ACT_NONE;
+    int32_t f[18] = {d->M, d->N, d->K, d->batch, d->a_layout, d->b_layout, d->a_conv ? 1 : 0,
+                     d->a_conv ? d->H : 0, d->a_conv ? d->W : 0, d->a_conv ? d->C : 0, d->a_conv ? d->CV : 0,
+                     d->a_conv ? d->R : 0, d->a_conv ? d->conv_stride : 0, d->a_conv ? d->conv_pad : 0,
+                     d->c_is_f32 ? 1 : 0, d->d2s, full ? 1 : 0, d->in_scale ? 1 : 0};
+    return gg_plan_key(f);
+}
+
+static bool gg_table_plan(const gg_gemm_desc* d, GemmPlan& pl) {
+    if (g_plan_table.empty() || d->force_tile != 0 || d->force_splitk != 0) return false;
+    auto it = g_plan_table.find(gg_plan_key_of(d));
+    if (it == g_plan_table.end()) return false;
+    const int tile = it->second.tile;
+    if (tile == 9) {
+        if (!gg_dconv_eligible(d)) return false;
+        pl.tile = 9; pl.bm = GG_DC_TH * GG_DC_TW; pl.bn = d->N <= 32 ? 32 : 64;
+        pl.splitk = 1; pl.k_per_split = d->K; pl.blocks_mn = d->M / pl.bm;
+        return true;
+    }
+    if (tile < 1 || tile > 6) return false;
+    if (tile >= 4 && !gg_v2_eligible(d)) return false;
+    const GgTileModel& tm = kTileModels[tile - 1];
+    const int ktiles = (d->K + tm.bk - 1) / tm.bk;
+    int sk = it->second.splitk < 1 ? 1 : it->second.splitk;
+    if (sk > ktiles) sk = ktiles;
+    if ((long long)d->batch * sk > 65535) return false;
+    const int per = (ktiles + sk - 1) / sk;
+    pl.tile = tile; pl.bm = tm.bm; pl.bn = tm.bn;
+    pl.splitk = (ktiles + per - 1) / per;
+    pl.k_per_split = per * tm.bk;
+    pl.blocks_mn = (long long)((d->M + tm.bm - 1) / tm.bm) * ((d->N + tm.bn - 1) / tm.bn);
+    return true;
+}
+
 GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     GemmPlan pl;
+    if (gg_table_plan(d, pl)) return pl;
     if (gg_use_dconv(d)) {
         pl.tile = 9; pl.bm = GG_DC_TH * GG_DC_TW; pl.bn = d->N <= 32 ? 32 : 64;
         pl.splitk = 1; pl.k_per_split = d->K; pl.blocks_mn = d->M / pl.bm;
@@ -349,6 +393,17 @@ void gg_launch_gemm2_tile(const GgGemmParams& p, bool akrow, bool bkrow, bool ac
 }
 
 }  // namespace
+
+extern "C" int gg_gemm_plan_table(const gg_plan_entry* entries, int32_t n) {
+    if (n < 0 || (n > 0 && !entries)) return gg_fail(-1, "gg_gemm_plan_table: bad arguments");
+    g_plan_table.clear();
+    for (int i = 0; i < n; ++i) {
+        const gg_plan_entry& e = entries[i];
+        if (e.tile < 1 || e.tile > 9 || e.splitk < 1) return gg_fail(-2, "gg_gemm_plan_table: entry %d has tile %d split-K %d", i, e.tile, e.splitk);
+        g_plan_table[gg_plan_key(&e.M)] = GgPlanChoice{e.tile, e.splitk};
+    }
+    return 0;
+}
 
 extern "C" size_t gg_gemm_workspace_bytes(const gg_gemm_desc* d) {
     if (gg_validate_gemm(d) != 0) return 0;

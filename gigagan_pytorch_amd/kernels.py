@@ -49,6 +49,7 @@ class GemmProfiler:
 
 profiler: GemmProfiler | None = None
 plan_log: list | None = None    # when a list: (tile, splitk) of every launch is appended (tuning scripts)
+desc_log: list | None = None    # when a list: a raw copy of every launch descriptor is appended (tests/gpu_plan_sweep.py)
 
 
 def _kernel_key(d: GemmDesc, L) -> str:
@@ -73,6 +74,8 @@ def _run_gemm(d: GemmDesc, like: torch.Tensor):
     L = _C.lib()
     need = L.lib.gg_gemm_workspace_bytes(C.byref(d))
     ws = _workspace(need, like) if need else None
+    if desc_log is not None:
+        desc_log.append(bytes(d))
     if plan_log is not None:
         tile, sk = C.c_int32(0), C.c_int32(0)
         L.lib.gg_gemm_plan(C.byref(d), C.byref(tile), C.byref(sk))

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 3
+#define GG_ABI_VERSION 4
 
 int gg_version(void);
 const char* gg_last_error(void);
@@ -83,6 +83,17 @@ typedef struct gg_gemm_desc {
     int32_t no_reduce;       /* 1: a split-K launch leaves its fp32 partials [splitk][M][N] in the workspace and skips the
                               * reduction pass (the caller folds them, e.g. gg_wgrad_finish with `splits`); batch must be 1 */
 } gg_gemm_desc;
+
+/* Per-device tuning cache (the only persistent native state besides the communicator): measured-best launch
+ * plans for exact problem geometries, consulted before the cost model whenever the caller forces neither tile nor split-K.
+ * `epi` = 1 when any of bias / out_scale / noise / residual / activation is present, `scaled` = 1 with in_scale. An entry whose
+ * tile is not eligible for the geometry is ignored. gg_gemm_plan_table copies `n` entries (n = 0 clears); not thread-safe
+ * against concurrent launches: set it once after loading the library (tests/gpu_plan_sweep.py produces the table). */
+typedef struct gg_plan_entry {
+    int32_t M, N, K, batch, a_layout, b_layout, a_conv, H, W, C, CV, R, conv_stride, conv_pad, c_is_f32, d2s, epi, scaled;
+    int32_t tile, splitk;
+} gg_plan_entry;
+int gg_gemm_plan_table(const gg_plan_entry* entries, int32_t n);
 
 size_t gg_gemm_workspace_bytes(const gg_gemm_desc* d);
 /* reports the launch plan the library will use for `d`: tile (1: 128x128, 2: 128x64, 3: 128x32, 4: 256x256,
