@@ -140,47 +140,49 @@ def cpu_baseline(budget_s=45.0):
 
 def modconv_forward_roofline(gan, batch, dev):
     """north-star sub-target: the style-modulated (demodulated 3x3) adaptive convolutions of ONE generator forward at the
-    bench batch, no-grad path (what the D-step runs): HIP events on the launch stream around every AdaptiveConv2DMod call
-    (coefficient kernel + fused implicit-GEMM launch, issued eagerly, so launch gaps of the tiny low-resolution layers
-    are inside the brackets), algorithmic flops 2*b*O*I*9*H*W per layer (171.5 GF at batch 32)."""
+    bench batch, no-grad path (what the D-step runs). HIP events on the launch stream around EVERY kernel the op launches
+    (coefficient / per-sample-weight kernel, modulation pass, convolution; kernels.LaunchProfiler), executed eagerly;
+    `achieved` = algorithmic flops 2*b*O*I*9*H*W per layer (171.5 GF at batch 32) / the sum of those kernel
+    times. call_ms additionally contains the eager launch gaps between them."""
     from gigagan_pytorch_amd import ops, kernels as K
     rec = []
     orig = ops.HipOps.modconv2d
 
-    def timed(self, x, weights, mod, kernel_mod=None, demod=True, **kw):
-        if not demod or weights.shape[-1] != 3:
-            return orig(self, x, weights, mod, kernel_mod, demod=demod, **kw)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n0 = len(K.profiler.records)
-        e0.record()
-        y = orig(self, x, weights, mod, kernel_mod, demod=demod, **kw)
-        e1.record()
-        b, _, H, W = x.shape
-        O, I = weights.shape[1], weights.shape[2]
-        rec.append((e0, e1, 2.0 * b * O * I * 9 * H * W, f'{I}->{O}@{H}x{W}', K.profiler.records[n0:]))
-        return y
-    ops.HipOps.modconv2d = timed
-    K.profiler = K.GemmProfiler()
-    try:
-        with torch.no_grad():
-            for _ in range(3):
-                rec.clear()
-                gan.G(noise=torch.randn(batch, gan.G.style_network_dim, device=dev))
-        torch.cuda.synchronize()
-    finally:
-        ops.HipOps.modconv2d = orig
-        K.profiler = None
+    with K.LaunchProfiler() as prof:
+        def timed(self, x, weights, mod, kernel_mod=None, demod=True, **kw):
+            if not demod or weights.shape[-1] != 3:
+                return orig(self, x, weights, mod, kernel_mod, demod=demod, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n0 = len(prof.records)
+            e0.record()
+            y = orig(self, x, weights, mod, kernel_mod, demod=demod, **kw)
+            e1.record()
+            b, _, H, W = x.shape
+            O, I = weights.shape[1], weights.shape[2]
+            rec.append((e0, e1, 2.0 * b * O * I * 9 * H * W, f'{I}->{O}@{H}x{W}', n0, len(prof.records)))
+            return y
+        ops.HipOps.modconv2d = timed
+        try:
+            with torch.no_grad():
+                for _ in range(3):
+                    rec.clear()
+                    gan.G(noise=torch.randn(batch, gan.G.style_network_dim, device=dev))
+            torch.cuda.synchronize()
+        finally:
+            ops.HipOps.modconv2d = orig
     layers, call_ms, kern_ms, fl = [], 0., 0., 0.
-    for e0, e1, f, name, launches in rec:
+    for e0, e1, f, name, n0, n1 in rec:
         t_call = e0.elapsed_time(e1)
-        t_kern = sum(a.elapsed_time(b) for _, _, a, b in launches)     # the implicit-GEMM launch(es) alone
-        layers.append(dict(layer=name, call_us=t_call * 1e3, kernel_us=t_kern * 1e3, kernel_tflops=f / t_kern / 1e9))
+        launches = [(nm, a.elapsed_time(b)) for nm, a, b in prof.records[n0:n1]]
+        t_kern = sum(t for _, t in launches)
+        layers.append(dict(layer=name, call_us=t_call * 1e3, kernel_us=t_kern * 1e3, kernel_tflops=f / t_kern / 1e9,
+                           launches={nm: round(t * 1e3, 1) for nm, t in launches}))
         call_ms, kern_ms, fl = call_ms + t_call, kern_ms + t_kern, fl + f
     return dict(achieved=fl / kern_ms / 1e9, peak=MFMA_PEAK_TF, unit='TFLOP/s', frac=fl / kern_ms / 1e9 / MFMA_PEAK_TF,
                 kernel_ms=kern_ms, call_ms=call_ms, gflop=fl / 1e9, batch=batch, layers=layers,
                 note='the 15 demodulated 3x3 adaptive convs of one no-grad generator forward: `achieved` = algorithmic flops '
-                     '(2*b*O*I*9*H*W) / time of the fused implicit-GEMM launches (HIP events around each launch); call_ms '
-                     'brackets whole eager calls incl. the coefficient kernel and launch gaps')
+                     '(2*b*O*I*9*H*W) / time of ALL kernels each layer launches (HIP events around every C-ABI launch); call_ms '
+                     'brackets the whole eager calls incl. launch gaps')
 
 
 def main():
@@ -249,15 +251,28 @@ def main():
     while (gan._steps_host - 1) % 4 != 0 or (gan.use_hip_graphs and gan._steps_host < 5):
         run_steps(1)
         warmup += 1
+    comm = gdist.native_comm()
+    if comm is not None:
+        comm.timing, comm.exposed_ms = True, []
     barrier()
     t0 = time.perf_counter()
     d_losses, g_losses = run_steps(steps)
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0         # this rank's own clock, before the closing barrier
     barrier()
     dt = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        exposed = 0.
+        if comm is not None:
+            comm.timing = False
+            exposed = sum(a.elapsed_time(b) for a, b in comm.exposed_ms) / steps
+        mine = dict(rank=rank, ms_per_step=dt_local / steps * 1e3, exposed_comm_ms_per_step=exposed)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     finite = bool(torch.isfinite(gan.G_opt.flat_p).all() and torch.isfinite(gan.D_opt.flat_p).all()
                   and torch.isfinite(gan.G_opt.flat_g).all() and torch.isfinite(gan.D_opt.flat_g).all())
     loss_vals = [float(v) for v in (*d_losses, *g_losses) if v is not None]
@@ -335,12 +350,13 @@ def main():
             config=dict(workload=f'{what} bf16 bs={args.batch}/GPU, GP every 4th step', global_batch=args.batch * world,
                         parallelism=f'dp{world}', hip_graphs=bool(gan._graphable(1))),
             roofline=roofline, cpu_baseline=cpu,
-            finite=finite, state_restored_every_cycle=snap is not None,
+            finite=finite, state_restored_every_cycle=snap is not None, per_rank=per_rank,
             last_losses=dict(d=float(d_losses.divergence), g=float(g_losses.divergence),
                              gp=float(d_losses.gradient_penalty), msd=float(d_losses.multiscale_divergence)))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
+        gdist.shutdown()
         dist.destroy_process_group()
 
 

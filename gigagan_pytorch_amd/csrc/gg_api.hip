@@ -11,6 +11,8 @@
 #include "gg_weights.h"
 #include "gg_dconv.h"
 #include "gg_modcoef.h"
+#include "gg_modfwd.h"
+#include "gg_comm.h"
 #include "../../include/gigagan_amd.h"
 
 #include <stdio.h>
@@ -767,6 +769,64 @@ extern "C" int gg_modulate_bwd(const void* g, const void* x, const float* s, voi
     return gg_check_launch();
 }
 
+extern "C" int gg_modulate_bank_fwd(const void* x, const float* s, const float* a, void* out, int32_t b, int32_t P, int32_t Cin,
+                                    int32_t Cout, void* stream) {
+    if (!x || !s || !a || !out) return gg_fail(-1, "gg_modulate_bank_fwd: null pointer");
+    if (b <= 0 || P <= 0 || Cin <= 0 || (Cin % 8) || Cout < Cin || (Cout % Cin))
+        return gg_fail(-2, "gg_modulate_bank_fwd: need Cin %% 8 == 0 and Cout a multiple of Cin (Cin=%d Cout=%d)", Cin, Cout);
+    GgModulateParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)x; p.s = s; p.a = a; p.out = (bf16_t*)out; p.b = b; p.P = P; p.C = Cout; p.Cin = Cin; p.chunks = 1;
+    GG_LAUNCH(gg_modulate_kernel, dim3(gg_grid_for((long long)b * P * (Cout / 8))), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+extern "C" int gg_modw_fwd(const float* w, const float* mod, const float* kmod, float* s, float* a, float* d, void* wmix,
+                           int32_t layout, int32_t b, int32_t N, int32_t O, int32_t I, int32_t T, int32_t Ip, int32_t Op,
+                           int32_t demod, float eps, void* stream) {
+    if (!w || !mod) return gg_fail(-1, "gg_modw_fwd: null pointer");
+    if (b <= 0 || b > GG_MW_BMAX || N <= 0 || N > GG_MW_NMAX || O <= 0 || I <= 0 || T <= 0 || Ip < I || Op < O)
+        return gg_fail(-2, "gg_modw_fwd: bad extents (b=%d N=%d O=%d I=%d T=%d)", b, N, O, I, T);
+    if ((long long)N * I * T > GG_MW_WMAX || (long long)(N * (N + 1) / 2) * I > GG_MW_GMAX)
+        return gg_fail(-3, "gg_modw_fwd: bank too large for one workgroup (N*I*T=%lld)", (long long)N * I * T);
+    if (N > 1 && !kmod) return gg_fail(-1, "gg_modw_fwd: kernel_mod is required for N > 1");
+    if (wmix) {
+        if (layout != 1 && layout != 2) return gg_fail(-4, "gg_modw_fwd: layout must be 1 or 2");
+        if (layout == 2 && ((I & 15) || O > 32)) return gg_fail(-4, "gg_modw_fwd: layout 2 needs I %% 16 == 0 and O <= 32");
+        if (((uintptr_t)wmix) & 15) return gg_fail(-4, "gg_modw_fwd: wmix must be 16-byte aligned");
+    }
+    GgModWParams p;
+    memset(&p, 0, sizeof(p));
+    p.w = w; p.mod = mod; p.kmod = kmod; p.s = s; p.a = a; p.d = d; p.wmix = (bf16_t*)wmix; p.layout = layout;
+    p.b = b; p.N = N; p.O = O; p.I = I; p.T = T; p.Ip = Ip; p.Op = Op; p.demod = demod; p.eps = eps;
+    GG_LAUNCH(gg_modw_kernel, dim3((unsigned)O), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+extern "C" int gg_sconv_fwd(const void* x, const void* w, int64_t w_bs, void* y, const float* noise, const float* noise_w,
+                            int32_t b, int32_t H, int32_t W, int32_t C, int32_t O, int32_t act, float slope, void* stream) {
+    if (!x || !w || !y) return gg_fail(-1, "gg_sconv_fwd: null pointer");
+    if (b <= 0 || H <= 0 || W <= 0 || (W & 31) || !(C == 16 || C == 32 || C == 64) || O <= 0 || O > 32 || (O & 7))
+        return gg_fail(-2, "gg_sconv_fwd: needs W %% 32 == 0, C in {16, 32, 64}, O <= 32 and O %% 8 == 0 (W=%d C=%d O=%d)", W, C, O);
+    if ((noise != nullptr) != (noise_w != nullptr)) return gg_fail(-1, "gg_sconv_fwd: noise and noise_w go together");
+    if (act < 0 || act > 1) return gg_fail(-3, "gg_sconv_fwd: activation must be none (0) or leaky-relu (1)");
+    if ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y)) & 15) return gg_fail(-4, "gg_sconv_fwd: 16-byte alignment required");
+    GgSconvParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.w_bs = w_bs; p.y = (bf16_t*)y; p.noise = noise; p.noise_w = noise_w;
+    p.b = b; p.H = H; p.W = W; p.O = O; p.act = act; p.slope = slope;
+    const long long gpi = (long long)H * (W >> 5);
+    int gpw = (int)((gpi * b + 4095) / 4096);          // ~4096 workgroups: 16 per CU to draw from
+    if (gpw < 8) gpw = 8;
+    if (gpw > gpi) gpw = (int)gpi;
+    p.groups_per_wg = gpw;
+    const long long blocks = (long long)b * ((gpi + gpw - 1) / gpw);
+    if (C == 16) GG_LAUNCH((gg_sconv_kernel<16>), dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, p);
+    else if (C == 32) GG_LAUNCH((gg_sconv_kernel<32>), dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, p);
+    else GG_LAUNCH((gg_sconv_kernel<64>), dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
 static int gg_modmix_common(GgModMixParams& p, int32_t b, int32_t P, int32_t O, int32_t Os, int32_t N, int32_t act, float slope) {
     if (b <= 0 || P <= 0 || O <= 0 || (O % 8) || Os < O || (Os % 8) || N < 1 || N > GG_MIX_MAXN)
         return gg_fail(-2, "gg_modmix: bad extents (O=%d Os=%d N=%d)", O, Os, N);
@@ -917,4 +977,68 @@ extern "C" int gg_attn_bwd2(const void* q, const void* k, const void* v, const v
     if (rc) return rc;
     GG_LAUNCH(gg_attn_bwd2_kv_kernel, grid, dim3(256), s, p);
     return gg_check_launch();
+}
+
+// ---- data-parallel exchange (gg_comm.h) -----------------------------------------------------------------------------
+
+static int gg_comm_rc(int rc, const char* what) {
+    if (rc == 0) return 0;
+    const char* msg = gg_comm::g_api.GetErrorString ? gg_comm::g_api.GetErrorString(rc) : "?";
+    snprintf(g_err, sizeof(g_err), "%s: ncclResult %d (%s)", what, rc, msg);
+    return 1000 + rc;
+}
+
+extern "C" int gg_comm_load(const char* librccl_path) {
+    return gg_comm::load(librccl_path, g_err, sizeof(g_err)) ? 0 : -30;
+}
+
+extern "C" int gg_comm_unique_id(void* id128) {
+    if (!id128) return gg_fail(-1, "gg_comm_unique_id: null pointer");
+    if (!gg_comm::load(nullptr, g_err, sizeof(g_err))) return -30;
+    return gg_comm_rc(gg_comm::g_api.GetUniqueId((gg_comm::UniqueId*)id128), "ncclGetUniqueId");
+}
+
+extern "C" int gg_comm_init(int32_t rank, int32_t world, const void* id128) {
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return gg_fail(-1, "gg_comm_init: bad arguments (rank %d of %d)", rank, world);
+    if (gg_comm::g_comm) return gg_fail(-31, "gg_comm_init: a communicator is already live (one per process)");
+    if (!gg_comm::load(nullptr, g_err, sizeof(g_err))) return -30;
+    gg_comm::UniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    int rc = gg_comm_rc(gg_comm::g_api.CommInitRank(&gg_comm::g_comm, world, id, rank), "ncclCommInitRank");
+    if (rc) { gg_comm::g_comm = nullptr; return rc; }
+    gg_comm::g_world = world;
+    gg_comm::g_rank = rank;
+    return 0;
+}
+
+extern "C" int gg_comm_world(void) {
+    if (!gg_comm::g_comm) return 0;
+    int n = 0;
+    if (gg_comm::g_api.CommCount(gg_comm::g_comm, &n) != 0) return 0;
+    return n;
+}
+
+extern "C" int gg_comm_allreduce(void* buf, size_t n, int32_t dtype, void* stream) {
+    if (!gg_comm::g_comm) return gg_fail(-32, "gg_comm_allreduce: no communicator (call gg_comm_init)");
+    size_t elem;
+    const int dt = gg_comm::dtype_of(dtype, &elem);
+    if (!buf || n == 0 || dt < 0) return gg_fail(-1, "gg_comm_allreduce: bad arguments");
+    return gg_comm_rc(gg_comm::g_api.AllReduce(buf, buf, n, dt, gg_comm::kSum, gg_comm::g_comm, stream), "ncclAllReduce");
+}
+
+extern "C" int gg_comm_allgather(const void* send, void* recv, size_t n_per_rank, int32_t dtype, void* stream) {
+    if (!gg_comm::g_comm) return gg_fail(-32, "gg_comm_allgather: no communicator (call gg_comm_init)");
+    size_t elem;
+    const int dt = gg_comm::dtype_of(dtype, &elem);
+    if (!send || !recv || n_per_rank == 0 || dt < 0) return gg_fail(-1, "gg_comm_allgather: bad arguments");
+    return gg_comm_rc(gg_comm::g_api.AllGather(send, recv, n_per_rank, dt, gg_comm::g_comm, stream), "ncclAllGather");
+}
+
+extern "C" int gg_comm_destroy(void) {
+    if (!gg_comm::g_comm) return 0;
+    int rc = gg_comm_rc(gg_comm::g_api.CommDestroy(gg_comm::g_comm), "ncclCommDestroy");
+    gg_comm::g_comm = nullptr;
+    gg_comm::g_world = 0;
+    gg_comm::g_rank = -1;
+    return rc;
 }

@@ -24,6 +24,8 @@ struct GgModulateParams {
     bf16_t* out;          // fwd: xs ; bwd: dx
     float* ds_part;       // bwd: [b][chunks][C] partial sums of g*x
     int b, P, C, chunks;  // chunks = workgroups per image
+    int Cin;              // fwd only: > 0: x has Cin channels, s is [b][Cin], `a` is [b][C / Cin] and output channel n*Cin + i is
+    const float* a;       // x[..., i] * s[b, i] * a[b, n] (the activation pre-scaled for each of the bank's N kernels); 0: plain x * s
 };
 
 GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modulate_kernel(GgModulateParams p) {
@@ -33,10 +35,18 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modulate_kernel(GgModulateParams p) {
         const int cg = (int)(idx % ncg);
         const long long row = idx / ncg;
         const int img = (int)(row / p.P);
-        u16x8 v = *(const u16x8*)(p.x + row * p.C + cg * 8);
-        const float* sc = p.s + (long long)img * p.C + cg * 8;
-        u16x8 o;
-        for (int e = 0; e < 8; ++e) o[e] = gg_f2bf(gg_bf2f(v[e]) * sc[e]);
+        u16x8 v, o;
+        if (p.Cin > 0) {
+            const int c = cg * 8, n = c / p.Cin, ci = c - n * p.Cin;
+            v = *(const u16x8*)(p.x + row * p.Cin + ci);
+            const float* sc = p.s + (long long)img * p.Cin + ci;
+            const float an = p.a[(long long)img * (p.C / p.Cin) + n];
+            for (int e = 0; e < 8; ++e) o[e] = gg_f2bf(gg_bf2f(v[e]) * (sc[e] * an));
+        } else {
+            v = *(const u16x8*)(p.x + row * p.C + cg * 8);
+            const float* sc = p.s + (long long)img * p.C + cg * 8;
+            for (int e = 0; e < 8; ++e) o[e] = gg_f2bf(gg_bf2f(v[e]) * sc[e]);
+        }
         *(u16x8*)(p.out + row * p.C + cg * 8) = o;
     }
 }

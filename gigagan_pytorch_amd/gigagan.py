@@ -171,6 +171,8 @@ class GigaGAN(nn.Module):
         if device is None:
             device = torch.device('cuda', local) if torch.cuda.is_available() else torch.device('cpu')
         self._device = torch.device(device)
+        if ws > 1 and self._device.type == 'cuda':
+            gdist.enable_native_comm(self._device)      # the gradient exchange runs on the library's own RCCL communicator
 
         self.train_upsampler = train_upsampler
         if train_upsampler:

@@ -47,6 +47,43 @@ class GemmProfiler:
         return agg
 
 
+class LaunchProfiler:
+    """context manager: HIP events (on the launch stream) around EVERY kernel launch that goes through the C ABI while it is
+    active - contraction, coefficient, modulation, mixing, resampling ... - so that an op's time is the time of everything it
+    launches. Implemented as a proxy in front of the ctypes library object; eager execution only."""
+    _NOT_LAUNCHES = ('gg_gemm_plan', 'gg_gemm_workspace_bytes', 'gg_last_error', 'gg_version', 'gg_is_emulator',
+                     'gg_bias_act_bwd_partials', 'gg_rmsnorm_blocks', 'gg_gemm_plan_table', 'gg_comm_')
+
+    def __init__(self):
+        self.records = []       # (entry point, start event, end event)
+
+    def __enter__(self):
+        L = _C.lib()
+        self._L, self._real = L, L.lib
+        prof, real = self, L.lib
+
+        class Proxy:
+            def __getattr__(self, name):
+                fn = getattr(real, name)
+                if not name.startswith('gg_') or any(name.startswith(x) for x in LaunchProfiler._NOT_LAUNCHES):
+                    return fn
+
+                def timed(*args):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    rc = fn(*args)
+                    e1.record()
+                    prof.records.append((name, e0, e1))
+                    return rc
+                return timed
+        L.lib = Proxy()
+        return self
+
+    def __exit__(self, *exc):
+        self._L.lib = self._real
+        return False
+
+
 profiler: GemmProfiler | None = None
 plan_log: list | None = None    # when a list: (tile, splitk) of every launch is appended (tuning scripts)
 desc_log: list | None = None    # when a list: a raw copy of every launch descriptor is appended (tests/gpu_plan_sweep.py)
@@ -517,6 +554,70 @@ def modulate(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
     rc = L.lib.gg_modulate_fwd(ptr(x), ptr(s), ptr(out), b, H * W, Cc, L.stream(x))
     L.check(rc, 'gg_modulate_fwd')
     return out
+
+
+def modulate_bank(x: torch.Tensor, s: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
+    """x (b, H, W, Cin) bf16, s (b, Cin) fp32, a (b, N) fp32 -> (b, H, W, N*Cin) bf16 with out[..., n*Cin + i] = x[..., i] * s[b, i] *
+    a[b, n]: the activation pre-scaled for each of the N kernels of a bank, channels laid out like the stacked reduction."""
+    L = _C.lib()
+    L.require(x, s, a)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    for t in (s, a):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    b, H, W, Cin = x.shape
+    N = a.shape[1]
+    assert s.shape == (b, Cin) and a.shape[0] == b
+    out = torch.empty((b, H, W, N * Cin), dtype=torch.bfloat16, device=x.device)
+    rc = L.lib.gg_modulate_bank_fwd(ptr(x), ptr(s), ptr(a), ptr(out), b, H * W, Cin, N * Cin, L.stream(x))
+    L.check(rc, 'gg_modulate_bank_fwd')
+    return out
+
+
+MODW_MAX_B, MODW_MAX_N, MODW_MAX_W, MODW_MAX_G = 64, 4, 18432, 5120
+
+
+def modw_eligible(b: int, N: int, I: int, T: int) -> bool:
+    return b <= MODW_MAX_B and N <= MODW_MAX_N and N * I * T <= MODW_MAX_W and (N * (N + 1) // 2) * I <= MODW_MAX_G
+
+
+def modw_fwd(w: torch.Tensor, mod: torch.Tensor, kmod, demod: bool, eps: float, Ip: int, Op: int, coef: bool = True,
+             wmix: torch.Tensor | None = None, layout: int = 0):
+    """one launch per adaptive-conv layer (gg_modfwd.h): returns (s (b, Ip), a (b, N), d (b, Op)) when `coef`, and fills `wmix`
+    (per-sample weights, layout 1 = (b, O, T*I) rows / layout 2 = (b, T, I/16, 32, 16)) when given."""
+    L = _C.lib()
+    L.require(w, mod, kmod, wmix)
+    N, O, I = w.shape[:3]
+    T = w.shape[3] * w.shape[4]
+    b = mod.shape[0]
+    assert w.dtype == torch.float32 and w.is_contiguous() and mod.dtype == torch.float32 and mod.is_contiguous()
+    assert mod.shape == (b, I) and (kmod is None or (kmod.shape == (b, N) and kmod.dtype == torch.float32 and kmod.is_contiguous()))
+    s = a = d = None
+    if coef:
+        s = torch.empty((b, Ip), dtype=torch.float32, device=w.device)
+        a = torch.empty((b, N), dtype=torch.float32, device=w.device)
+        d = torch.empty((b, Op), dtype=torch.float32, device=w.device)
+    if wmix is not None:
+        assert wmix.dtype == torch.bfloat16 and wmix.is_contiguous()
+    rc = L.lib.gg_modw_fwd(ptr(w), ptr(mod), ptr(kmod), ptr(s), ptr(a), ptr(d), ptr(wmix), layout, b, N, O, I, T, Ip, Op,
+                           int(bool(demod)), float(eps), L.stream(w))
+    L.check(rc, 'gg_modw_fwd')
+    return s, a, d
+
+
+def sconv(x: torch.Tensor, wmix: torch.Tensor, O: int, noise=None, noise_w=None, act=None, slope: float = 0.2) -> torch.Tensor:
+    """streaming 3x3 convolution with per-image filter banks (gg_sconv_fwd): x (b, H, W, C) bf16, wmix (b, 9, C/16, 32, 16) bf16
+    (or (1, ...) shared) -> (b, H, W, O) bf16 = act(conv + noise * noise_w)."""
+    L = _C.lib()
+    L.require(x, wmix, noise, noise_w)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and wmix.dtype == torch.bfloat16 and wmix.is_contiguous()
+    b, H, W, Cc = x.shape
+    assert wmix.shape[1:] == (9, Cc // 16, 32, 16) and wmix.shape[0] in (1, b)
+    y = torch.empty((b, H, W, O), dtype=torch.bfloat16, device=x.device)
+    w_bs = wmix.stride(0) if wmix.shape[0] > 1 else 0
+    rc = L.lib.gg_sconv_fwd(ptr(x), ptr(wmix), w_bs, ptr(y), ptr(noise), ptr(noise_w), b, H, W, Cc, O,
+                            1 if act == 'lrelu' else 0, float(slope), L.stream(x))
+    L.check(rc, 'gg_sconv_fwd')
+    return y
 
 
 def modulate_bwd(g: torch.Tensor, x: torch.Tensor, s: torch.Tensor):

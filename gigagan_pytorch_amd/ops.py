@@ -906,6 +906,33 @@ class HipOps:
         Ip, Op = _round8(I), _round8(O)
         needs_grad = torch.is_grad_enabled() and any(
             t is not None and t.requires_grad for t in (x, weights, mod, kernel_mod, noise_weight))
+        w_ok = weights.dtype == torch.float32 and weights.is_contiguous()
+        if not needs_grad and k == 3 and w_ok and K.modw_eligible(b, N, I, k * k) and Ip == I and Op == O:
+            # no-grad forward (the discriminator step's generator pass, generate()): csrc/gg_modfwd.h
+            km = kernel_mod.detach().float().contiguous() if N > 1 else None
+            md = mod.detach().float().contiguous()
+            wd = weights.detach()
+            nz = nw = None
+            if noise is not None:
+                nz = noise.reshape(-1).float().contiguous()
+                nw = noise_weight.detach().reshape(-1).float().contiguous()
+            if I in (16, 32, 64) and O <= 32 and W % 32 == 0 and b * H * W >= 32768:
+                # narrow high-resolution layers: the reference's per-sample weights (a few KiB each) + the streaming convolution
+                wm = _wmix_buffer(weights, b, I)
+                K.modw_fwd(wd, md, km, demod, eps, Ip, Op, coef=False, wmix=wm, layout=2)
+                return nchw(K.sconv(nhwc(x), wm, O, nz, nw, act, LRELU_SLOPE))
+            # wide layers: shared bank, the N kernels stacked along the reduction on a pre-modulated activation
+            s, a, d = K.modw_fwd(wd, md, km, demod, eps, Ip, Op)
+            x2 = K.modulate_bank(nhwc(x), s, a)
+            wk = None
+            if (isinstance(weights, torch.nn.Parameter) and getattr(weights, '_gg_pack_table', None) is not None
+                    and not _DEBUG_NO_TABLE):
+                wk = _table_pack(weights, 'modk')
+            if wk is None:
+                wk = wd.permute(1, 3, 4, 0, 2).reshape(O, k * k * N * I).to(ACT_DTYPE).contiguous()
+            y = K.conv2d_nhwc(x2, wk, ksize=k, out_scale=d if demod else None, noise=nz, noise_w=nw, act=act,
+                              act_slope=LRELU_SLOPE)
+            return nchw(y)
         fused_coef = (demod and not second_order and N <= K.MODCOEF_MAX_N and max(I, O) <= K.MODCOEF_MAX_C
                       and weights.dtype == torch.float32 and weights.is_contiguous())
         s_padded = d_padded = False
@@ -1097,6 +1124,16 @@ class HipOps:
             return x
         xa = to_act(x)
         return nchw(ResampleFn.apply(nhwc(xa), K.ResampleSpec.nearest(H, W, *size)))
+
+
+def _wmix_buffer(weights, b: int, I: int):
+    """the per-sample filter banks of one layer for gg_sconv_fwd, (b, 9, I/16, 32, 16) bf16: persistent per weight tensor (rows
+    beyond O stay zero; a captured hipGraph keeps pointing at it), re-filled by gg_modw_fwd on every forward."""
+    slot = weights.__dict__.setdefault('_gg_wmix', {}) if isinstance(weights, torch.nn.Parameter) else {}
+    buf = slot.get(b)
+    if buf is None or buf.device != weights.device:
+        buf = slot[b] = torch.zeros((b, 9, I // 16, 32, 16), dtype=ACT_DTYPE, device=weights.device)
+    return buf
 
 
 def demod_coefficients(weights, s, a, eps):

@@ -260,6 +260,38 @@ int gg_attn_bwd2(const void* q, const void* k, const void* v, const void* k0, co
                  float* mu, float* gi, void* gq, void* gk, void* gv, void* gdo, float* null_part, int32_t B, int32_t n,
                  int32_t h, float alpha, float beta, void* stream);
 
+/* ---- no-grad forward of the adaptive convolution (gp.py:344-409; what the discriminator step's generator pass and generate()
+ * run), csrc/gg_modfwd.h ----
+ * gg_modw_fwd: ONE launch per layer: s = mod + 1 (b, Ip), a = softmax(kernel_mod) (b, N), d (b, Op) = demodulation coefficients
+ *   (ones when demod == 0; any of s / a / d may be null), and optionally the reference's per-sample weights
+ *   wmix = d[b,o] s[b,i] sum_n a[b,n] W_n[o,i,t] in bf16: layout 1 = [b][O][T][I] (rows of T*I: the implicit GEMM's weight operand of
+ *   image b), layout 2 = [b][T][I/16][32][16] (gg_sconv_fwd's filter bank; rows O..31 are left untouched: zero them once).
+ *   b <= 64, N <= 4, N*I*T <= 18432.
+ * gg_sconv_fwd: 3x3 / stride 1 / pad 1 convolution of an NHWC bf16 activation with per-image banks (w_bs = elements between
+ *   banks, 0 = shared) as a streaming direct convolution: y = act(conv + noise[b][pixel] * noise_w[o]). W %% 32 == 0,
+ *   C in {16, 32, 64}, O <= 32, O %% 8 == 0.
+ * gg_modulate_bank_fwd: out[b][p][n*Cin + i] = x[b][p][i] * s[b][i] * a[b][n] for the N = Cout / Cin kernels of a bank in one pass
+ *   (s is [b][Cin], a is [b][N]). */
+int gg_modw_fwd(const float* w, const float* mod, const float* kmod, float* s, float* a, float* d, void* wmix, int32_t layout,
+                int32_t b, int32_t N, int32_t O, int32_t I, int32_t T, int32_t Ip, int32_t Op, int32_t demod, float eps, void* stream);
+int gg_sconv_fwd(const void* x, const void* w, int64_t w_bs, void* y, const float* noise, const float* noise_w, int32_t b,
+                 int32_t H, int32_t W, int32_t C, int32_t O, int32_t act, float slope, void* stream);
+int gg_modulate_bank_fwd(const void* x, const float* s, const float* a, void* out, int32_t b, int32_t P, int32_t Cin, int32_t Cout,
+                         void* stream);
+
+/* ---- data-parallel exchange: RCCL over xGMI (replaces accelerate / DDP's gradient all-reduce, gp.py:1898-1908, :1987, and the
+ * reference's all_gather, distributed.py:20-68). One communicator per process (one process per GPU). RCCL is bound at run time
+ * from the librccl already mapped into the process (PyTorch-ROCm's); gg_comm_load(path) names a specific one. Collectives are
+ * enqueued on `stream` (the host code uses a dedicated side stream with event fences); calls are serialised by the caller.
+ * Errors: < 0 argument / state, 1000 + ncclResult_t for RCCL failures. dtype: 0 = fp32, 1 = bf16, 2 = bytes. */
+int gg_comm_load(const char* librccl_path);
+int gg_comm_unique_id(void* id128);                       /* rank 0: 128-byte ncclUniqueId to hand to every rank (host memory) */
+int gg_comm_init(int32_t rank, int32_t world, const void* id128);
+int gg_comm_world(void);                                  /* ncclCommCount of the live communicator, 0 when there is none */
+int gg_comm_allreduce(void* buf, size_t n, int32_t dtype, void* stream);      /* in-place sum over ranks */
+int gg_comm_allgather(const void* send, void* recv, size_t n_per_rank, int32_t dtype, void* stream);
+int gg_comm_destroy(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -538,9 +538,9 @@ def test_fused_adaptive_conv_coefficients_match_tensor_algebra(cfg):
     check_modcoef(cfg, 'cpu')
 
 
-def test_narrow_modconv_layers_take_the_direct_convolution():
-    """no-grad adaptive conv on a narrow high-resolution layer: direct convolution with the modulation applied on load + the
-    mix / demodulate / noise / activation pass (plan tile 9), against the oracle."""
+def test_narrow_modconv_layers_take_the_streaming_convolution():
+    """no-grad adaptive conv on a narrow high-resolution layer: per-sample weights (gg_modw_fwd) + the streaming direct
+    convolution (gg_sconv_fwd), no implicit-GEMM launch at all, against the oracle."""
     from gigagan_pytorch_amd.modules import AdaptiveConv2DMod
     torch.manual_seed(0)
     I, O, b, H, W = 16, 16, 2, 128, 256
@@ -551,7 +551,7 @@ def test_narrow_modconv_layers_take_the_direct_convolution():
         with torch.no_grad():
             K.plan_log = []
             y1 = conv(x, mod, km, noise=nz, noise_weight=nw, act='lrelu')
-            assert [t for t, _ in K.plan_log] == [9]          # the direct-convolution kernel
+            assert K.plan_log == []                           # no contraction launch: gg_modw_fwd + gg_sconv_fwd
     finally:
         K.plan_log = None
     with torch.no_grad(), ops.use_impl(OracleOps(bf16_operands=True)):
@@ -642,14 +642,90 @@ def test_premodulated_modconv_path_matches_oracle():
     conv = AdaptiveConv2DMod(64, 72, 3, num_conv_kernels=2)
     x, mod, km = torch.randn(2, 64, 8, 8), torch.randn(2, 64) * 0.3, torch.randn(2, 2)
     nz, nw = torch.randn(2, 1, 8, 8), torch.randn(72, 1, 1) * 0.1
-    calls, orig = [], K.modulate
+    calls, orig = [], K.modulate_bank
     try:
-        K.modulate = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        K.modulate_bank = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
         with torch.no_grad():
             y1 = conv(x, mod, km, noise=nz, noise_weight=nw, act='lrelu')
-            assert len(calls) == 2                      # one pointwise pass per kernel of the bank
+            assert len(calls) == 1                      # one pointwise pass for both kernels of the bank
     finally:
-        K.modulate = orig
+        K.modulate_bank = orig
     with torch.no_grad(), ops.use_impl(OracleOps(bf16_operands=True)):
         y0 = conv(x, mod, km, noise=nz, noise_weight=nw, act='lrelu')
+    assert rel_err(y1, y0) < 1e-2
+
+
+# ---- no-grad forward of the adaptive convolution (gg_modfwd.h) -----------------------------------------------------------
+
+@pytest.mark.parametrize('cfg', [(5, 2, 24, 32, 3), (3, 1, 16, 16, 3), (4, 3, 8, 48, 3), (2, 2, 40, 64, 1)])
+def test_modw_coefficients_and_per_sample_weights_match_the_reference_formulation(cfg):
+    """gg_modw_fwd: s, a, d and the per-sample weights (both layouts) against the reference's tensor algebra (gp.py:378-400:
+    softmax over the kernels, (mod + 1), demodulation over (i, k))."""
+    b, N, O, I, k = cfg
+    torch.manual_seed(0)
+    w = torch.randn(N, O, I, k, k) * 0.2
+    mod, kmod = torch.randn(b, I) * 0.5, (torch.randn(b, N) if N > 1 else None)
+    r8 = lambda n: (n + 7) // 8 * 8
+    attn = kmod.softmax(-1) if N > 1 else torch.ones(b, 1)
+    wts = (w[None] * attn[:, :, None, None, None, None]).sum(1) * (mod[:, None, :, None, None] + 1)
+    inv = wts.pow(2).sum(dim=(2, 3, 4), keepdim=True).clamp(min=1e-8).rsqrt()
+    ref_w = wts * inv                                                       # (b, O, I, k, k): the reference's per-sample weights
+    s, a, d = K.modw_fwd(w, mod, kmod, True, 1e-8, r8(I), r8(O))
+    assert torch.allclose(s[:, :I], mod + 1, atol=1e-6) and torch.allclose(a, attn, atol=1e-6)
+    assert rel_err(d[:, :O], inv.reshape(b, O)) < 1e-5 and float(d[:, O:].abs().max() if r8(O) > O else 0.) == 0.
+    wm1 = torch.zeros(b, O, k * k * I, dtype=torch.bfloat16)
+    K.modw_fwd(w, mod, kmod, True, 1e-8, r8(I), r8(O), coef=False, wmix=wm1, layout=1)
+    assert rel_err(wm1.float().view(b, O, k * k, I), ref_w.reshape(b, O, I, k * k).transpose(2, 3)) < 4e-3
+    if I % 16 == 0 and O <= 32 and k == 3:
+        wm2 = torch.zeros(b, 9, I // 16, 32, 16, dtype=torch.bfloat16)
+        K.modw_fwd(w, mod, kmod, True, 1e-8, r8(I), r8(O), coef=False, wmix=wm2, layout=2)
+        got = wm2.float().permute(0, 3, 2, 4, 1).reshape(b, 32, I, 9)     # (b, o, i, tap)
+        assert rel_err(got[:, :O], ref_w.reshape(b, O, I, 9)) < 4e-3 and float(got[:, O:].abs().max() if O < 32 else 0.) == 0.
+    _, _, d0 = K.modw_fwd(w, mod, kmod, False, 1e-8, r8(I), r8(O))
+    assert torch.equal(d0[:, :O], torch.ones(b, O))
+
+
+@pytest.mark.parametrize('cfg', [(2, 16, 64, 16, 16), (1, 8, 32, 32, 32), (3, 8, 64, 64, 24), (2, 5, 32, 32, 8)])
+def test_streaming_conv_matches_per_sample_convolution(cfg):
+    """gg_sconv_fwd against F.conv2d with groups = batch on the same bf16 operands, with noise + leaky-relu, image borders and
+    a shared bank."""
+    b, H, W, C, O = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(b, H, W, C))
+    wps = bf(torch.randn(b, O, C, 3, 3) * 0.1)
+    wm = torch.zeros(b, 9, C // 16, 32, 16, dtype=torch.bfloat16)
+    wm[:, :, :, :O] = wps.reshape(b, O, C // 16, 16, 9).permute(0, 4, 2, 1, 3)
+    nz, nw = torch.randn(b * H * W), torch.randn(O) * 0.3
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2).reshape(1, b * C, H, W), wps.float().reshape(b * O, C, 3, 3), padding=1, groups=b)
+    ref = ref.reshape(b, O, H, W) + nz.view(b, 1, H, W) * nw.view(1, O, 1, 1)
+    y = K.sconv(x, wm, O, nz, nw, 'lrelu')
+    assert rel_err(y.permute(0, 3, 1, 2), F.leaky_relu(ref, 0.2)) < 4e-3
+    y1 = K.sconv(x, wm[:1].contiguous(), O)                               # one shared bank, plain epilogue
+    ref1 = F.conv2d(x.float().permute(0, 3, 1, 2), wps[0].float(), padding=1)
+    assert rel_err(y1.permute(0, 3, 1, 2), ref1) < 4e-3
+
+
+def test_modulate_bank_lays_the_kernels_side_by_side():
+    torch.manual_seed(0)
+    x, s, a = bf(torch.randn(2, 4, 4, 16)), torch.rand(2, 16) + 0.5, torch.rand(2, 3)
+    out = K.modulate_bank(x, s, a)
+    want = torch.cat([x.float() * (s * a[:, n:n + 1])[:, None, None, :] for n in range(3)], dim=-1)
+    assert out.shape == (2, 4, 4, 48) and rel_err(out, want) < 4e-3
+
+
+@pytest.mark.parametrize('cfg', [(16, 16, 32, 64, True), (64, 32, 16, 32, True), (64, 72, 8, 8, True), (32, 24, 8, 8, False)])
+def test_no_grad_adaptive_conv_paths_match_oracle(cfg):
+    """the whole no-grad forward through ops.modconv2d: the streaming path (narrow layers) and the stacked path (wide layers),
+    with demodulation on and off, noise and activation, against the oracle."""
+    from gigagan_pytorch_amd.modules import AdaptiveConv2DMod
+    I, O, H, W, demod = cfg
+    torch.manual_seed(0)
+    conv = AdaptiveConv2DMod(I, O, 3, num_conv_kernels=2, demod=demod)
+    b = 4 if H * W >= 2048 else 2
+    x, mod, km = torch.randn(b, I, H, W), torch.randn(b, I) * 0.3, torch.randn(b, 2)
+    nz, nw = torch.randn(b, 1, H, W), torch.randn(O, 1, 1) * 0.1
+    with torch.no_grad():
+        y1 = conv(x, mod, km, noise=nz, noise_weight=nw, act='lrelu')
+        with ops.use_impl(OracleOps(bf16_operands=True)):
+            y0 = conv(x, mod, km, noise=nz, noise_weight=nw, act='lrelu')
     assert rel_err(y1, y0) < 1e-2

@@ -184,3 +184,54 @@ def test_squeeze_excite_pool_and_channel_scale_vs_fp32():
     ghx, ghs = torch.autograd.grad([yh.float(), mh], [xh, sh], [g.to(d), gm.to(d)])
     gox, gos = torch.autograd.grad([yo, mo], [xo, so], [g, gm])
     assert rel_err(ghx.float().cpu(), gox) < 1e-2 and rel_err(ghs.cpu(), gos) < 1e-3
+
+
+def test_native_rccl_communicator_on_one_gpu():
+    """gg_comm_* (RCCL bound at run time from the librccl PyTorch carries) with a one-rank communicator: init from a unique id,
+    in-place all-reduce on the side stream with event fences (identity for world 1), all-gather, ncclCommCount, destroy — the
+    same calls a data-parallel step issues (gp.py:1898-1908 replaced). The two-rank case is tests/test_rccl_two_gpus.py."""
+    from gigagan_pytorch_amd import distributed as gdist, _C
+    d = dev()
+    comm = gdist.NativeComm().init(d, rank=0, world=1)
+    try:
+        assert _C.lib().lib.gg_comm_world() == 1
+        g = torch.randn(3_000_000, device=d)
+        want = g.clone()
+        comm.timing = True
+        h = comm.all_reduce_(g, n_slices=4)
+        h.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(g, want)
+        assert len(comm.exposed_ms) == 1 and comm.exposed_ms[0][0].elapsed_time(comm.exposed_ms[0][1]) >= 0
+        x = torch.randn(5, 7, device=d).to(torch.bfloat16)
+        out = comm.all_gather(x)
+        torch.cuda.synchronize()
+        assert torch.equal(out, x)
+        with pytest.raises(RuntimeError, match='already live'):
+            gdist.NativeComm().init(d, rank=0, world=1)
+    finally:
+        comm.destroy()
+    assert _C.lib().lib.gg_comm_world() == 0
+
+
+@pytest.mark.parametrize('cfg', [(512, 512, 4, 32), (512, 256, 16, 32), (128, 64, 64, 8), (64, 32, 128, 8), (32, 32, 128, 8),
+                                 (32, 16, 256, 4), (16, 16, 256, 4)])
+def test_no_grad_adaptive_conv_at_config2_layer_shapes(cfg):
+    """the generator's demodulated 3x3 adaptive convs (gp.py:344-409 + noise + leaky-relu) at BASELINE config-2 layer shapes, no-grad
+    path (gg_modw_fwd + gg_sconv_fwd for the narrow layers, gg_modw_fwd + gg_modulate_bank_fwd + the implicit GEMM for the wide
+    ones) against the oracle with bf16-rounded operands: 1e-2 relative L2 (bf16 output rounding + the per-sample weights being
+    rounded to bf16 AFTER modulation / demodulation, as the reference's autocast conv does)."""
+    from gigagan_pytorch_amd.modules import AdaptiveConv2DMod
+    I, O, R, b = cfg
+    torch.manual_seed(0)
+    conv = AdaptiveConv2DMod(I, O, 3, num_conv_kernels=2)
+    x, mod, km = torch.randn(b, I, R, R), torch.randn(b, I) * 0.3, torch.randn(b, 2)
+    nz, nw = torch.randn(b, 1, R, R), torch.randn(O, 1, 1) * 0.1
+    with torch.no_grad():
+        with ops.use_impl(OracleOps(bf16_operands=True)):
+            y0 = conv(x, mod, km, noise=nz, noise_weight=nw, act='lrelu')
+        d = dev()
+        conv = conv.to(d)
+        with ops.use_impl(ops.HipOps()):
+            y1 = conv(x.to(d), mod.to(d), km.to(d), noise=nz.to(d), noise_weight=nw.to(d), act='lrelu')
+    assert rel_err(y1.float().cpu(), y0) < 1e-2
