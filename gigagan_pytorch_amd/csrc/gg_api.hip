@@ -93,6 +93,12 @@ int gg_validate_gemm(const gg_gemm_desc* d) {
         if (d->a_batch_stride % 8) return gg_fail(-9, "gg_gemm: A batch stride must be a multiple of 8");
         if (d->in_scale) return gg_fail(-9, "gg_gemm: in_scale only applies to the conv gather");
     }
+    if (d->b_image_stride) {
+        if (!d->a_conv || d->a_layout != GG_ROWK || d->b_layout != GG_ROWK || d->b_image_stride < 0 || (d->b_image_stride & 7))
+            return gg_fail(-10, "gg_gemm: b_image_stride applies to the conv forward (row-major operands), multiple of 8");
+        const int oh = (d->H + 2 * d->conv_pad - d->R) / d->conv_stride + 1, ow = (d->W + 2 * d->conv_pad - d->S) / d->conv_stride + 1;
+        if ((oh * ow) % 128) return gg_fail(-10, "gg_gemm: b_image_stride needs OH*OW %% 128 == 0 (got %d)", oh * ow);
+    }
     if (d->ldb % 8) return gg_fail(-10, "gg_gemm: ldb must be a multiple of 8 (got %d)", d->ldb);
     {
         int need = d->b_layout == GG_ROWK ? d->K : d->N;
@@ -213,7 +219,13 @@ static bool gg_dconv_eligible(const gg_gemm_desc* d) {
     return true;
 }
 
+static int gg_img_pixels(const gg_gemm_desc* d) {
+    const int oh = (d->H + 2 * d->conv_pad - d->R) / d->conv_stride + 1, ow = (d->W + 2 * d->conv_pad - d->S) / d->conv_stride + 1;
+    return oh * ow;
+}
+
 static bool gg_use_dconv(const gg_gemm_desc* d) {
+    if (d->b_image_stride) return false;
     if (!gg_dconv_eligible(d)) return false;
     if (d->force_tile == 9) return true;
     if (d->force_tile != 0 || d->force_splitk > 1) return false;
@@ -252,7 +264,7 @@ static std::string gg_plan_key_of(const gg_gemm_desc* d) {
 }
 
 static bool gg_table_plan(const gg_gemm_desc* d, GemmPlan& pl) {
-    if (g_plan_table.empty() || d->force_tile != 0 || d->force_splitk != 0) return false;
+    if (g_plan_table.empty() || d->force_tile != 0 || d->force_splitk != 0 || d->b_image_stride) return false;
     auto it = g_plan_table.find(gg_plan_key_of(d));
     if (it == g_plan_table.end()) return false;
     const int tile = it->second.tile;
@@ -293,6 +305,10 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     if ((forced == 7 || forced == 8) && !gg_v3_eligible(d)) forced = 0;
     if (forced == 8 && d->a_layout == GG_KROW) forced = 7;     // the weight-gradient ring has no staggered variant yet
     if (forced >= 4 && forced <= 6 && !gg_v2_eligible(d)) forced = 0;
+    if (d->b_image_stride && forced) {
+        if (forced >= 7) forced = 0;
+        else if (gg_img_pixels(d) % kTileModels[forced - 1].bm) forced = 0;
+    }
     if (forced < 0 || forced > 8) forced = 0;      // (9 = direct convolution: handled above when eligible)
     double best = 1e30;
     pl.tile = v1_tile; pl.splitk = 1;
@@ -302,6 +318,7 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
         } else {
             // experimental LDS-DMA ring: forced, or offered to the cost model when GG_GEMM_V3=1 (next round's A/B switch)
             if (tm.tile == 8) continue;
+            if (d->b_image_stride && gg_img_pixels(d) % tm.bm) continue;     // a row tile must stay inside one image
             if (tm.tile == 7 && !(gg_v3_policy() && gg_v3_eligible(d) && d->N >= 192 && d->M >= 192)) continue;
             if (tm.tile <= 3 && tm.tile != v1_tile) continue;
             if (tm.tile >= 4 && (!v2ok || !pol)) continue;
@@ -461,6 +478,7 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     p.act = d->act; p.act_slope = d->act_slope;
     p.partial = (float*)workspace;
     p.zero_page = (const bf16_t*)d->zero_page;
+    p.b_img_stride = d->b_image_stride;
 #ifdef GG2_PROBE
     if (pl.tile > 3) p.xcd_slices = getenv("GG2_DBG") ? atoi(getenv("GG2_DBG")) : 0;   // probe builds: k-loop phase mask
 #endif
@@ -785,7 +803,7 @@ extern "C" int gg_modw_fwd(const float* w, const float* mod, const float* kmod, 
                            int32_t layout, int32_t b, int32_t N, int32_t O, int32_t I, int32_t T, int32_t Ip, int32_t Op,
                            int32_t demod, float eps, void* stream) {
     if (!w || !mod) return gg_fail(-1, "gg_modw_fwd: null pointer");
-    if (b <= 0 || b > GG_MW_BMAX || N <= 0 || N > GG_MW_NMAX || O <= 0 || I <= 0 || T <= 0 || Ip < I || Op < O)
+    if (b <= 0 || b > GG_MW_BMAX || N <= 0 || N > GG_MW_NMAX || O <= 0 || I <= 0 || (I & 3) || T <= 0 || Ip < I || Op < O)
         return gg_fail(-2, "gg_modw_fwd: bad extents (b=%d N=%d O=%d I=%d T=%d)", b, N, O, I, T);
     if ((long long)N * I * T > GG_MW_WMAX || (long long)(N * (N + 1) / 2) * I > GG_MW_GMAX)
         return gg_fail(-3, "gg_modw_fwd: bank too large for one workgroup (N*I*T=%lld)", (long long)N * I * T);
@@ -799,7 +817,16 @@ extern "C" int gg_modw_fwd(const float* w, const float* mod, const float* kmod, 
     memset(&p, 0, sizeof(p));
     p.w = w; p.mod = mod; p.kmod = kmod; p.s = s; p.a = a; p.d = d; p.wmix = (bf16_t*)wmix; p.layout = layout;
     p.b = b; p.N = N; p.O = O; p.I = I; p.T = T; p.Ip = Ip; p.Op = Op; p.demod = demod; p.eps = eps;
-    GG_LAUNCH(gg_modw_kernel, dim3((unsigned)O), dim3(256), (hipStream_t)stream, p);
+    // coefficient-only launches: one workgroup per channel handles every sample; with per-sample weights the samples are spread
+    // over enough workgroups to fill the chip (a 16-channel layer would otherwise run on 16 CUs)
+    int bc = b;
+    if (wmix) {
+        bc = (int)(((long long)b * O + 767) / 768);
+        if (bc < 1) bc = 1;
+        if (bc > b) bc = b;
+    }
+    p.bc = bc;
+    GG_LAUNCH(gg_modw_kernel, dim3((unsigned)O, (unsigned)((b + bc - 1) / bc)), dim3(256), (hipStream_t)stream, p);
     return gg_check_launch();
 }
 
@@ -816,8 +843,8 @@ extern "C" int gg_sconv_fwd(const void* x, const void* w, int64_t w_bs, void* y,
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.w_bs = w_bs; p.y = (bf16_t*)y; p.noise = noise; p.noise_w = noise_w;
     p.b = b; p.H = H; p.W = W; p.O = O; p.act = act; p.slope = slope;
     const long long gpi = (long long)H * (W >> 5);
-    int gpw = (int)((gpi * b + 4095) / 4096);          // ~4096 workgroups: 16 per CU to draw from
-    if (gpw < 8) gpw = 8;
+    int gpw = (int)((gpi * b + 2047) / 2048);          // ~2048 workgroups (8 per CU); a workgroup first loads its image's bank,
+    if (gpw < 32) gpw = 32;                             // so give it at least 8 row groups per wave to amortise that
     if (gpw > gpi) gpw = (int)gpi;
     p.groups_per_wg = gpw;
     const long long blocks = (long long)b * ((gpi + gpw - 1) / gpw);

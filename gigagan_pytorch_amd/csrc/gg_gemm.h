@@ -76,6 +76,7 @@ struct GgGemmParams {
     // one k-slice land on the same XCD (block b -> XCD b % 8), so the slice of x / dy they all stream is fetched from
     // HBM once and shared through that XCD's L2. 0: (tiles, 1, batch*splitk) grid.
     int xcd_slices;
+    long long b_img_stride;    // conv forward only: > 0: image i's weights start at B + i * b_img_stride (per-sample weights)
     const bf16_t* zero_page;   // experimental tile 7 (gg_gemm3.h): >= 16 bytes of zeros for the conv gather's padding taps
 };
 
@@ -406,7 +407,8 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_gemm_kernel(GgGemmParams p) {
     if (kend > p.K) kend = p.K;
 
     const bf16_t* Ab = p.A + (long long)b * p.a_bs;
-    const bf16_t* Bb = p.B + (long long)b * p.b_bs;
+    // per-image weight operand (per-sample weights of the adaptive conv): a tile never straddles two images (planner)
+    const bf16_t* Bb = p.B + (long long)b * p.b_bs + ((A_CONV && !A_KROW && p.b_img_stride) ? (long long)(m0 / (p.OH * p.OW)) * p.b_img_stride : 0);
 
     GgConvRow crow[A_CONV && !A_KROW ? ANV : 1];
     if (A_CONV && !A_KROW) gg_conv_rows_init<BM>(crow, p, m0);

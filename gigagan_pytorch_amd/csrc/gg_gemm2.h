@@ -382,7 +382,8 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_gemm2_kernel(GgGemmParams p) {
     if (kend > p.K) kend = p.K;
 
     const bf16_t* Ab = p.A + (long long)b * p.a_bs;
-    const bf16_t* Bb = p.B + (long long)b * p.b_bs;
+    // per-image weight operand (per-sample weights of the adaptive conv): a tile never straddles two images (planner)
+    const bf16_t* Bb = p.B + (long long)b * p.b_bs + ((A_CONV && !A_KROW && p.b_img_stride) ? (long long)(m0 / (p.OH * p.OW)) * p.b_img_stride : 0);
 
     Gg2ConvRow crow[A_CONV && !A_KROW ? ANV : 1];
     if (A_CONV && !A_KROW) gg2_conv_rows_init<BM>(crow, p, m0);

@@ -19,8 +19,8 @@
 
 #define GG_MW_NMAX 4
 #define GG_MW_BMAX 64          // samples per launch
-#define GG_MW_WMAX 18432       // N * I * T floats staged per workgroup (72 KiB)
-#define GG_MW_GMAX 5120        // pairs * I floats (Gram rows)
+#define GG_MW_WMAX 9216        // N * I * T floats staged per workgroup (36 KiB: two 512-channel 3x3 kernels)
+#define GG_MW_GMAX 1536        // pairs * I floats (Gram rows)
 
 struct GgModWParams {
     const float* w;        // (N, O, I, T) fp32 parameter layout
@@ -34,6 +34,7 @@ struct GgModWParams {
     int b, N, O, I, T, Ip, Op;
     int demod;
     float eps;
+    int bc;                // samples per workgroup: grid = (O, ceil(b / bc)); every workgroup re-derives the Gram rows of its channel
 };
 
 GG_DEVICE float gg_mw_wave_sum(float v) {
@@ -42,7 +43,7 @@ GG_DEVICE float gg_mw_wave_sum(float v) {
     return v;
 }
 
-// grid: O workgroups of 256 threads, workgroup o owns output channel o for every sample
+// grid: (O, ceil(b / bc)) workgroups of 256 threads: workgroup (o, c) owns output channel o for samples c*bc .. c*bc + bc - 1
 GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modw_kernel(GgModWParams p) {
     GG_SHARED float wl[GG_MW_WMAX];                       // [n][i*T + t]
     GG_SHARED float gram[GG_MW_GMAX];                     // [pair][i], pair = (n, m >= n) in row-major upper-triangle order
@@ -51,30 +52,56 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modw_kernel(GgModWParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int o = blockIdx.x;
     const int IT = p.I * p.T;
-    // s / a / the zero padding of d: written row by row by the workgroups in turn
-    for (int row = blockIdx.x; row < p.b; row += gridDim.x) {
-        if (p.s)
-            for (int i = tid; i < p.Ip; i += 256) p.s[(long long)row * p.Ip + i] = i < p.I ? p.mod[(long long)row * p.I + i] + 1.f : 0.f;
-        if (p.d)
-            for (int c = p.O + tid; c < p.Op; c += 256) p.d[(long long)row * p.Op + c] = 0.f;
-    }
-    for (int n = 0; n < p.N; ++n)
-        for (int e = tid; e < IT; e += 256) wl[n * IT + e] = p.w[((long long)n * p.O + o) * IT + e];
-    if (tid < p.b) {
-        float v[GG_MW_NMAX];
-        for (int n = 0; n < GG_MW_NMAX; ++n) v[n] = 0.f;
-        if (p.kmod && p.N > 1) {
-            float mx = -3.0e38f;
-            for (int n = 0; n < p.N; ++n) { v[n] = p.kmod[tid * p.N + n]; mx = v[n] > mx ? v[n] : mx; }
-            float sum = 0.f;
-            for (int n = 0; n < p.N; ++n) { v[n] = gg_expf(v[n] - mx); sum += v[n]; }
-            for (int n = 0; n < p.N; ++n) v[n] /= sum;
-        } else {
-            v[0] = 1.f;
+    const int b_lo = blockIdx.y * p.bc;
+    const int b_hi = b_lo + p.bc < p.b ? b_lo + p.bc : p.b;
+    // s / a / the zero padding of d of this chunk's samples: written by the workgroups of channel 0
+    if (o == 0)
+        for (int row = b_lo; row < b_hi; ++row) {
+            if (p.s)
+                for (int i = tid; i < p.Ip; i += 256) p.s[(long long)row * p.Ip + i] = i < p.I ? p.mod[(long long)row * p.I + i] + 1.f : 0.f;
+            if (p.d)
+                for (int c = p.O + tid; c < p.Op; c += 256) p.d[(long long)row * p.Op + c] = 0.f;
         }
-        for (int n = 0; n < GG_MW_NMAX; ++n) a_s[tid][n] = v[n];
-        if (p.a && blockIdx.x == 0)
-            for (int n = 0; n < p.N; ++n) p.a[tid * p.N + n] = v[n];
+    {   // the bank rows of this channel: 16-byte loads, several in flight per thread (I % 4 == 0: rows are 16-byte aligned)
+        const int nv = (p.N * IT) >> 2;
+        const int ivn = IT >> 2;
+        for (int v0 = tid; v0 < nv; v0 += 256 * 4) {
+            f32x4 r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int v = v0 + u * 256;
+                if (v < nv) {
+                    const int n = v / ivn, e4 = v - n * ivn;
+                    r[u] = *(const f32x4*)(p.w + ((long long)n * p.O + o) * IT + e4 * 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int v = v0 + u * 256;
+                if (v < nv) *(f32x4*)(wl + v * 4) = r[u];
+            }
+        }
+    }
+    if (tid >= b_lo && tid < b_hi) {
+        float a0 = 1.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (p.kmod && p.N > 1) {
+            const float* km = p.kmod + tid * p.N;
+            const float k0 = km[0], k1 = km[1], k2 = p.N > 2 ? km[2] : -3.0e38f, k3 = p.N > 3 ? km[3] : -3.0e38f;
+            float mx = k0 > k1 ? k0 : k1;
+            mx = k2 > mx ? k2 : mx;
+            mx = k3 > mx ? k3 : mx;
+            a0 = gg_expf(k0 - mx); a1 = gg_expf(k1 - mx);
+            a2 = p.N > 2 ? gg_expf(k2 - mx) : 0.f; a3 = p.N > 3 ? gg_expf(k3 - mx) : 0.f;
+            const float inv = 1.f / (a0 + a1 + a2 + a3);
+            a0 *= inv; a1 *= inv; a2 *= inv; a3 *= inv;
+        }
+        a_s[tid][0] = a0; a_s[tid][1] = a1; a_s[tid][2] = a2; a_s[tid][3] = a3;
+        if (p.a && o == 0) {
+            p.a[tid * p.N] = a0;
+            if (p.N > 1) p.a[tid * p.N + 1] = a1;
+            if (p.N > 2) p.a[tid * p.N + 2] = a2;
+            if (p.N > 3) p.a[tid * p.N + 3] = a3;
+        }
     }
     gg_sync();
     if (p.demod) {
@@ -87,7 +114,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modw_kernel(GgModWParams p) {
                     gram[pair * p.I + i] = acc;
                 }
         gg_sync();
-        for (int bb = wave; bb < p.b; bb += 4) {
+        for (int bb = b_lo + wave; bb < b_hi; bb += 4) {
             float acc = 0.f;
             for (int i = lane; i < p.I; i += 64) {
                 const float sv = p.mod[(long long)bb * p.I + i] + 1.f;
@@ -106,7 +133,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modw_kernel(GgModWParams p) {
             }
         }
     } else {
-        if (tid < p.b) {
+        if (tid >= b_lo && tid < b_hi) {
             d_s[tid] = 1.f;
             if (p.d) p.d[(long long)tid * p.Op + o] = 1.f;
         }
@@ -114,7 +141,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modw_kernel(GgModWParams p) {
     if (!p.wmix) return;
     gg_sync();
     // per-sample weights: threads run along (t, i) with i fastest, so the bf16 stores of a wave are contiguous
-    for (int bb = 0; bb < p.b; ++bb) {
+    for (int bb = b_lo; bb < b_hi; ++bb) {
         const float dv = d_s[bb];
         for (int e = tid; e < IT; e += 256) {
             const int t = e / p.I, i = e - t * p.I;
@@ -171,11 +198,14 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_sconv_kernel(GgSconvParams p) {
             u16x8 xa[9];
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
+                // always load (from a clamped address) and zero the out-of-image taps afterwards: a load under a per-lane
+                // condition is branched around and waited for one at a time, nine dependent round trips instead of nine in flight
                 const int iy = yy + tap / 3 - 1, ix = x0 + pl + tap % 3 - 1;
-                u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                    v = *(const u16x8*)(xi + ((long long)iy * p.W + ix) * C + kc * 16 + hi * 8);
-                xa[tap] = v;
+                const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                const int cy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy), cx = ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix);
+                u16x8 v = *(const u16x8*)(xi + ((long long)cy * p.W + cx) * C + kc * 16 + hi * 8);
+                const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                xa[tap] = in ? v : z;
             }
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {

@@ -211,7 +211,7 @@ def _conv_out(size: int, ksize: int, stride: int, pad: int) -> int:
 def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, *, ksize: int, stride: int = 1, pad: int | None = None,
                 cv: int | None = None, in_scale=None, out_dtype=torch.bfloat16, alpha=1.0, bias=None, bias_scale=1.0,
                 act=None, act_slope=0.2, out_scale=None, noise=None, noise_w=None, residual=None, res_scale=1.0,
-                force_splitk=0, force_tile=0):
+                force_splitk=0, force_tile=0, per_image_weights=False):
     """Convolution of an NHWC bf16 activation x (n, H, W, C) with weights w (Cout, ksize*ksize*CV) bf16 laid out
     [co][kh][kw][cv]; window stride `stride`, zero padding `pad` (default: 'same', ksize//2); returns
     (n, OH, OW, Cout) = act(alpha*conv*out_scale + bias*bias_scale + noise) + residual*res_scale."""
@@ -222,14 +222,20 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, *, ksize: int, stride: int = 1
     cv = cv or Cc
     pad = ksize // 2 if pad is None else pad
     OH, OW = _conv_out(H, ksize, stride, pad), _conv_out(Wd, ksize, stride, pad)
-    cout = w.shape[0]
-    assert w.shape[1] == ksize * ksize * cv, (w.shape, ksize, cv)
+    if per_image_weights:        # w (n, Cout, ksize*ksize*CV): image i is convolved with w[i] (per-sample weights)
+        assert w.dim() == 3 and w.shape[0] == n and stride == 1
+        cout, wrow = w.shape[1], w.shape[2]
+    else:
+        cout, wrow = w.shape[0], w.shape[1]
+    assert wrow == ksize * ksize * cv, (w.shape, ksize, cv)
     out = torch.empty((n, OH, OW, cout), dtype=out_dtype, device=x.device)
     keep = [x, w, out]
     d = GemmDesc()
     d.M, d.N, d.K, d.batch = n * OH * OW, cout, ksize * ksize * cv, 1
     d.A, d.a_layout, d.a_conv = ptr(x), ROWK, 1
-    d.B, d.ldb, d.b_layout = ptr(w), w.stride(0), ROWK
+    d.B, d.ldb, d.b_layout = ptr(w), w.stride(-2), ROWK
+    if per_image_weights:
+        d.b_image_stride = w.stride(0)
     d.H, d.W, d.C, d.CV, d.R, d.S = H, Wd, Cc, cv, ksize, ksize
     d.conv_stride, d.conv_pad = stride, pad
     if in_scale is not None:
@@ -573,11 +579,12 @@ def modulate_bank(x: torch.Tensor, s: torch.Tensor, a: torch.Tensor) -> torch.Te
     return out
 
 
-MODW_MAX_B, MODW_MAX_N, MODW_MAX_W, MODW_MAX_G = 64, 4, 18432, 5120
+MODW_MAX_B, MODW_MAX_N, MODW_MAX_W, MODW_MAX_G = 64, 4, 9216, 1536
 
 
 def modw_eligible(b: int, N: int, I: int, T: int) -> bool:
-    return b <= MODW_MAX_B and N <= MODW_MAX_N and N * I * T <= MODW_MAX_W and (N * (N + 1) // 2) * I <= MODW_MAX_G
+    return (b <= MODW_MAX_B and N <= MODW_MAX_N and I % 4 == 0 and N * I * T <= MODW_MAX_W
+            and (N * (N + 1) // 2) * I <= MODW_MAX_G)
 
 
 def modw_fwd(w: torch.Tensor, mod: torch.Tensor, kmod, demod: bool, eps: float, Ip: int, Op: int, coef: bool = True,

@@ -921,6 +921,15 @@ class HipOps:
                 wm = _wmix_buffer(weights, b, I)
                 K.modw_fwd(wd, md, km, demod, eps, Ip, Op, coef=False, wmix=wm, layout=2)
                 return nchw(K.sconv(nhwc(x), wm, O, nz, nw, act, LRELU_SLOPE))
+            if H * W % 128 == 0 and H * W >= 1024 and b * O * I * 9 <= (16 << 20):
+                # mid resolutions: the per-sample weights are still small next to the activation (<= 32 MiB of bf16), so the
+                # reference's formulation (one kernel per sample, algorithmic flops) beats the shared bank's doubled reduction:
+                # implicit GEMM with a per-image weight operand, modulation / demodulation folded into the weights
+                wm = _wmix_rows(weights, b, O, 9 * I)
+                K.modw_fwd(wd, md, km, demod, eps, Ip, Op, coef=False, wmix=wm, layout=1)
+                y = K.conv2d_nhwc(nhwc(x), wm, ksize=3, noise=nz, noise_w=nw, act=act, act_slope=LRELU_SLOPE,
+                                  per_image_weights=True)
+                return nchw(y)
             # wide layers: shared bank, the N kernels stacked along the reduction on a pre-modulated activation
             s, a, d = K.modw_fwd(wd, md, km, demod, eps, Ip, Op)
             x2 = K.modulate_bank(nhwc(x), s, a)
@@ -1133,6 +1142,15 @@ def _wmix_buffer(weights, b: int, I: int):
     buf = slot.get(b)
     if buf is None or buf.device != weights.device:
         buf = slot[b] = torch.zeros((b, 9, I // 16, 32, 16), dtype=ACT_DTYPE, device=weights.device)
+    return buf
+
+
+def _wmix_rows(weights, b: int, O: int, Kw: int):
+    """the per-sample weight operands of one layer for the implicit GEMM, (b, O, 9*I) bf16, persistent per weight tensor."""
+    slot = weights.__dict__.setdefault('_gg_wmix', {}) if isinstance(weights, torch.nn.Parameter) else {}
+    buf = slot.get(('rows', b))
+    if buf is None or buf.device != weights.device:
+        buf = slot[('rows', b)] = torch.empty((b, O, Kw), dtype=ACT_DTYPE, device=weights.device)
     return buf
 
 

@@ -80,6 +80,9 @@ typedef struct gg_gemm_desc {
     const void* zero_page;   /* optional: >= 16 bytes of zeros on the device. Only the experimental LDS-DMA tile (force_tile 7)
                               * reads it: padding taps of its conv gather load from here, so every stage issues the same
                               * number of loads and nothing has to be zero-filled in LDS */
+    int64_t b_image_stride;  /* a_conv forward (GG_ROWK x GG_ROWK) only: > 0 = per-image weight operands, image i reads B + i * b_image_stride
+                              * elements (the reference's per-sample weights of AdaptiveConv2DMod, gp.py:388-407); OH*OW must be a
+                              * multiple of the row tile, which the planner guarantees (128 or 256 rows) or rejects */
     int32_t no_reduce;       /* 1: a split-K launch leaves its fp32 partials [splitk][M][N] in the workspace and skips the
                               * reduction pass (the caller folds them, e.g. gg_wgrad_finish with `splits`); batch must be 1 */
 } gg_gemm_desc;

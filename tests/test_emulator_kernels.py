@@ -713,9 +713,11 @@ def test_modulate_bank_lays_the_kernels_side_by_side():
     assert out.shape == (2, 4, 4, 48) and rel_err(out, want) < 4e-3
 
 
-@pytest.mark.parametrize('cfg', [(16, 16, 32, 64, True), (64, 32, 16, 32, True), (64, 72, 8, 8, True), (32, 24, 8, 8, False)])
+@pytest.mark.parametrize('cfg', [(16, 16, 32, 64, True), (64, 32, 16, 32, True), (64, 72, 8, 8, True), (32, 24, 8, 8, False),
+                                 (64, 40, 32, 32, True), (128, 128, 32, 32, True)])
 def test_no_grad_adaptive_conv_paths_match_oracle(cfg):
-    """the whole no-grad forward through ops.modconv2d: the streaming path (narrow layers) and the stacked path (wide layers),
+    """the whole no-grad forward through ops.modconv2d: the streaming path (narrow layers), per-sample weights through the implicit
+    GEMM (mid resolutions) and the stacked path (wide layers),
     with demodulation on and off, noise and activation, against the oracle."""
     from gigagan_pytorch_amd.modules import AdaptiveConv2DMod
     I, O, H, W, demod = cfg
