@@ -842,12 +842,15 @@ extern "C" int gg_sconv_fwd(const void* x, const void* w, int64_t w_bs, void* y,
     memset(&p, 0, sizeof(p));
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.w_bs = w_bs; p.y = (bf16_t*)y; p.noise = noise; p.noise_w = noise_w;
     p.b = b; p.H = H; p.W = W; p.O = O; p.act = act; p.slope = slope;
-    const long long gpi = (long long)H * (W >> 5);
-    int gpw = (int)((gpi * b + 2047) / 2048);          // ~2048 workgroups (8 per CU); a workgroup first loads its image's bank,
-    if (gpw < 32) gpw = 32;                             // so give it at least 8 row groups per wave to amortise that
-    if (gpw > gpi) gpw = (int)gpi;
-    p.groups_per_wg = gpw;
-    const long long blocks = (long long)b * ((gpi + gpw - 1) / gpw);
+    // work item of a wavefront: a 32-pixel-wide strip of `rows` rows (+ one halo row above and below: 2 / rows extra reads);
+    // a workgroup = 4 wavefronts inside one image sharing that image's filter bank in LDS
+    const int rows = ((long long)b * H * W >= (2 << 20)) ? 16 : 8;
+    const int items = (W >> 5) * ((H + rows - 1) / rows);
+    int ipw = 1;
+    while ((long long)b * ((items + 4 * ipw - 1) / (4 * ipw)) > 2048) ++ipw;
+    p.rows_per_item = rows;
+    p.items_per_wave = ipw;
+    const long long blocks = (long long)b * ((items + 4 * ipw - 1) / (4 * ipw));
     if (C == 16) GG_LAUNCH((gg_sconv_kernel<16>), dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, p);
     else if (C == 32) GG_LAUNCH((gg_sconv_kernel<32>), dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, p);
     else GG_LAUNCH((gg_sconv_kernel<64>), dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, p);

@@ -114,22 +114,47 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modw_kernel(GgModWParams p) {
                     gram[pair * p.I + i] = acc;
                 }
         gg_sync();
-        for (int bb = b_lo + wave; bb < b_hi; bb += 4) {
-            float acc = 0.f;
-            for (int i = lane; i < p.I; i += 64) {
-                const float sv = p.mod[(long long)bb * p.I + i] + 1.f;
-                float q = 0.f;
-                int pr = 0;
-                for (int n = 0; n < p.N; ++n)
-                    for (int m = n; m < p.N; ++m, ++pr)
-                        q += (n == m ? 1.f : 2.f) * a_s[bb][n] * a_s[bb][m] * gram[pr * p.I + i];
-                acc += sv * sv * q;
+        // d[b] = rsqrt(sum_i s_i^2 * (a^T G_i a)): a wave takes samples b_lo + wave, +4, ...; lanes run along i. The modulation
+        // values of FOUR samples are fetched before any of them is used (independent loads in flight, not one round trip each)
+        for (int bb0 = b_lo + wave; bb0 < b_hi; bb0 += 16) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int i0 = 0; i0 < p.I; i0 += 512) {
+                float mv[4][8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int bb = bb0 + 4 * u;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = i0 + lane + 64 * j;
+                        mv[u][j] = (bb < b_hi && i < p.I) ? p.mod[(long long)bb * p.I + i] + 1.f : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int bb = bb0 + 4 * u < b_hi ? bb0 + 4 * u : b_lo;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = i0 + lane + 64 * j;
+                        if (i < p.I) {
+                            float q = 0.f;
+                            int pr = 0;
+                            for (int n = 0; n < p.N; ++n)
+                                for (int m = n; m < p.N; ++m, ++pr)
+                                    q += (n == m ? 1.f : 2.f) * a_s[bb][n] * a_s[bb][m] * gram[pr * p.I + i];
+                            acc[u] += mv[u][j] * mv[u][j] * q;
+                        }
+                    }
+                }
             }
-            acc = gg_mw_wave_sum(acc);
-            if (lane == 0) {
-                const float dv = gg_rsqrtf(acc > p.eps ? acc : p.eps);
-                d_s[bb] = dv;
-                if (p.d) p.d[(long long)bb * p.Op + o] = dv;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int bb = bb0 + 4 * u;
+                const float tot = gg_mw_wave_sum(acc[u]);
+                if (lane == 0 && bb < b_hi) {
+                    const float dv = gg_rsqrtf(tot > p.eps ? tot : p.eps);
+                    d_s[bb] = dv;
+                    if (p.d) p.d[(long long)bb * p.Op + o] = dv;
+                }
             }
         }
     } else {
@@ -168,17 +193,90 @@ struct GgSconvParams {
     int b, H, W, O;
     int act;                // 0 none, 1 leaky relu
     float slope;
-    int groups_per_wg;      // 32-pixel row groups per workgroup (a workgroup stays inside one image)
+    int rows_per_item;      // a wavefront's work item: a 32-pixel-wide strip of this many rows
+    int items_per_wave;     // items a wavefront walks through (a workgroup of 4 wavefronts stays inside one image)
 };
+
+// one image row of a strip as MFMA B fragments: (dx = -1, 0, +1) x (C / 16) 16-byte loads per lane; pixels beyond the image
+// borders are loaded from a clamped address and zeroed afterwards (a load under a per-lane condition is branched around and
+// waited for one at a time), rows beyond the image are zeros without any load (the condition is wave-uniform)
+template <int C>
+GG_DEVICE void gg_sc_load_row(u16x8 (&row)[3 * (C / 16)], const bf16_t* xi, int iy, int x0, int H, int W, int pl, int hi) {
+    constexpr int KC = C / 16;
+    const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (iy < 0 || iy >= H) {
+#pragma unroll
+        for (int f = 0; f < 3 * KC; ++f) row[f] = z;
+        return;
+    }
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int ix = x0 + pl + dx - 1;
+        const bool in = ix >= 0 && ix < W;
+        const int cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+        const bf16_t* src = xi + ((long long)iy * W + cx) * C + hi * 8;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const u16x8 v = *(const u16x8*)(src + kc * 16);
+            row[dx * KC + kc] = in ? v : z;
+        }
+    }
+}
+
+template <int C>
+GG_DEVICE f32x16 gg_sc_row_mfma(f32x16 acc, const u16x8 (&row)[3 * (C / 16)], const bf16_t* wl, int ky, int pl, int hi) {
+    constexpr int KC = C / 16;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const u16x8 wf = *(const u16x8*)(wl + (((ky * 3 + dx) * KC + kc) * 32 + pl) * 16 + hi * 8);
+            acc = gg_mfma_32x32x16_bf16(wf, row[dx * KC + kc], acc);     // D[out channel][pixel]: registers run along channels
+        }
+    return acc;
+}
+
+// one output row: the row below is fetched first (its loads fly during the 6 * C/16 MFMAs of the two rows already in registers)
+template <int C>
+GG_DEVICE void gg_sc_step(const GgSconvParams& p, const bf16_t* wl, const bf16_t* xi, long long img_pix0, int yy, int x0,
+                          const u16x8 (&top)[3 * (C / 16)], const u16x8 (&mid)[3 * (C / 16)], u16x8 (&bot)[3 * (C / 16)], int pl, int hi) {
+    gg_sc_load_row<C>(bot, xi, yy + 1, x0, p.H, p.W, pl, hi);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    acc = gg_sc_row_mfma<C>(acc, top, wl, 0, pl, hi);
+    acc = gg_sc_row_mfma<C>(acc, mid, wl, 1, pl, hi);
+    acc = gg_sc_row_mfma<C>(acc, bot, wl, 2, pl, hi);
+    const long long pix = img_pix0 + (long long)yy * p.W + x0 + pl;
+    const float nz = p.noise ? p.noise[pix] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ch0 = 8 * q + 4 * hi;
+        if (ch0 < p.O) {
+            u16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[q * 4 + e];
+                if (p.noise) v += nz * p.noise_w[ch0 + e];
+                if (p.act == 1) v = v > 0.f ? v : v * p.slope;
+                o[e] = gg_f2bf(v);
+            }
+            *(u16x4*)(p.y + pix * p.O + ch0) = o;
+        }
+    }
+}
 
 template <int C>
 GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_sconv_kernel(GgSconvParams p) {
     constexpr int KC = C / 16;
     GG_SHARED __attribute__((aligned(16))) bf16_t wl[9 * KC * 32 * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int gpi = p.H * (p.W >> 5);                           // groups per image
-    const int chunks = (gpi + p.groups_per_wg - 1) / p.groups_per_wg;
-    const int img = blockIdx.x / chunks, chunk = blockIdx.x - img * chunks;
+    const int strips = p.W >> 5;
+    const int chunks = (p.H + p.rows_per_item - 1) / p.rows_per_item;
+    const int items = strips * chunks;                                   // per image; strip index fastest
+    const int per_wg = 4 * p.items_per_wave;
+    const int wgs_per_img = (items + per_wg - 1) / per_wg;
+    const int img = blockIdx.x / wgs_per_img, first = (blockIdx.x - img * wgs_per_img) * per_wg;
     {
         const u16x8* src = (const u16x8*)(p.w + (long long)img * p.w_bs);
         u16x8* dst = (u16x8*)wl;
@@ -186,49 +284,23 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_sconv_kernel(GgSconvParams p) {
     }
     gg_sync();
     const int pl = lane & 31, hi = lane >> 5;
-    const int g_end = (chunk + 1) * p.groups_per_wg < gpi ? (chunk + 1) * p.groups_per_wg : gpi;
     const bf16_t* xi = p.x + (long long)img * p.H * p.W * C;
-    for (int g = chunk * p.groups_per_wg + wave; g < g_end; g += 4) {
-        const int yy = g / (p.W >> 5), x0 = (g - yy * (p.W >> 5)) << 5;
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-            u16x8 xa[9];
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                // always load (from a clamped address) and zero the out-of-image taps afterwards: a load under a per-lane
-                // condition is branched around and waited for one at a time, nine dependent round trips instead of nine in flight
-                const int iy = yy + tap / 3 - 1, ix = x0 + pl + tap % 3 - 1;
-                const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                const int cy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy), cx = ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix);
-                u16x8 v = *(const u16x8*)(xi + ((long long)cy * p.W + cx) * C + kc * 16 + hi * 8);
-                const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                xa[tap] = in ? v : z;
-            }
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const u16x8 wf = *(const u16x8*)(wl + ((tap * KC + kc) * 32 + pl) * 16 + hi * 8);
-                acc = gg_mfma_32x32x16_bf16(wf, xa[tap], acc);      // D[out channel][pixel]: the lane's registers run along channels
-            }
-        }
-        const long long pix = (long long)img * p.H * p.W + (long long)yy * p.W + x0 + pl;
-        const float nz = p.noise ? p.noise[pix] : 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int ch0 = 8 * q + 4 * hi;
-            if (ch0 < p.O) {
-                u16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[q * 4 + e];
-                    if (p.noise) v += nz * p.noise_w[ch0 + e];
-                    if (p.act == 1) v = v > 0.f ? v : v * p.slope;
-                    o[e] = gg_f2bf(v);
-                }
-                *(u16x4*)(p.y + pix * p.O + ch0) = o;
-            }
+    const long long img_pix0 = (long long)img * p.H * p.W;
+    for (int it = 0; it < p.items_per_wave; ++it) {
+        const int item = first + it * 4 + wave;
+        if (item >= items) break;
+        const int cy = item / strips, x0 = (item - cy * strips) << 5;
+        const int y_lo = cy * p.rows_per_item;
+        const int y_hi = y_lo + p.rows_per_item < p.H ? y_lo + p.rows_per_item : p.H;
+        // three register rows rotate through the roles (above, centre, below): the loop is unrolled by three so that every
+        // access is statically indexed; each input row is fetched once per strip instead of three times
+        u16x8 r0[3 * KC], r1[3 * KC], r2[3 * KC];
+        gg_sc_load_row<C>(r0, xi, y_lo - 1, x0, p.H, p.W, pl, hi);
+        gg_sc_load_row<C>(r1, xi, y_lo, x0, p.H, p.W, pl, hi);
+        for (int yy = y_lo; yy < y_hi; yy += 3) {
+            gg_sc_step<C>(p, wl, xi, img_pix0, yy, x0, r0, r1, r2, pl, hi);
+            if (yy + 1 < y_hi) gg_sc_step<C>(p, wl, xi, img_pix0, yy + 1, x0, r1, r2, r0, pl, hi);
+            if (yy + 2 < y_hi) gg_sc_step<C>(p, wl, xi, img_pix0, yy + 2, x0, r2, r0, r1, pl, hi);
         }
     }
 }
