@@ -43,9 +43,7 @@ class GemmDesc(C.Structure):
         ('residual', C.c_void_p), ('ldr', C.c_int32), ('res_scale', C.c_float),
         ('d2s', C.c_int32), ('d2s_taps', C.c_int32), ('d2s_c', C.c_int32), ('d2s_oh', C.c_int32),
         ('d2s_ow', C.c_int32),
-        ('zero_page', C.c_void_p),
         ('b_image_stride', C.c_int64),
-        ('no_reduce', C.c_int32),
     ]
 
 

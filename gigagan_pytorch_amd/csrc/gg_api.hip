@@ -3,7 +3,6 @@
 #include "gg_device.h"
 #include "gg_gemm.h"
 #include "gg_gemm2.h"
-#include "gg_gemm3.h"
 #include "gg_elementwise.h"
 #include "gg_modconv.h"
 #include "gg_attention.h"
@@ -158,33 +157,7 @@ static const GgTileModel kTileModels[] = {
     {4, 256, 256, 64, 2.25, 256, 3.0},
     {5, 256, 128, 64, 1.45, 256, 3.0},
     {6, 128, 128, 64, 1.50, 512, 2.5},    // 8 waves, 72 KB LDS: 2 workgroups per CU (small-M layers: no split-K needed)
-    {7, 256, 256, 32, 1.10, 256, 3.0},    // EXPERIMENTAL LDS-DMA ring (gg_gemm3.h): force_tile = 7 only, never planned
-    {8, 256, 256, 32, 1.00, 256, 3.0},    // the same ring with the two wave rows staggered (ping-pong): force_tile = 8 only
 };
-
-// tile 7: dense row-major x row-major, whole 32-k stages, 16-byte aligned rows
-static int gg_v3_policy() {   // GG_GEMM_V3=1 lets the planner choose the experimental tile 7, =2 forces it (default 0: never)
-    static int policy = -1;
-    if (policy < 0) {
-        const char* e = getenv("GG_GEMM_V3");
-        policy = e ? (atoi(e) > 0 ? atoi(e) : 0) : 0;      // 2: use it wherever eligible (integration tests on small shapes)
-    }
-    return policy;
-}
-
-static bool gg_v3_eligible(const gg_gemm_desc* d) {
-    if (d->K % 32 || d->K < 32 || d->d2s) return false;
-    if (d->a_layout == GG_KROW && d->b_layout == GG_KROW) {     // weight gradients: plain epilogue, whole 8-column groups
-        const bool full = d->bias || d->out_scale || d->noise || d->residual || d->act != GG_ACT_NONE;
-        if (full || (d->M & 7) || (d->N & 7) || d->M < 8 || d->N < 8) return false;
-        if (!d->a_conv) return true;
-        return d->CV % 8 == 0 && d->C % 8 == 0 && d->zero_page != nullptr && d->in_scale == nullptr;
-    }
-    if (d->a_layout != GG_ROWK || d->b_layout != GG_ROWK) return false;
-    if (!d->a_conv) return true;
-    // conv gather: a 32-k stage lies inside one tap; padding taps load from the caller's zero page; no per-sample input scale
-    return d->CV % 32 == 0 && d->C % 8 == 0 && d->R * d->S <= 32 && d->zero_page != nullptr && d->in_scale == nullptr;
-}
 
 static double gg_plan_cost(const gg_gemm_desc* d, const GgTileModel& tm, int sk, int* k_per_split) {
     const long long blocks = (long long)((d->M + tm.bm - 1) / tm.bm) * ((d->N + tm.bn - 1) / tm.bn) * d->batch;
@@ -301,25 +274,16 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     const int pol = gg_v2_policy();
     const int v1_tile = d->N <= 32 ? 3 : (d->N <= 64 ? 2 : 1);
     int forced = d->force_tile;
-    if (forced == 0 && gg_v3_policy() >= 2 && gg_v3_eligible(d)) forced = 7;
-    if ((forced == 7 || forced == 8) && !gg_v3_eligible(d)) forced = 0;
-    if (forced == 8 && d->a_layout == GG_KROW) forced = 7;     // the weight-gradient ring has no staggered variant yet
-    if (forced >= 4 && forced <= 6 && !gg_v2_eligible(d)) forced = 0;
-    if (d->b_image_stride && forced) {
-        if (forced >= 7) forced = 0;
-        else if (gg_img_pixels(d) % kTileModels[forced - 1].bm) forced = 0;
-    }
-    if (forced < 0 || forced > 8) forced = 0;      // (9 = direct convolution: handled above when eligible)
+    if (forced < 0 || forced > 6) forced = 0;      // (9 = direct convolution: handled above when eligible)
+    if (forced >= 4 && !gg_v2_eligible(d)) forced = 0;
+    if (d->b_image_stride && forced && gg_img_pixels(d) % kTileModels[forced - 1].bm) forced = 0;
     double best = 1e30;
     pl.tile = v1_tile; pl.splitk = 1;
     for (const GgTileModel& tm : kTileModels) {
         if (forced) {
             if (tm.tile != forced) continue;
         } else {
-            // experimental LDS-DMA ring: forced, or offered to the cost model when GG_GEMM_V3=1 (next round's A/B switch)
-            if (tm.tile == 8) continue;
             if (d->b_image_stride && gg_img_pixels(d) % tm.bm) continue;     // a row tile must stay inside one image
-            if (tm.tile == 7 && !(gg_v3_policy() && gg_v3_eligible(d) && d->N >= 192 && d->M >= 192)) continue;
             if (tm.tile <= 3 && tm.tile != v1_tile) continue;
             if (tm.tile >= 4 && (!v2ok || !pol)) continue;
             if (tm.tile == 4 && d->N < 192) continue;
@@ -334,7 +298,6 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
         // the 4-wave tiles may split much further: a narrow weight gradient (M*N of a few thousand, K = millions of
         // pixels) needs thousands of workgroups in flight to pull HBM bandwidth; its partials stay small
         const int sk_cap = tm.tile <= 3 ? 4096 : 256;
-        if (tm.tile >= 7) max_sk = ktiles / 8 > 0 ? ktiles / 8 : 1;
         if (max_sk > sk_cap) max_sk = sk_cap;
         if ((long long)d->batch * max_sk > 65535) max_sk = (int)(65535 / d->batch);
         int lo = 1, hi = max_sk;
@@ -477,7 +440,6 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     p.noise = d->noise; p.noise_w = d->noise_w;
     p.act = d->act; p.act_slope = d->act_slope;
     p.partial = (float*)workspace;
-    p.zero_page = (const bf16_t*)d->zero_page;
     p.b_img_stride = d->b_image_stride;
 #ifdef GG2_PROBE
     if (pl.tile > 3) p.xcd_slices = getenv("GG2_DBG") ? atoi(getenv("GG2_DBG")) : 0;   // probe builds: k-loop phase mask
@@ -498,29 +460,6 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
         else if (d->C == 32) { if (wide) gg_launch_dconv<32, 2>(p, s); else gg_launch_dconv<32, 1>(p, s); }
         else { if (wide) gg_launch_dconv<64, 2>(p, s); else gg_launch_dconv<64, 1>(p, s); }
     }
-    else if (pl.tile == 8) {
-        const bool full = p.bias || p.out_scale || p.noise || p.residual || p.act != GG_ACT_NONE;
-        if (aconv) {
-            if (full) GG_LAUNCH((gg_gemm3_kernel<true, true, true>), grid2, dim3(GG2_NT), s, p);
-            else GG_LAUNCH((gg_gemm3_kernel<true, false, true>), grid2, dim3(GG2_NT), s, p);
-        } else {
-            if (full) GG_LAUNCH((gg_gemm3_kernel<false, true, true>), grid2, dim3(GG2_NT), s, p);
-            else GG_LAUNCH((gg_gemm3_kernel<false, false, true>), grid2, dim3(GG2_NT), s, p);
-        }
-    }
-    else if (pl.tile == 7) {
-        const bool full = p.bias || p.out_scale || p.noise || p.residual || p.act != GG_ACT_NONE;
-        if (akrow) {
-            if (aconv) GG_LAUNCH((gg_gemm3k_kernel<true>), grid2, dim3(GG2_NT), s, p);
-            else GG_LAUNCH((gg_gemm3k_kernel<false>), grid2, dim3(GG2_NT), s, p);
-        } else if (aconv) {
-            if (full) GG_LAUNCH((gg_gemm3_kernel<true, true, false>), grid2, dim3(GG2_NT), s, p);
-            else GG_LAUNCH((gg_gemm3_kernel<true, false, false>), grid2, dim3(GG2_NT), s, p);
-        } else {
-            if (full) GG_LAUNCH((gg_gemm3_kernel<false, true, false>), grid2, dim3(GG2_NT), s, p);
-            else GG_LAUNCH((gg_gemm3_kernel<false, false, false>), grid2, dim3(GG2_NT), s, p);
-        }
-    }
     else if (pl.tile == 4) gg_launch_gemm2_tile<256, 256, 2, 4>(p, akrow, bkrow, aconv, grid2, s);
     else if (pl.tile == 5) gg_launch_gemm2_tile<256, 128, 2, 4>(p, akrow, bkrow, aconv, grid2, s);
     else if (pl.tile == 6) gg_launch_gemm2_tile<128, 128, 2, 4>(p, akrow, bkrow, aconv, grid2, s);
@@ -529,7 +468,7 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     else gg_launch_gemm_tile<128, 32, 4, 1>(p, akrow, bkrow, aconv, grid, s);
     rc = gg_check_launch();
     if (rc) return rc;
-    if (pl.splitk > 1 && !(d->no_reduce && d->batch == 1)) {
+    if (pl.splitk > 1) {
         long long total = (long long)d->M * d->N * d->batch;
         long long nb = pl.splitk <= 8 ? (total + 255) / 256 : (total + 63) / 64;
         if (nb > 8192) nb = 8192;
@@ -600,22 +539,13 @@ extern "C" int gg_pack_weights(const gg_pack_entry* table, const int64_t* header
     return gg_check_launch();
 }
 
-extern "C" int gg_wgrad_finish_splits(const float* g, float* dst, int32_t O, int32_t I, int32_t T, int32_t C8, int32_t O8,
-                                      float alpha, int32_t accumulate, int32_t splits, int64_t split_stride, void* stream);
-
 extern "C" int gg_wgrad_finish(const float* g, float* dst, int32_t O, int32_t I, int32_t T, int32_t C8, int32_t O8,
                                float alpha, int32_t accumulate, void* stream) {
-    return gg_wgrad_finish_splits(g, dst, O, I, T, C8, O8, alpha, accumulate, 1, 0, stream);
-}
-
-extern "C" int gg_wgrad_finish_splits(const float* g, float* dst, int32_t O, int32_t I, int32_t T, int32_t C8, int32_t O8,
-                                      float alpha, int32_t accumulate, int32_t splits, int64_t split_stride, void* stream) {
     if (!g || !dst) return gg_fail(-1, "gg_wgrad_finish: null pointer");
     if (O <= 0 || I <= 0 || T <= 0 || C8 < I || O8 < O) return gg_fail(-2, "gg_wgrad_finish: bad extents");
-    if (splits < 1 || (splits > 1 && split_stride < (int64_t)T * C8 * O8)) return gg_fail(-3, "gg_wgrad_finish: bad split layout");
     GgWgradFinishParams p;
     p.g = g; p.dst = dst; p.O = O; p.I = I; p.T = T; p.C8 = C8; p.O8 = O8; p.accumulate = accumulate; p.alpha = alpha;
-    p.splits = splits; p.split_stride = split_stride;
+    p.splits = 1; p.split_stride = 0;
     GG_LAUNCH(gg_wgrad_finish_kernel, dim3((unsigned)((O + 31) / 32), (unsigned)((I + 31) / 32)), dim3(256),
               (hipStream_t)stream, p);
     return gg_check_launch();

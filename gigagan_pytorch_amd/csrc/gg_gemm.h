@@ -77,7 +77,6 @@ struct GgGemmParams {
     // HBM once and shared through that XCD's L2. 0: (tiles, 1, batch*splitk) grid.
     int xcd_slices;
     long long b_img_stride;    // conv forward only: > 0: image i's weights start at B + i * b_img_stride (per-sample weights)
-    const bf16_t* zero_page;   // experimental tile 7 (gg_gemm3.h): >= 16 bytes of zeros for the conv gather's padding taps
 };
 
 GG_DEVICE float gg_apply_act(float v, int act, float slope) {

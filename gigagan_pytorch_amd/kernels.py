@@ -192,18 +192,6 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=True, out_d
     return out
 
 
-_zero_pages: dict = {}
-_V3_POLICY = bool(int(__import__('os').environ.get('GG_GEMM_V3', '0') or 0))   # experimental tile 7 offered to the planner
-
-
-def _zero_page(device) -> torch.Tensor:
-    """256 bytes of zeros per device, kept for the process lifetime (gg_gemm_desc.zero_page)."""
-    z = _zero_pages.get(device)
-    if z is None:
-        z = _zero_pages[device] = torch.zeros(128, dtype=torch.bfloat16, device=device)
-    return z
-
-
 def _conv_out(size: int, ksize: int, stride: int, pad: int) -> int:
     return (size + 2 * pad - ksize) // stride + 1
 
@@ -244,8 +232,6 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, *, ksize: int, stride: int = 1
         keep.append(in_scale)
     d.C_out, d.ldc, d.c_is_f32 = ptr(out), cout, int(out_dtype == torch.float32)
     d.force_splitk, d.force_tile = force_splitk, force_tile
-    if force_tile in (7, 8) or _V3_POLICY:     # experimental LDS-DMA tiles: padding taps read a page of zeros
-        d.zero_page = ptr(_zero_page(x.device))
     if residual is not None:
         assert residual.shape == out.shape
     _epilogue(d, alpha, bias, out_scale, OH * OW if out_scale is not None else 0, noise, noise_w, act,
@@ -281,8 +267,6 @@ def conv2d_wgrad_nhwc(x: torch.Tensor, dy: torch.Tensor, *, ksize: int, stride: 
     d.alpha = 1.0
     d.bias_scale = 1.0
     d.force_splitk, d.force_tile = force_splitk, force_tile
-    if force_tile in (7, 8) or _V3_POLICY:
-        d.zero_page = ptr(_zero_page(x.device))
     _run_gemm(d, x)
     return out
 

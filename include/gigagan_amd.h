@@ -77,14 +77,9 @@ typedef struct gg_gemm_desc {
     float bias_scale;     /* multiplies bias (set 1.0f) */
     const void* residual; int32_t ldr; float res_scale;   /* bf16 [M][ldr], optional */
     int32_t d2s, d2s_taps, d2s_c, d2s_oh, d2s_ow;
-    const void* zero_page;   /* optional: >= 16 bytes of zeros on the device. Only the experimental LDS-DMA tile (force_tile 7)
-                              * reads it: padding taps of its conv gather load from here, so every stage issues the same
-                              * number of loads and nothing has to be zero-filled in LDS */
     int64_t b_image_stride;  /* a_conv forward (GG_ROWK x GG_ROWK) only: > 0 = per-image weight operands, image i reads B + i * b_image_stride
                               * elements (the reference's per-sample weights of AdaptiveConv2DMod, gp.py:388-407); OH*OW must be a
                               * multiple of the row tile, which the planner guarantees (128 or 256 rows) or rejects */
-    int32_t no_reduce;       /* 1: a split-K launch leaves its fp32 partials [splitk][M][N] in the workspace and skips the
-                              * reduction pass (the caller folds them, e.g. gg_wgrad_finish with `splits`); batch must be 1 */
 } gg_gemm_desc;
 
 /* Per-device tuning cache (the only persistent native state besides the communicator): measured-best launch
@@ -149,10 +144,6 @@ int gg_pack_weights(const gg_pack_entry* table, const int64_t* header, int32_t m
 int gg_wgrad_finish(const float* g, float* dst, int32_t O, int32_t I, int32_t T, int32_t C8, int32_t O8, float alpha,
                     int32_t accumulate, void* stream);
 
-/* Same, reading `splits` fp32 slices of (T*C8, O8) laid `split_stride` elements apart and summing them on the way: folds
- * the split-K reduction of the weight-gradient GEMM (gg_gemm_desc.no_reduce) into the transpose / accumulate pass. */
-int gg_wgrad_finish_splits(const float* g, float* dst, int32_t O, int32_t I, int32_t T, int32_t C8, int32_t O8, float alpha,
-                           int32_t accumulate, int32_t splits, int64_t split_stride, void* stream);
 
 /* Per-sample coefficients of the adaptive convolution (AdaptiveConv2DMod.forward, gp.py:378-400) in one launch:
  *   s[b,i] = mod[b,i] + 1 (zero for I <= i < Ip),  a[b,n] = softmax_n(kmod[b,:]) (1 when N == 1, kmod may be NULL),

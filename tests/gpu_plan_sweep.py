@@ -62,8 +62,6 @@ def materialise(d, dev):
         d.noise_w = buf(d.N, f32)
     if d.residual:
         d.residual = buf(d.M * d.ldr, bf)
-    if d.zero_page:
-        d.zero_page = buf(128, bf, 0.0)
     return keep
 
 

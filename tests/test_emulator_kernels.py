@@ -559,81 +559,6 @@ def test_narrow_modconv_layers_take_the_streaming_convolution():
     assert rel_err(y1, y0) < 1e-2
 
 
-@pytest.mark.parametrize('shape', [(256, 256, 64, 1, 0), (300, 520, 96, 1, 0), (257, 129, 256, 2, 0), (512, 256, 512, 1, 2)])
-def test_experimental_lds_ring_gemm_index_math(shape):
-    """gg_gemm3.h (force_tile 7, never planned): the LDS-DMA ring's chunk swizzle, slot rotation, clamped edge rows,
-    split-K and shared epilogue on the emulator — which executes the DMA at issue time, so this checks index math and
-    ordering of the code, not the asynchronous behaviour (tests/gpu_ring_gemm_probe.py is the GPU race screen)."""
-    M, N, Kd, batch, sk = shape
-    torch.manual_seed(0)
-    a = bf(torch.randn(batch, M, Kd)); b = bf(torch.randn(batch, N, Kd))
-    ref = torch.einsum('bmk,bnk->bmn', a.float(), b.float())
-    K.plan_log = []
-    try:
-        out = K.gemm(a, b, out_dtype=torch.float32, force_tile=7, force_splitk=sk)
-        assert [t for t, _ in K.plan_log] == [7]
-    finally:
-        K.plan_log = None
-    assert rel_err(out, ref) < 1e-5
-    if N % 8 == 0:
-        bias = torch.randn(N)
-        out = K.gemm(a, b, force_tile=7, bias=bias, act='lrelu', alpha=0.5)
-        assert rel_err(out, F.leaky_relu(ref * 0.5 + bias, 0.2)) < 4e-3
-    K.plan_log = []
-    try:
-        K.gemm(a, b, out_dtype=torch.float32)           # the planner itself never picks the experimental tile
-        assert all(t != 7 for t, _ in K.plan_log)
-    finally:
-        K.plan_log = None
-
-
-@pytest.mark.parametrize('cfg', [(2, 12, 12, 64, 136, 3, 0), (1, 9, 7, 32, 128, 3, 0), (2, 8, 8, 96, 64, 3, 3), (3, 8, 8, 64, 104, 1, 0)])
-def test_experimental_lds_ring_conv_gather_index_math(cfg):
-    """conv gather of gg_gemm3.h (force_tile 7): per-row window corners and tap masks, padding taps served from the zero
-    page, stacked-stage tap decode, split-K; forward and (same kernel, flipped weights) data gradient."""
-    n, H, W, Ci, Co, ks, sk = cfg
-    torch.manual_seed(0)
-    x = bf(torch.randn(n, Ci, H, W)); w = bf(torch.randn(Co, Ci, ks, ks) * 0.1); dy = bf(torch.randn(n, Co, H, W))
-    xf, wf = x.float().requires_grad_(), w.float()
-    ref = F.conv2d(xf, wf, padding=ks // 2)
-    ref.backward(dy.float())
-    xh, dyh = x.permute(0, 2, 3, 1).contiguous(), dy.permute(0, 2, 3, 1).contiguous()
-    wh = w.permute(0, 2, 3, 1).reshape(Co, -1).contiguous()
-    K.plan_log = []
-    try:
-        out = K.conv2d_nhwc(xh, wh, ksize=ks, out_dtype=torch.float32, force_tile=7, force_splitk=sk)
-        assert [t for t, _ in K.plan_log] == [7]
-    finally:
-        K.plan_log = None
-    assert rel_err(out.permute(0, 3, 1, 2), ref) < 1e-5
-    if Co % 32 == 0:       # the data gradient's reduction is over Co: a stage must lie inside one tap
-        wT = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Ci, -1).contiguous()
-        dx = K.conv2d_nhwc(dyh, wT, ksize=ks, out_dtype=torch.float32, force_tile=7)
-        assert rel_err(dx.permute(0, 3, 1, 2), xf.grad) < 1e-5
-
-
-@pytest.mark.parametrize('cfg', [(2, 8, 8, 64, 136, 3, 0), (2, 8, 8, 96, 64, 3, 2), (2, 4, 4, 64, 104, 1, 0), (2, 16, 8, 16, 40, 3, 0)])
-def test_experimental_lds_ring_weight_gradient_index_math(cfg):
-    """reduction-major variant of gg_gemm3.h (force_tile 7): rows staged as they sit in HBM, quarter-XOR swizzle on the DMA
-    source and the ds_read_b64_tr_b16 address, im2col column decode with zero-page padding taps, split-K; dense too."""
-    n, H, W, Ci, Co, ks, sk = cfg
-    torch.manual_seed(0)
-    x = bf(torch.randn(n, H, W, Ci)); dy = bf(torch.randn(n, H, W, Co))
-    wf = torch.zeros(Co, Ci, ks, ks, requires_grad=True)
-    F.conv2d(x.float().permute(0, 3, 1, 2), wf, padding=ks // 2).backward(dy.float().permute(0, 3, 1, 2))
-    ref = wf.grad.permute(2, 3, 1, 0).reshape(-1, Co)
-    K.plan_log = []
-    try:
-        g = K.conv2d_wgrad_nhwc(x, dy, ksize=ks, force_tile=7, force_splitk=sk)
-        assert [t for t, _ in K.plan_log] == [7]
-    finally:
-        K.plan_log = None
-    assert rel_err(g[:, :Co], ref) < 1e-5
-    a, b = bf(torch.randn(96, 264)), bf(torch.randn(96, 136))          # dense (K, M) x (K, N)
-    out = K.gemm(a, b, trans_a=True, trans_b=False, out_dtype=torch.float32, force_tile=7)
-    assert rel_err(out[0], a.float().t() @ b.float()) < 1e-5
-
-
 def test_premodulated_modconv_path_matches_oracle():
     """low / mid-resolution no-grad adaptive conv: activation scaled per kernel of the bank by a pointwise pass, then the plain
     conv gather over (n, ci) channels with the demodulation / noise / activation in the epilogue."""
