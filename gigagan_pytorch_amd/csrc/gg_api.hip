@@ -729,15 +729,16 @@ extern "C" int gg_modulate_bank_fwd(const void* x, const float* s, const float* 
     return gg_check_launch();
 }
 
-extern "C" int gg_modw_fwd(const float* w, const float* mod, const float* kmod, float* s, float* a, float* d, void* wmix,
-                           int32_t layout, int32_t b, int32_t N, int32_t O, int32_t I, int32_t T, int32_t Ip, int32_t Op,
-                           int32_t demod, float eps, void* stream) {
+extern "C" int gg_modw_fwd(const float* w, const float* mod, int32_t mod_ld, const float* kmod, int32_t kmod_ld, float* s, float* a,
+                           float* d, void* wmix, int32_t layout, int32_t b, int32_t N, int32_t O, int32_t I, int32_t T, int32_t Ip,
+                           int32_t Op, int32_t demod, float eps, void* stream) {
     if (!w || !mod) return gg_fail(-1, "gg_modw_fwd: null pointer");
     if (b <= 0 || b > GG_MW_BMAX || N <= 0 || N > GG_MW_NMAX || O <= 0 || I <= 0 || (I & 3) || T <= 0 || Ip < I || Op < O)
         return gg_fail(-2, "gg_modw_fwd: bad extents (b=%d N=%d O=%d I=%d T=%d)", b, N, O, I, T);
     if ((long long)N * I * T > GG_MW_WMAX || (long long)(N * (N + 1) / 2) * I > GG_MW_GMAX)
         return gg_fail(-3, "gg_modw_fwd: bank too large for one workgroup (N*I*T=%lld)", (long long)N * I * T);
     if (N > 1 && !kmod) return gg_fail(-1, "gg_modw_fwd: kernel_mod is required for N > 1");
+    if (mod_ld < I || (kmod && kmod_ld < N)) return gg_fail(-2, "gg_modw_fwd: row pitches smaller than the rows");
     if (wmix) {
         if (layout != 1 && layout != 2) return gg_fail(-4, "gg_modw_fwd: layout must be 1 or 2");
         if (layout == 2 && ((I & 15) || O > 32)) return gg_fail(-4, "gg_modw_fwd: layout 2 needs I %% 16 == 0 and O <= 32");
@@ -747,6 +748,7 @@ extern "C" int gg_modw_fwd(const float* w, const float* mod, const float* kmod, 
     memset(&p, 0, sizeof(p));
     p.w = w; p.mod = mod; p.kmod = kmod; p.s = s; p.a = a; p.d = d; p.wmix = (bf16_t*)wmix; p.layout = layout;
     p.b = b; p.N = N; p.O = O; p.I = I; p.T = T; p.Ip = Ip; p.Op = Op; p.demod = demod; p.eps = eps;
+    p.mod_ld = mod_ld; p.kmod_ld = kmod_ld;
     // coefficient-only launches: one workgroup per channel handles every sample; with per-sample weights the samples are spread
     // over enough workgroups to fill the chip (a 16-channel layer would otherwise run on 16 CUs)
     int bc = b;

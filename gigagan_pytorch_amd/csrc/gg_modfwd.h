@@ -34,6 +34,7 @@ struct GgModWParams {
     int b, N, O, I, T, Ip, Op;
     int demod;
     float eps;
+    int mod_ld, kmod_ld;   // row pitches of mod / kmod in floats (they are column slices of the style network's output)
     int bc;                // samples per workgroup: grid = (O, ceil(b / bc)); every workgroup re-derives the Gram rows of its channel
 };
 
@@ -58,7 +59,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modw_kernel(GgModWParams p) {
     if (o == 0)
         for (int row = b_lo; row < b_hi; ++row) {
             if (p.s)
-                for (int i = tid; i < p.Ip; i += 256) p.s[(long long)row * p.Ip + i] = i < p.I ? p.mod[(long long)row * p.I + i] + 1.f : 0.f;
+                for (int i = tid; i < p.Ip; i += 256) p.s[(long long)row * p.Ip + i] = i < p.I ? p.mod[(long long)row * p.mod_ld + i] + 1.f : 0.f;
             if (p.d)
                 for (int c = p.O + tid; c < p.Op; c += 256) p.d[(long long)row * p.Op + c] = 0.f;
         }
@@ -66,14 +67,12 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modw_kernel(GgModWParams p) {
         const int nv = (p.N * IT) >> 2;
         const int ivn = IT >> 2;
         for (int v0 = tid; v0 < nv; v0 += 256 * 4) {
-            f32x4 r[4];
-#pragma unroll
+            f32x4 r[4];      // loads are unconditional (clamped index): a load under a per-lane condition is branched around and
+#pragma unroll       // waited for on its own - a chain of dependent round trips instead of four in flight
             for (int u = 0; u < 4; ++u) {
-                const int v = v0 + u * 256;
-                if (v < nv) {
-                    const int n = v / ivn, e4 = v - n * ivn;
-                    r[u] = *(const f32x4*)(p.w + ((long long)n * p.O + o) * IT + e4 * 4);
-                }
+                const int v = v0 + u * 256 < nv ? v0 + u * 256 : nv - 1;
+                const int n = v / ivn, e4 = v - n * ivn;
+                r[u] = *(const f32x4*)(p.w + ((long long)n * p.O + o) * IT + e4 * 4);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -85,7 +84,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modw_kernel(GgModWParams p) {
     if (tid >= b_lo && tid < b_hi) {
         float a0 = 1.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         if (p.kmod && p.N > 1) {
-            const float* km = p.kmod + tid * p.N;
+            const float* km = p.kmod + (long long)tid * p.kmod_ld;
             const float k0 = km[0], k1 = km[1], k2 = p.N > 2 ? km[2] : -3.0e38f, k3 = p.N > 3 ? km[3] : -3.0e38f;
             float mx = k0 > k1 ? k0 : k1;
             mx = k2 > mx ? k2 : mx;
@@ -126,7 +125,9 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modw_kernel(GgModWParams p) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int i = i0 + lane + 64 * j;
-                        mv[u][j] = (bb < b_hi && i < p.I) ? p.mod[(long long)bb * p.I + i] + 1.f : 0.f;
+                        const int bc = bb < b_hi ? bb : b_hi - 1, ic = i < p.I ? i : p.I - 1;      // unconditional loads
+                        const float v = p.mod[(long long)bc * p.mod_ld + ic] + 1.f;
+                        mv[u][j] = (bb < b_hi && i < p.I) ? v : 0.f;
                     }
                 }
 #pragma unroll
@@ -134,15 +135,13 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modw_kernel(GgModWParams p) {
                     const int bb = bb0 + 4 * u < b_hi ? bb0 + 4 * u : b_lo;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const int i = i0 + lane + 64 * j;
-                        if (i < p.I) {
-                            float q = 0.f;
-                            int pr = 0;
-                            for (int n = 0; n < p.N; ++n)
-                                for (int m = n; m < p.N; ++m, ++pr)
-                                    q += (n == m ? 1.f : 2.f) * a_s[bb][n] * a_s[bb][m] * gram[pr * p.I + i];
-                            acc[u] += mv[u][j] * mv[u][j] * q;
-                        }
+                        const int i = i0 + lane + 64 * j < p.I ? i0 + lane + 64 * j : p.I - 1;     // (mv is 0 beyond I)
+                        float q = 0.f;
+                        int pr = 0;
+                        for (int n = 0; n < p.N; ++n)
+                            for (int m = n; m < p.N; ++m, ++pr)
+                                q += (n == m ? 1.f : 2.f) * a_s[bb][n] * a_s[bb][m] * gram[pr * p.I + i];
+                        acc[u] += mv[u][j] * mv[u][j] * q;
                     }
                 }
             }
@@ -172,7 +171,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modw_kernel(GgModWParams p) {
             const int t = e / p.I, i = e - t * p.I;
             float m = 0.f;
             for (int n = 0; n < p.N; ++n) m += a_s[bb][n] * wl[n * IT + i * p.T + t];
-            const float v = dv * (p.mod[(long long)bb * p.I + i] + 1.f) * m;
+            const float v = dv * (p.mod[(long long)bb * p.mod_ld + i] + 1.f) * m;
             long long off;
             if (p.layout == 1) off = (((long long)bb * p.O + o) * p.T + t) * p.I + i;
             else off = ((((long long)bb * p.T + t) * (p.I >> 4) + (i >> 4)) * 32 + o) * 16 + (i & 15);
@@ -239,16 +238,17 @@ GG_DEVICE f32x16 gg_sc_row_mfma(f32x16 acc, const u16x8 (&row)[3 * (C / 16)], co
 // one output row: the row below is fetched first (its loads fly during the 6 * C/16 MFMAs of the two rows already in registers)
 template <int C>
 GG_DEVICE void gg_sc_step(const GgSconvParams& p, const bf16_t* wl, const bf16_t* xi, long long img_pix0, int yy, int x0,
-                          const u16x8 (&top)[3 * (C / 16)], const u16x8 (&mid)[3 * (C / 16)], u16x8 (&bot)[3 * (C / 16)], int pl, int hi) {
+                          const u16x8 (&top)[3 * (C / 16)], const u16x8 (&mid)[3 * (C / 16)], u16x8 (&bot)[3 * (C / 16)], int pl, int hi,
+                          const float (&nw)[16]) {
     gg_sc_load_row<C>(bot, xi, yy + 1, x0, p.H, p.W, pl, hi);
+    const long long pix = img_pix0 + (long long)yy * p.W + x0 + pl;
+    const float nz = p.noise ? p.noise[pix] : 0.f;        // issued with the row's loads, consumed after the MFMAs
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     acc = gg_sc_row_mfma<C>(acc, top, wl, 0, pl, hi);
     acc = gg_sc_row_mfma<C>(acc, mid, wl, 1, pl, hi);
     acc = gg_sc_row_mfma<C>(acc, bot, wl, 2, pl, hi);
-    const long long pix = img_pix0 + (long long)yy * p.W + x0 + pl;
-    const float nz = p.noise ? p.noise[pix] : 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int ch0 = 8 * q + 4 * hi;
@@ -256,8 +256,7 @@ GG_DEVICE void gg_sc_step(const GgSconvParams& p, const bf16_t* wl, const bf16_t
             u16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v = acc[q * 4 + e];
-                if (p.noise) v += nz * p.noise_w[ch0 + e];
+                float v = acc[q * 4 + e] + nz * nw[q * 4 + e];
                 if (p.act == 1) v = v > 0.f ? v : v * p.slope;
                 o[e] = gg_f2bf(v);
             }
@@ -286,6 +285,13 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_sconv_kernel(GgSconvParams p) {
     const int pl = lane & 31, hi = lane >> 5;
     const bf16_t* xi = p.x + (long long)img * p.H * p.W * C;
     const long long img_pix0 = (long long)img * p.H * p.W;
+    float nw[16];            // the noise weights of this lane's 16 output channels, fetched once (0 without noise / beyond O)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ch = 8 * (r >> 2) + 4 * hi + (r & 3);
+        const float v = p.noise_w ? p.noise_w[ch < p.O ? ch : 0] : 0.f;
+        nw[r] = (p.noise_w && ch < p.O) ? v : 0.f;
+    }
     for (int it = 0; it < p.items_per_wave; ++it) {
         const int item = first + it * 4 + wave;
         if (item >= items) break;
@@ -298,9 +304,9 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_sconv_kernel(GgSconvParams p) {
         gg_sc_load_row<C>(r0, xi, y_lo - 1, x0, p.H, p.W, pl, hi);
         gg_sc_load_row<C>(r1, xi, y_lo, x0, p.H, p.W, pl, hi);
         for (int yy = y_lo; yy < y_hi; yy += 3) {
-            gg_sc_step<C>(p, wl, xi, img_pix0, yy, x0, r0, r1, r2, pl, hi);
-            if (yy + 1 < y_hi) gg_sc_step<C>(p, wl, xi, img_pix0, yy + 1, x0, r1, r2, r0, pl, hi);
-            if (yy + 2 < y_hi) gg_sc_step<C>(p, wl, xi, img_pix0, yy + 2, x0, r2, r0, r1, pl, hi);
+            gg_sc_step<C>(p, wl, xi, img_pix0, yy, x0, r0, r1, r2, pl, hi, nw);
+            if (yy + 1 < y_hi) gg_sc_step<C>(p, wl, xi, img_pix0, yy + 1, x0, r1, r2, r0, pl, hi, nw);
+            if (yy + 2 < y_hi) gg_sc_step<C>(p, wl, xi, img_pix0, yy + 2, x0, r2, r0, r1, pl, hi, nw);
         }
     }
 }

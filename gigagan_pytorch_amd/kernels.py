@@ -580,8 +580,8 @@ def modw_fwd(w: torch.Tensor, mod: torch.Tensor, kmod, demod: bool, eps: float, 
     N, O, I = w.shape[:3]
     T = w.shape[3] * w.shape[4]
     b = mod.shape[0]
-    assert w.dtype == torch.float32 and w.is_contiguous() and mod.dtype == torch.float32 and mod.is_contiguous()
-    assert mod.shape == (b, I) and (kmod is None or (kmod.shape == (b, N) and kmod.dtype == torch.float32 and kmod.is_contiguous()))
+    assert w.dtype == torch.float32 and w.is_contiguous() and mod.dtype == torch.float32 and mod.stride(1) == 1
+    assert mod.shape == (b, I) and (kmod is None or (kmod.shape == (b, N) and kmod.dtype == torch.float32 and kmod.stride(1) == 1))
     s = a = d = None
     if coef:
         s = torch.empty((b, Ip), dtype=torch.float32, device=w.device)
@@ -589,8 +589,8 @@ def modw_fwd(w: torch.Tensor, mod: torch.Tensor, kmod, demod: bool, eps: float, 
         d = torch.empty((b, Op), dtype=torch.float32, device=w.device)
     if wmix is not None:
         assert wmix.dtype == torch.bfloat16 and wmix.is_contiguous()
-    rc = L.lib.gg_modw_fwd(ptr(w), ptr(mod), ptr(kmod), ptr(s), ptr(a), ptr(d), ptr(wmix), layout, b, N, O, I, T, Ip, Op,
-                           int(bool(demod)), float(eps), L.stream(w))
+    rc = L.lib.gg_modw_fwd(ptr(w), ptr(mod), mod.stride(0), ptr(kmod), 0 if kmod is None else kmod.stride(0), ptr(s), ptr(a), ptr(d),
+                           ptr(wmix), layout, b, N, O, I, T, Ip, Op, int(bool(demod)), float(eps), L.stream(w))
     L.check(rc, 'gg_modw_fwd')
     return s, a, d
 

@@ -909,8 +909,8 @@ class HipOps:
         w_ok = weights.dtype == torch.float32 and weights.is_contiguous()
         if not needs_grad and k == 3 and w_ok and K.modw_eligible(b, N, I, k * k) and Ip == I and Op == O:
             # no-grad forward (the discriminator step's generator pass, generate()): csrc/gg_modfwd.h
-            km = kernel_mod.detach().float().contiguous() if N > 1 else None
-            md = mod.detach().float().contiguous()
+            km = _rows_f32(kernel_mod) if N > 1 else None       # column slices of the style network's output: read in place
+            md = _rows_f32(mod)
             wd = weights.detach()
             nz = nw = None
             if noise is not None:
@@ -1133,6 +1133,14 @@ class HipOps:
             return x
         xa = to_act(x)
         return nchw(ResampleFn.apply(nhwc(xa), K.ResampleSpec.nearest(H, W, *size)))
+
+
+def _rows_f32(t: torch.Tensor) -> torch.Tensor:
+    """(b, n) fp32 with unit column stride, without a copy when it already is one (a column slice of a wider fp32 matrix)."""
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if (t.dim() == 2 and t.stride(1) == 1) else t.contiguous()
 
 
 def _wmix_buffer(weights, b: int, I: int):
