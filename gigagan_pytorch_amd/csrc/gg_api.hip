@@ -500,7 +500,16 @@ extern "C" int gg_resample_nhwc_bf16(const void* in, void* out, int32_t n, int32
     p.n = n; p.IH = ih; p.IW = iw; p.OH = oh; p.OW = ow; p.C = c; p.TY = ty; p.TX = tx;
     p.iy0 = iy0; p.ix0 = ix0; p.wy = wy; p.wx = wx;
     long long total = (long long)n * oh * ow * ((c + 7) / 8);
-    GG_LAUNCH(gg_resample_kernel, dim3(gg_grid_for(total)), dim3(256), (hipStream_t)stream, p);
+    const dim3 grid(gg_grid_for(total));
+    hipStream_t s = (hipStream_t)stream;
+    if ((c % 8) == 0 && ty == tx && (ty == 1 || ty == 2 || ty == 3 || ty == 6)) {
+        if (ty == 1) GG_LAUNCH((gg_resample_taps_kernel<1, 1>), grid, dim3(256), s, p);
+        else if (ty == 2) GG_LAUNCH((gg_resample_taps_kernel<2, 2>), grid, dim3(256), s, p);
+        else if (ty == 3) GG_LAUNCH((gg_resample_taps_kernel<3, 3>), grid, dim3(256), s, p);
+        else GG_LAUNCH((gg_resample_taps_kernel<6, 6>), grid, dim3(256), s, p);
+    } else {
+        GG_LAUNCH(gg_resample_kernel, grid, dim3(256), s, p);
+    }
     return gg_check_launch();
 }
 
@@ -729,16 +738,16 @@ extern "C" int gg_modulate_bank_fwd(const void* x, const float* s, const float* 
     return gg_check_launch();
 }
 
-extern "C" int gg_modw_fwd(const float* w, const float* mod, int32_t mod_ld, const float* kmod, int32_t kmod_ld, float* s, float* a,
-                           float* d, void* wmix, int32_t layout, int32_t b, int32_t N, int32_t O, int32_t I, int32_t T, int32_t Ip,
-                           int32_t Op, int32_t demod, float eps, void* stream) {
+extern "C" int gg_modw_fwd(const float* w, const float* mod, int32_t mod_ld, const float* kmod, int32_t kmod_ld, const float* xs,
+                           int32_t xs_ld, float* s, float* a, float* d, void* wmix, int32_t layout, int32_t b, int32_t N, int32_t O,
+                           int32_t I, int32_t T, int32_t Ip, int32_t Op, int32_t demod, float eps, void* stream) {
     if (!w || !mod) return gg_fail(-1, "gg_modw_fwd: null pointer");
     if (b <= 0 || b > GG_MW_BMAX || N <= 0 || N > GG_MW_NMAX || O <= 0 || I <= 0 || (I & 3) || T <= 0 || Ip < I || Op < O)
         return gg_fail(-2, "gg_modw_fwd: bad extents (b=%d N=%d O=%d I=%d T=%d)", b, N, O, I, T);
     if ((long long)N * I * T > GG_MW_WMAX || (long long)(N * (N + 1) / 2) * I > GG_MW_GMAX)
         return gg_fail(-3, "gg_modw_fwd: bank too large for one workgroup (N*I*T=%lld)", (long long)N * I * T);
     if (N > 1 && !kmod) return gg_fail(-1, "gg_modw_fwd: kernel_mod is required for N > 1");
-    if (mod_ld < I || (kmod && kmod_ld < N)) return gg_fail(-2, "gg_modw_fwd: row pitches smaller than the rows");
+    if (mod_ld < I || (kmod && kmod_ld < N) || (xs && xs_ld < I)) return gg_fail(-2, "gg_modw_fwd: row pitches smaller than the rows");
     if (wmix) {
         if (layout != 1 && layout != 2) return gg_fail(-4, "gg_modw_fwd: layout must be 1 or 2");
         if (layout == 2 && ((I & 15) || O > 32)) return gg_fail(-4, "gg_modw_fwd: layout 2 needs I %% 16 == 0 and O <= 32");
@@ -748,7 +757,7 @@ extern "C" int gg_modw_fwd(const float* w, const float* mod, int32_t mod_ld, con
     memset(&p, 0, sizeof(p));
     p.w = w; p.mod = mod; p.kmod = kmod; p.s = s; p.a = a; p.d = d; p.wmix = (bf16_t*)wmix; p.layout = layout;
     p.b = b; p.N = N; p.O = O; p.I = I; p.T = T; p.Ip = Ip; p.Op = Op; p.demod = demod; p.eps = eps;
-    p.mod_ld = mod_ld; p.kmod_ld = kmod_ld;
+    p.mod_ld = mod_ld; p.kmod_ld = kmod_ld; p.xs = xs; p.xs_ld = xs_ld;
     // coefficient-only launches: one workgroup per channel handles every sample; with per-sample weights the samples are spread
     // over enough workgroups to fill the chip (a 16-channel layer would otherwise run on 16 CUs)
     int bc = b;
@@ -758,7 +767,11 @@ extern "C" int gg_modw_fwd(const float* w, const float* mod, int32_t mod_ld, con
         if (bc > b) bc = b;
     }
     p.bc = bc;
-    GG_LAUNCH(gg_modw_kernel, dim3((unsigned)O, (unsigned)((b + bc - 1) / bc)), dim3(256), (hipStream_t)stream, p);
+    const dim3 grid((unsigned)O, (unsigned)((b + bc - 1) / bc));
+    if (N == 1) GG_LAUNCH((gg_modw_kernel<1>), grid, dim3(256), (hipStream_t)stream, p);
+    else if (N == 2) GG_LAUNCH((gg_modw_kernel<2>), grid, dim3(256), (hipStream_t)stream, p);
+    else if (N == 3) GG_LAUNCH((gg_modw_kernel<3>), grid, dim3(256), (hipStream_t)stream, p);
+    else GG_LAUNCH((gg_modw_kernel<4>), grid, dim3(256), (hipStream_t)stream, p);
     return gg_check_launch();
 }
 

@@ -21,6 +21,7 @@
 #define GG_KERNEL __global__
 #define GG_SHARED __shared__
 #define GG_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+#define GG_LAUNCH_BOUNDS2(n, waves_per_simd) __launch_bounds__(n, waves_per_simd)   // caps the register allocation for that occupancy
 #define GG_LAUNCH(kernel, grid, block, stream, ...) \
     hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
 

@@ -63,6 +63,61 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_resample_kernel(GgResampleParams p) {
     }
 }
 
+// The same operator with the tap counts known at compile time and C % 8 == 0 (every call of the training step: 1x1 nearest /
+// transposed bilinear, 2x2 bilinear, 3x3 upsample+blur / blur, 6x6 their adjoints): all loads of a tap row are issued
+// unconditionally from clamped coordinates and weighted by zero when the tap lies outside the image. In the generic kernel above
+// every load sits under a per-lane condition and feeds the accumulator at once, so the compiler branches around each one and
+// waits for it before issuing the next: up to 36 dependent round trips per output vector (measured 1.26 TB/s on the 128 -> 256
+// feature upsample).
+template <int TY, int TX>
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_resample_taps_kernel(GgResampleParams p) {
+    const int cg = p.C / 8;
+    const long long total = (long long)p.n * p.OH * p.OW * cg;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int g = (int)(idx % cg);
+        const long long pix = idx / cg;
+        const int ox = (int)(pix % p.OW);
+        const long long t = pix / p.OW;
+        const int oy = (int)(t % p.OH);
+        const int img = (int)(t / p.OH);
+        const int y0 = p.iy0[oy], x0 = p.ix0[ox];
+        float wyv[TY], wxv[TX];
+        int cx[TX];
+#pragma unroll
+        for (int a = 0; a < TY; ++a) wyv[a] = p.wy[oy * TY + a];
+#pragma unroll
+        for (int b = 0; b < TX; ++b) {
+            const int ix = x0 + b;
+            const bool in = ix >= 0 && ix < p.IW;
+            wxv[b] = in ? p.wx[ox * TX + b] : 0.f;
+            cx[b] = ix < 0 ? 0 : (ix >= p.IW ? p.IW - 1 : ix);
+        }
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        const bf16_t* base = p.in + (long long)img * p.IH * p.IW * p.C + g * 8;
+#pragma unroll
+        for (int a = 0; a < TY; ++a) {
+            const int iy = y0 + a;
+            const float wya = (iy >= 0 && iy < p.IH) ? wyv[a] : 0.f;
+            const int cy = iy < 0 ? 0 : (iy >= p.IH ? p.IH - 1 : iy);
+            u16x8 v[TX];
+#pragma unroll
+            for (int b = 0; b < TX; ++b) v[b] = *(const u16x8*)(base + ((long long)cy * p.IW + cx[b]) * p.C);
+#pragma unroll
+            for (int b = 0; b < TX; ++b) {
+                const float w = wya * wxv[b];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += w * gg_bf2f(v[b][e]);
+            }
+        }
+        u16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = gg_f2bf(acc[e]);
+        *(u16x8*)(p.out + (((long long)img * p.OH + oy) * p.OW + ox) * p.C + g * 8) = o;
+    }
+}
+
 // ---- fused multi-tensor AdamW -------------------------------------------------------------------------
 // One launch updates a whole model (reference: torch.optim.AdamW built by optimizer.py:10-34, stepped at
 // gp.py:2477 / :2596). Parameters, gradients and both moments live in flat fp32 buffers; every parameter

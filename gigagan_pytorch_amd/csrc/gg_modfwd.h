@@ -35,6 +35,8 @@ struct GgModWParams {
     int demod;
     float eps;
     int mod_ld, kmod_ld;   // row pitches of mod / kmod in floats (they are column slices of the style network's output)
+    const float* xs;       // optional (b, I) extra scale of the INPUT activation (skip-layer excitation, gp.py:1023-1024) folded into
+    int xs_ld;             // s and the per-sample weights - not into the demodulation, which the reference computes from mod + 1 alone
     int bc;                // samples per workgroup: grid = (O, ceil(b / bc)); every workgroup re-derives the Gram rows of its channel
 };
 
@@ -44,9 +46,14 @@ GG_DEVICE float gg_mw_wave_sum(float v) {
     return v;
 }
 
-// grid: (O, ceil(b / bc)) workgroups of 256 threads: workgroup (o, c) owns output channel o for samples c*bc .. c*bc + bc - 1
+// grid: (O, ceil(b / bc)) workgroups of 256 threads: workgroup (o, c) owns output channel o for samples c*bc .. c*bc + bc - 1.
+// N (kernels in the bank) is a template parameter and every global load is unconditional (indices clamped, results weighted by
+// 0 / 1): with run-time loop bounds and loads under conditions the compiler emitted one branch + `s_waitcnt vmcnt(0)` per load,
+// i.e. a chain of ~60 dependent memory round trips per workgroup (50 us for a 512-channel layer; measured, profiles/).
+template <int N>
 GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modw_kernel(GgModWParams p) {
-    GG_SHARED float wl[GG_MW_WMAX];                       // [n][i*T + t]
+    constexpr int NP = N * (N + 1) / 2;
+    GG_SHARED __attribute__((aligned(16))) float wl[GG_MW_WMAX];   // [n][i*T + t]
     GG_SHARED float gram[GG_MW_GMAX];                     // [pair][i], pair = (n, m >= n) in row-major upper-triangle order
     GG_SHARED float a_s[GG_MW_BMAX][GG_MW_NMAX];
     GG_SHARED float d_s[GG_MW_BMAX];
@@ -55,93 +62,104 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modw_kernel(GgModWParams p) {
     const int IT = p.I * p.T;
     const int b_lo = blockIdx.y * p.bc;
     const int b_hi = b_lo + p.bc < p.b ? b_lo + p.bc : p.b;
-    // s / a / the zero padding of d of this chunk's samples: written by the workgroups of channel 0
+    // s / the zero padding of d of this chunk's samples: written by the workgroups of channel 0
     if (o == 0)
         for (int row = b_lo; row < b_hi; ++row) {
             if (p.s)
-                for (int i = tid; i < p.Ip; i += 256) p.s[(long long)row * p.Ip + i] = i < p.I ? p.mod[(long long)row * p.mod_ld + i] + 1.f : 0.f;
+                for (int i = tid; i < p.Ip; i += 256) {
+                    const int ic = i < p.I ? i : p.I - 1;
+                    const float v = (p.mod[(long long)row * p.mod_ld + ic] + 1.f) * (p.xs ? p.xs[(long long)row * p.xs_ld + ic] : 1.f);
+                    p.s[(long long)row * p.Ip + i] = i < p.I ? v : 0.f;
+                }
             if (p.d)
                 for (int c = p.O + tid; c < p.Op; c += 256) p.d[(long long)row * p.Op + c] = 0.f;
         }
-    {   // the bank rows of this channel: 16-byte loads, several in flight per thread (I % 4 == 0: rows are 16-byte aligned)
-        const int nv = (p.N * IT) >> 2;
+    // the bank rows of this channel: 16-byte loads, four in flight per thread (I % 4 == 0: rows are 16-byte aligned)
+    {
         const int ivn = IT >> 2;
-        for (int v0 = tid; v0 < nv; v0 += 256 * 4) {
-            f32x4 r[4];      // loads are unconditional (clamped index): a load under a per-lane condition is branched around and
-#pragma unroll       // waited for on its own - a chain of dependent round trips instead of four in flight
-            for (int u = 0; u < 4; ++u) {
-                const int v = v0 + u * 256 < nv ? v0 + u * 256 : nv - 1;
-                const int n = v / ivn, e4 = v - n * ivn;
-                r[u] = *(const f32x4*)(p.w + ((long long)n * p.O + o) * IT + e4 * 4);
-            }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int v = v0 + u * 256;
-                if (v < nv) *(f32x4*)(wl + v * 4) = r[u];
+        for (int n = 0; n < N; ++n) {
+            const float* src = p.w + ((long long)n * p.O + o) * IT;
+            for (int v0 = tid; v0 < ivn; v0 += 1024) {
+                f32x4 r[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int v = v0 + 256 * u < ivn ? v0 + 256 * u : ivn - 1;
+                    r[u] = *(const f32x4*)(src + v * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (v0 + 256 * u < ivn) *(f32x4*)(wl + n * IT + (v0 + 256 * u) * 4) = r[u];
             }
         }
     }
     if (tid >= b_lo && tid < b_hi) {
-        float a0 = 1.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        if (p.kmod && p.N > 1) {
-            const float* km = p.kmod + (long long)tid * p.kmod_ld;
-            const float k0 = km[0], k1 = km[1], k2 = p.N > 2 ? km[2] : -3.0e38f, k3 = p.N > 3 ? km[3] : -3.0e38f;
-            float mx = k0 > k1 ? k0 : k1;
-            mx = k2 > mx ? k2 : mx;
-            mx = k3 > mx ? k3 : mx;
-            a0 = gg_expf(k0 - mx); a1 = gg_expf(k1 - mx);
-            a2 = p.N > 2 ? gg_expf(k2 - mx) : 0.f; a3 = p.N > 3 ? gg_expf(k3 - mx) : 0.f;
-            const float inv = 1.f / (a0 + a1 + a2 + a3);
-            a0 *= inv; a1 *= inv; a2 *= inv; a3 *= inv;
+        float av[GG_MW_NMAX] = {1.f, 0.f, 0.f, 0.f};
+        if (N > 1) {
+            float kv[N], mx = -3.0e38f, sum = 0.f;
+#pragma unroll
+            for (int n = 0; n < N; ++n) { kv[n] = p.kmod[(long long)tid * p.kmod_ld + n]; mx = kv[n] > mx ? kv[n] : mx; }
+#pragma unroll
+            for (int n = 0; n < N; ++n) { kv[n] = gg_expf(kv[n] - mx); sum += kv[n]; }
+#pragma unroll
+            for (int n = 0; n < N; ++n) av[n] = kv[n] / sum;
         }
-        a_s[tid][0] = a0; a_s[tid][1] = a1; a_s[tid][2] = a2; a_s[tid][3] = a3;
-        if (p.a && o == 0) {
-            p.a[tid * p.N] = a0;
-            if (p.N > 1) p.a[tid * p.N + 1] = a1;
-            if (p.N > 2) p.a[tid * p.N + 2] = a2;
-            if (p.N > 3) p.a[tid * p.N + 3] = a3;
-        }
+#pragma unroll
+        for (int n = 0; n < GG_MW_NMAX; ++n) a_s[tid][n] = av[n];
+        if (p.a && o == 0)
+#pragma unroll
+            for (int n = 0; n < N; ++n) p.a[tid * N + n] = av[n];
     }
     gg_sync();
     if (p.demod) {
-        int pair = 0;
-        for (int n = 0; n < p.N; ++n)
-            for (int m = n; m < p.N; ++m, ++pair)
-                for (int i = tid; i < p.I; i += 256) {
-                    float acc = 0.f;
-                    for (int t = 0; t < p.T; ++t) acc += wl[n * IT + i * p.T + t] * wl[m * IT + i * p.T + t];
-                    gram[pair * p.I + i] = acc;
-                }
+        {
+            int pair = 0;
+#pragma unroll
+            for (int n = 0; n < N; ++n)
+#pragma unroll
+                for (int m = n; m < N; ++m, ++pair)
+                    for (int i = tid; i < p.I; i += 256) {
+                        float acc = 0.f;
+                        for (int t = 0; t < p.T; ++t) acc += wl[n * IT + i * p.T + t] * wl[m * IT + i * p.T + t];
+                        gram[pair * p.I + i] = (n == m ? 1.f : 2.f) * acc;       // the symmetric pair counted twice
+                    }
+        }
         gg_sync();
-        // d[b] = rsqrt(sum_i s_i^2 * (a^T G_i a)): a wave takes samples b_lo + wave, +4, ...; lanes run along i. The modulation
-        // values of FOUR samples are fetched before any of them is used (independent loads in flight, not one round trip each)
+        // d[b] = rsqrt(sum_i s_i^2 * (a^T G_i a)): a wave takes samples b_lo + wave, +4, ...; lanes run along i; the modulation
+        // rows of four samples are fetched back to back before any value is used
         for (int bb0 = b_lo + wave; bb0 < b_hi; bb0 += 16) {
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             for (int i0 = 0; i0 < p.I; i0 += 512) {
                 float mv[4][8];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int bb = bb0 + 4 * u;
+                    const int bc = bb0 + 4 * u < b_hi ? bb0 + 4 * u : b_hi - 1;
+                    const float* mrow = p.mod + (long long)bc * p.mod_ld;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const int i = i0 + lane + 64 * j;
-                        const int bc = bb < b_hi ? bb : b_hi - 1, ic = i < p.I ? i : p.I - 1;      // unconditional loads
-                        const float v = p.mod[(long long)bc * p.mod_ld + ic] + 1.f;
-                        mv[u][j] = (bb < b_hi && i < p.I) ? v : 0.f;
+                        const int ic = i0 + lane + 64 * j < p.I ? i0 + lane + 64 * j : p.I - 1;
+                        mv[u][j] = mrow[ic];
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int bb = bb0 + 4 * u < b_hi ? bb0 + 4 * u : b_lo;
+                for (int j = 0; j < 8; ++j) {
+                    const int i = i0 + lane + 64 * j;
+                    const int ic = i < p.I ? i : p.I - 1;
+                    const float live = i < p.I ? 1.f : 0.f;
+                    float g[NP];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int i = i0 + lane + 64 * j < p.I ? i0 + lane + 64 * j : p.I - 1;     // (mv is 0 beyond I)
+                    for (int pr = 0; pr < NP; ++pr) g[pr] = gram[pr * p.I + ic] * live;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int bc = bb0 + 4 * u < b_hi ? bb0 + 4 * u : b_hi - 1;
                         float q = 0.f;
                         int pr = 0;
-                        for (int n = 0; n < p.N; ++n)
-                            for (int m = n; m < p.N; ++m, ++pr)
-                                q += (n == m ? 1.f : 2.f) * a_s[bb][n] * a_s[bb][m] * gram[pr * p.I + i];
-                        acc[u] += mv[u][j] * mv[u][j] * q;
+#pragma unroll
+                        for (int n = 0; n < N; ++n)
+#pragma unroll
+                            for (int m = n; m < N; ++m, ++pr) q += a_s[bc][n] * a_s[bc][m] * g[pr];
+                        const float sv = mv[u][j] + 1.f;
+                        acc[u] += sv * sv * q;
                     }
                 }
             }
@@ -167,11 +185,14 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modw_kernel(GgModWParams p) {
     // per-sample weights: threads run along (t, i) with i fastest, so the bf16 stores of a wave are contiguous
     for (int bb = b_lo; bb < b_hi; ++bb) {
         const float dv = d_s[bb];
+        const float* mrow = p.mod + (long long)bb * p.mod_ld;
+        const float* xrow = p.xs ? p.xs + (long long)bb * p.xs_ld : nullptr;
         for (int e = tid; e < IT; e += 256) {
             const int t = e / p.I, i = e - t * p.I;
             float m = 0.f;
-            for (int n = 0; n < p.N; ++n) m += a_s[bb][n] * wl[n * IT + i * p.T + t];
-            const float v = dv * (p.mod[(long long)bb * p.mod_ld + i] + 1.f) * m;
+#pragma unroll
+            for (int n = 0; n < N; ++n) m += a_s[bb][n] * wl[n * IT + i * p.T + t];
+            const float v = dv * (mrow[i] + 1.f) * (xrow ? xrow[i] : 1.f) * m;
             long long off;
             if (p.layout == 1) off = (((long long)bb * p.O + o) * p.T + t) * p.I + i;
             else off = ((((long long)bb * p.T + t) * (p.I >> 4) + (i >> 4)) * 32 + o) * 16 + (i & 15);
@@ -196,59 +217,64 @@ struct GgSconvParams {
     int items_per_wave;     // items a wavefront walks through (a workgroup of 4 wavefronts stays inside one image)
 };
 
-// one image row of a strip as MFMA B fragments: (dx = -1, 0, +1) x (C / 16) 16-byte loads per lane; pixels beyond the image
-// borders are loaded from a clamped address and zeroed afterwards (a load under a per-lane condition is branched around and
-// waited for one at a time), rows beyond the image are zeros without any load (the condition is wave-uniform)
+// one image row of a strip as MFMA B fragments: (dx = -1, 0, +1) x (C / 16) 16-byte loads per lane, ALWAYS issued and from a
+// clamped address (a load under a per-lane condition is branched around and waited for on the spot); what lies outside the image
+// is zeroed when the fragment is used (gg_sc_row_mfma), many instructions later, so the loads stay in flight meanwhile
 template <int C>
 GG_DEVICE void gg_sc_load_row(u16x8 (&row)[3 * (C / 16)], const bf16_t* xi, int iy, int x0, int H, int W, int pl, int hi) {
     constexpr int KC = C / 16;
-    const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (iy < 0 || iy >= H) {
-#pragma unroll
-        for (int f = 0; f < 3 * KC; ++f) row[f] = z;
-        return;
-    }
+    const int cy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
         const int ix = x0 + pl + dx - 1;
-        const bool in = ix >= 0 && ix < W;
         const int cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
-        const bf16_t* src = xi + ((long long)iy * W + cx) * C + hi * 8;
+        const bf16_t* src = xi + ((long long)cy * W + cx) * C + hi * 8;
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-            const u16x8 v = *(const u16x8*)(src + kc * 16);
-            row[dx * KC + kc] = in ? v : z;
-        }
+        for (int kc = 0; kc < KC; ++kc) row[dx * KC + kc] = *(const u16x8*)(src + kc * 16);
     }
 }
 
+// the 3 * C/16 MFMAs of one kernel row; `iy` / x0 say which fragments lie outside the image (zeroed here)
 template <int C>
-GG_DEVICE f32x16 gg_sc_row_mfma(f32x16 acc, const u16x8 (&row)[3 * (C / 16)], const bf16_t* wl, int ky, int pl, int hi) {
+GG_DEVICE f32x16 gg_sc_row_mfma(f32x16 acc, const u16x8 (&row)[3 * (C / 16)], const bf16_t* wl, int ky, int iy, int x0,
+                                int H, int W, int pl, int hi) {
     constexpr int KC = C / 16;
+#if !defined(GG_HOST_EMULATION)
+    // the bank is loop invariant, and the compiler would park all 9 * C/16 fragments in registers for the whole strip (72 of
+    // them at C = 32: one wave per SIMD): an address it cannot see through keeps the 18 ds_read_b128 per row in the loop
+    asm volatile("" : "+v"(wl));
+#endif
+    const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool row_in = iy >= 0 && iy < H;
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx)
+    for (int dx = 0; dx < 3; ++dx) {
+        const int ix = x0 + pl + dx - 1;
+        const bool in = row_in && ix >= 0 && ix < W;
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-            const u16x8 wf = *(const u16x8*)(wl + (((ky * 3 + dx) * KC + kc) * 32 + pl) * 16 + hi * 8);
-            acc = gg_mfma_32x32x16_bf16(wf, row[dx * KC + kc], acc);     // D[out channel][pixel]: registers run along channels
+        for (int kc = 0; kc < KC; ++kc)
+        {
+            const u16x8 wf = *(const u16x8*)(wl + (((ky * 3 + dx) * KC + kc) * 32 + pl) * 16 + hi * 8);   // A fragment from the bank in LDS
+            acc = gg_mfma_32x32x16_bf16(wf, in ? row[dx * KC + kc] : z, acc);                              // D[channel][pixel]
         }
+    }
     return acc;
 }
 
-// one output row: the row below is fetched first (its loads fly during the 6 * C/16 MFMAs of the two rows already in registers)
-template <int C>
-GG_DEVICE void gg_sc_step(const GgSconvParams& p, const bf16_t* wl, const bf16_t* xi, long long img_pix0, int yy, int x0,
-                          const u16x8 (&top)[3 * (C / 16)], const u16x8 (&mid)[3 * (C / 16)], u16x8 (&bot)[3 * (C / 16)], int pl, int hi,
-                          const float (&nw)[16]) {
-    gg_sc_load_row<C>(bot, xi, yy + 1, x0, p.H, p.W, pl, hi);
+// one output row yy: the row TWO below is fetched first (two rows of loads in flight per wavefront: the memory latency is ~8x the
+// 9 * C/16 MFMAs of a row), then the three rows already in registers are multiplied, noise and activation applied, stored
+template <int C, int AHEAD>
+GG_DEVICE void gg_sc_step(const GgSconvParams& p, const bf16_t* wl, const bf16_t* xi, long long img_pix0, int yy,
+                          int x0, const u16x8 (&top)[3 * (C / 16)], const u16x8 (&mid)[3 * (C / 16)], const u16x8 (&bot)[3 * (C / 16)],
+                          u16x8 (&next)[3 * (C / 16)], int pl, int hi, const float (&nw)[16]) {
     const long long pix = img_pix0 + (long long)yy * p.W + x0 + pl;
-    const float nz = p.noise ? p.noise[pix] : 0.f;        // issued with the row's loads, consumed after the MFMAs
+    const float nz = p.noise ? p.noise[pix] : 0.f;     // BEFORE the row loads: waiting for it must not drain them (vmcnt is in order)
+    gg_sc_load_row<C>(next, xi, yy + AHEAD, x0, p.H, p.W, pl, hi);      // AHEAD = 2: `next` is a fourth buffer; 1: `next` IS `bot`
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    acc = gg_sc_row_mfma<C>(acc, top, wl, 0, pl, hi);
-    acc = gg_sc_row_mfma<C>(acc, mid, wl, 1, pl, hi);
-    acc = gg_sc_row_mfma<C>(acc, bot, wl, 2, pl, hi);
+    acc = gg_sc_row_mfma<C>(acc, top, wl, 0, yy - 1, x0, p.H, p.W, pl, hi);
+    acc = gg_sc_row_mfma<C>(acc, mid, wl, 1, yy, x0, p.H, p.W, pl, hi);
+    acc = gg_sc_row_mfma<C>(acc, bot, wl, 2, yy + 1, x0, p.H, p.W, pl, hi);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int ch0 = 8 * q + 4 * hi;
@@ -266,8 +292,9 @@ GG_DEVICE void gg_sc_step(const GgSconvParams& p, const bf16_t* wl, const bf16_t
 }
 
 template <int C>
-GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_sconv_kernel(GgSconvParams p) {
+GG_KERNEL GG_LAUNCH_BOUNDS2(256, (C <= 16 ? 3 : 2)) void gg_sconv_kernel(GgSconvParams p) {
     constexpr int KC = C / 16;
+    constexpr int NV = 9 * KC * 32 * 2;                                  // 16-byte vectors of one filter bank
     GG_SHARED __attribute__((aligned(16))) bf16_t wl[9 * KC * 32 * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int strips = p.W >> 5;
@@ -276,10 +303,15 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_sconv_kernel(GgSconvParams p) {
     const int per_wg = 4 * p.items_per_wave;
     const int wgs_per_img = (items + per_wg - 1) / per_wg;
     const int img = blockIdx.x / wgs_per_img, first = (blockIdx.x - img * wgs_per_img) * per_wg;
-    {
+    {   // this image's bank -> LDS, all of a thread's loads in flight together
         const u16x8* src = (const u16x8*)(p.w + (long long)img * p.w_bs);
-        u16x8* dst = (u16x8*)wl;
-        for (int v = tid; v < 9 * KC * 32 * 2; v += 256) dst[v] = src[v];
+        constexpr int PER = (NV + 255) / 256;
+        u16x8 r[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) r[u] = src[tid + 256 * u < NV ? tid + 256 * u : NV - 1];
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            if (tid + 256 * u < NV) ((u16x8*)wl)[tid + 256 * u] = r[u];
     }
     gg_sync();
     const int pl = lane & 31, hi = lane >> 5;
@@ -298,15 +330,30 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_sconv_kernel(GgSconvParams p) {
         const int cy = item / strips, x0 = (item - cy * strips) << 5;
         const int y_lo = cy * p.rows_per_item;
         const int y_hi = y_lo + p.rows_per_item < p.H ? y_lo + p.rows_per_item : p.H;
-        // three register rows rotate through the roles (above, centre, below): the loop is unrolled by three so that every
-        // access is statically indexed; each input row is fetched once per strip instead of three times
-        u16x8 r0[3 * KC], r1[3 * KC], r2[3 * KC];
-        gg_sc_load_row<C>(r0, xi, y_lo - 1, x0, p.H, p.W, pl, hi);
-        gg_sc_load_row<C>(r1, xi, y_lo, x0, p.H, p.W, pl, hi);
-        for (int yy = y_lo; yy < y_hi; yy += 3) {
-            gg_sc_step<C>(p, wl, xi, img_pix0, yy, x0, r0, r1, r2, pl, hi, nw);
-            if (yy + 1 < y_hi) gg_sc_step<C>(p, wl, xi, img_pix0, yy + 1, x0, r1, r2, r0, pl, hi, nw);
-            if (yy + 2 < y_hi) gg_sc_step<C>(p, wl, xi, img_pix0, yy + 2, x0, r2, r0, r1, pl, hi, nw);
+        if constexpr (C <= 32) {
+            // four register rows rotate through the roles (above, centre, below, in flight): the loop is unrolled by four so
+            // that every access is statically indexed; each input row is fetched once per strip, two rows ahead of its use
+            u16x8 r0[3 * KC], r1[3 * KC], r2[3 * KC], r3[3 * KC];
+            gg_sc_load_row<C>(r0, xi, y_lo - 1, x0, p.H, p.W, pl, hi);
+            gg_sc_load_row<C>(r1, xi, y_lo, x0, p.H, p.W, pl, hi);
+            gg_sc_load_row<C>(r2, xi, y_lo + 1, x0, p.H, p.W, pl, hi);
+            for (int yy = y_lo; yy < y_hi; yy += 4) {
+                gg_sc_step<C, 2>(p, wl, xi, img_pix0, yy, x0, r0, r1, r2, r3, pl, hi, nw);
+                if (yy + 1 < y_hi) gg_sc_step<C, 2>(p, wl, xi, img_pix0, yy + 1, x0, r1, r2, r3, r0, pl, hi, nw);
+                if (yy + 2 < y_hi) gg_sc_step<C, 2>(p, wl, xi, img_pix0, yy + 2, x0, r2, r3, r0, r1, pl, hi, nw);
+                if (yy + 3 < y_hi) gg_sc_step<C, 2>(p, wl, xi, img_pix0, yy + 3, x0, r3, r0, r1, r2, pl, hi, nw);
+            }
+        } else {
+            // 64 channels: a row is 12 fragments (48 registers), so three rows rotate and the row below is fetched at the top
+            // of its own step (its loads fly during the MFMAs of the two rows above)
+            u16x8 r0[3 * KC], r1[3 * KC], r2[3 * KC];
+            gg_sc_load_row<C>(r0, xi, y_lo - 1, x0, p.H, p.W, pl, hi);
+            gg_sc_load_row<C>(r1, xi, y_lo, x0, p.H, p.W, pl, hi);
+            for (int yy = y_lo; yy < y_hi; yy += 3) {
+                gg_sc_step<C, 1>(p, wl, xi, img_pix0, yy, x0, r0, r1, r2, r2, pl, hi, nw);
+                if (yy + 1 < y_hi) gg_sc_step<C, 1>(p, wl, xi, img_pix0, yy + 1, x0, r1, r2, r0, r0, pl, hi, nw);
+                if (yy + 2 < y_hi) gg_sc_step<C, 1>(p, wl, xi, img_pix0, yy + 2, x0, r2, r0, r1, r1, pl, hi, nw);
+            }
         }
     }
 }

@@ -183,12 +183,12 @@ class Generator(BaseGenerator):
             if exists(squeeze_excite):
                 excitations.append(squeeze_excite(x))
             excite = excitations.pop(0) if excitations else None
-            if exists(excite):
-                x = ops.impl.channel_scale(x, excite)
+            # `x = x * excite` (gp.py:1023-1024): x has one consumer, the first conv of the block, which takes the scale along
+            # (no-grad: folded into its per-sample weights; otherwise the fused multiply with its one-pass backward)
 
             h, w = x.shape[-2:]
             # noise draws: same order, shape and device as the reference's Noise modules (gp.py:938)
-            x = conv1(x, mod=next(conv_mods), kernel_mod=next(conv_mods),
+            x = conv1(x, mod=next(conv_mods), kernel_mod=next(conv_mods), in_excite=excite,
                       noise=torch.randn(batch, 1, h, w, device=device), noise_weight=noise1.weight, act='lrelu')
             x = conv2(x, mod=next(conv_mods), kernel_mod=next(conv_mods),
                       noise=torch.randn(batch, 1, h, w, device=device), noise_weight=noise2.weight, act='lrelu')

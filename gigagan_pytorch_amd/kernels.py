@@ -572,11 +572,11 @@ def modw_eligible(b: int, N: int, I: int, T: int) -> bool:
 
 
 def modw_fwd(w: torch.Tensor, mod: torch.Tensor, kmod, demod: bool, eps: float, Ip: int, Op: int, coef: bool = True,
-             wmix: torch.Tensor | None = None, layout: int = 0):
+             wmix: torch.Tensor | None = None, layout: int = 0, xs: torch.Tensor | None = None):
     """one launch per adaptive-conv layer (gg_modfwd.h): returns (s (b, Ip), a (b, N), d (b, Op)) when `coef`, and fills `wmix`
     (per-sample weights, layout 1 = (b, O, T*I) rows / layout 2 = (b, T, I/16, 32, 16)) when given."""
     L = _C.lib()
-    L.require(w, mod, kmod, wmix)
+    L.require(w, mod, kmod, wmix, xs)
     N, O, I = w.shape[:3]
     T = w.shape[3] * w.shape[4]
     b = mod.shape[0]
@@ -589,7 +589,10 @@ def modw_fwd(w: torch.Tensor, mod: torch.Tensor, kmod, demod: bool, eps: float, 
         d = torch.empty((b, Op), dtype=torch.float32, device=w.device)
     if wmix is not None:
         assert wmix.dtype == torch.bfloat16 and wmix.is_contiguous()
-    rc = L.lib.gg_modw_fwd(ptr(w), ptr(mod), mod.stride(0), ptr(kmod), 0 if kmod is None else kmod.stride(0), ptr(s), ptr(a), ptr(d),
+    if xs is not None:
+        assert xs.dtype == torch.float32 and xs.shape == (b, I) and xs.stride(1) == 1
+    rc = L.lib.gg_modw_fwd(ptr(w), ptr(mod), mod.stride(0), ptr(kmod), 0 if kmod is None else kmod.stride(0), ptr(xs),
+                           0 if xs is None else xs.stride(0), ptr(s), ptr(a), ptr(d),
                            ptr(wmix), layout, b, N, O, I, T, Ip, Op, int(bool(demod)), float(eps), L.stream(w))
     L.check(rc, 'gg_modw_fwd')
     return s, a, d

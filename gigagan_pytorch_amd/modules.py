@@ -211,7 +211,7 @@ class AdaptiveConv2DMod(nn.Module):
         self.demod = demod
         nn.init.kaiming_normal_(self.weights, a=0, mode='fan_in', nonlinearity='leaky_relu')
 
-    def forward(self, fmap, mod, kernel_mod=None, noise=None, noise_weight=None, act=None):
+    def forward(self, fmap, mod, kernel_mod=None, noise=None, noise_weight=None, act=None, in_excite=None):
         b = fmap.shape[0]
         mod = tile_batch(mod, b)
         if exists(kernel_mod):
@@ -221,7 +221,7 @@ class AdaptiveConv2DMod(nn.Module):
         if self.adaptive:
             assert exists(kernel_mod)
         return ops.impl.modconv2d(fmap, self.weights, mod, kernel_mod if self.adaptive else None, demod=self.demod,
-                                  eps=self.eps, noise=noise, noise_weight=noise_weight, act=act)
+                                  eps=self.eps, noise=noise, noise_weight=noise_weight, act=act, in_excite=in_excite)
 
 
 # ---- attention ------------------------------------------------------------------------------------------------

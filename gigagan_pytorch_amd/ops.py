@@ -899,18 +899,21 @@ class HipOps:
 
     # -- adaptive / modulated conv (gp.py:315-409) -----------------------------------------------
     def modconv2d(self, x, weights, mod, kernel_mod=None, demod=True, eps=1e-8, noise=None, noise_weight=None,
-                  act=None):
+                  act=None, in_excite=None):
+        """`in_excite` (b, I[, 1, 1]): a per-sample scale of the input activation (the skip-layer excitation the generator applies
+        right before this conv, gp.py:1023-1024); the no-grad path folds it into the per-sample weights / the modulation pass."""
         x = to_act(x)
         b, _, H, W = x.shape
         N, O, I, k, _ = weights.shape
         Ip, Op = _round8(I), _round8(O)
         needs_grad = torch.is_grad_enabled() and any(
-            t is not None and t.requires_grad for t in (x, weights, mod, kernel_mod, noise_weight))
+            t is not None and t.requires_grad for t in (x, weights, mod, kernel_mod, noise_weight, in_excite))
         w_ok = weights.dtype == torch.float32 and weights.is_contiguous()
         if not needs_grad and k == 3 and w_ok and K.modw_eligible(b, N, I, k * k) and Ip == I and Op == O:
             # no-grad forward (the discriminator step's generator pass, generate()): csrc/gg_modfwd.h
             km = _rows_f32(kernel_mod) if N > 1 else None       # column slices of the style network's output: read in place
             md = _rows_f32(mod)
+            xs = None if in_excite is None else _rows_f32(in_excite.reshape(b, I))
             wd = weights.detach()
             nz = nw = None
             if noise is not None:
@@ -919,19 +922,19 @@ class HipOps:
             if I in (16, 32, 64) and O <= 32 and W % 32 == 0 and b * H * W >= 32768:
                 # narrow high-resolution layers: the reference's per-sample weights (a few KiB each) + the streaming convolution
                 wm = _wmix_buffer(weights, b, I)
-                K.modw_fwd(wd, md, km, demod, eps, Ip, Op, coef=False, wmix=wm, layout=2)
+                K.modw_fwd(wd, md, km, demod, eps, Ip, Op, coef=False, wmix=wm, layout=2, xs=xs)
                 return nchw(K.sconv(nhwc(x), wm, O, nz, nw, act, LRELU_SLOPE))
             if H * W % 128 == 0 and H * W >= 1024 and b * O * I * 9 <= (16 << 20):
                 # mid resolutions: the per-sample weights are still small next to the activation (<= 32 MiB of bf16), so the
                 # reference's formulation (one kernel per sample, algorithmic flops) beats the shared bank's doubled reduction:
                 # implicit GEMM with a per-image weight operand, modulation / demodulation folded into the weights
                 wm = _wmix_rows(weights, b, O, 9 * I)
-                K.modw_fwd(wd, md, km, demod, eps, Ip, Op, coef=False, wmix=wm, layout=1)
+                K.modw_fwd(wd, md, km, demod, eps, Ip, Op, coef=False, wmix=wm, layout=1, xs=xs)
                 y = K.conv2d_nhwc(nhwc(x), wm, ksize=3, noise=nz, noise_w=nw, act=act, act_slope=LRELU_SLOPE,
                                   per_image_weights=True)
                 return nchw(y)
             # wide layers: shared bank, the N kernels stacked along the reduction on a pre-modulated activation
-            s, a, d = K.modw_fwd(wd, md, km, demod, eps, Ip, Op)
+            s, a, d = K.modw_fwd(wd, md, km, demod, eps, Ip, Op, xs=xs)
             x2 = K.modulate_bank(nhwc(x), s, a)
             wk = None
             if (isinstance(weights, torch.nn.Parameter) and getattr(weights, '_gg_pack_table', None) is not None
@@ -942,6 +945,8 @@ class HipOps:
             y = K.conv2d_nhwc(x2, wk, ksize=k, out_scale=d if demod else None, noise=nz, noise_w=nw, act=act,
                               act_slope=LRELU_SLOPE)
             return nchw(y)
+        if in_excite is not None:        # every other path: the plain multiply (with its fused backward when gradients flow)
+            x = self.channel_scale(x, in_excite)
         fused_coef = (demod and not second_order and N <= K.MODCOEF_MAX_N and max(I, O) <= K.MODCOEF_MAX_C
                       and weights.dtype == torch.float32 and weights.is_contiguous())
         s_padded = d_padded = False

@@ -260,6 +260,8 @@ int gg_attn_bwd2(const void* q, const void* k, const void* v, const void* k0, co
  *   (ones when demod == 0; any of s / a / d may be null), and optionally the reference's per-sample weights
  *   wmix = d[b,o] s[b,i] sum_n a[b,n] W_n[o,i,t] in bf16: layout 1 = [b][O][T][I] (rows of T*I: the implicit GEMM's weight operand of
  *   image b), layout 2 = [b][T][I/16][32][16] (gg_sconv_fwd's filter bank; rows O..31 are left untouched: zero them once).
+ *   xs (optional, (b, I) fp32): an extra per-sample scale of the INPUT activation (the skip-layer excitation `x * excite`,
+ *   gp.py:1023-1024) folded into s and wmix but not into d, which the reference derives from mod + 1 alone.
  *   mod (b, I) / kmod (b, N) are fp32 rows `mod_ld` / `kmod_ld` floats apart (column slices of the style network's output).
  *   b <= 64, N <= 4, N*I*T <= 9216, I %% 4 == 0.
  * gg_sconv_fwd: 3x3 / stride 1 / pad 1 convolution of an NHWC bf16 activation with per-image banks (w_bs = elements between
@@ -267,9 +269,9 @@ int gg_attn_bwd2(const void* q, const void* k, const void* v, const void* k0, co
  *   C in {16, 32, 64}, O <= 32, O %% 8 == 0.
  * gg_modulate_bank_fwd: out[b][p][n*Cin + i] = x[b][p][i] * s[b][i] * a[b][n] for the N = Cout / Cin kernels of a bank in one pass
  *   (s is [b][Cin], a is [b][N]). */
-int gg_modw_fwd(const float* w, const float* mod, int32_t mod_ld, const float* kmod, int32_t kmod_ld, float* s, float* a, float* d,
-                void* wmix, int32_t layout, int32_t b, int32_t N, int32_t O, int32_t I, int32_t T, int32_t Ip, int32_t Op, int32_t demod,
-                float eps, void* stream);
+int gg_modw_fwd(const float* w, const float* mod, int32_t mod_ld, const float* kmod, int32_t kmod_ld, const float* xs, int32_t xs_ld,
+                float* s, float* a, float* d, void* wmix, int32_t layout, int32_t b, int32_t N, int32_t O, int32_t I, int32_t T,
+                int32_t Ip, int32_t Op, int32_t demod, float eps, void* stream);
 int gg_sconv_fwd(const void* x, const void* w, int64_t w_bs, void* y, const float* noise, const float* noise_w, int32_t b,
                  int32_t H, int32_t W, int32_t C, int32_t O, int32_t act, float slope, void* stream);
 int gg_modulate_bank_fwd(const void* x, const float* s, const float* a, void* out, int32_t b, int32_t P, int32_t Cin, int32_t Cout,

@@ -17,6 +17,7 @@
 #define GG_KERNEL static
 #define GG_SHARED static
 #define GG_LAUNCH_BOUNDS(n)
+#define GG_LAUNCH_BOUNDS2(n, w)
 
 typedef unsigned short bf16_t;
 typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
