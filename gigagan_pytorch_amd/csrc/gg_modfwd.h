@@ -239,11 +239,15 @@ template <int C>
 GG_DEVICE f32x16 gg_sc_row_mfma(f32x16 acc, const u16x8 (&row)[3 * (C / 16)], const bf16_t* wl, int ky, int iy, int x0,
                                 int H, int W, int pl, int hi) {
     constexpr int KC = C / 16;
-#if !defined(GG_HOST_EMULATION)
     // the bank is loop invariant, and the compiler would park all 9 * C/16 fragments in registers for the whole strip (72 of
-    // them at C = 32: one wave per SIMD): an address it cannot see through keeps the 18 ds_read_b128 per row in the loop
-    asm volatile("" : "+v"(wl));
+    // them at C = 32: one wave per SIMD): an OFFSET it cannot see through keeps the ds_read_b128 in the loop. (Laundering the
+    // pointer itself loses the LDS address space: the reads become flat loads, which count on vmcnt AND lgkmcnt out of order,
+    // and every wait turns into vmcnt(0): no prefetch left.)
+    int opaque = 0;
+#if !defined(GG_HOST_EMULATION)
+    asm volatile("" : "+v"(opaque));
 #endif
+    wl += opaque;
     const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool row_in = iy >= 0 && iy < H;
 #pragma unroll
@@ -265,9 +269,16 @@ GG_DEVICE f32x16 gg_sc_row_mfma(f32x16 acc, const u16x8 (&row)[3 * (C / 16)], co
 template <int C, int AHEAD>
 GG_DEVICE void gg_sc_step(const GgSconvParams& p, const bf16_t* wl, const bf16_t* xi, long long img_pix0, int yy,
                           int x0, const u16x8 (&top)[3 * (C / 16)], const u16x8 (&mid)[3 * (C / 16)], const u16x8 (&bot)[3 * (C / 16)],
-                          u16x8 (&next)[3 * (C / 16)], int pl, int hi, const float (&nw)[16]) {
-    const long long pix = img_pix0 + (long long)yy * p.W + x0 + pl;
-    const float nz = p.noise ? p.noise[pix] : 0.f;     // BEFORE the row loads: waiting for it must not drain them (vmcnt is in order)
+                          u16x8 (&next)[3 * (C / 16)], int pl, int hi, const float* nw, bool live) {
+    // `live` (wave uniform) is false for the padding steps of the unrolled ring past the strip's last row: their loads are
+    // clamped into the image and nothing is stored (no control flow around the register rotation: no copies between rows)
+    const int yc = live ? yy : p.H - 1;
+    const long long pix = img_pix0 + (long long)yc * p.W + x0 + pl;
+    // BEFORE the row loads: waiting for it must not drain them (vmcnt is in order). Always issued (without a noise map it reads
+    // the activations, in range: a pixel is >= 32 bytes there) so that no branch splits the step
+    const float* nsrc = p.noise ? p.noise : (const float*)p.x;
+    float nz = nsrc[pix];
+    nz = p.noise ? nz : 0.f;
     gg_sc_load_row<C>(next, xi, yy + AHEAD, x0, p.H, p.W, pl, hi);      // AHEAD = 2: `next` is a fourth buffer; 1: `next` IS `bot`
     f32x16 acc;
 #pragma unroll
@@ -275,14 +286,19 @@ GG_DEVICE void gg_sc_step(const GgSconvParams& p, const bf16_t* wl, const bf16_t
     acc = gg_sc_row_mfma<C>(acc, top, wl, 0, yy - 1, x0, p.H, p.W, pl, hi);
     acc = gg_sc_row_mfma<C>(acc, mid, wl, 1, yy, x0, p.H, p.W, pl, hi);
     acc = gg_sc_row_mfma<C>(acc, bot, wl, 2, yy + 1, x0, p.H, p.W, pl, hi);
+    int opaque = 0;       // as for the bank: keep the four ds_read_b128 of the noise weights in the loop instead of 16 registers
+#if !defined(GG_HOST_EMULATION)
+    asm volatile("" : "+v"(opaque));
+#endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int ch0 = 8 * q + 4 * hi;
-        if (ch0 < p.O) {
+        if (live && ch0 < p.O) {
             u16x4 o;
+            const f32x4 w4 = *(const f32x4*)(nw + opaque + ch0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v = acc[q * 4 + e] + nz * nw[q * 4 + e];
+                float v = acc[q * 4 + e] + nz * w4[e];
                 if (p.act == 1) v = v > 0.f ? v : v * p.slope;
                 o[e] = gg_f2bf(v);
             }
@@ -292,11 +308,16 @@ GG_DEVICE void gg_sc_step(const GgSconvParams& p, const bf16_t* wl, const bf16_t
 }
 
 template <int C>
-GG_KERNEL GG_LAUNCH_BOUNDS2(256, (C <= 16 ? 3 : 2)) void gg_sconv_kernel(GgSconvParams p) {
+GG_KERNEL GG_LAUNCH_BOUNDS2(256, (C <= 32 ? 3 : 2)) void gg_sconv_kernel(GgSconvParams p) {
     constexpr int KC = C / 16;
     constexpr int NV = 9 * KC * 32 * 2;                                  // 16-byte vectors of one filter bank
     GG_SHARED __attribute__((aligned(16))) bf16_t wl[9 * KC * 32 * 16];
+    GG_SHARED __attribute__((aligned(16))) float nw[32];                 // noise weights by output channel (0 without noise / beyond O)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 32) {
+        const float v = p.noise_w ? p.noise_w[tid < p.O ? tid : 0] : 0.f;
+        nw[tid] = (p.noise_w && tid < p.O) ? v : 0.f;
+    }
     const int strips = p.W >> 5;
     const int chunks = (p.H + p.rows_per_item - 1) / p.rows_per_item;
     const int items = strips * chunks;                                   // per image; strip index fastest
@@ -317,13 +338,6 @@ GG_KERNEL GG_LAUNCH_BOUNDS2(256, (C <= 16 ? 3 : 2)) void gg_sconv_kernel(GgSconv
     const int pl = lane & 31, hi = lane >> 5;
     const bf16_t* xi = p.x + (long long)img * p.H * p.W * C;
     const long long img_pix0 = (long long)img * p.H * p.W;
-    float nw[16];            // the noise weights of this lane's 16 output channels, fetched once (0 without noise / beyond O)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int ch = 8 * (r >> 2) + 4 * hi + (r & 3);
-        const float v = p.noise_w ? p.noise_w[ch < p.O ? ch : 0] : 0.f;
-        nw[r] = (p.noise_w && ch < p.O) ? v : 0.f;
-    }
     for (int it = 0; it < p.items_per_wave; ++it) {
         const int item = first + it * 4 + wave;
         if (item >= items) break;
@@ -338,10 +352,10 @@ GG_KERNEL GG_LAUNCH_BOUNDS2(256, (C <= 16 ? 3 : 2)) void gg_sconv_kernel(GgSconv
             gg_sc_load_row<C>(r1, xi, y_lo, x0, p.H, p.W, pl, hi);
             gg_sc_load_row<C>(r2, xi, y_lo + 1, x0, p.H, p.W, pl, hi);
             for (int yy = y_lo; yy < y_hi; yy += 4) {
-                gg_sc_step<C, 2>(p, wl, xi, img_pix0, yy, x0, r0, r1, r2, r3, pl, hi, nw);
-                if (yy + 1 < y_hi) gg_sc_step<C, 2>(p, wl, xi, img_pix0, yy + 1, x0, r1, r2, r3, r0, pl, hi, nw);
-                if (yy + 2 < y_hi) gg_sc_step<C, 2>(p, wl, xi, img_pix0, yy + 2, x0, r2, r3, r0, r1, pl, hi, nw);
-                if (yy + 3 < y_hi) gg_sc_step<C, 2>(p, wl, xi, img_pix0, yy + 3, x0, r3, r0, r1, r2, pl, hi, nw);
+                gg_sc_step<C, 2>(p, wl, xi, img_pix0, yy, x0, r0, r1, r2, r3, pl, hi, nw, true);
+                gg_sc_step<C, 2>(p, wl, xi, img_pix0, yy + 1, x0, r1, r2, r3, r0, pl, hi, nw, yy + 1 < y_hi);
+                gg_sc_step<C, 2>(p, wl, xi, img_pix0, yy + 2, x0, r2, r3, r0, r1, pl, hi, nw, yy + 2 < y_hi);
+                gg_sc_step<C, 2>(p, wl, xi, img_pix0, yy + 3, x0, r3, r0, r1, r2, pl, hi, nw, yy + 3 < y_hi);
             }
         } else {
             // 64 channels: a row is 12 fragments (48 registers), so three rows rotate and the row below is fetched at the top
@@ -350,9 +364,9 @@ GG_KERNEL GG_LAUNCH_BOUNDS2(256, (C <= 16 ? 3 : 2)) void gg_sconv_kernel(GgSconv
             gg_sc_load_row<C>(r0, xi, y_lo - 1, x0, p.H, p.W, pl, hi);
             gg_sc_load_row<C>(r1, xi, y_lo, x0, p.H, p.W, pl, hi);
             for (int yy = y_lo; yy < y_hi; yy += 3) {
-                gg_sc_step<C, 1>(p, wl, xi, img_pix0, yy, x0, r0, r1, r2, r2, pl, hi, nw);
-                if (yy + 1 < y_hi) gg_sc_step<C, 1>(p, wl, xi, img_pix0, yy + 1, x0, r1, r2, r0, r0, pl, hi, nw);
-                if (yy + 2 < y_hi) gg_sc_step<C, 1>(p, wl, xi, img_pix0, yy + 2, x0, r2, r0, r1, r1, pl, hi, nw);
+                gg_sc_step<C, 1>(p, wl, xi, img_pix0, yy, x0, r0, r1, r2, r2, pl, hi, nw, true);
+                gg_sc_step<C, 1>(p, wl, xi, img_pix0, yy + 1, x0, r1, r2, r0, r0, pl, hi, nw, yy + 1 < y_hi);
+                gg_sc_step<C, 1>(p, wl, xi, img_pix0, yy + 2, x0, r2, r0, r1, r1, pl, hi, nw, yy + 2 < y_hi);
             }
         }
     }
