@@ -11,7 +11,7 @@ hip: gigagan_pytorch_amd/libgigagan_amd.so
 emu: tests/emu/libgigagan_amd_emu.so
 
 gigagan_pytorch_amd/libgigagan_amd.so: $(SRCS) $(HDRS)
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC $(SRCS) -o $@
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -shared -fPIC $(SRCS) -o $@
 
 tests/emu/libgigagan_amd_emu.so: $(SRCS) $(HDRS) tests/emu/gg_emu.cpp tests/emu/gg_device_emu.h
 	$(HOSTCXX) -x c++ -std=c++17 -O2 -Wno-psabi -DGG_HOST_EMULATION -Itests/emu -I$(CSRC) -shared -fPIC $(SRCS) tests/emu/gg_emu.cpp -o $@

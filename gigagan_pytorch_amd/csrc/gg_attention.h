@@ -97,7 +97,7 @@ GG_DEVICE GgaTileRegs gga_tile_load(const bf16_t* base, long long row_stride, in
     return r;
 }
 
-GG_DEVICE void gga_tile_store(const GgaTileRegs& r, bf16_t (*rowk)[GGA_KP], char* tr, float* sq) {
+GG_DEVICE void gga_tile_store(const GgaTileRegs& r, bf16_t (*rowk)[GGA_KP], char* tr, float* sq, float sq_scale = 1.f) {
     const int t = threadIdx.x;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -112,7 +112,7 @@ GG_DEVICE void gga_tile_store(const GgaTileRegs& r, bf16_t (*rowk)[GGA_KP], char
             s += gg_shfl_xor(s, 1);
             s += gg_shfl_xor(s, 2);
             s += gg_shfl_xor(s, 4);
-            if (c8 == 0) sq[row] = s;
+            if (c8 == 0) sq[row] = s * sq_scale;
         }
     }
 }
@@ -123,11 +123,25 @@ GG_DEVICE f32x4 gga_rows4(const float* arr, int blk, int g, int lane) {
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------------
-// grid: (n / 128, B*h); 256 threads; wave w owns queries q0 + 32w .. +31
+// grid: (n / 128, B*h); 256 threads; wave w owns queries q0 + 32w .. +31.
+//
+// The kernel is bound by the vector ALU (the softmax), not by the matrix pipe: per 64-key tile a wave issues 16 MFMAs (512
+// cycles) but the exponentials of its 32 x 64 scores cost more than that. So the per-score work is kept to
+//     x = fma(s, alpha', bias'_j)   max3   x - m   v_exp_f32   (+ row sum, bf16 pack)
+// by (1) working in the log2 domain (alpha' = alpha log2 e, bias'_j = beta log2 e |k_j|^2, written to LDS with the tile),
+// (2) rescaling the running output only when some row's maximum grew by more than 2^GGA_TAU since the last rescale (a
+// wave-uniform branch; until then the stale maximum is the reference of BOTH the probabilities and the row sums, so the
+// final O / l is unchanged; probabilities stay below 2^GGA_TAU), which removes the 32 accumulator read-modify-writes per
+// tile, and (3) keeping the row sums per lane (the two half-wave partners own different keys of the same query) until the end.
+// K / V tiles are double buffered: one barrier per tile.
+#define GGA_LOG2E 1.4426950408889634f
+#define GGA_LN2 0.6931471805599453f
+#define GGA_TAU 8.0f
+
 GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_fwd_kernel(GgAttnParams p) {
-    GG_SHARED __attribute__((aligned(16))) bf16_t sK[64][GGA_KP];
-    GG_SHARED __attribute__((aligned(16))) char sV[64 * GGA_TP];
-    GG_SHARED __attribute__((aligned(16))) float sKsq[64];
+    GG_SHARED __attribute__((aligned(16))) bf16_t sK[2][64][GGA_KP];
+    GG_SHARED __attribute__((aligned(16))) char sV[2][64 * GGA_TP];
+    GG_SHARED __attribute__((aligned(16))) float sKb[2][64];          // beta' |k_j|^2 of the tile's keys
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
     const int bh = blockIdx.y, b = bh / p.h, hd = bh % p.h;
@@ -136,12 +150,13 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_fwd_kernel(GgAttnParams p) {
     const bf16_t* kb = p.k + (long long)b * p.n * rs + hd * GGA_D;
     const bf16_t* vb = p.v + (long long)b * p.n * rs + hd * GGA_D;
     const int qi0 = blockIdx.x * 128 + wave * 32;
+    const float a2 = p.alpha * GGA_LOG2E, b2 = p.beta * GGA_LOG2E, inv_a2 = 1.f / a2;
 
     u16x8 qf[4];
     gga_load_frags(qf, qb, rs, qi0, lane);
 
-    // null key / value: initial state of the online softmax
-    float m, l = 1.f;
+    // null key / value: initial state of the online softmax (its probability 2^0 = 1 is counted by the hi = 0 lane)
+    float m, l = hi ? 0.f : 1.f;
     f32x16 ot[2];
     {
         const bf16_t* k0 = p.k0 + hd * GGA_D;
@@ -157,7 +172,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_fwd_kernel(GgAttnParams p) {
         }
         dot += gg_shfl_xor(dot, 32);
         sq += gg_shfl_xor(sq, 32);
-        m = p.alpha * dot + p.beta * sq;
+        m = a2 * dot + b2 * sq;
         const bf16_t* v0 = p.v0 + hd * GGA_D;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
@@ -166,55 +181,75 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_fwd_kernel(GgAttnParams p) {
     }
 
     GgaTileRegs rk = gga_tile_load(kb, rs, 0), rv = gga_tile_load(vb, rs, 0);
-    for (int j0 = 0; j0 < p.n; j0 += 64) {
-        gg_sync();
-        gga_tile_store(rk, sK, nullptr, sKsq);
-        gga_tile_store(rv, nullptr, sV, nullptr);
-        gg_sync();
+    gga_tile_store(rk, sK[0], nullptr, sKb[0], b2);
+    gga_tile_store(rv, nullptr, sV[0], nullptr);
+    if (64 < p.n) {
+        rk = gga_tile_load(kb, rs, 64);
+        rv = gga_tile_load(vb, rs, 64);
+    }
+    gg_sync();
+    for (int j0 = 0, buf = 0; j0 < p.n; j0 += 64, buf ^= 1) {
+        // tile j0 + 64 sits in the staging registers: park it in the other buffer (free since the barrier that ended the
+        // previous iteration) and put tile j0 + 128 in flight
         if (j0 + 64 < p.n) {
-            rk = gga_tile_load(kb, rs, j0 + 64);
-            rv = gga_tile_load(vb, rs, j0 + 64);
+            gga_tile_store(rk, sK[buf ^ 1], nullptr, sKb[buf ^ 1], b2);
+            gga_tile_store(rv, nullptr, sV[buf ^ 1], nullptr);
+            if (j0 + 128 < p.n) {
+                rk = gga_tile_load(kb, rs, j0 + 128);
+                rv = gga_tile_load(vb, rs, j0 + 128);
+            }
         }
 
+        // the accumulators start at -m / alpha', so that alpha' * S + bias' comes out of the fma already relative to the reference
+        // maximum m (the subtraction rides on the MFMA's accumulate input)
+        const float minit = -m * inv_a2;
         f32x16 st[2];
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[jb][r] = 0.f;
+            for (int r = 0; r < 16; ++r) st[jb][r] = minit;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) st[jb] = gg_mfma_32x32x16_bf16(gga_frag_rowk(sK, jb * 32, kk, lane), qf[kk], st[jb]);
+            for (int kk = 0; kk < 4; ++kk) st[jb] = gg_mfma_32x32x16_bf16(gga_frag_rowk(sK[buf], jb * 32, kk, lane), qf[kk], st[jb]);
         }
         float mx = -3.0e38f;
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                f32x4 ks = gga_rows4(sKsq, jb, g, lane);
+                const f32x4 kb4 = gga_rows4(sKb[buf], jb, g, lane);
+#pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float x = p.alpha * st[jb][4 * g + e] + p.beta * ks[e];
+                    const float x = a2 * st[jb][4 * g + e] + kb4[e];        // log2 score - m
                     st[jb][4 * g + e] = x;
                     mx = fmaxf(mx, x);
                 }
             }
         mx = fmaxf(mx, gg_shfl_xor(mx, 32));
-        const float mn = fmaxf(m, mx);
-        const float corr = gg_expf(m - mn);
-        float rowsum = 0.f;
+        if (gg_wave_any(mx > GGA_TAU)) {        // rare after the first tiles: move the reference to the new maxima
+            const float up = fmaxf(mx, 0.f);
+            const float corr = gg_exp2f(-up);
+            l *= corr;
+            m += up;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[db][r] *= corr;
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[jb][r] -= up;
+        }
+        f32x2 rowsum = {0.f, 0.f};          // pairs: v_pk_add_f32
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pv = gg_expf(st[jb][r] - mn);
-                st[jb][r] = pv;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 pv = {gg_exp2f(st[jb][r]), gg_exp2f(st[jb][r + 1])};
+                st[jb][r] = pv[0];
+                st[jb][r + 1] = pv[1];
                 rowsum += pv;
             }
-        rowsum += gg_shfl_xor(rowsum, 32);
-        l = l * corr + rowsum;
-        m = mn;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ot[db][r] *= corr;
+        l += rowsum[0] + rowsum[1];
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
@@ -222,10 +257,12 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_fwd_kernel(GgAttnParams p) {
                 u16x8 pf = gga_pack8(st[jb], c);
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
-                    ot[db] = gg_mfma_32x32x16_bf16(gga_frag_tr(sV, db * 32, jb * 32 + 16 * c, lane), pf, ot[db]);
+                    ot[db] = gg_mfma_32x32x16_bf16(gga_frag_tr(sV[buf], db * 32, jb * 32 + 16 * c, lane), pf, ot[db]);
             }
+        gg_sync();
     }
 
+    l += gg_shfl_xor(l, 32);
     const float inv = 1.f / l;
     const int qi = qi0 + (lane & 31);
     bf16_t* orow = p.o + ((long long)b * p.n + qi) * rs + hd * GGA_D;
@@ -237,16 +274,16 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_fwd_kernel(GgAttnParams p) {
                         gg_f2bf(ot[db][4 * g + 3] * inv)};
             *(u16x4*)(orow + db * 32 + 8 * g + 4 * hi) = o4;
         }
-    if (hi == 0) p.lse[(long long)bh * p.n + qi] = m + logf(l);
+    if (hi == 0) p.lse[(long long)bh * p.n + qi] = m * GGA_LN2 + logf(l);
 }
 
 // ---- backward, part 1: dq (+ rowsum(dO*O), + the null key/value partial gradients) ---------------------------------
 // grid: (n / 128, B*h); wave w owns queries q0 + 32w .. +31
 GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dq_kernel(GgAttnParams p) {
-    GG_SHARED __attribute__((aligned(16))) bf16_t sK[64][GGA_KP];
-    GG_SHARED __attribute__((aligned(16))) bf16_t sV[64][GGA_KP];
-    GG_SHARED __attribute__((aligned(16))) char sKt[64 * GGA_TP];
-    GG_SHARED __attribute__((aligned(16))) float sKsq[64];
+    GG_SHARED __attribute__((aligned(16))) bf16_t sK[2][64][GGA_KP];
+    GG_SHARED __attribute__((aligned(16))) bf16_t sV[2][64][GGA_KP];
+    GG_SHARED __attribute__((aligned(16))) char sKt[2][64 * GGA_TP];
+    GG_SHARED __attribute__((aligned(16))) float sKb[2][64];          // beta' |k_j|^2 (log2 domain)
     GG_SHARED float sRed[4][3][64];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
@@ -255,6 +292,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dq_kernel(GgAttnParams p) {
     const long long boff = (long long)b * p.n * rs + hd * GGA_D;
     const int qi0 = blockIdx.x * 128 + wave * 32;
     const int qi = qi0 + (lane & 31);
+    const float a2 = p.alpha * GGA_LOG2E, b2 = p.beta * GGA_LOG2E, inv_a2 = 1.f / a2;
 
     u16x8 qf[4], dof[4];
     gga_load_frags(qf, p.q + boff, rs, qi0, lane);
@@ -319,32 +357,43 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dq_kernel(GgAttnParams p) {
         if (lane == 0) sRed[wave][2][0] = s0;
     }
 
+    // per score: p = 2^(alpha' s + bias'_j - lse'), dS = p (dP - D): the two subtractions ride on the MFMAs' accumulate
+    // inputs (S starts at -lse' / alpha', dP at -D), leaving fma, v_exp_f32, mul and the bf16 pack on the vector ALU
+    const float sinit = -lse * GGA_LOG2E * inv_a2, dinit = -dsum;
     GgaTileRegs rk = gga_tile_load(p.k + boff, rs, 0), rv = gga_tile_load(p.v + boff, rs, 0);
-    for (int j0 = 0; j0 < p.n; j0 += 64) {
-        gg_sync();
-        gga_tile_store(rk, sK, sKt, sKsq);
-        gga_tile_store(rv, sV, nullptr, nullptr);
-        gg_sync();
+    gga_tile_store(rk, sK[0], sKt[0], sKb[0], b2);
+    gga_tile_store(rv, sV[0], nullptr, nullptr);
+    if (64 < p.n) {
+        rk = gga_tile_load(p.k + boff, rs, 64);
+        rv = gga_tile_load(p.v + boff, rs, 64);
+    }
+    gg_sync();
+    for (int j0 = 0, buf = 0; j0 < p.n; j0 += 64, buf ^= 1) {
         if (j0 + 64 < p.n) {
-            rk = gga_tile_load(p.k + boff, rs, j0 + 64);
-            rv = gga_tile_load(p.v + boff, rs, j0 + 64);
+            gga_tile_store(rk, sK[buf ^ 1], sKt[buf ^ 1], sKb[buf ^ 1], b2);
+            gga_tile_store(rv, sV[buf ^ 1], nullptr, nullptr);
+            if (j0 + 128 < p.n) {
+                rk = gga_tile_load(p.k + boff, rs, j0 + 128);
+                rv = gga_tile_load(p.v + boff, rs, j0 + 128);
+            }
         }
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
             f32x16 st, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { st[r] = sinit; dp[r] = dinit; }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                st = gg_mfma_32x32x16_bf16(gga_frag_rowk(sK, jb * 32, kk, lane), qf[kk], st);
-                dp = gg_mfma_32x32x16_bf16(gga_frag_rowk(sV, jb * 32, kk, lane), dof[kk], dp);
+                st = gg_mfma_32x32x16_bf16(gga_frag_rowk(sK[buf], jb * 32, kk, lane), qf[kk], st);
+                dp = gg_mfma_32x32x16_bf16(gga_frag_rowk(sV[buf], jb * 32, kk, lane), dof[kk], dp);
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                f32x4 ks = gga_rows4(sKsq, jb, g, lane);
+                const f32x4 kb4 = gga_rows4(sKb[buf], jb, g, lane);
+#pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float pv = gg_expf(p.alpha * st[4 * g + e] + p.beta * ks[e] - lse);
-                    st[4 * g + e] = pv * (dp[4 * g + e] - dsum);      // dS^T
+                    const float pv = gg_exp2f(a2 * st[4 * g + e] + kb4[e]);
+                    st[4 * g + e] = pv * dp[4 * g + e];      // dS^T
                 }
             }
 #pragma unroll
@@ -352,9 +401,10 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dq_kernel(GgAttnParams p) {
                 u16x8 dsf = gga_pack8(st, c);
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
-                    dqt[db] = gg_mfma_32x32x16_bf16(gga_frag_tr(sKt, db * 32, jb * 32 + 16 * c, lane), dsf, dqt[db]);
+                    dqt[db] = gg_mfma_32x32x16_bf16(gga_frag_tr(sKt[buf], db * 32, jb * 32 + 16 * c, lane), dsf, dqt[db]);
             }
         }
+        gg_sync();
     }
 
     bf16_t* dqrow = p.dq + ((long long)b * p.n + qi) * rs + hd * GGA_D;
@@ -401,7 +451,8 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dkv_kernel(GgAttnParams p) {
     for (int kk = 0; kk < 4; ++kk)
         for (int e = 0; e < 8; ++e) { float f = gg_bf2f(kf[kk][e]); ksq += f * f; }
     ksq += gg_shfl_xor(ksq, 32);
-    const float bias = p.beta * ksq;
+    const float a2 = p.alpha * GGA_LOG2E;
+    const float sinit = p.beta * ksq / p.alpha;            // (beta' |k_j|^2) / alpha'
 
     f32x16 dkt[2], dvt[2];
 #pragma unroll
@@ -421,7 +472,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dkv_kernel(GgAttnParams p) {
         gga_tile_store(rq, sQ, sQt, nullptr);
         gga_tile_store(rdo, sDO, sDOt, nullptr);
         if (threadIdx.x < 64) {
-            sLse[threadIdx.x] = r_lse;
+            sLse[threadIdx.x] = r_lse * GGA_LOG2E;
             sD[threadIdx.x] = r_d;
         }
         gg_sync();
@@ -435,9 +486,10 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dkv_kernel(GgAttnParams p) {
         }
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib) {
+            // S starts at bias'_j / alpha' (this lane's key), so p = 2^(alpha' S - lse'_i) is one fma (negated LDS operand) + v_exp_f32
             f32x16 s, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { s[r] = sinit; dp[r] = 0.f; }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 s = gg_mfma_32x32x16_bf16(gga_frag_rowk(sQ, ib * 32, kk, lane), kf[kk], s);
@@ -446,12 +498,13 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dkv_kernel(GgAttnParams p) {
             f32x16 pr;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                f32x4 ls = gga_rows4(sLse, ib, g, lane);
-                f32x4 dd = gga_rows4(sD, ib, g, lane);
+                const f32x4 ls = gga_rows4(sLse, ib, g, lane);       // lse' = lse log2 e
+                const f32x4 dd = gga_rows4(sD, ib, g, lane);
+#pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float pv = gg_expf(p.alpha * s[4 * g + e] + bias - ls[e]);
+                    const float pv = gg_exp2f(a2 * s[4 * g + e] - ls[e]);
                     pr[4 * g + e] = pv;
-                    float ds = pv * (dp[4 * g + e] - dd[e]);
+                    const float ds = pv * (dp[4 * g + e] - dd[e]);
                     s[4 * g + e] = ds;
                     dbias += ds;
                 }

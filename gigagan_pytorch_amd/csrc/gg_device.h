@@ -95,6 +95,8 @@ GG_DEVICE float gg_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64);
 GG_DEVICE float gg_shfl(float v, int src) { return __shfl(v, src, 64); }
 GG_DEVICE void gg_atomic_add(float* p, float v) { atomicAdd(p, v); }
 GG_DEVICE float gg_expf(float x) { return __expf(x); }
+GG_DEVICE float gg_exp2f(float x) { return __builtin_amdgcn_exp2f(x); }     // bare v_exp_f32 (no range fix-ups: x <= 128 here)
+GG_DEVICE bool gg_wave_any(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0; }    // wave-uniform result
 GG_DEVICE float gg_rsqrtf(float x) { return rsqrtf(x); }
 
 #endif  // GG_HOST_EMULATION

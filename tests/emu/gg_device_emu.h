@@ -82,4 +82,10 @@ static inline float gg_shfl(float v, int src) { return gg_emu_shfl(v, src & 63);
 static inline void gg_atomic_add(float* p, float v) { *p += v; }
 
 static inline float gg_expf(float x) { return expf(x); }
+static inline float gg_exp2f(float x) { return exp2f(x); }
+static inline bool gg_wave_any(bool pred) {     // wave collective: every fiber of the wave calls it
+    float f = pred ? 1.f : 0.f;
+    for (int o = 1; o < 64; o <<= 1) f = fmaxf(f, gg_shfl_xor(f, o));
+    return f > 0.f;
+}
 static inline float gg_rsqrtf(float x) { return 1.0f / sqrtf(x); }
