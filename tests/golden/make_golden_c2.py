@@ -121,6 +121,9 @@ def main():
         losses={k: {n: (of[k][n], rf[k][n]) for n in of[k]} for k in ('d_plain', 'd_gp', 'g')},
         grad_norms={k: (of[k + '_grad_norm'], rf[k + '_gradnorm']) for k in ('d_plain', 'd_gp', 'g')})
     fx['oracle_f32_grad_norms'] = {k: of[k + '_grad_norm'] for k in ('d_plain', 'd_gp', 'g')}
+    # ... and the subsampled fp32 gradients: the yardstick for the bf16 paths (the test bounds the HIP path's distance to these
+    # by the bf16-operand oracle's own distance to them)
+    fx['oracle_f32_grad_sub'] = {k: of[k + '_grad_sub'] for k in ('d_plain', 'd_gp', 'g')}
     rf.pop('rgbs')
     print(fx['oracle_f32_vs_reference'])
     torch.save(fx, OUT / 'c2_step1.pt')
