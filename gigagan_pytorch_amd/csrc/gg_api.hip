@@ -913,10 +913,10 @@ extern "C" int gg_rmsnorm_fwd(const void* x, const float* gamma, void* y, int64_
     return gg_rms_launch(0, x, nullptr, nullptr, gamma, y, nullptr, nullptr, rows, C, gg_rmsnorm_blocks(rows), eps, stream);
 }
 
-extern "C" int gg_rmsnorm_bwd(const void* x, const void* g, const float* gamma, void* dx, float* dgamma_part, int64_t rows,
-                              int32_t C, float eps, void* stream) {
+extern "C" int gg_rmsnorm_bwd(const void* x, const void* g, const float* gamma, const void* carry, void* dx, float* dgamma_part,
+                              int64_t rows, int32_t C, float eps, void* stream) {
     if (!g) return gg_fail(-1, "gg_rmsnorm_bwd: null gradient");
-    return gg_rms_launch(1, x, g, nullptr, gamma, dx, nullptr, dgamma_part, rows, C, gg_rmsnorm_blocks(rows), eps, stream);
+    return gg_rms_launch(1, x, g, carry, gamma, dx, nullptr, dgamma_part, rows, C, gg_rmsnorm_blocks(rows), eps, stream);
 }
 
 extern "C" int gg_rmsnorm_bwd2(const void* x, const void* g, const void* v, const float* gamma, void* gx, void* gg,

@@ -521,7 +521,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_gelu_kernel(GgGeluParams p) {
 struct GgRmsParams {
     const bf16_t* x;      // [rows][C]
     const bf16_t* g;      // bwd/bwd2: gradient w.r.t. y
-    const bf16_t* v;      // bwd2: gradient w.r.t. dx
+    const bf16_t* v;      // bwd2: gradient w.r.t. dx ; bwd: optional carry added to dx (the skip branch's gradient)
     const float* gamma;   // [C]
     bf16_t* out0;         // fwd: y ; bwd: dx ; bwd2: gx
     bf16_t* out1;         // bwd2: gg
@@ -585,12 +585,14 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_rmsnorm_kernel(GgRmsParams p) {
             const int c = t * 512 + lane * 8;
             if (c < p.C) {
                 u16x8 o0, o1;
+                u16x8 cv = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (MODE == 1 && p.v) cv = *(const u16x8*)(p.v + r * p.C + c);
                 for (int e = 0; e < 8; ++e) {
                     const float u = xf[t][e] / n;
                     if (MODE == 0) {
                         o0[e] = gg_f2bf(xf[t][e] * rn * p.gamma[c + e]);
                     } else if (MODE == 1) {
-                        o0[e] = gg_f2bf(rn * (hf[t][e] - u * uh));
+                        o0[e] = gg_f2bf(rn * (hf[t][e] - u * uh) + gg_bf2f(cv[e]));
                         dgam[t][e] += rn * xf[t][e] * gf[t][e];
                     } else {
                         const float pv = vf[t][e] - u * uv;          // (P v)_c

@@ -335,8 +335,13 @@ class Discriminator(nn.Module):
                 feats = tile_batch(feats, x.shape[0])
                 x = torch.cat((x + feats, feats), dim=0)
 
+            # x feeds the residual conv and the block: the block's first conv hands x on (fork), so that the residual branch's
+            # gradient is added inside that conv's data-gradient pass
+            y, x = block[0](x, fork=True)
             residual = residual_fn(x)
-            x = block(x)
+            for m in list(block)[1:]:
+                y = m(y)
+            x = y
 
             if exists(attn):
                 x = attn(x)

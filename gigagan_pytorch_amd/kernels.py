@@ -742,15 +742,17 @@ def rmsnorm_fwd(x: torch.Tensor, gamma: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def rmsnorm_bwd(x, g, gamma, want_dgamma: bool):
+def rmsnorm_bwd(x, g, gamma, want_dgamma: bool, carry=None):
+    """(dx [+ carry], dgamma or None); `carry` (x's shape, bf16) is the skip branch's gradient, added inside the pass."""
     L = _C.lib()
-    L.require(x, g, gamma)
+    L.require(x, g, gamma, carry)
     assert g.dtype == torch.bfloat16 and g.is_contiguous() and g.shape == x.shape
+    assert carry is None or (carry.dtype == torch.bfloat16 and carry.is_contiguous() and carry.shape == x.shape)
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     dx = torch.empty_like(x)
     part = torch.empty((L.lib.gg_rmsnorm_blocks(rows), Cc), dtype=torch.float32, device=x.device) if want_dgamma else None
-    rc = L.lib.gg_rmsnorm_bwd(ptr(x), ptr(g), ptr(gamma), ptr(dx), ptr(part), rows, Cc, RMS_EPS, L.stream(x))
+    rc = L.lib.gg_rmsnorm_bwd(ptr(x), ptr(g), ptr(gamma), ptr(carry), ptr(dx), ptr(part), rows, Cc, RMS_EPS, L.stream(x))
     L.check(rc, 'gg_rmsnorm_bwd')
     return dx, (part.sum(0) if part is not None else None)
 

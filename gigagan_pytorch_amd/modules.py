@@ -43,15 +43,21 @@ class Conv2d(nn.Conv2d):
     act = None
     out_scale = 1.0     # y = out_scale * (conv + bias): lets a following "(a + b) * c" merge be folded into its producers
 
-    def forward(self, x, residual=None):
-        """`residual` (same shape as the output) is added in the kernel's epilogue: conv(x) + bias + residual."""
+    def forward(self, x, residual=None, fork=False):
+        """`residual` (same shape as the output) is added in the kernel's epilogue: conv(x) + bias + residual.
+        `fork=True` returns (y, x'): x' is x for its second consumer; where the ops implementation fuses forks, that
+        consumer's gradient is added inside this conv's data-gradient pass instead of by a separate accumulation."""
         k = self.kernel_size[0]
         if self.stride[0] != 1:
             assert k == 1 and self.padding[0] == 0 and self.stride[0] == 2
         else:
             assert self.padding[0] == k // 2
-        return ops.impl.conv2d(x, self.weight, self.bias, act=self.act, stride=self.stride[0], scale=self.out_scale,
-                               residual=residual)
+        kw = dict(act=self.act, stride=self.stride[0], scale=self.out_scale, residual=residual)
+        if fork:
+            if getattr(ops.impl, 'fuses_forks', False):
+                return ops.impl.conv2d(x, self.weight, self.bias, fork=True, **kw)
+            return ops.impl.conv2d(x, self.weight, self.bias, **kw), x
+        return ops.impl.conv2d(x, self.weight, self.bias, **kw)
 
 
 class Linear(nn.Linear):
@@ -105,7 +111,12 @@ class ChannelRMSNorm(nn.Module):
         super().__init__()
         self.gamma = nn.Parameter(torch.ones(dim, 1, 1))
 
-    def forward(self, x):
+    def forward(self, x, fork=False):
+        """`fork=True` returns (norm(x), x'): x' feeds the skip connection around the normalised branch (see Conv2d.forward)."""
+        if fork:
+            if getattr(ops.impl, 'fuses_forks', False):
+                return ops.impl.channel_rmsnorm(x, self.gamma, fork=True)
+            return ops.impl.channel_rmsnorm(x, self.gamma), x
         return ops.impl.channel_rmsnorm(x, self.gamma)
 
 
@@ -258,12 +269,24 @@ class SelfAttention(nn.Module):
         self.null_kv = nn.Parameter(torch.randn(2, heads, dim_head))
         self.to_out = Conv2d(dim_inner, dim, 1, bias=False)
 
-    def forward(self, fmap, residual=None):
+    def forward(self, fmap, skip=False):
+        """`skip=True`: attn(fmap) + fmap (the block's residual, gp.py:757-758), the sum in to_out's epilogue and the skip
+        gradient joining inside the norm's backward pass."""
         b, _, x, y = fmap.shape
         h = self.heads
-        fmap = self.norm(fmap)
-        q, v = self.to_q(fmap), self.to_v(fmap)
-        k = self.to_k(fmap) if exists(self.to_k) else q
+        residual = None
+        if skip:
+            fmap, residual = self.norm(fmap, fork=True)
+        else:
+            fmap = self.norm(fmap)
+        # the normalised map has two (dot product: three) consumers: chained forks, one gradient pass each
+        if exists(self.to_k):
+            q, fmap = self.to_q(fmap, fork=True)
+            k, fmap = self.to_k(fmap, fork=True)
+        else:
+            q, fmap = self.to_q(fmap, fork=True)
+            k = q
+        v = self.to_v(fmap)
         out = ops.impl.self_attention(q, k, v, self.null_kv, heads=h, scale=self.scale, l2=not self.dot_product)
         return self.to_out(out, residual=residual)
 
@@ -308,7 +331,8 @@ def FeedForward(dim, mult=4, channel_first=False):
 def _ff_residual(ff, x):
     """ff(x) + x for the channel-first FeedForward (norm, 1x1, gelu, 1x1) with the skip added in the last 1x1's epilogue."""
     norm, conv_in, act, conv_out = ff
-    return conv_out(act(conv_in(norm(x))), residual=x)
+    n, x = norm(x, fork=True)
+    return conv_out(act(conv_in(n)), residual=x)
 
 
 class SelfAttentionBlock(nn.Module):
@@ -318,7 +342,7 @@ class SelfAttentionBlock(nn.Module):
         self.ff = FeedForward(dim=dim, mult=ff_mult, channel_first=True)
 
     def forward(self, x):
-        x = self.attn(x, residual=x)       # attn(x) + x, the skip added in to_out's epilogue (gp.py:757-758)
+        x = self.attn(x, skip=True)        # attn(x) + x, the skip added in to_out's epilogue (gp.py:757-758)
         x = _ff_residual(self.ff, x)
         return x
 

@@ -252,7 +252,9 @@ class ConvFn(Function):
     """y = act(alpha * (conv(x * in_scale, w) + bias)) + residual ;  x: (b,H,W,C8) bf16, w: float parameter layout."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, in_scale, act, geom, alpha, residual):
+    def forward(ctx, x, w, bias, in_scale, act, geom, alpha, residual, fork=False):
+        """`fork=True` returns (y, x): x's OTHER consumer takes the returned alias; its gradient then arrives here and is
+        added in the data-gradient GEMM's epilogue (no separate accumulation pass over the activation gradient)."""
         ksize, stride, pad, wkind = geom
         wmat = packed_weight(w, 's2d' if wkind == 's2d' else 'fwd')
         o8 = wmat.shape[0]
@@ -266,12 +268,17 @@ class ConvFn(Function):
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
         ctx.n_bias = bias.shape[0] if bias is not None else 0
+        if fork:
+            ctx.set_materialize_grads(False)
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, g_alias=None):
         x, w, in_scale, y, bias = ctx.saved_tensors
         geom, alpha = ctx.geom, ctx.alpha
+        if dy is None:          # only the alias was used downstream
+            return g_alias, None, None, None, None, None, None, None, None
         dy = dy.contiguous()
         want_db = ctx.has_bias and ctx.needs_input_grad[2] and not inputs_only
         db = None
@@ -291,20 +298,25 @@ class ConvFn(Function):
             dz = dy
         dx = dw = ds = None
         if ctx.needs_input_grad[0] or (in_scale is not None and ctx.needs_input_grad[3]):
-            dxs = DgradFn.apply(dz, w, geom, alpha, x.shape[1], x.shape[2])
+            carry = g_alias if (g_alias is not None and in_scale is None) else None
+            dxs = DgradFn.apply(dz, w, geom, alpha, x.shape[1], x.shape[2], carry)
             if in_scale is None:
                 dx = dxs
             else:
                 if ctx.needs_input_grad[3]:
                     ds = (x.float() * dxs.float()).sum(dim=(1, 2))
                 dx = (dxs.float() * in_scale[:, None, None, :]).to(dxs.dtype)
+                if g_alias is not None:
+                    dx = dx + g_alias
+        elif g_alias is not None:
+            dx = g_alias
         if ctx.needs_input_grad[1] and not inputs_only:
             sink = _grad_sink_of(w)
             if sink is not None:
                 WgradFn.compute(x, dz, in_scale, geom, alpha, tuple(w.shape), sink)
             else:
                 dw = WgradFn.apply(x, dz, in_scale, geom, alpha, tuple(w.shape)).to(w.dtype)
-        return dx, dw, db, ds, None, None, None, (dy if ctx.has_res and ctx.needs_input_grad[7] else None)
+        return dx, dw, db, ds, None, None, None, (dy if ctx.has_res and ctx.needs_input_grad[7] else None), None
 
 
 class DgradFn(Function):
@@ -313,16 +325,20 @@ class DgradFn(Function):
     with the depth-to-space scatter store."""
 
     @staticmethod
-    def forward(ctx, dz, w, geom, alpha, H, W):
+    def forward(ctx, dz, w, geom, alpha, H, W, carry=None):
+        """`carry` (dx's shape): a gradient that reached the conv's input over another branch, added in the epilogue."""
         ksize, stride, pad, wkind = geom
         if stride == 1:
             wmat = packed_weight(w, 'bwd')
-            dx = K.conv2d_nhwc(dz, wmat, ksize=ksize, stride=1, pad=ksize - 1 - pad, alpha=alpha)
+            dx = K.conv2d_nhwc(dz, wmat, ksize=ksize, stride=1, pad=ksize - 1 - pad, alpha=alpha,
+                               residual=None if carry is None else carry.contiguous())
         else:
             assert pad == 0 and ksize <= stride
             wmat = packed_weight(w, 's2d' if wkind == 's2d' else 'fwd')
             dx = K.conv2d_dgrad_d2s(dz, wmat, cell=stride, taps=ksize, alpha=alpha)
             assert dx.shape[1] == H and dx.shape[2] == W
+            if carry is not None:       # the scatter store has no residual operand
+                dx = dx + carry
         ctx.geom, ctx.alpha = geom, alpha
         ctx.save_for_backward(dz, w)
         return dx
@@ -341,7 +357,7 @@ class DgradFn(Function):
                 WgradFn.compute(g, dz, None, geom, alpha, tuple(w.shape), sink)
             else:
                 dw = WgradFn.apply(g, dz, None, geom, alpha, tuple(w.shape)).to(w.dtype)
-        return ddz, dw, None, None, None, None
+        return ddz, dw, None, None, None, None, (g if ctx.needs_input_grad[6] else None)
 
 
 class BiasActBwdFn(Function):
@@ -488,19 +504,26 @@ class ModMixFn(Function):
 
 
 class RmsNormFn(Function):
-    """ChannelRMSNorm over the last (channel) axis of an NHWC bf16 tensor, one fused pass (gg_rmsnorm_kernel)."""
+    """ChannelRMSNorm over the last (channel) axis of an NHWC bf16 tensor, one fused pass (gg_rmsnorm_kernel).
+    `fork=True` returns (y, x): x's second consumer (the skip connection around the normalised branch) takes the returned
+    alias, and its gradient is added inside this op's backward pass instead of by autograd's accumulation."""
 
     @staticmethod
-    def forward(ctx, x, gamma):
+    def forward(ctx, x, gamma, fork=False):
         ctx.save_for_backward(x, gamma)
-        return K.rmsnorm_fwd(x, gamma)
+        ctx.set_materialize_grads(False)
+        y = K.rmsnorm_fwd(x, gamma)
+        return (y, x.view_as(x)) if fork else y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_alias=None):
         x, gamma = ctx.saved_tensors
         want_dgamma = ctx.needs_input_grad[1] and not inputs_only
-        dx, dgamma = RmsNormBwdFn.apply(x, g.contiguous(), gamma, want_dgamma)
-        return dx, (dgamma if want_dgamma else None)
+        if g is None:
+            return g_alias, None, None
+        carry = None if g_alias is None else g_alias.contiguous()
+        dx, dgamma = RmsNormBwdFn.apply(x, g.contiguous(), gamma, want_dgamma, carry)
+        return dx, (dgamma if want_dgamma else None), None
 
 
 class RmsNormBwdFn(Function):
@@ -508,9 +531,9 @@ class RmsNormBwdFn(Function):
     The second-order pass ignores gradients flowing into `dgamma` (nothing in the GigaGAN losses produces them)."""
 
     @staticmethod
-    def forward(ctx, x, g, gamma, want_dgamma):
+    def forward(ctx, x, g, gamma, want_dgamma, carry=None):
         ctx.set_materialize_grads(False)
-        dx, dgamma = K.rmsnorm_bwd(x, g, gamma, want_dgamma)
+        dx, dgamma = K.rmsnorm_bwd(x, g, gamma, want_dgamma, carry)
         ctx.save_for_backward(x, g, gamma)
         if dgamma is None:
             dgamma = x.new_empty(0, dtype=torch.float32)     # placeholder (no launch)
@@ -522,10 +545,10 @@ class RmsNormBwdFn(Function):
     def backward(ctx, v, v_dgamma):
         x, g, gamma = ctx.saved_tensors
         if v is None:
-            return None, None, None, None
+            return None, None, None, None, None
         want = ctx.needs_input_grad[2] and not inputs_only
         gx, gg, dgamma = K.rmsnorm_bwd2(x, g, v.contiguous(), gamma, want)
-        return gx, gg, dgamma, None
+        return gx, gg, dgamma, None, (v if ctx.needs_input_grad[4] else None)     # dx = ... + carry: d/d(carry) is v itself
 
 
 class FlashAttnFn(Function):
@@ -821,15 +844,19 @@ class HipOps:
         return to_act(x)
 
     # -- convolution -------------------------------------------------------------------------------
-    def conv2d(self, x, weight, bias=None, act=None, stride=1, scale=1.0, residual=None):
+    fuses_forks = True      # conv2d / channel_rmsnorm accept fork=True (second consumer's gradient joins inside the backward pass)
+
+    def conv2d(self, x, weight, bias=None, act=None, stride=1, scale=1.0, residual=None, fork=False):
         """scale * (conv(x, w) + bias) [-> leaky relu]: stride-1 'same' conv (odd square kernel) — the reference's
         nn.Conv2d(…, padding=k//2) call sites — or the stride-2 1x1 residual conv (gp.py:1612), whose pixel
-        sub-sampling is part of the kernel's gather."""
+        sub-sampling is part of the kernel's gather. `fork=True` returns (y, x'): hand x' to x's other consumer."""
         x = to_act(x)
         o, i, k = weight.shape[0], weight.shape[1], weight.shape[-1]
         assert stride == 1 or k == 1
         xh = nhwc(x)
         ip = _round8(i)
+        if fork and (ip != i or o % 8 or stride != 1):
+            return self.conv2d(x, weight, bias, act, stride, scale, residual), x      # ragged channels: plain fork
         if ip != i:
             xh = F.pad(xh, (0, ip - i))
         geom = (k, stride, k // 2 if stride == 1 else 0, 'oihw')
@@ -838,6 +865,10 @@ class HipOps:
             if o % 8:        # ragged channel count: add outside the kernel
                 return self.conv2d(x, weight, bias, act, stride, scale) + residual.to(ACT_DTYPE)
             res = nhwc(to_act(residual))
+        if fork:
+            y, xa = ConvFn.apply(xh, weight, None if bias is None else bias.float().contiguous(), None, act, geom,
+                                 float(scale), res, True)
+            return nchw(y), nchw(xa)
         y = ConvFn.apply(xh, weight, None if bias is None else bias.float().contiguous(), None, act, geom, float(scale),
                          res)
         if y.shape[-1] != o:
@@ -1071,11 +1102,17 @@ class HipOps:
         return self_attention_unfused(self, q, k, v, null_kv, heads, scale, l2)
 
     # -- norms / resampling ------------------------------------------------------------------------
-    def channel_rmsnorm(self, x, gamma, act=None):
+    def channel_rmsnorm(self, x, gamma, act=None, fork=False):
         """F.normalize(x, dim=1) * sqrt(C) * gamma (gp.py:224-232, unet.py:224-234), fp32 statistics, one fused pass
-        over NHWC; `act='silu'` is the unet Block's activation (unet.py:268-269)."""
+        over NHWC; `act='silu'` is the unet Block's activation (unet.py:268-269). `fork=True` returns (y, x'): x' goes to the
+        skip connection around the normalised branch."""
         x = to_act(x)
         c = x.shape[1]
+        if fork:
+            if c % 8 or act is not None:
+                return self.channel_rmsnorm(x, gamma, act), x
+            y, xa = RmsNormFn.apply(nhwc(x), gamma.float().reshape(c).contiguous(), True)
+            return nchw(y), nchw(xa)
         if c % 8:
             xf = x.float()
             nrm = xf.norm(dim=1, keepdim=True).clamp(min=1e-12)

@@ -237,8 +237,10 @@ int gg_attn_bwd(const void* q, const void* k, const void* v, const void* k0, con
  * gx (w.r.t. x), gg (w.r.t. g) and the partial sums of that pass's dgamma — gradient-penalty steps only. */
 int32_t gg_rmsnorm_blocks(int64_t rows);
 int gg_rmsnorm_fwd(const void* x, const float* gamma, void* y, int64_t rows, int32_t C, float eps, void* stream);
-int gg_rmsnorm_bwd(const void* x, const void* g, const float* gamma, void* dx, float* dgamma_part, int64_t rows, int32_t C,
-                   float eps, void* stream);
+/* `carry` (optional, [rows][C] bf16) is added to dx inside the pass: the gradient arriving over the skip connection around
+ * the normalised branch (x + f(norm(x)), gp.py:757-758), which autograd would otherwise add in a pass of its own */
+int gg_rmsnorm_bwd(const void* x, const void* g, const float* gamma, const void* carry, void* dx, float* dgamma_part,
+                   int64_t rows, int32_t C, float eps, void* stream);
 int gg_rmsnorm_bwd2(const void* x, const void* g, const void* v, const float* gamma, void* gx, void* gg, float* dgamma_part,
                     int64_t rows, int32_t C, float eps, void* stream);
 

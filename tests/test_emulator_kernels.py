@@ -414,7 +414,7 @@ def test_self_attention_module_on_fused_kernels_vs_oracle(dot):
     def run(I):
         with ops.use_impl(I):
             x = x0.clone().requires_grad_()
-            y = attn(x, residual=x).float()
+            y = attn(x, skip=True).float()
             g = torch.autograd.grad((y * torch.linspace(-1, 1, y.numel()).view_as(y)).sum(), [x, *attn.parameters()])
         return y, g
 
@@ -656,3 +656,37 @@ def test_no_grad_adaptive_conv_paths_match_oracle(cfg):
         with ops.use_impl(OracleOps(bf16_operands=True)):
             y0 = conv(x, mod, km, noise=nz, noise_weight=nw, act='lrelu')
     assert rel_err(y1, y0) < 1e-2
+
+
+def test_forked_conv_and_norm_match_the_plain_fork_first_and_second_order():
+    """`fork=True` (the second consumer's gradient joins inside the op's backward pass: dgrad GEMM epilogue / rmsnorm_bwd carry)
+    gives the same first- and second-order gradients as letting autograd accumulate the two branches."""
+    torch.manual_seed(0)
+    H_ = ops.HipOps()
+    x0 = bf(torch.randn(2, 16, 8, 8)).float()
+    w1 = (torch.randn(24, 16, 3, 3) * 0.2).requires_grad_()
+    w2 = (torch.randn(16, 16, 1, 1) * 0.3).requires_grad_()
+    gamma = (torch.rand(16, 1, 1) + 0.5).requires_grad_()
+
+    def run(fork):
+        x = x0.clone().requires_grad_()
+        with ops.use_impl(H_):
+            if fork:
+                n, xs = H_.channel_rmsnorm(x, gamma, fork=True)
+                y, n2 = H_.conv2d(n, w1, None, act='lrelu', fork=True)
+            else:
+                n, xs = H_.channel_rmsnorm(x, gamma), x
+                y, n2 = H_.conv2d(n, w1, None, act='lrelu'), n
+            z = H_.conv2d(n2, w2, None, residual=xs)          # second consumer of n; the skip joins in its epilogue
+            loss = (y.float() * torch.linspace(-1, 1, y.numel()).view_as(y)).sum() + z.float().pow(2).sum()
+            g1 = torch.autograd.grad(loss, [w1, w2, gamma], retain_graph=True)
+            gx, = torch.autograd.grad(loss, x, create_graph=True)
+            g2 = torch.autograd.grad(gx.float().pow(2).sum(), [x, w1, w2, gamma])
+        return gx.detach(), g1, g2
+
+    gxa, g1a, g2a = run(True); gxb, g1b, g2b = run(False)
+    assert rel_err(gxa, gxb) < 1e-2
+    for a, b in zip(g1a, g1b):
+        assert rel_err(a, b) < 1e-2
+    for a, b in zip(g2a, g2b):
+        assert rel_err(a, b) < 3e-2
