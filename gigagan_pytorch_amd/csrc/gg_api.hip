@@ -738,6 +738,59 @@ extern "C" int gg_modulate_bank_fwd(const void* x, const float* s, const float* 
     return gg_check_launch();
 }
 
+extern "C" int gg_addcat_fwd(const void* x, const void* feats, void* out, int32_t B, int32_t f, int64_t n, void* stream) {
+    if (!x || !feats || !out) return gg_fail(-1, "gg_addcat_fwd: null pointer");
+    if (B <= 0 || f <= 0 || (B % f) || n <= 0 || (n & 7)) return gg_fail(-2, "gg_addcat_fwd: need B %% f == 0 and n %% 8 == 0");
+    GgAddCatParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)x; p.feats = (const bf16_t*)feats; p.out = (bf16_t*)out; p.n = n; p.B = B; p.f = f;
+    GG_LAUNCH(gg_addcat_fwd_kernel, dim3(gg_grid_for((long long)B * (n >> 3))), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+extern "C" int gg_addcat_bwd(const void* g, void* gfeats, int32_t B, int32_t f, int64_t n, void* stream) {
+    if (!g || !gfeats) return gg_fail(-1, "gg_addcat_bwd: null pointer");
+    if (B <= 0 || f <= 0 || (B % f) || n <= 0 || (n & 7)) return gg_fail(-2, "gg_addcat_bwd: need B %% f == 0 and n %% 8 == 0");
+    GgAddCatParams p;
+    memset(&p, 0, sizeof(p));
+    p.g = (const bf16_t*)g; p.out = (bf16_t*)gfeats; p.n = n; p.B = B; p.f = f;
+    GG_LAUNCH(gg_addcat_bwd_kernel, dim3(gg_grid_for((long long)f * (n >> 3))), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+extern "C" int32_t gg_pool_chunks(int32_t b, int32_t P) {
+    // enough workgroups to fill the chip (>= 1024) without chunks shorter than 64 pixels
+    int c = (1024 + b - 1) / (b > 0 ? b : 1);
+    if (c > (P + 63) / 64) c = (P + 63) / 64;
+    if (c < 1) c = 1;
+    return c;
+}
+
+extern "C" int gg_pool_mean_fwd(const void* x, float* part, float* out, int32_t b, int32_t P, int32_t C, void* stream) {
+    if (!x || !part || !out) return gg_fail(-1, "gg_pool_mean_fwd: null pointer");
+    if (b <= 0 || P <= 0 || C <= 0 || (C % 8) || C > 512 || b > 65535)
+        return gg_fail(-2, "gg_pool_mean_fwd: need C %% 8 == 0, C <= 512, b <= 65535 (b=%d C=%d)", b, C);
+    GgPoolParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)x; p.part = part; p.out = out; p.b = b; p.P = P; p.C = C; p.chunks = gg_pool_chunks(b, P);
+    p.scale = 1.f / (float)P;
+    GG_LAUNCH(gg_pool_partial_kernel, dim3((unsigned)p.chunks, (unsigned)b), dim3(256), (hipStream_t)stream, p);
+    int rc = gg_check_launch();
+    if (rc) return rc;
+    GG_LAUNCH(gg_pool_finish_kernel, dim3(gg_grid_for((long long)b * C)), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+extern "C" int gg_pool_mean_bwd(const void* g, const float* gs, void* y, int32_t b, int32_t P, int32_t C, void* stream) {
+    if (!gs || !y) return gg_fail(-1, "gg_pool_mean_bwd: null pointer");
+    if (b <= 0 || P <= 0 || C <= 0 || (C % 8)) return gg_fail(-2, "gg_pool_mean_bwd: need C %% 8 == 0 (C=%d)", C);
+    GgPoolParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)g; p.gs = gs; p.y = (bf16_t*)y; p.b = b; p.P = P; p.C = C;
+    GG_LAUNCH(gg_pool_bwd_kernel, dim3(gg_grid_for((long long)b * P * (C / 8))), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
 extern "C" int gg_modw_fwd(const float* w, const float* mod, int32_t mod_ld, const float* kmod, int32_t kmod_ld, const float* xs,
                            int32_t xs_ld, float* s, float* a, float* d, void* wmix, int32_t layout, int32_t b, int32_t N, int32_t O,
                            int32_t I, int32_t T, int32_t Ip, int32_t Op, int32_t demod, float eps, void* stream) {

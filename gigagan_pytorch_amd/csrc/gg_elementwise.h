@@ -619,3 +619,125 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_rmsnorm_kernel(GgRmsParams p) {
             p.dgamma_part[(long long)blockIdx.x * p.C + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
     }
 }
+
+// ---- SqueezeExcite's pool (gp.py:300: mean over the pixels) and its backward -------------------------------------
+// forward: x [b][P][C] bf16 -> part [b][chunks][C] fp32 partial sums (grid (chunks, b); deterministic: no atomics), then
+// out [b][C] = scale * sum over chunks. backward: y[b][p][c] = g[b][p][c] + gs[b][c] (g optional: the gradient that reached
+// the pooled tensor over its other consumer; y may alias g), one pass instead of expand + cast + add.
+struct GgPoolParams {
+    const bf16_t* x;     // fwd: activation ; bwd: incoming gradient of the other branch (may be null)
+    float* part;
+    float* out;          // fwd: [b][C]
+    const float* gs;     // bwd: [b][C] per-sample per-channel constant
+    bf16_t* y;           // bwd: output
+    int b, P, C, chunks;
+    float scale;
+};
+
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_pool_partial_kernel(GgPoolParams p) {
+    GG_SHARED float red[256 * 8];
+    const int cvs = p.C >> 3;                    // 16-byte vectors per pixel (<= 64)
+    const int pl_n = 256 / cvs;                  // pixel lanes
+    const int t = threadIdx.x, cv = t % cvs, pl = t / cvs;
+    const int chunk = blockIdx.x, img = blockIdx.y;
+    const int per = (p.P + p.chunks - 1) / p.chunks;
+    const int p0 = chunk * per, p1 = p0 + per < p.P ? p0 + per : p.P;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (pl < pl_n) {
+        const bf16_t* base = p.x + ((long long)img * p.P) * p.C + cv * 8;
+        for (int q = p0 + pl; q < p1; q += pl_n) {
+            const u16x8 v = *(const u16x8*)(base + (long long)q * p.C);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += gg_bf2f(v[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[t * 8 + e] = acc[e];
+    gg_sync();
+    for (int c = t; c < p.C; c += 256) {
+        float s = 0.f;
+        for (int l = 0; l < pl_n; ++l) s += red[(l * cvs + (c >> 3)) * 8 + (c & 7)];
+        p.part[((long long)img * p.chunks + chunk) * p.C + c] = s;
+    }
+}
+
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_pool_finish_kernel(GgPoolParams p) {
+    const long long n = (long long)p.b * p.C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int img = (int)(i / p.C), c = (int)(i - (long long)img * p.C);
+        float s = 0.f;
+        for (int k = 0; k < p.chunks; ++k) s += p.part[((long long)img * p.chunks + k) * p.C + c];
+        p.out[i] = s * p.scale;
+    }
+}
+
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_pool_bwd_kernel(GgPoolParams p) {
+    const int cvs = p.C >> 3;
+    const long long n = (long long)p.b * p.P * cvs;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % cvs);
+        const long long pix = i / cvs;
+        const int img = (int)(pix / p.P);
+        const float* g8 = p.gs + (long long)img * p.C + cv * 8;
+        u16x8 o;
+        if (p.x) {
+            const u16x8 v = *(const u16x8*)(p.x + i * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = gg_f2bf(gg_bf2f(v[e]) + g8[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = gg_f2bf(g8[e]);
+        }
+        *(u16x8*)(p.y + i * 8) = o;
+    }
+}
+
+// ---- multi-scale input merge of the discriminator (gp.py:1797-1803): x = cat((x + feats, feats)) with feats tiled over the
+// scale-major batch. forward: out [2B][n] from x [B][n] and feats [f][n] (B % f == 0, row r of the tiled feats = feats[r % f]);
+// backward w.r.t. feats: gfeats[j] = sum over r = j (mod f) of (g[r] + g[B + r]) in fp32 (the gradient w.r.t. x is the view g[:B]).
+struct GgAddCatParams {
+    const bf16_t* x;
+    const bf16_t* feats;
+    bf16_t* out;         // fwd: [2B][n] ; bwd: gfeats [f][n]
+    const bf16_t* g;     // bwd: [2B][n]
+    long long n;         // elements per sample (multiple of 8)
+    int B, f;
+};
+
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_addcat_fwd_kernel(GgAddCatParams p) {
+    const long long nv = p.n >> 3, total = (long long)p.B * nv;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / nv, v = i - r * nv;
+        const u16x8 a = *(const u16x8*)(p.x + i * 8);
+        const u16x8 fv = *(const u16x8*)(p.feats + ((r % p.f) * nv + v) * 8);
+        u16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = gg_f2bf(gg_bf2f(a[e]) + gg_bf2f(fv[e]));
+        *(u16x8*)(p.out + i * 8) = o;
+        *(u16x8*)(p.out + (total + i) * 8) = fv;
+    }
+}
+
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_addcat_bwd_kernel(GgAddCatParams p) {
+    const long long nv = p.n >> 3, total = (long long)p.f * nv;
+    const int reps = p.B / p.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long j = i / nv, v = i - j * nv;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int half = 0; half < 2; ++half)
+            for (int t = 0; t < reps; ++t) {
+                const long long r = (long long)half * p.B + (long long)t * p.f + j;
+                const u16x8 gv = *(const u16x8*)(p.g + (r * nv + v) * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += gg_bf2f(gv[e]);
+            }
+        u16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = gg_f2bf(acc[e]);
+        *(u16x8*)(p.out + i * 8) = o;
+    }
+}

@@ -14,7 +14,7 @@ from torch import nn
 
 from . import ops
 from .modules import (AdaptiveConv2DMod, Conv2d, Downsample, LeakyReLU, Linear, Placeholder, SelfAttentionBlock,
-                      SqueezeExcite, Upsample, conv_lrelu, exists, default, tile_batch)
+                      SqueezeExcite, Upsample, conv_lrelu, exists, default, squeeze_excite_fork, tile_batch)
 from .text import TextEncoder
 
 
@@ -89,16 +89,25 @@ class Predictor(nn.Module):
         self.to_logits = Conv2d(dim, 1, 1)
 
     def forward(self, x, mod=None, kernel_mod=None):
-        residual = self.residual_fn(x)
+        """reference gp.py:1482-1498: residual = conv1x1(x); per layer x = (conv2(conv1(x)) + x) * c; x + residual; to_logits.
+        Unconditional convs: every merge rides on a conv epilogue (c * lrelu(z) == lrelu(c * z): conv2 runs with out_scale c
+        and adds c * inner; the final `+ residual` is the residual conv's own epilogue), and every fork hands its input on
+        (Conv2d.forward `fork`), so the backward has no stand-alone elementwise passes either."""
+        x_in = x
+        c = self.residual_scale
         for conv1, _, conv2, _ in self.layers:
-            inner = x
             if self.unconditional:
-                x = conv2(conv1(x))
+                h, inner = conv1(x, fork=True)
+                if conv1 is self.layers[0][0]:
+                    x_in = inner
+                conv2.out_scale = c
+                x = conv2(h, residual=inner, res_scale=c)
             else:
+                inner = x
                 x = conv1(x, mod=mod, kernel_mod=kernel_mod, act='lrelu')
                 x = conv2(x, mod=mod, kernel_mod=kernel_mod, act='lrelu')
-            x = (x + inner) * self.residual_scale
-        x = x + residual
+                x = (x + inner) * c
+        x = self.residual_fn(x_in, residual=x)
         return self.to_logits(x)
 
 
@@ -323,7 +332,8 @@ class Discriminator(nn.Module):
             resolution = x.shape[-1]
 
             if exists(squeeze_excite):
-                excitations.append(squeeze_excite(x))
+                excite_new, x = squeeze_excite_fork(squeeze_excite, x)
+                excitations.append(excite_new)
             excite = excitations.pop(0) if excitations else None
             if exists(excite):
                 x = ops.impl.channel_scale(x, tile_batch(excite, x.shape[0]))
@@ -332,8 +342,7 @@ class Discriminator(nn.Module):
             if resolution in self.multiscale_input_resolutions:
                 rgb = rgbs_index[resolution]
                 feats = from_rgb(ops.impl.prepare(rgb))
-                feats = tile_batch(feats, x.shape[0])
-                x = torch.cat((x + feats, feats), dim=0)
+                x = ops.impl.add_cat(x, feats)          # cat((x + feats, feats)) with feats tiled over the scale-major batch
 
             # x feeds the residual conv and the block: the block's first conv hands x on (fork), so that the residual branch's
             # gradient is added inside that conv's data-gradient pass
@@ -351,7 +360,8 @@ class Discriminator(nn.Module):
                 if not self.unconditional:
                     pred_kwargs = dict(mod=next(conv_mods), kernel_mod=next(conv_mods))
                 if return_multiscale_outputs:
-                    multiscale_outputs.append(predictor(ops.impl.take_rows(x, batch_prev_stage), **pred_kwargs))
+                    rows, x = ops.impl.take_rows(x, batch_prev_stage, fork=True)
+                    multiscale_outputs.append(predictor(rows, **pred_kwargs))
 
             if exists(downsample):
                 x = downsample(x, residual=residual, scale=self.residual_scale)   # merge fused into the conv epilogue

@@ -12,7 +12,7 @@ from torch import nn
 
 from . import ops
 from .modules import (AdaptiveConv2DMod, CrossAttentionBlock, LeakyReLU, Linear, Conv2d, Noise, PixelShuffleUpsample,
-                      SelfAttentionBlock, SqueezeExcite, StyleNetwork, Upsample, exists)
+                      SelfAttentionBlock, SqueezeExcite, StyleNetwork, Upsample, exists, squeeze_excite_fork)
 from .text import TextEncoder
 
 
@@ -181,7 +181,8 @@ class Generator(BaseGenerator):
             if exists(upsample):
                 x = upsample(x)
             if exists(squeeze_excite):
-                excitations.append(squeeze_excite(x))
+                excite_new, x = squeeze_excite_fork(squeeze_excite, x)
+                excitations.append(excite_new)
             excite = excitations.pop(0) if excitations else None
             # `x = x * excite` (gp.py:1023-1024): x has one consumer, the first conv of the block, which takes the scale along
             # (no-grad: folded into its per-sample weights; otherwise the fused multiply with its one-pass backward)

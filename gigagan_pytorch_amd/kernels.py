@@ -730,6 +730,61 @@ def attn_bwd2(q, k, v, k0, v0, d_o, lse, dvec, aq, ak, av, ak0, av0, heads: int,
 RMS_EPS = 1e-12     # F.normalize's eps (gp.py:230)
 
 
+def addcat(x: torch.Tensor, feats: torch.Tensor) -> torch.Tensor:
+    """cat((x + tile(feats), tile(feats)), 0) for dense bf16 x (B, ...) and feats (f, ...) with B % f == 0 (same trailing shape)."""
+    L = _C.lib()
+    L.require(x, feats)
+    assert x.dtype == torch.bfloat16 and feats.dtype == torch.bfloat16 and x.is_contiguous() and feats.is_contiguous()
+    B, f = x.shape[0], feats.shape[0]
+    n = x[0].numel()
+    assert B % f == 0 and feats[0].numel() == n and n % 8 == 0
+    out = torch.empty((2 * B,) + tuple(x.shape[1:]), dtype=torch.bfloat16, device=x.device)
+    rc = L.lib.gg_addcat_fwd(ptr(x), ptr(feats), ptr(out), B, f, n, L.stream(x))
+    L.check(rc, 'gg_addcat_fwd')
+    return out
+
+
+def addcat_bwd(g: torch.Tensor, f: int) -> torch.Tensor:
+    """gradient w.r.t. feats of `addcat`: g (2B, ...) bf16 dense -> (f, ...)."""
+    L = _C.lib()
+    L.require(g)
+    assert g.dtype == torch.bfloat16 and g.is_contiguous() and g.shape[0] % 2 == 0
+    B = g.shape[0] // 2
+    n = g[0].numel()
+    out = torch.empty((f,) + tuple(g.shape[1:]), dtype=torch.bfloat16, device=g.device)
+    rc = L.lib.gg_addcat_bwd(ptr(g), ptr(out), B, f, n, L.stream(g))
+    L.check(rc, 'gg_addcat_bwd')
+    return out
+
+
+def pool_mean(x: torch.Tensor) -> torch.Tensor:
+    """x (b, H, W, C) bf16 contiguous -> (b, C) fp32 mean over the pixels (SqueezeExcite's pool)."""
+    L = _C.lib()
+    L.require(x)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 4
+    b, H, W, Cc = x.shape
+    P = H * W
+    part = torch.empty((b, L.lib.gg_pool_chunks(b, P), Cc), dtype=torch.float32, device=x.device)
+    out = torch.empty((b, Cc), dtype=torch.float32, device=x.device)
+    rc = L.lib.gg_pool_mean_fwd(ptr(x), ptr(part), ptr(out), b, P, Cc, L.stream(x))
+    L.check(rc, 'gg_pool_mean_fwd')
+    return out
+
+
+def pool_mean_bwd(gs: torch.Tensor, shape, g=None, inplace: bool = False) -> torch.Tensor:
+    """y (b, H, W, C) bf16 = g + gs[b, c] (gs fp32 (b, C), already divided by H*W); g None: the plain broadcast."""
+    L = _C.lib()
+    L.require(gs, g)
+    b, H, W, Cc = shape
+    assert gs.dtype == torch.float32 and gs.is_contiguous() and gs.shape == (b, Cc)
+    if g is not None:
+        assert g.dtype == torch.bfloat16 and g.is_contiguous() and tuple(g.shape) == tuple(shape)
+    y = g if (inplace and g is not None) else torch.empty(shape, dtype=torch.bfloat16, device=gs.device)
+    rc = L.lib.gg_pool_mean_bwd(ptr(g), ptr(gs), ptr(y), b, H * W, Cc, L.stream(gs))
+    L.check(rc, 'gg_pool_mean_bwd')
+    return y
+
+
 def rmsnorm_fwd(x: torch.Tensor, gamma: torch.Tensor) -> torch.Tensor:
     """x (..., C) bf16 contiguous, gamma (C,) fp32 -> y bf16."""
     L = _C.lib()

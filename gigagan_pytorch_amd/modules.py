@@ -43,7 +43,7 @@ class Conv2d(nn.Conv2d):
     act = None
     out_scale = 1.0     # y = out_scale * (conv + bias): lets a following "(a + b) * c" merge be folded into its producers
 
-    def forward(self, x, residual=None, fork=False):
+    def forward(self, x, residual=None, fork=False, res_scale=1.0):
         """`residual` (same shape as the output) is added in the kernel's epilogue: conv(x) + bias + residual.
         `fork=True` returns (y, x'): x' is x for its second consumer; where the ops implementation fuses forks, that
         consumer's gradient is added inside this conv's data-gradient pass instead of by a separate accumulation."""
@@ -52,7 +52,7 @@ class Conv2d(nn.Conv2d):
             assert k == 1 and self.padding[0] == 0 and self.stride[0] == 2
         else:
             assert self.padding[0] == k // 2
-        kw = dict(act=self.act, stride=self.stride[0], scale=self.out_scale, residual=residual)
+        kw = dict(act=self.act, stride=self.stride[0], scale=self.out_scale, residual=residual, res_scale=res_scale)
         if fork:
             if getattr(ops.impl, 'fuses_forks', False):
                 return ops.impl.conv2d(x, self.weight, self.bias, fork=True, **kw)
@@ -204,6 +204,14 @@ def SqueezeExcite(dim, dim_out, reduction=4, dim_min=32):
         Act(torch.sigmoid),
         Placeholder(lambda x: x[:, :, None, None]),
     )
+
+
+def squeeze_excite_fork(se, x):
+    """(se(x), x'): the excitation of a SqueezeExcite stack and x for the trunk (its gradient and the pool's meet in one pass)."""
+    m, x = ops.impl.global_mean(x, fork=True)
+    for layer in list(se)[1:]:
+        m = layer(m)
+    return m, x
 
 
 # ---- adaptive conv (gp.py:315-409) ---------------------------------------------------------------------------

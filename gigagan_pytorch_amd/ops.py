@@ -39,10 +39,12 @@ inputs_only = False    # set while a backward pass is run only for gradients w.r
 
 def to_act(x: torch.Tensor) -> torch.Tensor:
     """logical NCHW tensor -> bf16, channels_last storage (no-op when already so)."""
+    if x.dim() == 4:
+        if x.dtype != ACT_DTYPE:
+            return x.to(ACT_DTYPE, memory_format=torch.channels_last)      # cast and re-layout in ONE pass
+        return x.contiguous(memory_format=torch.channels_last)
     if x.dtype != ACT_DTYPE:
         x = x.to(ACT_DTYPE)
-    if x.dim() == 4:
-        x = x.contiguous(memory_format=torch.channels_last)
     return x
 
 
@@ -249,10 +251,10 @@ def _grad_sink_of(w):
 
 
 class ConvFn(Function):
-    """y = act(alpha * (conv(x * in_scale, w) + bias)) + residual ;  x: (b,H,W,C8) bf16, w: float parameter layout."""
+    """y = act(alpha * (conv(x * in_scale, w) + bias)) + res_scale * residual ;  x: (b,H,W,C8) bf16, w: float parameter layout."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, in_scale, act, geom, alpha, residual, fork=False):
+    def forward(ctx, x, w, bias, in_scale, act, geom, alpha, residual, fork=False, res_scale=1.0):
         """`fork=True` returns (y, x): x's OTHER consumer takes the returned alias; its gradient then arrives here and is
         added in the data-gradient GEMM's epilogue (no separate accumulation pass over the activation gradient)."""
         ksize, stride, pad, wkind = geom
@@ -262,8 +264,8 @@ class ConvFn(Function):
         if bias is not None and bias.shape[0] != o8:
             b8 = F.pad(bias, (0, o8 - bias.shape[0]))
         y = K.conv2d_nhwc(x, wmat, ksize=ksize, stride=stride, pad=pad, in_scale=in_scale, bias=b8, bias_scale=alpha,
-                          alpha=alpha, act=act, act_slope=LRELU_SLOPE, residual=residual)
-        ctx.act, ctx.geom, ctx.alpha = act, geom, alpha
+                          alpha=alpha, act=act, act_slope=LRELU_SLOPE, residual=residual, res_scale=res_scale)
+        ctx.act, ctx.geom, ctx.alpha, ctx.res_scale = act, geom, alpha, res_scale
         ctx.save_for_backward(x, w, in_scale, y if act else None, bias)
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
@@ -278,7 +280,7 @@ class ConvFn(Function):
         x, w, in_scale, y, bias = ctx.saved_tensors
         geom, alpha = ctx.geom, ctx.alpha
         if dy is None:          # only the alias was used downstream
-            return g_alias, None, None, None, None, None, None, None, None
+            return g_alias, None, None, None, None, None, None, None, None, None
         dy = dy.contiguous()
         want_db = ctx.has_bias and ctx.needs_input_grad[2] and not inputs_only
         db = None
@@ -316,7 +318,10 @@ class ConvFn(Function):
                 WgradFn.compute(x, dz, in_scale, geom, alpha, tuple(w.shape), sink)
             else:
                 dw = WgradFn.apply(x, dz, in_scale, geom, alpha, tuple(w.shape)).to(w.dtype)
-        return dx, dw, db, ds, None, None, None, (dy if ctx.has_res and ctx.needs_input_grad[7] else None), None
+        dres = None
+        if ctx.has_res and ctx.needs_input_grad[7]:
+            dres = dy if ctx.res_scale == 1.0 else dy * ctx.res_scale
+        return dx, dw, db, ds, None, None, None, dres, None, None
 
 
 class DgradFn(Function):
@@ -742,21 +747,36 @@ def matmul_nt(x: torch.Tensor, w: torch.Tensor, bias=None, act=None, out_f32=Fal
 
 
 class GlobalMeanFn(Function):
-    """(b, C, H, W) bf16 channels_last -> (b, C) fp32 mean over the pixels (SqueezeExcite's pool, gp.py:300) read straight
-    from the bf16 tensor; the backward hands autograd a bf16 channels_last gradient, so its accumulation into the main
-    path's gradient is a plain contiguous add (the stock mean backward materialises an fp32 NCHW expansion, casts it and
-    adds it through the strided kernel: five more passes over the activation)."""
+    """(b, C, H, W) bf16 channels_last -> (b, C) fp32 mean over the pixels (SqueezeExcite's pool, gp.py:300): a two-stage HIP
+    reduction over the bf16 tensor (gg_pool_mean_fwd). `fork=True` returns (mean, x): the trunk continues with the alias and
+    its gradient meets the pool's broadcast gradient inside ONE pass (gg_pool_mean_bwd, in place on the trunk's gradient)
+    instead of expand + cast + strided add. First order only (the gradient-penalty graphs use the tensor-algebra form)."""
 
     @staticmethod
-    def forward(ctx, x):
-        ctx.shape, ctx.dtype = x.shape, x.dtype
-        return x.mean(dim=(2, 3), dtype=torch.float32)
+    def forward(ctx, x, fork=False):
+        ctx.shape = x.shape
+        ctx.set_materialize_grads(False)
+        C = x.shape[1]
+        if C % 8 or C > 512:
+            m = x.mean(dim=(2, 3), dtype=torch.float32)
+        else:
+            m = K.pool_mean(nhwc(x))
+        return (m, x.view_as(x)) if fork else m
 
     @staticmethod
-    def backward(ctx, g):
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g, g_alias=None):
         b, C, H, W = ctx.shape
-        gs = (g * (1.0 / (H * W))).to(ctx.dtype)
-        return gs[:, None, None, :].expand(b, H, W, C).contiguous().permute(0, 3, 1, 2)
+        if g is None:
+            return g_alias, None
+        gs = (g.float() * (1.0 / (H * W))).contiguous()
+        if C % 8:
+            out = gs.to(ACT_DTYPE)[:, None, None, :].expand(b, H, W, C).contiguous().permute(0, 3, 1, 2)
+            return (out if g_alias is None else out + g_alias), None
+        ga = None
+        if g_alias is not None:
+            ga = nhwc(g_alias.contiguous(memory_format=torch.channels_last))
+        return nchw(K.pool_mean_bwd(gs, (b, H, W, C), ga, inplace=True)), None
 
 
 class GeluFn(Function):
@@ -814,6 +834,56 @@ class TakeRowsFn(Function):
         return torch.cat((g, pad), dim=0), None
 
 
+class AddCatFn(Function):
+    """cat((x + tile(feats), tile(feats))) over the batch axis — the discriminator's multi-scale input merge (gp.py:1797-1803)
+    — in one pass over NHWC bf16 tensors (the stock form is a tile copy, an add and a cat); backward: the x gradient is the
+    first half of g (a view), the feats gradient one reduction pass. First order (penalty graphs keep the tensor algebra)."""
+
+    @staticmethod
+    def forward(ctx, x, feats):
+        ctx.f = feats.shape[0]
+        return K.addcat(x, feats)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        g = g.contiguous()
+        gx = g[:g.shape[0] // 2] if ctx.needs_input_grad[0] else None
+        gf = K.addcat_bwd(g, ctx.f) if ctx.needs_input_grad[1] else None
+        return gx, gf
+
+
+class RowsForkFn(Function):
+    """(x[:n], x): the first n batch rows for one consumer (a predictor) and x itself for the other (the rest of the
+    trunk). The backward adds the rows' gradient INTO the trunk gradient's first n rows (in place: that buffer is the fresh
+    output of the trunk's data-gradient pass and has no other reader) instead of zero-padding it to full size and letting
+    autograd add two full-size tensors."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n, ctx.total = n, x.shape[0]
+        ctx.set_materialize_grads(False)
+        return x[:n], x.view_as(x)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_rows, g_all):
+        n = ctx.n
+        if g_all is None:           # the trunk contributed nothing (never the case in the discriminator): zero-padded rows
+            if g_rows is None:
+                return None, None
+            g_rows = g_rows.contiguous(memory_format=torch.channels_last)
+            pad = torch.zeros((ctx.total - n,) + tuple(g_rows.shape[1:]), dtype=g_rows.dtype,
+                              device=g_rows.device).contiguous(memory_format=torch.channels_last)
+            return torch.cat((g_rows, pad), dim=0), None
+        if g_rows is None:
+            return g_all, None
+        if not (g_all.is_contiguous(memory_format=torch.channels_last) or g_all.is_contiguous()):
+            g_all = g_all.contiguous(memory_format=torch.channels_last)
+        g_all[:n].add_(g_rows)
+        return g_all, None
+
+
 class ResampleFn(Function):
     """Separable banded linear resampling of an NHWC tensor (bilinear x2 + binomial blur, bilinear resize,
     and their adjoints), closed under differentiation: backward = the same kernel with the transposed
@@ -846,7 +916,7 @@ class HipOps:
     # -- convolution -------------------------------------------------------------------------------
     fuses_forks = True      # conv2d / channel_rmsnorm accept fork=True (second consumer's gradient joins inside the backward pass)
 
-    def conv2d(self, x, weight, bias=None, act=None, stride=1, scale=1.0, residual=None, fork=False):
+    def conv2d(self, x, weight, bias=None, act=None, stride=1, scale=1.0, residual=None, fork=False, res_scale=1.0):
         """scale * (conv(x, w) + bias) [-> leaky relu]: stride-1 'same' conv (odd square kernel) — the reference's
         nn.Conv2d(…, padding=k//2) call sites — or the stride-2 1x1 residual conv (gp.py:1612), whose pixel
         sub-sampling is part of the kernel's gather. `fork=True` returns (y, x'): hand x' to x's other consumer."""
@@ -856,21 +926,21 @@ class HipOps:
         xh = nhwc(x)
         ip = _round8(i)
         if fork and (ip != i or o % 8 or stride != 1):
-            return self.conv2d(x, weight, bias, act, stride, scale, residual), x      # ragged channels: plain fork
+            return self.conv2d(x, weight, bias, act, stride, scale, residual, res_scale=res_scale), x      # ragged channels: plain fork
         if ip != i:
             xh = F.pad(xh, (0, ip - i))
         geom = (k, stride, k // 2 if stride == 1 else 0, 'oihw')
         res = None
         if residual is not None:
             if o % 8:        # ragged channel count: add outside the kernel
-                return self.conv2d(x, weight, bias, act, stride, scale) + residual.to(ACT_DTYPE)
+                return self.conv2d(x, weight, bias, act, stride, scale) + residual.to(ACT_DTYPE) * res_scale
             res = nhwc(to_act(residual))
         if fork:
             y, xa = ConvFn.apply(xh, weight, None if bias is None else bias.float().contiguous(), None, act, geom,
-                                 float(scale), res, True)
+                                 float(scale), res, True, float(res_scale))
             return nchw(y), nchw(xa)
         y = ConvFn.apply(xh, weight, None if bias is None else bias.float().contiguous(), None, act, geom, float(scale),
-                         res)
+                         res, False, float(res_scale))
         if y.shape[-1] != o:
             y = y[..., :o]
         return nchw(y)
@@ -913,20 +983,40 @@ class HipOps:
         b, c, h, w = x.shape
         return y.view(b, h, w, c).permute(0, 3, 1, 2)
 
-    def take_rows(self, x, n):
-        """x[:n] (batch rows) with a channels_last gradient."""
+    def add_cat(self, x, feats):
+        """cat((x + tile(feats), tile(feats)), dim=0), feats (f, C, H, W) tiled scale-major over x's batch (gp.py:1797-1803)."""
+        x, feats = to_act(x), to_act(feats)
+        if second_order or x.shape[1] % 8:
+            from .modules import tile_batch
+            ft = tile_batch(feats, x.shape[0])
+            return torch.cat((x + ft, ft), dim=0)
+        return nchw(AddCatFn.apply(nhwc(x), nhwc(feats)))
+
+    def take_rows(self, x, n, fork=False):
+        """x[:n] (batch rows) with a channels_last gradient. `fork=True` returns (x[:n], x'): the caller continues with x'
+        and the rows' gradient is added into the trunk's gradient in place (RowsForkFn)."""
+        if fork:
+            if n >= x.shape[0] or second_order or x.dim() != 4 or not (torch.is_grad_enabled() and x.requires_grad):
+                return self.take_rows(x, n), x
+            return RowsForkFn.apply(x, n)
         if n >= x.shape[0]:
             return x
         if second_order or x.dim() != 4 or not (torch.is_grad_enabled() and x.requires_grad):
             return x[:n]
         return TakeRowsFn.apply(x, n)
 
-    def global_mean(self, x):
-        """mean over the pixels in fp32 (the squeeze of SqueezeExcite, gp.py:300)."""
+    def global_mean(self, x, fork=False):
+        """mean over the pixels in fp32 (the squeeze of SqueezeExcite, gp.py:300). `fork=True` returns (mean, x'): the trunk
+        continues with x' (GlobalMeanFn)."""
         x = to_act(x)
-        if second_order or not (torch.is_grad_enabled() and x.requires_grad):
-            return x.mean(dim=(2, 3), dtype=torch.float32)
-        return GlobalMeanFn.apply(x)
+        if second_order:
+            m = x.mean(dim=(2, 3), dtype=torch.float32)
+            return (m, x) if fork else m
+        if not (torch.is_grad_enabled() and x.requires_grad):
+            C = x.shape[1]
+            m = x.mean(dim=(2, 3), dtype=torch.float32) if (C % 8 or C > 512) else K.pool_mean(nhwc(x))
+            return (m, x) if fork else m
+        return GlobalMeanFn.apply(x, True) if fork else GlobalMeanFn.apply(x)
 
     # -- adaptive / modulated conv (gp.py:315-409) -----------------------------------------------
     def modconv2d(self, x, weights, mod, kernel_mod=None, demod=True, eps=1e-8, noise=None, noise_weight=None,

@@ -235,6 +235,22 @@ int gg_attn_bwd(const void* q, const void* k, const void* v, const void* k0, con
  * (NHWC pixels as rows), fp32 statistics, C %% 8 == 0, C <= 2048. bwd: dx and per-workgroup partial sums of dgamma
  * ([gg_rmsnorm_blocks(rows)][C] fp32, optional). bwd2 differentiates bwd for an incoming gradient v w.r.t. dx:
  * gx (w.r.t. x), gg (w.r.t. g) and the partial sums of that pass's dgamma — gradient-penalty steps only. */
+/* The discriminator's multi-scale input merge (reference gp.py:1797-1803): out [2B][n] = cat(x + tile(feats), tile(feats)) for
+ * x [B][n] and feats [f][n] bf16 (n elements per sample, B % f == 0, tiled row r = feats[r % f]); backward w.r.t. feats:
+ * gfeats [f][n] = sum over the 2 B / f rows of g that came from feats row j (fp32 accumulation). The gradient w.r.t. x is the
+ * view g[:B]. */
+int gg_addcat_fwd(const void* x, const void* feats, void* out, int32_t B, int32_t f, int64_t n, void* stream);
+int gg_addcat_bwd(const void* g, void* gfeats, int32_t B, int32_t f, int64_t n, void* stream);
+
+/* SqueezeExcite's pool (reference gp.py:300, `Reduce('b c h w -> b c', 'mean')`) over an NHWC bf16 activation x [b][P][C]:
+ * out [b][C] fp32 = mean over the P pixels (fp32 accumulation, deterministic two-stage sum; `part` is caller-owned scratch of
+ * b * gg_pool_chunks(b, P) * C floats). Backward: y = g + gs[b, c] broadcast over the pixels (gs = dL/dmean / P, fp32
+ * [b][C]); g (optional) is the gradient that reached x over its other consumer, so the branch merge costs no extra pass;
+ * y may alias g. */
+int32_t gg_pool_chunks(int32_t b, int32_t P);
+int gg_pool_mean_fwd(const void* x, float* part, float* out, int32_t b, int32_t P, int32_t C, void* stream);
+int gg_pool_mean_bwd(const void* g, const float* gs, void* y, int32_t b, int32_t P, int32_t C, void* stream);
+
 int32_t gg_rmsnorm_blocks(int64_t rows);
 int gg_rmsnorm_fwd(const void* x, const float* gamma, void* y, int64_t rows, int32_t C, float eps, void* stream);
 /* `carry` (optional, [rows][C] bf16) is added to dx inside the pass: the gradient arriving over the skip connection around

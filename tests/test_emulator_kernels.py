@@ -690,3 +690,52 @@ def test_forked_conv_and_norm_match_the_plain_fork_first_and_second_order():
         assert rel_err(a, b) < 1e-2
     for a, b in zip(g2a, g2b):
         assert rel_err(a, b) < 3e-2
+
+
+def test_pool_mean_kernels_and_row_fork_match_tensor_algebra():
+    """gg_pool_mean_fwd / _bwd (SqueezeExcite's pool and the one-pass merge of its gradient with the trunk's) and RowsForkFn
+    (a predictor's rows gradient added into the trunk gradient in place) vs plain autograd."""
+    torch.manual_seed(0)
+    H_ = ops.HipOps()
+    x0 = bf(torch.randn(3, 24, 6, 10)).float()
+    wt = torch.randn(3, 24)
+
+    def run(fork):
+        x = x0.clone().requires_grad_()
+        with ops.use_impl(H_):
+            xa = H_.prepare(x)
+            if fork:
+                m, xt = H_.global_mean(xa, fork=True)
+                rows, xt = H_.take_rows(xt, 2, fork=True)
+            else:
+                m, xt = xa.float().mean(dim=(2, 3)), xa
+                rows = xt[:2]
+            loss = (m * wt).sum() + (xt.float() * 0.5).pow(2).sum() + rows.float().sin().sum()
+            g, = torch.autograd.grad(loss, x)
+        return m.detach(), g
+
+    ma, ga = run(True); mb, gb = run(False)
+    assert rel_err(ma, mb) < 1e-5
+    assert rel_err(ga, gb) < 1e-2
+    # the plain broadcast (no trunk gradient)
+    gs = torch.randn(3, 24)
+    y = K.pool_mean_bwd(gs.contiguous(), (3, 6, 10, 24))
+    assert rel_err(y.float(), gs[:, None, None, :].expand(3, 6, 10, 24)) < 5e-3
+
+
+def test_add_cat_merge_matches_tensor_algebra():
+    """gg_addcat_fwd / _bwd (the discriminator's multi-scale input merge, gp.py:1797-1803) vs cat((x + tile(f), tile(f)))."""
+    torch.manual_seed(0)
+    H_, O_ = ops.HipOps(), OracleOps()
+    x0, f0 = bf(torch.randn(6, 16, 4, 6)).float(), bf(torch.randn(2, 16, 4, 6)).float()
+    w = torch.randn(12, 16, 4, 6)
+
+    def run(I):
+        x, f = x0.clone().requires_grad_(), f0.clone().requires_grad_()
+        with ops.use_impl(I):
+            y = I.add_cat(I.prepare(x), I.prepare(f))
+        gx, gf = torch.autograd.grad((y.float() * w).sum(), [x, f])
+        return y.float(), gx, gf
+
+    ya, gxa, gfa = run(H_); yb, gxb, gfb = run(O_)
+    assert rel_err(ya, yb) < 5e-3 and rel_err(gxa, gxb) < 5e-3 and rel_err(gfa, gfb) < 1e-2

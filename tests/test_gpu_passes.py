@@ -184,6 +184,17 @@ def test_squeeze_excite_pool_and_channel_scale_vs_fp32():
     ghx, ghs = torch.autograd.grad([yh.float(), mh], [xh, sh], [g.to(d), gm.to(d)])
     gox, gos = torch.autograd.grad([yo, mo], [xo, so], [g, gm])
     assert rel_err(ghx.float().cpu(), gox) < 1e-2 and rel_err(ghs.cpu(), gos) < 1e-3
+    # forked form: the trunk's gradient and the pool's broadcast gradient meet in one in-place pass; a predictor's rows join
+    # the trunk gradient in place (RowsForkFn)
+    xf = x0.to(d).requires_grad_()
+    xa = H_.prepare(xf)
+    mf, xt = H_.global_mean(xa, fork=True)
+    rows, xt = H_.take_rows(xt, 3, fork=True)
+    gr = bf(torch.randn(3, 128, 64, 64)).float()
+    gf, = torch.autograd.grad([xt.float(), mf, rows.float()], [xf], [g.to(d), gm.to(d), gr.to(d)])
+    want = g + (gm / (64 * 64))[:, :, None, None]
+    want[:3] += gr
+    assert rel_err(mf.cpu(), mo) < 1e-5 and rel_err(gf.float().cpu(), want) < 1e-2
 
 
 def test_native_rccl_communicator_on_one_gpu():
