@@ -741,3 +741,30 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_addcat_bwd_kernel(GgAddCatParams p) {
         *(u16x8*)(p.out + i * 8) = o;
     }
 }
+
+// ---- y = (a + b) * c over dense bf16 buffers (b optional): the predictor's residual merge (gp.py:1493) in one pass; with b
+// null it is the merge's backward (g * c for both inputs).
+struct GgScaledAddParams {
+    const bf16_t* a;
+    const bf16_t* b;
+    bf16_t* y;
+    long long n;     // multiple of 8
+    float c;
+};
+
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_scaled_add_kernel(GgScaledAddParams p) {
+    const long long nv = p.n >> 3;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+        const u16x8 av = *(const u16x8*)(p.a + i * 8);
+        u16x8 o;
+        if (p.b) {
+            const u16x8 bv = *(const u16x8*)(p.b + i * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = gg_f2bf((gg_bf2f(av[e]) + gg_bf2f(bv[e])) * p.c);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = gg_f2bf(gg_bf2f(av[e]) * p.c);
+        }
+        *(u16x8*)(p.y + i * 8) = o;
+    }
+}

@@ -90,9 +90,10 @@ class Predictor(nn.Module):
 
     def forward(self, x, mod=None, kernel_mod=None):
         """reference gp.py:1482-1498: residual = conv1x1(x); per layer x = (conv2(conv1(x)) + x) * c; x + residual; to_logits.
-        Unconditional convs: every merge rides on a conv epilogue (c * lrelu(z) == lrelu(c * z): conv2 runs with out_scale c
-        and adds c * inner; the final `+ residual` is the residual conv's own epilogue), and every fork hands its input on
-        (Conv2d.forward `fork`), so the backward has no stand-alone elementwise passes either."""
+        Unconditional convs: each layer's first conv hands its input on to the skip (Conv2d.forward `fork`: the skip's gradient
+        joins inside that conv's data-gradient pass), the merge is one pass (ops.scaled_add) and the final `+ residual` rides
+        on the residual conv's epilogue. (The merge cannot ride on conv2's epilogue: its leaky-relu mask is recovered from the
+        sign of the stored output, which a residual added after the activation would destroy.)"""
         x_in = x
         c = self.residual_scale
         for conv1, _, conv2, _ in self.layers:
@@ -100,8 +101,7 @@ class Predictor(nn.Module):
                 h, inner = conv1(x, fork=True)
                 if conv1 is self.layers[0][0]:
                     x_in = inner
-                conv2.out_scale = c
-                x = conv2(h, residual=inner, res_scale=c)
+                x = ops.impl.scaled_add(conv2(h), inner, c)
             else:
                 inner = x
                 x = conv1(x, mod=mod, kernel_mod=kernel_mod, act='lrelu')

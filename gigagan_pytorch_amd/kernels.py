@@ -730,6 +730,19 @@ def attn_bwd2(q, k, v, k0, v0, d_o, lse, dvec, aq, ak, av, ak0, av0, heads: int,
 RMS_EPS = 1e-12     # F.normalize's eps (gp.py:230)
 
 
+def scaled_add(a: torch.Tensor, b, c: float) -> torch.Tensor:
+    """(a + b) * c (b None: a * c) over dense bf16 tensors of one shape and one memory layout."""
+    L = _C.lib()
+    L.require(a, b)
+    assert a.dtype == torch.bfloat16 and a.numel() % 8 == 0
+    assert b is None or (b.dtype == torch.bfloat16 and b.shape == a.shape and b.stride() == a.stride())
+    y = torch.empty_like(a)
+    assert y.stride() == a.stride()
+    rc = L.lib.gg_scaled_add(ptr(a), ptr(b), ptr(y), a.numel(), float(c), L.stream(a))
+    L.check(rc, 'gg_scaled_add')
+    return y
+
+
 def addcat(x: torch.Tensor, feats: torch.Tensor) -> torch.Tensor:
     """cat((x + tile(feats), tile(feats)), 0) for dense bf16 x (B, ...) and feats (f, ...) with B % f == 0 (same trailing shape)."""
     L = _C.lib()

@@ -258,6 +258,8 @@ class ConvFn(Function):
         """`fork=True` returns (y, x): x's OTHER consumer takes the returned alias; its gradient then arrives here and is
         added in the data-gradient GEMM's epilogue (no separate accumulation pass over the activation gradient)."""
         ksize, stride, pad, wkind = geom
+        # the backward recovers the leaky-relu mask from the sign of the stored output: not with a residual added after it
+        assert not (act and residual is not None and torch.is_grad_enabled()), 'ConvFn: activation + residual epilogue is forward-only'
         wmat = packed_weight(w, 's2d' if wkind == 's2d' else 'fwd')
         o8 = wmat.shape[0]
         b8 = bias
@@ -834,6 +836,21 @@ class TakeRowsFn(Function):
         return torch.cat((g, pad), dim=0), None
 
 
+class ScaledAddFn(Function):
+    """(a + b) * c in one pass over dense bf16 tensors (b may be None); linear, so every derivative is the op itself: both
+    inputs receive g * c — ONE tensor, computed once."""
+
+    @staticmethod
+    def forward(ctx, a, b, c):
+        ctx.c, ctx.two = c, b is not None
+        return K.scaled_add(a, b, c)
+
+    @staticmethod
+    def backward(ctx, g):
+        gs = ScaledAddFn.apply(g.contiguous(), None, ctx.c)
+        return gs, (gs if ctx.two else None), None
+
+
 class AddCatFn(Function):
     """cat((x + tile(feats), tile(feats))) over the batch axis — the discriminator's multi-scale input merge (gp.py:1797-1803)
     — in one pass over NHWC bf16 tensors (the stock form is a tile copy, an add and a cat); backward: the x gradient is the
@@ -982,6 +999,13 @@ class HipOps:
             return y.view(x.shape)
         b, c, h, w = x.shape
         return y.view(b, h, w, c).permute(0, 3, 1, 2)
+
+    def scaled_add(self, a, b, c):
+        """(a + b) * c: the predictor blocks' residual merge (gp.py:1493)."""
+        a, b = to_act(a), to_act(b)
+        if a.numel() % 8 or a.stride() != b.stride() or _dense_view(a) is None:
+            return (a + b) * c
+        return ScaledAddFn.apply(a, b, float(c))
 
     def add_cat(self, x, feats):
         """cat((x + tile(feats), tile(feats)), dim=0), feats (f, C, H, W) tiled scale-major over x's batch (gp.py:1797-1803)."""
