@@ -738,12 +738,12 @@ extern "C" int gg_modulate_bank_fwd(const void* x, const float* s, const float* 
     return gg_check_launch();
 }
 
-extern "C" int gg_scaled_add(const void* a, const void* b, void* y, int64_t n, float c, void* stream) {
+extern "C" int gg_scaled_add(const void* a, const void* b, const void* d, void* y, int64_t n, float c, void* stream) {
     if (!a || !y) return gg_fail(-1, "gg_scaled_add: null pointer");
     if (n <= 0 || (n & 7)) return gg_fail(-2, "gg_scaled_add: n must be a positive multiple of 8");
     GgScaledAddParams p;
     memset(&p, 0, sizeof(p));
-    p.a = (const bf16_t*)a; p.b = (const bf16_t*)b; p.y = (bf16_t*)y; p.n = n; p.c = c;
+    p.a = (const bf16_t*)a; p.b = (const bf16_t*)b; p.d = (const bf16_t*)d; p.y = (bf16_t*)y; p.n = n; p.c = c;
     GG_LAUNCH(gg_scaled_add_kernel, dim3(gg_grid_for(n >> 3)), dim3(256), (hipStream_t)stream, p);
     return gg_check_launch();
 }

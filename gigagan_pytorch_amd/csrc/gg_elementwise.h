@@ -742,11 +742,12 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_addcat_bwd_kernel(GgAddCatParams p) {
     }
 }
 
-// ---- y = (a + b) * c over dense bf16 buffers (b optional): the predictor's residual merge (gp.py:1493) in one pass; with b
-// null it is the merge's backward (g * c for both inputs).
+// ---- y = (a + b) * c [+ d] over dense bf16 buffers (b, d optional): the predictor's residual merges (gp.py:1493, :1495) in one
+// pass; with b, d null it is the merge's backward (g * c for both inputs).
 struct GgScaledAddParams {
     const bf16_t* a;
     const bf16_t* b;
+    const bf16_t* d;     // optional: y = (a + b) * c + d
     bf16_t* y;
     long long n;     // multiple of 8
     float c;
@@ -764,6 +765,11 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_scaled_add_kernel(GgScaledAddParams p) {
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = gg_f2bf(gg_bf2f(av[e]) * p.c);
+        }
+        if (p.d) {
+            const u16x8 dv = *(const u16x8*)(p.d + i * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = gg_f2bf(gg_bf2f(o[e]) + gg_bf2f(dv[e]));
         }
         *(u16x8*)(p.y + i * 8) = o;
     }

@@ -91,23 +91,26 @@ class Predictor(nn.Module):
     def forward(self, x, mod=None, kernel_mod=None):
         """reference gp.py:1482-1498: residual = conv1x1(x); per layer x = (conv2(conv1(x)) + x) * c; x + residual; to_logits.
         Unconditional convs: each layer's first conv hands its input on to the skip (Conv2d.forward `fork`: the skip's gradient
-        joins inside that conv's data-gradient pass), the merge is one pass (ops.scaled_add) and the final `+ residual` rides
-        on the residual conv's epilogue. (The merge cannot ride on conv2's epilogue: its leaky-relu mask is recovered from the
-        sign of the stored output, which a residual added after the activation would destroy.)"""
-        x_in = x
+        joins inside that conv's data-gradient pass) and the merges are one pass each (ops.scaled_add, the last one including
+        `+ residual`). (A merge cannot ride on conv2's epilogue: its leaky-relu mask is recovered from the sign of the stored
+        output, which a residual added after the activation would destroy.)"""
         c = self.residual_scale
-        for conv1, _, conv2, _ in self.layers:
-            if self.unconditional:
-                h, inner = conv1(x, fork=True)
-                if conv1 is self.layers[0][0]:
-                    x_in = inner
-                x = ops.impl.scaled_add(conv2(h), inner, c)
-            else:
+        if not self.unconditional:
+            residual = self.residual_fn(x)
+            for conv1, _, conv2, _ in self.layers:
                 inner = x
                 x = conv1(x, mod=mod, kernel_mod=kernel_mod, act='lrelu')
                 x = conv2(x, mod=mod, kernel_mod=kernel_mod, act='lrelu')
                 x = (x + inner) * c
-        x = self.residual_fn(x_in, residual=x)
+            return self.to_logits(x + residual)
+        # x -> first conv (fork) -> residual conv (fork) -> first skip: a chain, every gradient merge inside a conv's backward
+        residual = None
+        last = len(self.layers) - 1
+        for i, (conv1, _, conv2, _) in enumerate(self.layers):
+            h, inner = conv1(x, fork=True)
+            if i == 0:
+                residual, inner = self.residual_fn(inner, fork=True)
+            x = ops.impl.scaled_add(conv2(h), inner, c, residual if i == last else None)
         return self.to_logits(x)
 
 

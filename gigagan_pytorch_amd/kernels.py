@@ -730,15 +730,17 @@ def attn_bwd2(q, k, v, k0, v0, d_o, lse, dvec, aq, ak, av, ak0, av0, heads: int,
 RMS_EPS = 1e-12     # F.normalize's eps (gp.py:230)
 
 
-def scaled_add(a: torch.Tensor, b, c: float) -> torch.Tensor:
-    """(a + b) * c (b None: a * c) over dense bf16 tensors of one shape and one memory layout."""
+def scaled_add(a: torch.Tensor, b, c: float, d=None) -> torch.Tensor:
+    """(a + b) * c + d (b, d optional) over dense bf16 tensors of one shape and ONE memory layout (any dimension order: the
+    kernel walks the storage)."""
     L = _C.lib()
-    L.require(a, b)
+    L.require(a, b, d)
     assert a.dtype == torch.bfloat16 and a.numel() % 8 == 0
-    assert b is None or (b.dtype == torch.bfloat16 and b.shape == a.shape and b.stride() == a.stride())
+    for t in (b, d):
+        assert t is None or (t.dtype == torch.bfloat16 and t.shape == a.shape and t.stride() == a.stride())
     y = torch.empty_like(a)
     assert y.stride() == a.stride()
-    rc = L.lib.gg_scaled_add(ptr(a), ptr(b), ptr(y), a.numel(), float(c), L.stream(a))
+    rc = L.lib.gg_scaled_add(ptr(a), ptr(b), ptr(d), ptr(y), a.numel(), float(c), L.stream(a))
     L.check(rc, 'gg_scaled_add')
     return y
 

@@ -837,18 +837,20 @@ class TakeRowsFn(Function):
 
 
 class ScaledAddFn(Function):
-    """(a + b) * c in one pass over dense bf16 tensors (b may be None); linear, so every derivative is the op itself: both
-    inputs receive g * c — ONE tensor, computed once."""
+    """(a + b) * c + d in one pass over dense bf16 tensors of one layout (b, d may be None); linear, so every derivative is the
+    op itself: a and b receive g * c — ONE tensor, computed once — and d receives g."""
 
     @staticmethod
-    def forward(ctx, a, b, c):
-        ctx.c, ctx.two = c, b is not None
-        return K.scaled_add(a, b, c)
+    def forward(ctx, a, b, c, d=None):
+        ctx.c, ctx.has = c, (b is not None, d is not None)
+        return K.scaled_add(a, b, c, d)
 
     @staticmethod
     def backward(ctx, g):
-        gs = ScaledAddFn.apply(g.contiguous(), None, ctx.c)
-        return gs, (gs if ctx.two else None), None
+        if _dense_view(g) is None:
+            g = g.contiguous(memory_format=torch.channels_last) if g.dim() == 4 else g.contiguous()
+        gs = ScaledAddFn.apply(g, None, ctx.c)
+        return gs, (gs if ctx.has[0] else None), None, (g if ctx.has[1] else None)
 
 
 class AddCatFn(Function):
@@ -1000,12 +1002,15 @@ class HipOps:
         b, c, h, w = x.shape
         return y.view(b, h, w, c).permute(0, 3, 1, 2)
 
-    def scaled_add(self, a, b, c):
-        """(a + b) * c: the predictor blocks' residual merge (gp.py:1493)."""
+    def scaled_add(self, a, b, c, d=None):
+        """(a + b) * c [+ d]: the predictor blocks' residual merges (gp.py:1493, :1495)."""
         a, b = to_act(a), to_act(b)
-        if a.numel() % 8 or a.stride() != b.stride() or _dense_view(a) is None:
-            return (a + b) * c
-        return ScaledAddFn.apply(a, b, float(c))
+        d = None if d is None else to_act(d)
+        ok = a.numel() % 8 == 0 and a.stride() == b.stride() and _dense_view(a) is not None and (d is None or d.stride() == a.stride())
+        if not ok:
+            y = (a + b) * c
+            return y if d is None else y + d
+        return ScaledAddFn.apply(a, b, float(c), d)
 
     def add_cat(self, x, feats):
         """cat((x + tile(feats), tile(feats)), dim=0), feats (f, C, H, W) tiled scale-major over x's batch (gp.py:1797-1803)."""

@@ -235,9 +235,9 @@ int gg_attn_bwd(const void* q, const void* k, const void* v, const void* k0, con
  * (NHWC pixels as rows), fp32 statistics, C %% 8 == 0, C <= 2048. bwd: dx and per-workgroup partial sums of dgamma
  * ([gg_rmsnorm_blocks(rows)][C] fp32, optional). bwd2 differentiates bwd for an incoming gradient v w.r.t. dx:
  * gx (w.r.t. x), gg (w.r.t. g) and the partial sums of that pass's dgamma — gradient-penalty steps only. */
-/* y = (a + b) * c over n bf16 elements (b may be null: y = a * c): the predictor blocks' residual merge
- * `(x + inner) * 2^-0.5` (reference gp.py:1493) as one pass, and its backward. */
-int gg_scaled_add(const void* a, const void* b, void* y, int64_t n, float c, void* stream);
+/* y = (a + b) * c + d over n bf16 elements (b, d may be null): the predictor blocks' residual merge `(x + inner) * 2^-0.5`
+ * (reference gp.py:1493), the last one together with the `+ residual` of gp.py:1495, as one pass; with b and d null its backward. */
+int gg_scaled_add(const void* a, const void* b, const void* d, void* y, int64_t n, float c, void* stream);
 
 /* The discriminator's multi-scale input merge (reference gp.py:1797-1803): out [2B][n] = cat(x + tile(feats), tile(feats)) for
  * x [B][n] and feats [f][n] bf16 (n elements per sample, B % f == 0, tiled row r = feats[r % f]); backward w.r.t. feats:

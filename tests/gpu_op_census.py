@@ -44,7 +44,8 @@ class M(TorchDispatchMode):
             if nd is not None:
                 loc += ' @' + nd.name()
             dt = str(ts[0].dtype).replace('torch.', '') if ts else ''
-            key = (name.replace('aten.', ''), loc, dt)
+            shp = tuple(ts[0].shape) if (ts and nbytes > (32 << 20)) else ()
+            key = (name.replace('aten.', ''), loc, dt, shp)
             cnt[key] += 1
             byt[key] += nbytes
         return out

@@ -5,8 +5,8 @@ export TMPDIR=/tmp
 O=gpurun_out
 step() { echo "=== $1 ($(date +%T))"; }
 step pytest; timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v amdgpu.ids | tail -4
-step census; timeout 300 python tests/gpu_op_census.py 2>&1 | grep -v amdgpu.ids > $O/r2c15_census.log; sed -n 5,40p $O/r2c15_census.log | cut -c1-150
-step bench; timeout 400 python bench.py --no-cpu-baseline 2>&1 | grep -v amdgpu.ids > $O/r2c15_bench.log; grep '^{' $O/r2c15_bench.log | python -c "
+step census; timeout 300 python tests/gpu_op_census.py 2>&1 | grep -v amdgpu.ids > $O/r2c17_census.log; sed -n 5,40p $O/r2c17_census.log | cut -c1-150
+step bench; timeout 400 python bench.py --no-cpu-baseline 2>&1 | grep -v amdgpu.ids > $O/r2c17_bench.log; grep '^{' $O/r2c17_bench.log | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); m = d['roofline']['modconv_forward']
 print(round(d['value'], 1), 'img/s', round(d['ms_per_step'], 2), 'ms finite', d.get('finite'), '; dominant', d['roofline']['kernel'][:50], round(d['roofline']['achieved'], 1), 'TF; all gemm', d['roofline']['all_gemm_kernels'])
