@@ -524,6 +524,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dkv_kernel(GgAttnParams p) {
 
     // dk_j = alpha * sum_i dS_ij q_i + dbias_j * 2*beta*k_j   (d/dk of beta*|k|^2)
     const bf16_t* krow = p.k + boff + (long long)kj * rs;
+    const bool tied = p.dk == p.dq;
     bf16_t* dkrow = p.dk + boff + (long long)kj * rs;
     bf16_t* dvrow = p.dv + boff + (long long)kj * rs;
 #pragma unroll
@@ -532,9 +533,11 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dkv_kernel(GgAttnParams p) {
         for (int g = 0; g < 4; ++g) {
             const int d = db * 32 + 8 * g + 4 * hi;
             u16x4 k4 = *(const u16x4*)(krow + d);
+            u16x4 q4 = {0, 0, 0, 0};
+            if (tied) q4 = *(const u16x4*)(dkrow + d);       // tied projections (k is q): dk aliases dq, the sum is stored
             u16x4 dk4, dv4;
             for (int e = 0; e < 4; ++e) {
-                dk4[e] = gg_f2bf(p.alpha * dkt[db][4 * g + e] + 2.f * p.beta * dbias * gg_bf2f(k4[e]));
+                dk4[e] = gg_f2bf(p.alpha * dkt[db][4 * g + e] + 2.f * p.beta * dbias * gg_bf2f(k4[e]) + gg_bf2f(q4[e]));
                 dv4[e] = gg_f2bf(dvt[db][4 * g + e]);
             }
             *(u16x4*)(dkrow + d) = dk4;

@@ -681,14 +681,16 @@ def attn_fwd(q, k, v, k0, v0, heads: int, alpha: float, beta: float):
     return o, lse
 
 
-def attn_bwd(q, k, v, k0, v0, o, lse, d_o, heads: int, alpha: float, beta: float, return_dvec: bool = False):
+def attn_bwd(q, k, v, k0, v0, o, lse, d_o, heads: int, alpha: float, beta: float, return_dvec: bool = False,
+             tied: bool = False):
     """returns (dq, dk, dv bf16 like q; dk0_q (heads, 64) fp32 = alpha * sum dS_i0 q_i; dv0 (heads, 64) fp32;
-    dbias0 (heads,) fp32 = sum dS_i0)."""
+    dbias0 (heads,) fp32 = sum dS_i0). `tied` (k is q): dq and dk are ONE tensor holding dq + dk."""
     L = _C.lib()
     L.require(q, k, v, k0, v0, o, lse, d_o)
     B, n, hd = q.shape
     assert d_o.dtype == torch.bfloat16 and d_o.is_contiguous() and d_o.shape == q.shape
-    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    dq, dv = torch.empty_like(q), torch.empty_like(q)
+    dk = dq if tied else torch.empty_like(q)
     dvec = torch.empty_like(lse)
     nblk = n // 128
     part = torch.empty((B, heads, nblk, 3, 64), dtype=torch.float32, device=q.device)

@@ -566,7 +566,12 @@ class FlashAttnFn(Function):
 
     @staticmethod
     def forward(ctx, q, k, v, k0, v0, heads, alpha, beta):
+        """k None: the keys ARE the queries (tied projections of the L2 attention, gp.py:566-569); the backward then stores
+        dq + dk in one buffer instead of handing autograd two tensors to add."""
         k0b, v0b = k0.to(ACT_DTYPE).contiguous(), v0.to(ACT_DTYPE).contiguous()
+        ctx.tied = k is None
+        if k is None:
+            k = q
         o, lse = K.attn_fwd(q, k, v, k0b, v0b, heads, alpha, beta)
         ctx.cfg = (heads, alpha, beta)
         ctx.save_for_backward(q, k, v, k0, v0, o, lse)
@@ -578,10 +583,15 @@ class FlashAttnFn(Function):
         heads, alpha, beta = ctx.cfg
         if torch.is_grad_enabled():       # this backward is being differentiated: keep it on the autograd tape
             dq, dk, dv, dk0, dv0 = FlashAttnBwdFn.apply(q, k, v, k0, v0, o, lse, d_o.contiguous(), heads, alpha, beta)
+            if ctx.tied:
+                dq, dk = dq + dk, None
         else:
             k0b, v0b = k0.to(ACT_DTYPE).contiguous(), v0.to(ACT_DTYPE).contiguous()
-            dq, dk, dv, dk0q, dv0, dbias0 = K.attn_bwd(q, k, v, k0b, v0b, o, lse, d_o.contiguous(), heads, alpha, beta)
+            dq, dk, dv, dk0q, dv0, dbias0 = K.attn_bwd(q, k, v, k0b, v0b, o, lse, d_o.contiguous(), heads, alpha, beta,
+                                                       tied=ctx.tied)
             dk0 = dk0q + (2.0 * beta) * dbias0[:, None] * k0b.float()
+            if ctx.tied:
+                dk = None
         return dq, dk, dv, dk0.to(k0.dtype), dv0.to(v0.dtype), None, None, None
 
 
@@ -1213,9 +1223,10 @@ class HipOps:
         b, c, x, y = q.shape
         n = x * y
         if c == heads * 64 and n % 128 == 0:
+            tied = k is q
             qh, kh, vh = (nhwc(to_act(t)).view(b, n, c) for t in (q, k, v))
             alpha, beta = (2.0 * scale, -scale) if l2 else (scale, 0.0)
-            o = FlashAttnFn.apply(qh, kh, vh, null_kv[0], null_kv[1], heads, alpha, beta)
+            o = FlashAttnFn.apply(qh, None if tied else kh, vh, null_kv[0], null_kv[1], heads, alpha, beta)
             return nchw(o.view(b, x, y, c))
         from .modules import self_attention_unfused
         return self_attention_unfused(self, q, k, v, null_kv, heads, scale, l2)

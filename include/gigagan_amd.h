@@ -230,6 +230,8 @@ int gg_attn_fwd(const void* q, const void* k, const void* v, const void* k0, con
 int gg_attn_bwd(const void* q, const void* k, const void* v, const void* k0, const void* v0, const void* o, const float* lse,
                 const void* d_o, float* dvec, void* dq, void* dk, void* dv, float* null_part, int32_t B, int32_t n, int32_t h,
                 float alpha, float beta, void* stream);
+/* gg_attn_bwd: `dk` may alias `dq` when the key projection IS the query projection (the L2-distance attention ties them,
+ * reference gp.py:566-569): the buffer then receives dq + dk, the gradient of the shared tensor, without a separate add. */
 
 /* ---- ChannelRMSNorm (gp.py:224-232): y = x / max(|x|_2, eps) * sqrt(C) * gamma over the channel axis of [rows][C] bf16
  * (NHWC pixels as rows), fp32 statistics, C %% 8 == 0, C <= 2048. bwd: dx and per-workgroup partial sums of dgamma
