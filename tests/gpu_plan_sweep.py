@@ -46,7 +46,10 @@ def materialise(d, dev):
             d.in_scale = buf(n_img * d.CV, f32)
     else:
         d.A = buf((d.batch - 1) * d.a_batch_stride + (d.M if d.a_layout == ROWK else d.K) * d.lda, bf)
-    d.B = buf((d.batch - 1) * d.b_batch_stride + (d.N if d.b_layout == ROWK else d.K) * d.ldb, bf, 0.05)
+    b_elems = (d.batch - 1) * d.b_batch_stride + (d.N if d.b_layout == ROWK else d.K) * d.ldb
+    if d.b_image_stride:          # per-image weights: image i reads B + i * b_image_stride
+        b_elems += (d.M // (oh * ow) - 1) * d.b_image_stride
+    d.B = buf(b_elems, bf, 0.05)
     if d.d2s:
         n_img = d.M // (d.d2s_oh * d.d2s_ow)
         celems = n_img * d.d2s_oh * d.d2s * d.d2s_ow * d.d2s * d.d2s_c
@@ -109,6 +112,8 @@ def main():
     uniq = {}
     for b in raw:
         d = GemmDesc.from_buffer_copy(b)
+        if d.b_image_stride:
+            continue            # per-image weights are always planned by the cost model (the table does not apply)
         k = key_of(d)
         if k not in uniq:
             uniq[k] = [d, 0]
