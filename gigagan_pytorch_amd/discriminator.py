@@ -337,7 +337,7 @@ class Discriminator(nn.Module):
             if exists(squeeze_excite):
                 excite_new, x = squeeze_excite_fork(squeeze_excite, x)
                 excitations.append(excite_new)
-            excite = ops.ready(excitations.pop(0)) if excitations else None
+            excite = excitations.pop(0) if excitations else None
             if exists(excite):
                 x = ops.impl.channel_scale(x, tile_batch(excite, x.shape[0]))
 

@@ -183,7 +183,7 @@ class Generator(BaseGenerator):
             if exists(squeeze_excite):
                 excite_new, x = squeeze_excite_fork(squeeze_excite, x)
                 excitations.append(excite_new)
-            excite = ops.ready(excitations.pop(0)) if excitations else None
+            excite = excitations.pop(0) if excitations else None
             # `x = x * excite` (gp.py:1023-1024): x has one consumer, the first conv of the block, which takes the scale along
             # (no-grad: folded into its per-sample weights; otherwise the fused multiply with its one-pass backward)
 

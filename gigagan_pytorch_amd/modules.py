@@ -209,12 +209,9 @@ def SqueezeExcite(dim, dim_out, reduction=4, dim_min=32):
 def squeeze_excite_fork(se, x):
     """(se(x), x'): the excitation of a SqueezeExcite stack and x for the trunk (its gradient and the pool's meet in one pass)."""
     m, x = ops.impl.global_mean(x, fork=True)
-
-    def mlp(m):
-        for layer in list(se)[1:]:
-            m = layer(m)
-        return m
-    return ops.run_on_side_stream(mlp, m), x         # consumed layers later: `ops.ready(excite)` at the point of use
+    for layer in list(se)[1:]:
+        m = layer(m)
+    return m, x
 
 
 # ---- adaptive conv (gp.py:315-409) ---------------------------------------------------------------------------

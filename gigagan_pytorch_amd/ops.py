@@ -929,49 +929,6 @@ class ResampleFn(Function):
 
 
 # --------------------------------------------------------------------------------------------------
-# side stream for the small chains (squeeze-excite MLPs): a few dozen tiny launches whose result is consumed layers later;
-# on the compute stream each of them would stall the big kernels for a launch latency, on a second stream (a parallel branch
-# of the captured graph) they hide behind them. Autograd runs each node's backward on its forward's stream, so the backward
-# of the chain overlaps the same way, and the engine joins the streams at the end of backward().
-# --------------------------------------------------------------------------------------------------
-_side_streams = {}
-
-
-def side_stream(device):
-    s = _side_streams.get(device)
-    if s is None:
-        s = _side_streams[device] = torch.cuda.Stream(device)
-    return s
-
-
-def run_on_side_stream(fn, *inputs):
-    """fn(*inputs) on the side stream; the result carries the event a consumer on the compute stream waits for (`ready`)."""
-    t0 = inputs[0]
-    if not t0.is_cuda or not getattr(impl, 'side_streams', False):
-        return fn(*inputs)
-    main, side = torch.cuda.current_stream(t0.device), side_stream(t0.device)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        for t in inputs:
-            t.record_stream(side)
-        out = fn(*inputs)
-        ev = torch.cuda.Event()
-        ev.record(side)
-    out._gg_ready = ev
-    return out
-
-
-def ready(t):
-    """make the current stream wait for a tensor produced by `run_on_side_stream` (no-op otherwise)."""
-    ev = getattr(t, '_gg_ready', None) if t is not None else None
-    if ev is not None:
-        cur = torch.cuda.current_stream(t.device)
-        cur.wait_event(ev)
-        t.record_stream(cur)
-    return t
-
-
-# --------------------------------------------------------------------------------------------------
 # the op set
 # --------------------------------------------------------------------------------------------------
 
@@ -986,7 +943,6 @@ class HipOps:
         return to_act(x)
 
     # -- convolution -------------------------------------------------------------------------------
-    side_streams = True     # small chains (squeeze-excite MLPs) run on a second stream (run_on_side_stream)
     fuses_forks = True      # conv2d / channel_rmsnorm accept fork=True (second consumer's gradient joins inside the backward pass)
 
     def conv2d(self, x, weight, bias=None, act=None, stride=1, scale=1.0, residual=None, fork=False, res_scale=1.0):
