@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 4
+#define GG_ABI_VERSION 5
 
 int gg_version(void);
 const char* gg_last_error(void);
