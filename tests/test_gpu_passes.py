@@ -246,3 +246,31 @@ def test_no_grad_adaptive_conv_at_config2_layer_shapes(cfg):
         with ops.use_impl(ops.HipOps()):
             y1 = conv(x.to(d), mod.to(d), km.to(d), noise=nz.to(d), noise_weight=nw.to(d), act='lrelu')
     assert rel_err(y1.float().cpu(), y0) < 1e-2
+
+
+def test_training_steps_never_read_uninitialised_memory():
+    """torch.empty() poisoned with NaN (deterministic-mode fill): four replayed config-2 steps (plain D, gradient-penalty D, G step
+    kinds; every workspace, partial-sum and padded buffer the kernels are handed) leave losses and both flat parameter buffers
+    finite — a kernel reading an element nobody wrote would not."""
+    import bench
+    from gigagan_pytorch_amd.data import SyntheticImages
+    from gigagan_pytorch_amd.gigagan import cycle
+    prev = (torch.are_deterministic_algorithms_enabled(), torch.is_deterministic_algorithms_warn_only_enabled(),
+            torch.utils.deterministic.fill_uninitialized_memory)
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    torch.utils.deterministic.fill_uninitialized_memory = True
+    try:
+        torch.manual_seed(0)
+        gan = bench.build_gan(256, dev(), use_hip_graphs=True)
+        it = cycle(SyntheticImages(32, 256, device=dev()))
+        for step in range(4):
+            d, g = gan.train_step(it, 32)
+            vals = [float(d.divergence), float(g.divergence), float(d.gradient_penalty)]
+            assert all(math.isfinite(v) for v in vals), (step, vals)
+        assert bool(torch.isfinite(gan.G_opt.flat_p).all()) and bool(torch.isfinite(gan.D_opt.flat_p).all())
+        assert float(d.gradient_penalty) > 0          # step 4 is the gradient-penalty step
+        del gan
+    finally:
+        torch.use_deterministic_algorithms(prev[0], warn_only=prev[1])
+        torch.utils.deterministic.fill_uninitialized_memory = prev[2]
+        torch.cuda.empty_cache()
