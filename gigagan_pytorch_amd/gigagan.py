@@ -397,6 +397,9 @@ class GigaGAN(nn.Module):
             static_src = getattr(self, '_static_G_src', None)
             if not exists(dl_iter) and self.unconditional and exists(static_src):
                 real_images = static_src     # hipGraph replay: the loader batch was copied into this buffer beforehand
+            elif not exists(dl_iter) and not self.unconditional and exists(static_src):
+                real_images, enc = static_src                 # hipGraph replay of a text-conditional step: staged (images, encodings)
+                maybe_text_kwargs['text_encodings'] = enc[:batch_size]
             elif self.unconditional:
                 assert exists(dl_iter)
                 real_images = next(dl_iter)
@@ -426,7 +429,26 @@ class GigaGAN(nn.Module):
 
     # -- hipGraph capture of one step kind ---------------------------------------------------------------------
     def _graphable(self, grad_accum_every):
-        return (self.use_hip_graphs and grad_accum_every == 1 and self.unconditional and not exists(self.diff_augment))
+        return self.use_hip_graphs and grad_accum_every == 1 and not exists(self.diff_augment)
+
+    def _take_graphable_batches(self, dl_iter, n):
+        """text-conditional steps are replayed as hipGraphs only when the loader hands over token ENCODINGS (tensors; raw captions
+        need the host-side tokenizer). Draws the step's n loader batches; returns (batches, dl_iter) with dl_iter re-chained in
+        front of them when the step has to run eagerly (batches is None then)."""
+        import itertools
+        got = [next(dl_iter) for _ in range(n)]
+        ok = all(isinstance(b, (tuple, list)) and len(b) == 2 and torch.is_tensor(b[1]) for b in got)
+        if ok:
+            return got, dl_iter
+        return None, itertools.chain(got, dl_iter)
+
+    def _stage(self, name, src):
+        """copy a loader tensor into the static device buffer the captured step reads."""
+        buf = self._graphs.get((name, tuple(src.shape), src.dtype))
+        if buf is None:
+            buf = self._graphs[(name, tuple(src.shape), src.dtype)] = torch.empty_like(src, device=self.device)
+        buf.copy_(src, non_blocking=True)
+        return buf
 
     def _stage_upsampler_source(self, dl_iter):
         """upsampler mode under hipGraphs: the generator's low-resolution conditioning comes from a loader batch of its own
@@ -581,20 +603,32 @@ class GigaGAN(nn.Module):
         self.G.train()
         self.D.train()
 
-        if self._graphable(grad_accum_every):
-            real = next(dl_iter)
+        graphed = self._graphable(grad_accum_every)
+        staged = None
+        if graphed and not self.unconditional:
+            # a text-conditional D step draws two loader batches: the real pairs and the generator's conditioning (gp.py:2269, :2196)
+            staged, dl_iter = self._take_graphable_batches(dl_iter, 2)
+            graphed = staged is not None
+        if graphed:
+            if self.unconditional:
+                real = next(dl_iter)
+                self._stage_upsampler_source(dl_iter)
+            else:
+                (real, _), (g_img, g_enc) = staged
+                self._static_G_src = (self._stage('g_img', g_img), self._stage('g_enc', g_enc))
             key = ('D', bool(apply_gradient_penalty), bool(calc_multiscale_loss), tuple(real.shape))
-            static_real = self._graphs.get(('in',) + key)
-            if static_real is None:
-                static_real = self._graphs[('in',) + key] = torch.empty_like(real, device=dev)
-            static_real.copy_(real, non_blocking=True)
-            self._stage_upsampler_source(dl_iter)
+            static_real = self._stage('d_real', real)
 
             def fn():
                 self.D_opt.zero_grad()
-                return self._d_micro(static_real, None, None, 1, apply_gradient_penalty, calc_multiscale_loss)
+                col = [] if has_matching_awareness else None
+                out = self._d_micro(static_real, None, None, 1, apply_gradient_penalty, calc_multiscale_loss, collect=col)
+                mal = self._matching_aware_pass(col, 1) if has_matching_awareness else torch.zeros((), device=dev)
+                return (*out, mal)
 
-            total_divergence, total_multiscale_divergence, total_gp_loss, total_aux_loss = self._run_graphed(key, fn)
+            (total_divergence, total_multiscale_divergence, total_gp_loss, total_aux_loss,
+             total_matching_aware_loss) = self._run_graphed(key, fn)
+            collected = None
             if not calc_multiscale_loss:
                 total_multiscale_divergence = None
         else:
@@ -618,18 +652,8 @@ class GigaGAN(nn.Module):
                 total_gp_loss += gp / grad_accum_every
                 total_aux_loss += aux / grad_accum_every
 
-        if has_matching_awareness:
-            # mismatched (image, text) pairs: rotate the conditioning by one inside each micro-batch
-            for fake_images, fake_rgbs, real_images, tk in collected:
-                tk = {k: (v[1:] + v[:1] if isinstance(v, list) else torch.roll(v, -1, 0)) for k, v in tk.items()}
-                fake_logits, *_ = self.D(fake_images, fake_rgbs, **tk, return_multiscale_outputs=False,
-                                         calc_aux_loss=False)
-                real_rgbs = self.D.real_images_to_rgbs(real_images)
-                real_logits, *_ = self.D(real_images, real_rgbs, **tk, return_multiscale_outputs=False,
-                                         calc_aux_loss=False)
-                matching_loss = aux_matching_loss(real_logits, fake_logits)
-                total_matching_aware_loss = matching_loss.detach() / grad_accum_every
-                _backward(matching_loss * self.matching_awareness_loss_weight / grad_accum_every)
+        if has_matching_awareness and collected is not None:
+            total_matching_aware_loss = self._matching_aware_pass(collected, grad_accum_every)
 
         works = gdist.all_reduce_flat_grads(self.D_opt.flat_g)
         gdist.wait_all(works)
@@ -643,6 +667,19 @@ class GigaGAN(nn.Module):
 
         return TrainDiscrLosses(total_divergence, total_multiscale_divergence, 0., total_matching_aware_loss,
                                 total_gp_loss, total_aux_loss)
+
+    def _matching_aware_pass(self, collected, grad_accum_every):
+        """mismatched (image, text) pairs (gp.py:2432-2475): rotate the conditioning by one inside each micro-batch."""
+        total = torch.zeros((), device=self.device)
+        for fake_images, fake_rgbs, real_images, tk in collected:
+            tk = {k: (v[1:] + v[:1] if isinstance(v, list) else torch.roll(v, -1, 0)) for k, v in tk.items()}
+            fake_logits, *_ = self.D(fake_images, fake_rgbs, **tk, return_multiscale_outputs=False, calc_aux_loss=False)
+            real_rgbs = self.D.real_images_to_rgbs(real_images)
+            real_logits, *_ = self.D(real_images, real_rgbs, **tk, return_multiscale_outputs=False, calc_aux_loss=False)
+            matching_loss = aux_matching_loss(real_logits, fake_logits)
+            total = matching_loss.detach() / grad_accum_every
+            _backward(matching_loss * self.matching_awareness_loss_weight / grad_accum_every)
+        return total
 
     def _g_micro(self, batch_size, dl_iter, grad_accum_every, calc_multiscale_loss, collect=None):
         """forward + backward of ONE generator micro-batch (gp.py:2516-2580). `collect`: (images, texts) lists for the CLIP
@@ -697,9 +734,16 @@ class GigaGAN(nn.Module):
         for p in self.D.parameters():
             p.requires_grad_(False)
         try:
-            if self._graphable(grad_accum_every):
+            graphed = self._graphable(grad_accum_every) and not exists(clip)
+            if graphed and not self.unconditional:
+                staged, dl_iter = self._take_graphable_batches(dl_iter, 1)
+                graphed = staged is not None
+                if graphed:
+                    self._static_G_src = (self._stage('g_img', staged[0][0]), self._stage('g_enc', staged[0][1]))
+            if graphed:
                 key = ('G', int(batch_size), bool(calc_multiscale_loss))
-                self._stage_upsampler_source(dl_iter)
+                if self.unconditional:
+                    self._stage_upsampler_source(dl_iter)
 
                 def fn():
                     self.G_opt.zero_grad()

@@ -174,6 +174,7 @@ def check_text_discriminator(fx, dev, with_penalty):
     for a, b in zip(ms, fx['ms']):
         assert rel_err(a.cpu(), b) < TOL_BF16
     if with_penalty:     # double backward through the text-modulated predictor convs (twice-differentiable variant)
+        print('MEASURED text_gp_rel', abs(float(pen) - float(fx['gp'])) / float(fx['gp']))
         assert abs(float(pen) - float(fx['gp'])) < 0.1 * float(fx['gp'])
     with ops.use_impl(OracleOps(bf16_operands=True)):
         _, _, _, go = run()

@@ -186,6 +186,7 @@ def test_hip_unet_forward_and_training_gradients(fx):
         dot += (a.float() * b.float()).sum().item()
         na += a.float().square().sum().item()
         nb += b.float().square().sum().item()
+    print('MEASURED unet_grad_cosine', float(dot / (na * nb) ** 0.5))
     assert dot / (na * nb) ** 0.5 > 0.9
 
 
