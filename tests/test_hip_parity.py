@@ -264,8 +264,7 @@ def test_models_vs_reference_golden_fixture():
     for a, b in zip(ms, fx['ms']):
         assert rel_err(a.cpu(), b) < 3e-2
     gp = gradient_penalty(real, [logits, *ms], grad_output_weights=[1., *(0.1,) * len(ms)])
-    print('MEASURED hip_parity_gp_rel', float(rel_err(gp.cpu(), fx['gp'])))
-    assert rel_err(gp.cpu(), fx['gp']) < 0.1          # second-order quantity through bf16 leaky-relu masks
+    assert rel_err(gp.cpu(), fx['gp']) < 0.04         # second-order quantity through bf16 leaky-relu masks; measured 0.020
 
 
 def test_train_step_runs_and_is_finite(tmp_path):

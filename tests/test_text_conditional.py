@@ -174,8 +174,7 @@ def check_text_discriminator(fx, dev, with_penalty):
     for a, b in zip(ms, fx['ms']):
         assert rel_err(a.cpu(), b) < TOL_BF16
     if with_penalty:     # double backward through the text-modulated predictor convs (twice-differentiable variant)
-        print('MEASURED text_gp_rel', abs(float(pen) - float(fx['gp'])) / float(fx['gp']))
-        assert abs(float(pen) - float(fx['gp'])) < 0.1 * float(fx['gp'])
+        assert abs(float(pen) - float(fx['gp'])) < 0.03 * float(fx['gp'])        # measured 0.0012 on the MI355X
     with ops.use_impl(OracleOps(bf16_operands=True)):
         _, _, _, go = run()
     assert _cosine(g, go, D.named_parameters()) > 0.98

@@ -186,8 +186,7 @@ def test_hip_unet_forward_and_training_gradients(fx):
         dot += (a.float() * b.float()).sum().item()
         na += a.float().square().sum().item()
         nb += b.float().square().sum().item()
-    print('MEASURED unet_grad_cosine', float(dot / (na * nb) ** 0.5))
-    assert dot / (na * nb) ** 0.5 > 0.9
+    assert dot / (na * nb) ** 0.5 > 0.99          # measured 0.9989 on the MI355X
 
 
 # ---- trainer with train_upsampler=True (gp.py:1912-1960, :2208-2212) ------------------------------------------------
