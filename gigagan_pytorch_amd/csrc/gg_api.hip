@@ -738,6 +738,76 @@ extern "C" int gg_modulate_bank_fwd(const void* x, const float* s, const float* 
     return gg_check_launch();
 }
 
+static int gg_linattn_check(const char* who, int32_t C, int32_t ld_x, int32_t ld_y) {
+    if (C <= 0 || (C & 63) || C > 2048 || ld_x < C || ld_y < C || (ld_x & 7) || (ld_y & 7))
+        return gg_fail(-2, "%s: need C %% 64 == 0, C <= 2048, row pitches >= C and multiples of 8 (C=%d ld_x=%d ld_y=%d)", who, C, ld_x, ld_y);
+    return 0;
+}
+
+extern "C" int gg_linattn_q_fwd(const void* q, int32_t ld_q, void* qs, int32_t ld_qs, int64_t rows, int32_t C, float scale, void* stream) {
+    if (!q || !qs) return gg_fail(-1, "gg_linattn_q_fwd: null pointer");
+    int rc = gg_linattn_check("gg_linattn_q_fwd", C, ld_q, ld_qs);
+    if (rc) return rc;
+    GgLinAttnParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)q; p.y = (bf16_t*)qs; p.ld_x = ld_q; p.ld_y = ld_qs; p.rows = rows; p.C = C; p.scale = scale;
+    GG_LAUNCH(gg_linattn_q_kernel<0>, dim3(gg_grid_for(rows * (C >> 6) * 8)), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+extern "C" int gg_linattn_q_bwd(const void* qs, int32_t ld_qs, const void* dqs, int32_t ld_dqs, void* dq, int32_t ld_dq, int64_t rows,
+                                int32_t C, float scale, void* stream) {
+    if (!qs || !dqs || !dq) return gg_fail(-1, "gg_linattn_q_bwd: null pointer");
+    int rc = gg_linattn_check("gg_linattn_q_bwd", C, ld_qs, ld_dq);
+    if (rc) return rc;
+    if (ld_dqs < C || (ld_dqs & 7) || scale == 0.f) return gg_fail(-2, "gg_linattn_q_bwd: bad gradient pitch / zero scale");
+    GgLinAttnParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)qs; p.g = (const bf16_t*)dqs; p.y = (bf16_t*)dq; p.ld_x = ld_qs; p.ld_g = ld_dqs; p.ld_y = ld_dq;
+    p.rows = rows; p.C = C; p.scale = scale;
+    GG_LAUNCH(gg_linattn_q_kernel<1>, dim3(gg_grid_for(rows * (C >> 6) * 8)), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+extern "C" int32_t gg_linattn_chunks(int32_t b, int32_t n) { return gg_pool_chunks(b, n); }
+
+// x [b][n][ld_x] (+ g for the backward); part / stat are caller-owned fp32 scratch: part b * chunks * C * (2 | 1), stat b * C * (2 | 1)
+static int gg_linattn_k(int mode, const void* x, int32_t ld_x, const void* g, int32_t ld_g, void* y, int32_t ld_y, float* part,
+                        float* stat, int32_t b, int32_t n, int32_t C, void* stream) {
+    if (!x || !y || !part || !stat || (mode == 1 && !g)) return gg_fail(-1, "gg_linattn_k: null pointer");
+    int rc = gg_linattn_check("gg_linattn_k", C, ld_x, ld_y);
+    if (rc) return rc;
+    if (C > 512 || b <= 0 || n <= 0 || b > 65535) return gg_fail(-2, "gg_linattn_k: need C <= 512 and 0 < b <= 65535 (C=%d b=%d)", C, b);
+    if (mode == 1 && (ld_g < C || (ld_g & 7))) return gg_fail(-2, "gg_linattn_k: bad gradient pitch");
+    GgLinAttnParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)x; p.g = (const bf16_t*)g; p.y = (bf16_t*)y; p.part = part; p.stat = stat;
+    p.ld_x = ld_x; p.ld_g = ld_g; p.ld_y = ld_y; p.C = C; p.b = b; p.n = n; p.chunks = gg_pool_chunks(b, n);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g1((unsigned)p.chunks, (unsigned)b);
+    const dim3 g2(gg_grid_for((long long)b * C)), g3(gg_grid_for((long long)b * n * (C >> 3)));
+    if (mode == 0) {
+        GG_LAUNCH(gg_linattn_kpart_kernel<0>, g1, dim3(256), s, p);
+        GG_LAUNCH(gg_linattn_kfinish_kernel<0>, g2, dim3(256), s, p);
+        GG_LAUNCH(gg_linattn_kapply_kernel<0>, g3, dim3(256), s, p);
+    } else {
+        GG_LAUNCH(gg_linattn_kpart_kernel<1>, g1, dim3(256), s, p);
+        GG_LAUNCH(gg_linattn_kfinish_kernel<1>, g2, dim3(256), s, p);
+        GG_LAUNCH(gg_linattn_kapply_kernel<1>, g3, dim3(256), s, p);
+    }
+    return gg_check_launch();
+}
+
+extern "C" int gg_linattn_k_fwd(const void* k, int32_t ld_k, void* eks, int32_t ld_eks, float* part, float* stat, int32_t b, int32_t n,
+                                int32_t C, void* stream) {
+    return gg_linattn_k(0, k, ld_k, nullptr, 0, eks, ld_eks, part, stat, b, n, C, stream);
+}
+
+extern "C" int gg_linattn_k_bwd(const void* eks, int32_t ld_eks, const void* deks, int32_t ld_deks, void* dk, int32_t ld_dk, float* part,
+                                float* stat, int32_t b, int32_t n, int32_t C, void* stream) {
+    return gg_linattn_k(1, eks, ld_eks, deks, ld_deks, dk, ld_dk, part, stat, b, n, C, stream);
+}
+
 extern "C" int gg_scaled_add(const void* a, const void* b, const void* d, void* y, int64_t n, float c, void* stream) {
     if (!a || !y) return gg_fail(-1, "gg_scaled_add: null pointer");
     if (n <= 0 || (n & 7)) return gg_fail(-2, "gg_scaled_add: n must be a positive multiple of 8");

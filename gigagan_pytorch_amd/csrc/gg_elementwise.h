@@ -774,3 +774,160 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_scaled_add_kernel(GgScaledAddParams p) {
         *(u16x8*)(p.y + i * 8) = o;
     }
 }
+
+// ---- LinearAttention softmaxes (unet.py:338-348) over NHWC bf16 channel slices -------------------------------------------
+// q: softmax over the 64 features of each head at every position, times `scale`; k: softmax over the positions of every
+// feature. Inputs are channel slices of the fused to_qkv output ([rows][ld_in], C = heads * 64 channels from a base pointer),
+// outputs dense [rows][C] (forward) or channel slices of the fused qkv gradient (backward). fp32 statistics.
+struct GgLinAttnParams {
+    const bf16_t* x;     // q-forward: q ; q-backward: qs ; k passes: k resp. eks
+    const bf16_t* g;     // backward passes: gradient w.r.t. qs resp. eks
+    bf16_t* y;
+    float* part;         // k passes: [b][chunks][C][2] partial (max, sum) resp. [b][chunks][C] partial dots
+    float* stat;         // k passes: [b][C][2] (max, sum) resp. [b][C] dots
+    long long rows;      // q passes: b * n
+    int ld_x, ld_g, ld_y, C, b, n, chunks;
+    float scale;
+};
+
+// q: one 8-lane group per (position, head); MODE 0: qs = scale * softmax ; MODE 1: dq = p * (scale*dqs - sum(p * scale*dqs)), p = qs / scale
+template <int MODE>
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_linattn_q_kernel(GgLinAttnParams p) {
+    const int heads = p.C >> 6;
+    const long long groups = p.rows * heads;
+    const int sub = threadIdx.x & 7;
+    for (long long gidx = ((long long)blockIdx.x * 256 + threadIdx.x) >> 3; gidx < groups; gidx += ((long long)gridDim.x * 256) >> 3) {
+        const long long row = gidx / heads;
+        const int h = (int)(gidx - row * heads);
+        const u16x8 xv = *(const u16x8*)(p.x + row * p.ld_x + h * 64 + sub * 8);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gg_bf2f(xv[e]);
+        u16x8 o;
+        if (MODE == 0) {
+            float mx = v[0];
+#pragma unroll
+            for (int e = 1; e < 8; ++e) mx = fmaxf(mx, v[e]);
+            mx = fmaxf(mx, gg_shfl_xor(mx, 1)); mx = fmaxf(mx, gg_shfl_xor(mx, 2)); mx = fmaxf(mx, gg_shfl_xor(mx, 4));
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[e] = gg_expf(v[e] - mx); s += v[e]; }
+            s += gg_shfl_xor(s, 1); s += gg_shfl_xor(s, 2); s += gg_shfl_xor(s, 4);
+            const float r = p.scale / s;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = gg_f2bf(v[e] * r);
+        } else {
+            const u16x8 gv = *(const u16x8*)(p.g + row * p.ld_g + h * 64 + sub * 8);
+            float gq[8], dot = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { gq[e] = gg_bf2f(gv[e]); dot += v[e] * gq[e]; }     // sum qs * dqs = scale * sum p * dqs
+            dot += gg_shfl_xor(dot, 1); dot += gg_shfl_xor(dot, 2); dot += gg_shfl_xor(dot, 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = gg_f2bf(v[e] * (gq[e] - dot / p.scale));
+        }
+        *(u16x8*)(p.y + row * p.ld_y + h * 64 + sub * 8) = o;
+    }
+}
+
+// k statistics, stage 1: grid (chunks, b); thread -> channel vector t % (C/8), position lane t / (C/8).
+// MODE 0: running (max, sum exp) per channel over the chunk's positions; MODE 1: sum of x * g per channel
+template <int MODE>
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_linattn_kpart_kernel(GgLinAttnParams p) {
+    GG_SHARED float red[256 * 8 * 2];
+    const int cvs = p.C >> 3, pl_n = 256 / cvs;
+    const int t = threadIdx.x, cv = t % cvs, pl = t / cvs;
+    const int chunk = blockIdx.x, img = blockIdx.y;
+    const int per = (p.n + p.chunks - 1) / p.chunks;
+    const int p0 = chunk * per, p1 = p0 + per < p.n ? p0 + per : p.n;
+    float m[8], s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { m[e] = -3.0e38f; s[e] = 0.f; }
+    if (pl < pl_n) {
+        const bf16_t* xb = p.x + (long long)img * p.n * p.ld_x + cv * 8;
+        const bf16_t* gb = MODE == 1 ? p.g + (long long)img * p.n * p.ld_g + cv * 8 : nullptr;
+        for (int q = p0 + pl; q < p1; q += pl_n) {
+            const u16x8 xv = *(const u16x8*)(xb + (long long)q * p.ld_x);
+            if (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = gg_bf2f(xv[e]);
+                    const float mn = fmaxf(m[e], x);
+                    s[e] = s[e] * gg_expf(m[e] - mn) + gg_expf(x - mn);
+                    m[e] = mn;
+                }
+            } else {
+                const u16x8 gv = *(const u16x8*)(gb + (long long)q * p.ld_g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += gg_bf2f(xv[e]) * gg_bf2f(gv[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[(t * 8 + e) * 2] = m[e]; red[(t * 8 + e) * 2 + 1] = s[e]; }
+    gg_sync();
+    for (int c = t; c < p.C; c += 256) {
+        float mm = -3.0e38f, ss = 0.f;
+        for (int l = 0; l < pl_n; ++l) {
+            const int idx = ((l * cvs + (c >> 3)) * 8 + (c & 7)) * 2;
+            if (MODE == 0) {
+                const float m2 = red[idx], s2 = red[idx + 1];
+                const float mn = fmaxf(mm, m2);
+                ss = ss * gg_expf(mm - mn) + s2 * gg_expf(m2 - mn);
+                mm = mn;
+            } else {
+                ss += red[idx + 1];
+            }
+        }
+        const long long o = ((long long)img * p.chunks + chunk) * p.C + c;
+        if (MODE == 0) { p.part[o * 2] = mm; p.part[o * 2 + 1] = ss; }
+        else p.part[o] = ss;
+    }
+}
+
+// stage 2: combine the chunks
+template <int MODE>
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_linattn_kfinish_kernel(GgLinAttnParams p) {
+    const long long nbc = (long long)p.b * p.C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nbc; i += (long long)gridDim.x * 256) {
+        const int img = (int)(i / p.C), c = (int)(i - (long long)img * p.C);
+        float mm = -3.0e38f, ss = 0.f;
+        for (int k = 0; k < p.chunks; ++k) {
+            const long long o = ((long long)img * p.chunks + k) * p.C + c;
+            if (MODE == 0) {
+                const float m2 = p.part[o * 2], s2 = p.part[o * 2 + 1];
+                const float mn = fmaxf(mm, m2);
+                ss = ss * gg_expf(mm - mn) + s2 * gg_expf(m2 - mn);
+                mm = mn;
+            } else {
+                ss += p.part[o];
+            }
+        }
+        if (MODE == 0) { p.stat[i * 2] = mm; p.stat[i * 2 + 1] = ss; }
+        else p.stat[i] = ss;
+    }
+}
+
+// apply: MODE 0: eks = exp(k - max) / sum ; MODE 1: dk = eks * (deks - dot)
+template <int MODE>
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_linattn_kapply_kernel(GgLinAttnParams p) {
+    const int cvs = p.C >> 3;
+    const long long total = (long long)p.b * p.n * cvs;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % cvs);
+        const long long row = i / cvs;
+        const int img = (int)(row / p.n);
+        const u16x8 xv = *(const u16x8*)(p.x + row * p.ld_x + cv * 8);
+        u16x8 o;
+        if (MODE == 0) {
+            const float* st = p.stat + ((long long)img * p.C + cv * 8) * 2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = gg_f2bf(gg_expf(gg_bf2f(xv[e]) - st[2 * e]) / st[2 * e + 1]);
+        } else {
+            const u16x8 gv = *(const u16x8*)(p.g + row * p.ld_g + cv * 8);
+            const float* st = p.stat + (long long)img * p.C + cv * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = gg_f2bf(gg_bf2f(xv[e]) * (gg_bf2f(gv[e]) - st[e]));
+        }
+        *(u16x8*)(p.y + row * p.ld_y + cv * 8) = o;
+    }
+}

@@ -732,6 +732,60 @@ def attn_bwd2(q, k, v, k0, v0, d_o, lse, dvec, aq, ak, av, ak0, av0, heads: int,
 RMS_EPS = 1e-12     # F.normalize's eps (gp.py:230)
 
 
+def _rows3(t: torch.Tensor):
+    """(b, n, C) bf16 view with unit channel stride and b * n uniformly pitched rows -> (ptr, row pitch)."""
+    assert t.dtype == torch.bfloat16 and t.dim() == 3 and t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1)
+    return ptr(t), t.stride(1)
+
+
+def linattn_q_fwd(q: torch.Tensor, scale: float) -> torch.Tensor:
+    """q (b, n, C) channel slice -> qs (b, n, C) contiguous = scale * softmax over each head's 64 features."""
+    L = _C.lib()
+    L.require(q)
+    b, n, Cc = q.shape
+    qs = torch.empty((b, n, Cc), dtype=torch.bfloat16, device=q.device)
+    pq, ldq = _rows3(q)
+    rc = L.lib.gg_linattn_q_fwd(pq, ldq, ptr(qs), Cc, b * n, Cc, float(scale), L.stream(q))
+    L.check(rc, 'gg_linattn_q_fwd')
+    return qs
+
+
+def linattn_q_bwd(qs: torch.Tensor, dqs: torch.Tensor, dq_out: torch.Tensor, scale: float) -> None:
+    L = _C.lib()
+    L.require(qs, dqs, dq_out)
+    b, n, Cc = qs.shape
+    (p0, l0), (p1, l1), (p2, l2) = _rows3(qs), _rows3(dqs), _rows3(dq_out)
+    rc = L.lib.gg_linattn_q_bwd(p0, l0, p1, l1, p2, l2, b * n, Cc, float(scale), L.stream(qs))
+    L.check(rc, 'gg_linattn_q_bwd')
+
+
+def linattn_k_fwd(k: torch.Tensor) -> torch.Tensor:
+    """k (b, n, C) channel slice -> eks (b, n, C) contiguous = softmax over the n positions of every channel."""
+    L = _C.lib()
+    L.require(k)
+    b, n, Cc = k.shape
+    eks = torch.empty((b, n, Cc), dtype=torch.bfloat16, device=k.device)
+    chunks = L.lib.gg_linattn_chunks(b, n)
+    part = torch.empty((b, chunks, Cc, 2), dtype=torch.float32, device=k.device)
+    stat = torch.empty((b, Cc, 2), dtype=torch.float32, device=k.device)
+    pk, ldk = _rows3(k)
+    rc = L.lib.gg_linattn_k_fwd(pk, ldk, ptr(eks), Cc, ptr(part), ptr(stat), b, n, Cc, L.stream(k))
+    L.check(rc, 'gg_linattn_k_fwd')
+    return eks
+
+
+def linattn_k_bwd(eks: torch.Tensor, deks: torch.Tensor, dk_out: torch.Tensor) -> None:
+    L = _C.lib()
+    L.require(eks, deks, dk_out)
+    b, n, Cc = eks.shape
+    chunks = L.lib.gg_linattn_chunks(b, n)
+    part = torch.empty((b, chunks, Cc), dtype=torch.float32, device=eks.device)
+    stat = torch.empty((b, Cc), dtype=torch.float32, device=eks.device)
+    (p0, l0), (p1, l1), (p2, l2) = _rows3(eks), _rows3(deks), _rows3(dk_out)
+    rc = L.lib.gg_linattn_k_bwd(p0, l0, p1, l1, p2, l2, ptr(part), ptr(stat), b, n, Cc, L.stream(eks))
+    L.check(rc, 'gg_linattn_k_bwd')
+
+
 def scaled_add(a: torch.Tensor, b, c: float, d=None) -> torch.Tensor:
     """(a + b) * c + d (b, d optional) over dense bf16 tensors of one shape and ONE memory layout (any dimension order: the
     kernel walks the storage)."""

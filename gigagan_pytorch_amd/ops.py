@@ -846,6 +846,61 @@ class TakeRowsFn(Function):
         return torch.cat((g, pad), dim=0), None
 
 
+def _heads_view(t: torch.Tensor, heads: int) -> torch.Tensor:
+    """(n, C) rows of one image (row pitch free, unit channel stride) -> (heads, n, 64) strided view, no copy."""
+    n, C = t.shape
+    return t.as_strided((heads, n, C // heads), (C // heads, t.stride(0), 1), t.storage_offset())
+
+
+class LinearAttnFn(Function):
+    """LinearAttention core (unet.py:338-348) on the fused to_qkv output qkv (b, n, 3C) NHWC bf16, heads of 64 features:
+    out = (scale * softmax_features(q)) @ (softmax_positions(k)^T v). Two HIP softmax passes (gg_linattn_q / _k) and, per
+    image, two batched MFMA GEMMs over strided head views — q, k, v, out and all their gradients stay in the (b, n, C)
+    channel-slice layout the 1x1 projections read and write (the stock formulation moves each operand through fp32 and two
+    transposing copies: 195 GB of elementwise traffic per upsampler step). First order (generator side)."""
+
+    @staticmethod
+    def forward(ctx_, qkv, heads, scale):
+        b, n, C3 = qkv.shape
+        C = C3 // 3
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        qs = K.linattn_q_fwd(q, scale)
+        eks = K.linattn_k_fwd(k)
+        d = C // heads
+        ctx = torch.empty((b, heads, d, d), dtype=ACT_DTYPE, device=qkv.device)
+        out = torch.empty((b, n, C), dtype=ACT_DTYPE, device=qkv.device)
+        for i in range(b):
+            K.gemm(_heads_view(eks[i], heads), _heads_view(v[i], heads), trans_a=True, trans_b=False, out=ctx[i])   # (h, d, e)
+            K.gemm(_heads_view(qs[i], heads), ctx[i], trans_a=False, trans_b=False, out=_heads_view(out[i], heads))
+        ctx_.cfg = (heads, scale)
+        ctx_.save_for_backward(qkv, qs, eks, ctx)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx_, g):
+        qkv, qs, eks, ctx = ctx_.saved_tensors
+        heads, scale = ctx_.cfg
+        b, n, C3 = qkv.shape
+        C = C3 // 3
+        d = C // heads
+        g = g.contiguous()
+        v = qkv[..., 2 * C:]
+        dqkv = torch.empty_like(qkv)
+        dqs = torch.empty((b, n, C), dtype=ACT_DTYPE, device=qkv.device)
+        deks = torch.empty((b, n, C), dtype=ACT_DTYPE, device=qkv.device)
+        dctx = torch.empty((heads, d, d), dtype=ACT_DTYPE, device=qkv.device)
+        for i in range(b):
+            gi, qi, ei, vi = (_heads_view(t[i], heads) for t in (g, qs, eks, v))
+            K.gemm(qi, gi, trans_a=True, trans_b=False, out=dctx)                                          # dctx[d, e] = sum_n qs g
+            K.gemm(gi, ctx[i], trans_a=False, trans_b=True, out=_heads_view(dqs[i], heads))               # dqs = g ctx^T
+            K.gemm(vi, dctx, trans_a=False, trans_b=True, out=_heads_view(deks[i], heads))                # deks = v dctx^T
+            K.gemm(ei, dctx, trans_a=False, trans_b=False, out=_heads_view(dqkv[i, :, 2 * C:], heads))    # dv = eks dctx
+        K.linattn_q_bwd(qs, dqs, dqkv[..., :C], scale)
+        K.linattn_k_bwd(eks, deks, dqkv[..., C:2 * C])
+        return dqkv, None, None
+
+
 class ScaledAddFn(Function):
     """(a + b) * c + d in one pass over dense bf16 tensors of one layout (b, d may be None); linear, so every derivative is the
     op itself: a and b receive g * c — ONE tensor, computed once — and d receives g."""
@@ -1262,6 +1317,16 @@ class HipOps:
         x = to_act(x)
         hf = (x.float() - self.blur(x).float()).to(ACT_DTYPE)
         return F.max_pool2d(x, kernel_size=2), hf
+
+    def linear_attention_qkv(self, qkv, *, heads, scale):
+        """the same on the fused to_qkv output (b, 3C, x, y) (channels: q | k | v): returns (b, C, x, y), or None when the
+        fused kernels do not apply (heads of 64 features only, first-order graphs)."""
+        b, c3, x, y = qkv.shape
+        c = c3 // 3
+        if second_order or c % heads or c // heads != 64 or c > 512:
+            return None
+        out = LinearAttnFn.apply(nhwc(to_act(qkv)).view(b, x * y, c3), heads, float(scale))
+        return nchw(out.view(b, x, y, c))
 
     def linear_attention(self, q, k, v, *, heads, scale):
         """LinearAttention core (unet.py:338-348): q softmax over the head features (times scale), k softmax over the

@@ -119,8 +119,12 @@ class LinearAttention(nn.Module):
 
     def forward(self, x):
         x = self.norm(x)
-        q, k, v = self.to_qkv(x).chunk(3, dim=1)
-        out = ops.impl.linear_attention(q, k, v, heads=self.heads, scale=self.scale)
+        qkv = self.to_qkv(x)
+        fused = getattr(ops.impl, 'linear_attention_qkv', None)
+        out = fused(qkv, heads=self.heads, scale=self.scale) if fused is not None else None
+        if out is None:
+            q, k, v = qkv.chunk(3, dim=1)
+            out = ops.impl.linear_attention(q, k, v, heads=self.heads, scale=self.scale)
         return self.to_out(out)
 
 

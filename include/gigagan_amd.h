@@ -237,6 +237,24 @@ int gg_attn_bwd(const void* q, const void* k, const void* v, const void* k0, con
  * (NHWC pixels as rows), fp32 statistics, C %% 8 == 0, C <= 2048. bwd: dx and per-workgroup partial sums of dgamma
  * ([gg_rmsnorm_blocks(rows)][C] fp32, optional). bwd2 differentiates bwd for an incoming gradient v w.r.t. dx:
  * gx (w.r.t. x), gg (w.r.t. g) and the partial sums of that pass's dgamma — gradient-penalty steps only. */
+/* LinearAttention's two softmaxes (reference unet.py:338-348) on NHWC bf16 channel slices (C = heads * 64 channels starting at
+ * the given pointers, row pitches ld_* in elements: the q / k / v slices of the fused to_qkv output and of its gradient are read
+ * and written in place, no head split / transpose copies):
+ *   gg_linattn_q_fwd: qs[r, h, :] = scale * softmax(q[r, h, :]) over the 64 features of head h at row (position) r;
+ *   gg_linattn_q_bwd: dq from qs and the gradient w.r.t. qs;
+ *   gg_linattn_k_fwd: eks[b, p, c] = softmax over the n positions p of k[b, :, c] (fp32 two-stage column statistics, `part`:
+ *                     b * gg_linattn_chunks(b, n) * C * 2 floats, `stat`: b * C * 2 floats, both caller-owned);
+ *   gg_linattn_k_bwd: dk = eks * (deks - sum_p eks * deks) (`part`: b * chunks * C floats, `stat`: b * C floats).
+ * The two contractions between them (context = eks^T v, out = qs context) are gg_gemm_bf16 launches on strided views. */
+int gg_linattn_q_fwd(const void* q, int32_t ld_q, void* qs, int32_t ld_qs, int64_t rows, int32_t C, float scale, void* stream);
+int gg_linattn_q_bwd(const void* qs, int32_t ld_qs, const void* dqs, int32_t ld_dqs, void* dq, int32_t ld_dq, int64_t rows, int32_t C,
+                     float scale, void* stream);
+int32_t gg_linattn_chunks(int32_t b, int32_t n);
+int gg_linattn_k_fwd(const void* k, int32_t ld_k, void* eks, int32_t ld_eks, float* part, float* stat, int32_t b, int32_t n, int32_t C,
+                     void* stream);
+int gg_linattn_k_bwd(const void* eks, int32_t ld_eks, const void* deks, int32_t ld_deks, void* dk, int32_t ld_dk, float* part,
+                     float* stat, int32_t b, int32_t n, int32_t C, void* stream);
+
 /* y = (a + b) * c + d over n bf16 elements (b, d may be null): the predictor blocks' residual merge `(x + inner) * 2^-0.5`
  * (reference gp.py:1493), the last one together with the `+ residual` of gp.py:1495, as one pass; with b and d null its backward. */
 int gg_scaled_add(const void* a, const void* b, const void* d, void* y, int64_t n, float c, void* stream);

@@ -1,6 +1,6 @@
 """Which PyTorch (non-gg) device ops does one eager training step launch, from where, and how many bytes do they touch?
 TorchDispatchMode census of one plain D+G step at config 2 / batch 32 (test infrastructure; feeds the glue-fusion work).
-usage: python tests/gpu_op_census.py [gp]"""
+usage: python tests/gpu_op_census.py [gp] [uncond|text|upsampler]"""
 import collections
 import sys
 import traceback
@@ -16,12 +16,14 @@ from gigagan_pytorch_amd.data import SyntheticImages   # noqa: E402
 from gigagan_pytorch_amd.gigagan import cycle   # noqa: E402
 
 dev = torch.device('cuda', 0)
-gan = bench.build_gan(256, dev, use_hip_graphs=False)
-it = cycle(SyntheticImages(32, 256, device=dev))
-gp = len(sys.argv) > 1 and sys.argv[1] == 'gp'
+workload = next((a for a in sys.argv[1:] if a in ('uncond', 'text', 'upsampler')), 'uncond')
+B = 32 if workload == 'uncond' else 16
+gan = bench.build_gan(256, dev, use_hip_graphs=False, workload=workload)
+it = iter(bench.SyntheticTextImages(B, 256, dev)) if workload == 'text' else cycle(SyntheticImages(B, 256, device=dev))
+gp = 'gp' in sys.argv[1:]
 for _ in range(2):
     gan.train_discriminator_step(dl_iter=it, apply_gradient_penalty=False)
-    gan.train_generator_step(batch_size=32, dl_iter=it)
+    gan.train_generator_step(batch_size=B, dl_iter=it)
 SKIP = ('view', 'reshape', 'permute', 'transpose', 'expand', 'slice', 'select', 'unsqueeze', 'squeeze', 'detach', 'alias',
         'as_strided', 't.default', 'unbind', 'split', '_unsafe_view', 'empty', 'lift_fresh', '_local_scalar', 'chunk', 'narrow',
         'unflatten', 'new_empty', 'is_same_size', 'record_function', 'profiler')
@@ -38,7 +40,7 @@ class M(TorchDispatchMode):
             outs = [o for o in (out if isinstance(out, (tuple, list)) else (out,)) if isinstance(o, torch.Tensor)]
             nbytes = sum(t.numel() * t.element_size() for t in ts + outs)
             st = traceback.extract_stack()
-            fr = [f for f in st if 'gigagan_pytorch_amd' in f.filename]
+            fr = [f for f in st if 'gigagan_pytorch_amd' in f.filename and 'autograd' not in f.filename]
             loc = f'{fr[-1].filename.split("/")[-1]}:{fr[-1].lineno}' if fr else 'engine'
             nd = torch._C._current_autograd_node()
             if nd is not None:
@@ -53,7 +55,7 @@ class M(TorchDispatchMode):
 
 with M():
     gan.train_discriminator_step(dl_iter=it, apply_gradient_penalty=gp)
-    gan.train_generator_step(batch_size=32, dl_iter=it)
+    gan.train_generator_step(batch_size=B, dl_iter=it)
 torch.cuda.synchronize()
 print('non-view torch ops in the step:', sum(cnt.values()), ' total bytes touched: %.1f GB' % (sum(byt.values()) / 1e9))
 print('--- by bytes')

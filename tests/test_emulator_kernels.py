@@ -802,3 +802,33 @@ def test_generator_parameter_gradients_through_the_discriminator_vs_oracle():
     la, ga = run(ops.HipOps()); lb, gb = run(OracleOps(bf16_operands=True))
     assert abs(la - lb) < 2e-2 * abs(lb)
     assert rel_err(ga, gb) < 5e-2, rel_err(ga, gb)
+
+
+def test_fused_linear_attention_on_qkv_slices_vs_oracle():
+    """LinearAttnFn (gg_linattn_q / _k softmax passes + strided head-view GEMMs on the fused to_qkv tensor) vs the oracle's
+    einsum formulation (unet.py:338-348): output and the gradient w.r.t. the fused qkv tensor."""
+    torch.manual_seed(0)
+    H_, O_ = ops.HipOps(), OracleOps(bf16_operands=True)
+    b, heads, d, x, y = 2, 2, 64, 8, 16
+    c = heads * d
+    qkv0 = bf(torch.randn(b, 3 * c, x, y) * 1.5).float()
+    w = torch.randn(b, c, x, y)
+
+    def run(fused):
+        qkv = qkv0.clone().requires_grad_()
+        if fused:
+            with ops.use_impl(H_):
+                out = H_.linear_attention_qkv(qkv, heads=heads, scale=d ** -0.5)
+            assert out is not None
+        else:
+            q, k, v = qkv.chunk(3, dim=1)
+            out = O_.linear_attention(q, k, v, heads=heads, scale=d ** -0.5)
+        g, = torch.autograd.grad((out.float() * w).sum(), qkv)
+        return out.float().detach(), g
+
+    oa, ga = run(True); ob, gb = run(False)
+    assert rel_err(oa, ob) < 1.5e-2, rel_err(oa, ob)
+    assert rel_err(ga, gb) < 3e-2, rel_err(ga, gb)
+    c3 = 3 * c
+    for name, sl in (('dq', slice(0, c)), ('dk', slice(c, 2 * c)), ('dv', slice(2 * c, c3))):
+        assert rel_err(ga[:, sl], gb[:, sl]) < 4e-2, (name, rel_err(ga[:, sl], gb[:, sl]))
