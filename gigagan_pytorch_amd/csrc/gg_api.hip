@@ -1020,7 +1020,7 @@ extern "C" int gg_attn_bwd(const void* q, const void* k, const void* v, const vo
 // ---- ChannelRMSNorm passes ------------------------------------------------------------------------------------------
 
 static int gg_rms_launch(int mode, const void* x, const void* g, const void* v, const float* gamma, void* out0, void* out1,
-                         float* dgamma_part, int64_t rows, int32_t C, int32_t blocks, float eps, void* stream) {
+                         float* dgamma_part, int64_t rows, int32_t C, int32_t blocks, float eps, void* stream, int act = 0) {
     if (!x || !gamma || !out0) return gg_fail(-1, "gg_rmsnorm: null pointer");
     if (rows <= 0 || C <= 0 || (C % 8) || C > 512 * GG_RMS_MAXV) return gg_fail(-2, "gg_rmsnorm: need C %% 8 == 0 and C <= %d (C=%d)", 512 * GG_RMS_MAXV, C);
     if (blocks <= 0) return gg_fail(-2, "gg_rmsnorm: blocks must be positive");
@@ -1028,6 +1028,8 @@ static int gg_rms_launch(int mode, const void* x, const void* g, const void* v, 
     memset(&p, 0, sizeof(p));
     p.x = (const bf16_t*)x; p.g = (const bf16_t*)g; p.v = (const bf16_t*)v; p.gamma = gamma;
     p.out0 = (bf16_t*)out0; p.out1 = (bf16_t*)out1; p.dgamma_part = dgamma_part; p.rows = rows; p.C = C; p.eps = eps;
+    p.act = act;
+    if (act < 0 || act > 1 || (act && mode == 2)) return gg_fail(-3, "gg_rmsnorm: activation must be none (0) or silu (1), first order only");
     hipStream_t s = (hipStream_t)stream;
     if (mode == 0) GG_LAUNCH(gg_rmsnorm_kernel<0>, dim3((unsigned)blocks), dim3(256), s, p);
     else if (mode == 1) GG_LAUNCH(gg_rmsnorm_kernel<1>, dim3((unsigned)blocks), dim3(256), s, p);
@@ -1042,14 +1044,14 @@ extern "C" int32_t gg_rmsnorm_blocks(int64_t rows) {
     return (int32_t)nb;
 }
 
-extern "C" int gg_rmsnorm_fwd(const void* x, const float* gamma, void* y, int64_t rows, int32_t C, float eps, void* stream) {
-    return gg_rms_launch(0, x, nullptr, nullptr, gamma, y, nullptr, nullptr, rows, C, gg_rmsnorm_blocks(rows), eps, stream);
+extern "C" int gg_rmsnorm_fwd(const void* x, const float* gamma, void* y, int64_t rows, int32_t C, float eps, int32_t act, void* stream) {
+    return gg_rms_launch(0, x, nullptr, nullptr, gamma, y, nullptr, nullptr, rows, C, gg_rmsnorm_blocks(rows), eps, stream, act);
 }
 
 extern "C" int gg_rmsnorm_bwd(const void* x, const void* g, const float* gamma, const void* carry, void* dx, float* dgamma_part,
-                              int64_t rows, int32_t C, float eps, void* stream) {
+                              int64_t rows, int32_t C, float eps, int32_t act, void* stream) {
     if (!g) return gg_fail(-1, "gg_rmsnorm_bwd: null gradient");
-    return gg_rms_launch(1, x, g, carry, gamma, dx, nullptr, dgamma_part, rows, C, gg_rmsnorm_blocks(rows), eps, stream);
+    return gg_rms_launch(1, x, g, carry, gamma, dx, nullptr, dgamma_part, rows, C, gg_rmsnorm_blocks(rows), eps, stream, act);
 }
 
 extern "C" int gg_rmsnorm_bwd2(const void* x, const void* g, const void* v, const float* gamma, void* gx, void* gg,

@@ -529,6 +529,7 @@ struct GgRmsParams {
     long long rows;
     int C;
     float eps;
+    int act;              // 1: y = silu(norm(x)) (the unet Block's activation, unet.py:268-269); fwd and bwd only
 };
 
 template <int MODE>   // 0 fwd, 1 bwd, 2 bwd2
@@ -576,6 +577,24 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_rmsnorm_kernel(GgRmsParams p) {
         const bool clamped = nrm < p.eps;
         const float n = clamped ? p.eps : nrm;
         const float rn = s / n;                   // s / n
+        if (MODE == 1 && p.act) {
+            // y = silu(z), z = x * rn * gamma: the incoming gradient is first taken through silu'(z) = s (1 + z (1 - s)), then the
+            // plain backward runs on it (h and u.h are rebuilt from the adjusted gradient)
+            uh = 0.f;
+#pragma unroll
+            for (int t = 0; t < GG_RMS_MAXV; ++t) {
+                if (t >= nv) break;
+                const int c = t * 512 + lane * 8;
+                if (c < p.C)
+                    for (int e = 0; e < 8; ++e) {
+                        const float z = xf[t][e] * rn * p.gamma[c + e];
+                        const float sg = 1.f / (1.f + gg_expf(-z));
+                        gf[t][e] *= sg * (1.f + z * (1.f - sg));
+                        hf[t][e] = gf[t][e] * p.gamma[c + e];
+                        uh += xf[t][e] * hf[t][e];
+                    }
+            }
+        }
         if (MODE >= 1) { uh = gg_wave_sum(uh) / n; }            // u.h  (u = x / n)
         if (MODE == 2) { uv = gg_wave_sum(uv) / n; vh = gg_wave_sum(vh); }
         if (clamped) { uh = 0.f; uv = 0.f; }      // y is linear in x below eps: the projection terms vanish
@@ -590,7 +609,9 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_rmsnorm_kernel(GgRmsParams p) {
                 for (int e = 0; e < 8; ++e) {
                     const float u = xf[t][e] / n;
                     if (MODE == 0) {
-                        o0[e] = gg_f2bf(xf[t][e] * rn * p.gamma[c + e]);
+                        float z = xf[t][e] * rn * p.gamma[c + e];
+                        if (p.act) z = z / (1.f + gg_expf(-z));
+                        o0[e] = gg_f2bf(z);
                     } else if (MODE == 1) {
                         o0[e] = gg_f2bf(rn * (hf[t][e] - u * uh) + gg_bf2f(cv[e]));
                         dgam[t][e] += rn * xf[t][e] * gf[t][e];

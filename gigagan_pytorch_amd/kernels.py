@@ -856,19 +856,19 @@ def pool_mean_bwd(gs: torch.Tensor, shape, g=None, inplace: bool = False) -> tor
     return y
 
 
-def rmsnorm_fwd(x: torch.Tensor, gamma: torch.Tensor) -> torch.Tensor:
-    """x (..., C) bf16 contiguous, gamma (C,) fp32 -> y bf16."""
+def rmsnorm_fwd(x: torch.Tensor, gamma: torch.Tensor, silu: bool = False) -> torch.Tensor:
+    """x (..., C) bf16 contiguous, gamma (C,) fp32 -> y bf16; `silu`: y = silu(norm(x)) in the same pass."""
     L = _C.lib()
     L.require(x, gamma)
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and gamma.dtype == torch.float32 and gamma.is_contiguous()
     Cc = x.shape[-1]
     y = torch.empty_like(x)
-    rc = L.lib.gg_rmsnorm_fwd(ptr(x), ptr(gamma), ptr(y), x.numel() // Cc, Cc, RMS_EPS, L.stream(x))
+    rc = L.lib.gg_rmsnorm_fwd(ptr(x), ptr(gamma), ptr(y), x.numel() // Cc, Cc, RMS_EPS, int(silu), L.stream(x))
     L.check(rc, 'gg_rmsnorm_fwd')
     return y
 
 
-def rmsnorm_bwd(x, g, gamma, want_dgamma: bool, carry=None):
+def rmsnorm_bwd(x, g, gamma, want_dgamma: bool, carry=None, silu: bool = False):
     """(dx [+ carry], dgamma or None); `carry` (x's shape, bf16) is the skip branch's gradient, added inside the pass."""
     L = _C.lib()
     L.require(x, g, gamma, carry)
@@ -878,7 +878,7 @@ def rmsnorm_bwd(x, g, gamma, want_dgamma: bool, carry=None):
     rows = x.numel() // Cc
     dx = torch.empty_like(x)
     part = torch.empty((L.lib.gg_rmsnorm_blocks(rows), Cc), dtype=torch.float32, device=x.device) if want_dgamma else None
-    rc = L.lib.gg_rmsnorm_bwd(ptr(x), ptr(g), ptr(gamma), ptr(carry), ptr(dx), ptr(part), rows, Cc, RMS_EPS, L.stream(x))
+    rc = L.lib.gg_rmsnorm_bwd(ptr(x), ptr(g), ptr(gamma), ptr(carry), ptr(dx), ptr(part), rows, Cc, RMS_EPS, int(silu), L.stream(x))
     L.check(rc, 'gg_rmsnorm_bwd')
     return dx, (part.sum(0) if part is not None else None)
 

@@ -513,13 +513,15 @@ class ModMixFn(Function):
 class RmsNormFn(Function):
     """ChannelRMSNorm over the last (channel) axis of an NHWC bf16 tensor, one fused pass (gg_rmsnorm_kernel).
     `fork=True` returns (y, x): x's second consumer (the skip connection around the normalised branch) takes the returned
-    alias, and its gradient is added inside this op's backward pass instead of by autograd's accumulation."""
+    alias, and its gradient is added inside this op's backward pass instead of by autograd's accumulation.
+    `silu=True`: y = silu(norm(x)) in the same pass (the unet Block, unet.py:268-269); first-order backward only."""
 
     @staticmethod
-    def forward(ctx, x, gamma, fork=False):
+    def forward(ctx, x, gamma, fork=False, silu=False):
         ctx.save_for_backward(x, gamma)
         ctx.set_materialize_grads(False)
-        y = K.rmsnorm_fwd(x, gamma)
+        ctx.silu = silu
+        y = K.rmsnorm_fwd(x, gamma, silu)
         return (y, x.view_as(x)) if fork else y
 
     @staticmethod
@@ -527,10 +529,14 @@ class RmsNormFn(Function):
         x, gamma = ctx.saved_tensors
         want_dgamma = ctx.needs_input_grad[1] and not inputs_only
         if g is None:
-            return g_alias, None, None
+            return g_alias, None, None, None
         carry = None if g_alias is None else g_alias.contiguous()
-        dx, dgamma = RmsNormBwdFn.apply(x, g.contiguous(), gamma, want_dgamma, carry)
-        return dx, (dgamma if want_dgamma else None), None
+        if ctx.silu:
+            assert not torch.is_grad_enabled(), 'RmsNormFn(silu=True) is first-order only'
+            dx, dgamma = K.rmsnorm_bwd(x, g.contiguous(), gamma, want_dgamma, carry, silu=True)
+        else:
+            dx, dgamma = RmsNormBwdFn.apply(x, g.contiguous(), gamma, want_dgamma, carry)
+        return dx, (dgamma if want_dgamma else None), None, None
 
 
 class RmsNormBwdFn(Function):
@@ -1298,6 +1304,8 @@ class HipOps:
                 return self.channel_rmsnorm(x, gamma, act), x
             y, xa = RmsNormFn.apply(nhwc(x), gamma.float().reshape(c).contiguous(), True)
             return nchw(y), nchw(xa)
+        if act == 'silu' and c % 8 == 0 and not second_order:
+            return nchw(RmsNormFn.apply(nhwc(x), gamma.float().reshape(c).contiguous(), False, True))
         if c % 8:
             xf = x.float()
             nrm = xf.norm(dim=1, keepdim=True).clamp(min=1e-12)

@@ -276,11 +276,13 @@ int gg_pool_mean_fwd(const void* x, float* part, float* out, int32_t b, int32_t 
 int gg_pool_mean_bwd(const void* g, const float* gs, void* y, int32_t b, int32_t P, int32_t C, void* stream);
 
 int32_t gg_rmsnorm_blocks(int64_t rows);
-int gg_rmsnorm_fwd(const void* x, const float* gamma, void* y, int64_t rows, int32_t C, float eps, void* stream);
+/* act = 1: y = silu(norm(x)) in the same pass (the unet Block's norm + activation, reference unet.py:224-234, :268-269); the
+ * backward then takes the incoming gradient through silu'(z) with z recomputed from x (first order only) */
+int gg_rmsnorm_fwd(const void* x, const float* gamma, void* y, int64_t rows, int32_t C, float eps, int32_t act, void* stream);
 /* `carry` (optional, [rows][C] bf16) is added to dx inside the pass: the gradient arriving over the skip connection around
  * the normalised branch (x + f(norm(x)), gp.py:757-758), which autograd would otherwise add in a pass of its own */
 int gg_rmsnorm_bwd(const void* x, const void* g, const float* gamma, const void* carry, void* dx, float* dgamma_part,
-                   int64_t rows, int32_t C, float eps, void* stream);
+                   int64_t rows, int32_t C, float eps, int32_t act, void* stream);
 int gg_rmsnorm_bwd2(const void* x, const void* g, const void* v, const float* gamma, void* gx, void* gg, float* dgamma_part,
                     int64_t rows, int32_t C, float eps, void* stream);
 

@@ -832,3 +832,21 @@ def test_fused_linear_attention_on_qkv_slices_vs_oracle():
     c3 = 3 * c
     for name, sl in (('dq', slice(0, c)), ('dk', slice(c, 2 * c)), ('dv', slice(2 * c, c3))):
         assert rel_err(ga[:, sl], gb[:, sl]) < 4e-2, (name, rel_err(ga[:, sl], gb[:, sl]))
+
+
+def test_rmsnorm_with_fused_silu_matches_oracle():
+    """gg_rmsnorm with act = silu (forward and first-order backward incl. dgamma) vs norm followed by silu on the oracle."""
+    torch.manual_seed(0)
+    H_, O_ = ops.HipOps(), OracleOps()
+    x0 = bf(torch.randn(2, 24, 6, 5)).float(); gamma0 = torch.rand(24) + 0.5
+    w = torch.randn(2, 24, 6, 5)
+
+    def run(I):
+        x = x0.clone().requires_grad_(); gamma = gamma0.clone().requires_grad_()
+        with ops.use_impl(I):
+            y = I.channel_rmsnorm(x, gamma.view(24, 1, 1), act='silu').float()
+        return y, torch.autograd.grad((y * w).sum(), [x, gamma])
+
+    ya, ga = run(H_); yb, gb = run(O_)
+    assert rel_err(ya, yb) < 6e-3
+    assert rel_err(ga[0], gb[0]) < 2e-2 and rel_err(ga[1], gb[1]) < 2e-2
