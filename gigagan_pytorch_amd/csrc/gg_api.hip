@@ -1031,7 +1031,9 @@ static int gg_rms_launch(int mode, const void* x, const void* g, const void* v, 
     p.act = act;
     if (act < 0 || act > 1 || (act && mode == 2)) return gg_fail(-3, "gg_rmsnorm: activation must be none (0) or silu (1), first order only");
     hipStream_t s = (hipStream_t)stream;
-    if (mode == 0) GG_LAUNCH(gg_rmsnorm_kernel<0>, dim3((unsigned)blocks), dim3(256), s, p);
+    if (mode == 0 && act) GG_LAUNCH((gg_rmsnorm_kernel<0, true>), dim3((unsigned)blocks), dim3(256), s, p);
+    else if (mode == 1 && act) GG_LAUNCH((gg_rmsnorm_kernel<1, true>), dim3((unsigned)blocks), dim3(256), s, p);
+    else if (mode == 0) GG_LAUNCH(gg_rmsnorm_kernel<0>, dim3((unsigned)blocks), dim3(256), s, p);
     else if (mode == 1) GG_LAUNCH(gg_rmsnorm_kernel<1>, dim3((unsigned)blocks), dim3(256), s, p);
     else GG_LAUNCH(gg_rmsnorm_kernel<2>, dim3((unsigned)blocks), dim3(256), s, p);
     return gg_check_launch();

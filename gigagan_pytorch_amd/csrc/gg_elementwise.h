@@ -532,7 +532,8 @@ struct GgRmsParams {
     int act;              // 1: y = silu(norm(x)) (the unet Block's activation, unet.py:268-269); fwd and bwd only
 };
 
-template <int MODE>   // 0 fwd, 1 bwd, 2 bwd2
+template <int MODE, bool ACT = false>   // MODE 0 fwd, 1 bwd, 2 bwd2; ACT: silu after the norm (a compile-time variant: the plain
+                                        // kernels keep their register budget)
 GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_rmsnorm_kernel(GgRmsParams p) {
     GG_SHARED float red[4][GG_RMS_MAXV * 512];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -577,7 +578,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_rmsnorm_kernel(GgRmsParams p) {
         const bool clamped = nrm < p.eps;
         const float n = clamped ? p.eps : nrm;
         const float rn = s / n;                   // s / n
-        if (MODE == 1 && p.act) {
+        if (MODE == 1 && ACT) {
             // y = silu(z), z = x * rn * gamma: the incoming gradient is first taken through silu'(z) = s (1 + z (1 - s)), then the
             // plain backward runs on it (h and u.h are rebuilt from the adjusted gradient)
             uh = 0.f;
@@ -610,7 +611,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_rmsnorm_kernel(GgRmsParams p) {
                     const float u = xf[t][e] / n;
                     if (MODE == 0) {
                         float z = xf[t][e] * rn * p.gamma[c + e];
-                        if (p.act) z = z / (1.f + gg_expf(-z));
+                        if (ACT) z = z / (1.f + gg_expf(-z));
                         o0[e] = gg_f2bf(z);
                     } else if (MODE == 1) {
                         o0[e] = gg_f2bf(rn * (hf[t][e] - u * uh) + gg_bf2f(cv[e]));
