@@ -121,10 +121,37 @@ int gg_validate_gemm(const gg_gemm_desc* d) {
     return 0;
 }
 
+// byte extent of an operand as seen from its base pointer (whole batch)
+static long long gg_a_bytes(const gg_gemm_desc* d) {
+    if (d->a_conv) {
+        const int oh = (d->H + 2 * d->conv_pad - d->R) / d->conv_stride + 1, ow = (d->W + 2 * d->conv_pad - d->S) / d->conv_stride + 1;
+        const long long rows = d->a_layout == GG_ROWK ? d->M : d->K;          // output pixels
+        const long long imgs = (rows + (long long)oh * ow - 1) / ((long long)oh * ow);
+        return imgs * d->H * d->W * d->C * 2;
+    }
+    const long long rows = d->a_layout == GG_ROWK ? d->M : d->K;
+    return ((long long)(d->batch - 1) * d->a_batch_stride + rows * d->lda) * 2;
+}
+static long long gg_b_bytes(const gg_gemm_desc* d) {
+    const long long rows = d->b_layout == GG_ROWK ? d->N : d->K;
+    long long e = (long long)(d->batch - 1) * d->b_batch_stride + rows * d->ldb;
+    if (d->b_image_stride) {
+        const int oh = (d->H + 2 * d->conv_pad - d->R) / d->conv_stride + 1, ow = (d->W + 2 * d->conv_pad - d->S) / d->conv_stride + 1;
+        e += ((long long)d->M / ((long long)oh * ow) - 1) * d->b_image_stride;
+    }
+    return e * 2;
+}
+
 bool gg_v2_has_variant(const gg_gemm_desc* d);
 
 bool gg_v2_eligible(const gg_gemm_desc* d) {
-    if (d->a_conv && d->a_layout == GG_ROWK && ((d->CV & 63) || d->R * d->S > 32)) return false;
+    if (d->a_conv && d->a_layout == GG_ROWK) {
+        if ((d->CV & 63) || d->R * d->S > 32) return false;
+        if (d->CV != d->C && (d->C & 63)) return false;     // a 64-wide k-tile must not wrap around the physical channels
+    }
+    // ROWK operands are read through 32-bit buffer offsets (gg_gemm2.h): keep a margin below 4 GiB
+    if (d->a_layout == GG_ROWK && gg_a_bytes(d) + (1ll << 24) >= (1ll << 32)) return false;
+    if (d->b_layout == GG_ROWK && gg_b_bytes(d) >= (1ll << 32)) return false;
     return gg_v2_has_variant(d);
 }
 
@@ -441,6 +468,7 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     p.act = d->act; p.act_slope = d->act_slope;
     p.partial = (float*)workspace;
     p.b_img_stride = d->b_image_stride;
+    p.a_bytes = gg_a_bytes(d); p.b_bytes = gg_b_bytes(d);
 #ifdef GG2_PROBE
     if (pl.tile > 3) p.xcd_slices = getenv("GG2_DBG") ? atoi(getenv("GG2_DBG")) : 0;   // probe builds: k-loop phase mask
 #endif

@@ -88,6 +88,23 @@ GG_DEVICE void gg_barrier_raw() {
     asm volatile("" ::: "memory");
 }
 
+// Buffer addressing (SRSRC): a wave-uniform 128-bit descriptor {base, bytes} plus a 32-bit per-lane byte offset and a scalar byte
+// offset. What it buys the convolution gather: no 64-bit per-lane address arithmetic in the k-loop (the per-lane part of an
+// operand address is loop invariant, the per-k-tile part is one scalar), and out-of-range rows / padding taps are zero-filled by
+// the hardware bounds check (voffset >= bytes -> 0; the scalar offset is not range-checked) instead of by branches around loads.
+typedef __amdgpu_buffer_rsrc_t GgBuf;
+GG_DEVICE GgBuf gg_make_buf(const void* base, unsigned long long bytes) {
+    // the descriptor must be PROVABLY wave-uniform or hipcc wraps every buffer op in a waterfall loop: readfirstlane its inputs
+    const unsigned long long a = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const unsigned nb = __builtin_amdgcn_readfirstlane((unsigned)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), (short)0, (int)nb, 0x00020000);
+}
+GG_DEVICE u16x8 gg_buf_load16(GgBuf r, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return __builtin_bit_cast(u16x8, v);
+}
+
 template <int P>
 GG_DEVICE void gg_setprio() { __builtin_amdgcn_s_setprio(P); }    // wave issue priority (arbitration between the waves of a SIMD)
 

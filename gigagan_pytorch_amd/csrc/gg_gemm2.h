@@ -79,6 +79,116 @@ GG_DEVICE void gg2_store_rowk(bf16_t (*s)[GG2_PITCH], const u16x8* regs) {
     }
 }
 
+// ---- buffer-addressed ROWK loaders -------------------------------------------------------------------------------------
+// per-lane byte offsets are loop invariant (set up once per workgroup), the k-tile contributes one scalar offset, rows beyond the
+// matrix and padding taps are zero-filled by the descriptor's bounds check: the k-loop issues its 16-byte loads back to back with
+// a handful of scalar / vector instructions in front of them (the pointer-arithmetic form spent ~30 per load: as many issue cycles
+// as the tile's MFMAs).
+template <int ROWS>
+GG_DEVICE void gg2_brows_init(unsigned* voff, int ld, int nrows, int r0) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < Gg2RowK<ROWS>::NV; ++i) {
+        const int v = t + GG2_NT * i;
+        const int row = v >> 3, kc = v & 7;
+        voff[i] = (r0 + row < nrows) ? (unsigned)(((long long)row * ld + kc * 8) * 2) : 0xFFFFFFFFu;
+    }
+}
+
+// full 64-wide k-tiles only (the caller sends ragged tails through gg2_load_rowk_dense)
+template <int ROWS>
+GG_DEVICE void gg2_bload_rowk_dense(u16x8* regs, GgBuf buf, const unsigned* voff, long long r0_ld, int k0) {
+    const unsigned soff = (unsigned)((r0_ld + k0) * 2);
+#pragma unroll
+    for (int i = 0; i < Gg2RowK<ROWS>::NV; ++i) regs[i] = gg_buf_load16(buf, voff[i], soff);
+}
+
+struct Gg2ConvRowB {
+    unsigned voff;      // byte offset of (window corner + lane's 8-channel chunk) from the biased base; 0xFFFFFFFF for rows beyond M
+    unsigned mask;      // bit (kh*S + kw) set when that tap reads inside the image
+    int img;
+};
+
+// `bias` (elements): the descriptor base sits that far BEFORE the tensor so that corners of padded windows stay non-negative
+template <int ROWS>
+GG_DEVICE void gg2_conv_rows_init_b(Gg2ConvRowB* rows, const GgGemmParams& p, int m0, long long bias) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < Gg2RowK<ROWS>::NV; ++i) {
+        const int v = t + GG2_NT * i;
+        const int m = m0 + (v >> 3), kc = v & 7;
+        Gg2ConvRowB r;
+        r.voff = 0xFFFFFFFFu; r.mask = 0; r.img = 0;
+        if (m < p.M) {
+            const int hw = p.OH * p.OW;
+            const int img = m / hw, rem = m - img * hw;
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+            r.img = img;
+            const long long corner = (((long long)img * p.H + ih0) * p.W + iw0) * p.C;
+            r.voff = (unsigned)((corner + bias + kc * 8) * 2);
+            unsigned int mask = 0;
+            for (int kh = 0; kh < p.R; ++kh)
+                for (int kw = 0; kw < p.S; ++kw) {
+                    const int ih = ih0 + kh, iw = iw0 + kw;
+                    if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) mask |= 1u << (kh * p.S + kw);
+                }
+            r.mask = mask;
+        }
+        rows[i] = r;
+    }
+}
+
+// position of the NEXT k-tile to load inside the (tap, channel) reduction index: k-tiles are visited in order, 64 at a time, so
+// the tap decode (two integer divisions per tile in scalar code, ~70 instructions) is done once and then stepped
+struct Gg2ConvCursor {
+    int tap, cv0, ci0, kh, kw;      // ci0 = cv0 % C: the physical channel of the tile's first element (CV = n * C for stacked inputs)
+};
+
+GG_DEVICE Gg2ConvCursor gg2_conv_cursor(const GgGemmParams& p, int k0) {
+    Gg2ConvCursor c;
+    c.tap = k0 / p.CV;
+    c.cv0 = k0 - c.tap * p.CV;
+    c.ci0 = (p.CV == p.C) ? c.cv0 : c.cv0 % p.C;
+    c.kh = c.tap / p.S;
+    c.kw = c.tap - c.kh * p.S;
+    return c;
+}
+
+template <int ROWS>
+GG_DEVICE void gg2_bload_rowk_conv(u16x8* regs, const Gg2ConvRowB* rows, GgBuf buf, const GgGemmParams& p, int kend, int k0,
+                                   Gg2ConvCursor& cur) {
+    // workgroup-uniform: the tap of this k-tile and its byte offset from a window corner
+    const unsigned soff = (unsigned)((((long long)cur.kh * p.W + cur.kw) * p.C + cur.ci0) * 2);
+    const int rem = kend - k0;                            // <= 0: the tile is past the slice; < 64: a 32-wide split-K tail
+    const unsigned lane_live = ((int)((threadIdx.x & 7) * 8) < rem) ? 1u : 0u;
+    const int tap = cur.tap;
+#pragma unroll
+    for (int i = 0; i < Gg2RowK<ROWS>::NV; ++i) {
+        const unsigned ok = (rows[i].mask >> tap) & lane_live;             // 1: inside the image and the slice
+        regs[i] = gg_buf_load16(buf, rows[i].voff | (ok - 1u), soff);      // not ok -> offset 0xFFFFFFFF -> hardware zero fill
+    }
+    cur.cv0 += GG2_BK;
+    cur.ci0 += GG2_BK;
+    if (cur.ci0 >= p.C) cur.ci0 -= p.C;            // C % 64 == 0 whenever CV != C (planner), so the step lands exactly
+    if (cur.cv0 >= p.CV) {
+        cur.cv0 = 0;
+        cur.ci0 = 0;
+        ++cur.tap;
+        if (++cur.kw == p.S) { cur.kw = 0; ++cur.kh; }
+    }
+}
+
+// the per-sample input scale of a modulated conv, applied when the staged tile is parked in LDS (one k-tile after its loads
+// were issued: the data has arrived, nothing stalls); k0 is the tile's first reduction index
+template <int ROWS>
+GG_DEVICE void gg2_scale_rowk_conv(u16x8* regs, const Gg2ConvRowB* rows, const GgGemmParams& p, int k0) {
+    const int tap = k0 / p.CV;
+    const int cv = k0 - tap * p.CV + (threadIdx.x & 7) * 8;
+#pragma unroll
+    for (int i = 0; i < Gg2RowK<ROWS>::NV; ++i) regs[i] = gg_scale8(regs[i], p.in_scale + (long long)rows[i].img * p.CV + cv);
+}
+
 template <int COLS>
 GG_DEVICE void gg2_load_krow_dense(u16x8* regs, const bf16_t* base, int ld, int ncols, int c0, int kend, int k0) {
     const int t = threadIdx.x;
@@ -120,66 +230,6 @@ GG_DEVICE u16x8 gg2_frag_krow(const char* tile, int col0, int kk, int lane) {
     u16x4 b = gg_lds_read_tr16((const bf16_t*)(p0 + 4 * Gg2KRow<COLS>::PITCH));
     u16x8 f = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     return f;
-}
-
-// conv gather, ROWK, CV % 64 == 0: per staged row the element offset of its window corner and a tap-validity mask
-struct Gg2ConvRow {
-    long long corner;   // ((img*H + oh*stride - pad) * W + ow*stride - pad) * C  (may point before the tensor)
-    unsigned int mask;  // bit (kh*S + kw) set when that tap reads inside the image; 0 for rows beyond M
-    int img;
-};
-
-template <int ROWS>
-GG_DEVICE void gg2_conv_rows_init(Gg2ConvRow* rows, const GgGemmParams& p, int m0) {
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < Gg2RowK<ROWS>::NV; ++i) {
-        int v = t + GG2_NT * i;
-        int m = m0 + (v >> 3);
-        Gg2ConvRow r;
-        r.corner = 0; r.mask = 0; r.img = 0;
-        if (m < p.M) {
-            int hw = p.OH * p.OW;
-            int img = m / hw, rem = m - img * hw;
-            int oh = rem / p.OW, ow = rem - oh * p.OW;
-            int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
-            r.img = img;
-            r.corner = (((long long)img * p.H + ih0) * p.W + iw0) * p.C;
-            unsigned int mask = 0;
-            for (int kh = 0; kh < p.R; ++kh)
-                for (int kw = 0; kw < p.S; ++kw) {
-                    int ih = ih0 + kh, iw = iw0 + kw;
-                    if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) mask |= 1u << (kh * p.S + kw);
-                }
-            r.mask = mask;
-        }
-        rows[i] = r;
-    }
-}
-
-template <int ROWS>
-GG_DEVICE void gg2_load_rowk_conv(u16x8* regs, const Gg2ConvRow* rows, const GgGemmParams& p, int kend, int k0) {
-    const int t = threadIdx.x;
-    // workgroup-uniform: the tap of this k-tile and its element offset from a window corner
-    const int tap = k0 / p.CV;
-    const int cv0 = k0 - tap * p.CV;
-    const int kh = tap / p.S, kw = tap - kh * p.S;
-    const long long tap_off = ((long long)kh * p.W + kw) * p.C;
-    const bool tile_live = k0 < kend;
-#pragma unroll
-    for (int i = 0; i < Gg2RowK<ROWS>::NV; ++i) {
-        int v = t + GG2_NT * i;
-        int kc = v & 7;
-        u16x8 x = gg_zero8();
-        const Gg2ConvRow& r = rows[i];
-        int cv = cv0 + kc * 8;
-        if (tile_live && ((r.mask >> tap) & 1u) && k0 + kc * 8 < kend) {
-            int ci = (p.CV == p.C) ? cv : cv % p.C;
-            x = *(const u16x8*)(p.A + r.corner + tap_off + ci);
-            if (p.in_scale) x = gg_scale8(x, p.in_scale + (long long)r.img * p.CV + cv);
-        }
-        regs[i] = x;
-    }
 }
 
 // conv gather, KROW (weight gradient): k = output pixel, column = (tap, cv); a thread stages ONE column group
@@ -385,26 +435,41 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_gemm2_kernel(GgGemmParams p) {
     // per-image weight operand (per-sample weights of the adaptive conv): a tile never straddles two images (planner)
     const bf16_t* Bb = p.B + (long long)b * p.b_bs + ((A_CONV && !A_KROW && p.b_img_stride) ? (long long)(m0 / (p.OH * p.OW)) * p.b_img_stride : 0);
 
-    Gg2ConvRow crow[A_CONV && !A_KROW ? ANV : 1];
-    if (A_CONV && !A_KROW) gg2_conv_rows_init<BM>(crow, p, m0);
+    // ROWK operands go through buffer descriptors (gg2_bload_*); the conv window corners are made non-negative by a base that
+    // sits (pad * W + pad) * C elements before the tensor
+    const long long abias = (A_CONV && !A_KROW) ? ((long long)p.pad * p.W + p.pad) * p.C : 0;
+    Gg2ConvRowB crow[A_CONV && !A_KROW ? ANV : 1];
+    if (A_CONV && !A_KROW) gg2_conv_rows_init_b<BM>(crow, p, m0, abias);
+    unsigned avoff[!A_CONV && !A_KROW ? ANV : 1], bvoff[!B_KROW ? BNV : 1];
+    if (!A_CONV && !A_KROW) gg2_brows_init<BM>(avoff, p.lda, p.M, m0);
+    if (!B_KROW) gg2_brows_init<BN>(bvoff, p.ldb, p.N, n0);
+    GgBuf bufA = gg_make_buf(!A_KROW ? (const void*)(Ab - abias) : (const void*)Ab,
+                             (unsigned long long)(p.a_bytes - (long long)b * p.a_bs * 2 + abias * 2));
+    GgBuf bufB = gg_make_buf((const void*)Bb, (unsigned long long)(p.b_bytes - (Bb - p.B) * 2));
     GgConvCol ccol;
     ccol.kh = ccol.kw = ccol.ci = ccol.cv = ccol.valid = 0;
     if (A_CONV && A_KROW) ccol = gg2_conv_col_init<BM>(p, m0);
 
     u16x8 ra[ANV], rb[BNV];
 
+    Gg2ConvCursor ccur = {0, 0, 0, 0, 0};              // load_tiles is called for kbeg, kbeg + 64, kbeg + 128, ... in this order
+    if (A_CONV && !A_KROW) ccur = gg2_conv_cursor(p, kbeg);
     auto load_tiles = [&](int k0) {
+        const bool full = kend - k0 >= GG2_BK;          // workgroup-uniform; ragged tails keep the pointer-arithmetic loaders
         if (A_CONV) {
             if (A_KROW) gg2_load_krow_conv<BM>(ra, ccol, p, kend, k0);
-            else gg2_load_rowk_conv<BM>(ra, crow, p, kend, k0);
+            else gg2_bload_rowk_conv<BM>(ra, crow, bufA, p, kend, k0, ccur);
         } else {
             if (A_KROW) gg2_load_krow_dense<BM>(ra, Ab, p.lda, p.M, m0, kend, k0);
+            else if (full) gg2_bload_rowk_dense<BM>(ra, bufA, avoff, (long long)m0 * p.lda, k0);
             else gg2_load_rowk_dense<BM>(ra, Ab, p.lda, p.M, m0, kend, k0);
         }
         if (B_KROW) gg2_load_krow_dense<BN>(rb, Bb, p.ldb, p.N, n0, kend, k0);
+        else if (full) gg2_bload_rowk_dense<BN>(rb, bufB, bvoff, (long long)n0 * p.ldb, k0);
         else gg2_load_rowk_dense<BN>(rb, Bb, p.ldb, p.N, n0, kend, k0);
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, int k0) {
+        if (A_CONV && !A_KROW && p.in_scale && k0 < kend) gg2_scale_rowk_conv<BM>(ra, crow, p, k0);
         if (A_KROW) gg2_store_krow<BM>(tileA(buf), ra);
         else gg2_store_rowk<BM>((bf16_t(*)[GG2_PITCH])tileA(buf), ra);
         if (B_KROW) gg2_store_krow<BN>(tileB(buf), rb);
@@ -422,7 +487,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_gemm2_kernel(GgGemmParams p) {
     const int nk = (kend > kbeg) ? (kend - kbeg + GG2_BK - 1) / GG2_BK : 0;
     if (nk > 0) {
         load_tiles(kbeg);
-        store_tiles(0);
+        store_tiles(0, kbeg);
         if (nk > 1) load_tiles(kbeg + GG2_BK);
     }
     gg_sync();
@@ -445,7 +510,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_gemm2_kernel(GgGemmParams p) {
         const int buf = kt & 1;
         // tile kt+1 sits in the staging registers (its loads were issued one MFMA phase ago): park it in the
         // other LDS buffer (free since the barrier that ended iteration kt-1), then put tile kt+2 in flight
-        if (kt + 1 < nk && !(dbg & 1)) store_tiles(buf ^ 1);
+        if (kt + 1 < nk && !(dbg & 1)) store_tiles(buf ^ 1, kbeg + (kt + 1) * GG2_BK);
         if (kt + 2 < nk && !(dbg & 2)) load_tiles(kbeg + (kt + 2) * GG2_BK);
 #pragma unroll
         for (int kk = 0; kk < GG2_BK / 16; ++kk) {

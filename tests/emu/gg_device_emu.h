@@ -66,6 +66,17 @@ static inline void gg_load_lds16(const void* g, void* lds_wave_base) {
 template <int N>
 static inline void gg_wait_vm() { gg_emu_dma_wait(N); }
 static inline void gg_barrier_raw() { gg_emu_syncthreads(); }
+// buffer addressing stand-in: the hardware range-checks the per-lane offset (not the scalar one) and returns zeros beyond `bytes`
+struct GgBuf { const char* base; unsigned long long bytes; };
+static inline GgBuf gg_make_buf(const void* base, unsigned long long bytes) {
+    GgBuf r = {(const char*)base, bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes};
+    return r;
+}
+static inline u16x8 gg_buf_load16(GgBuf r, unsigned voff, unsigned soff) {
+    u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if ((unsigned long long)voff + 16 <= r.bytes) memcpy(&v, r.base + voff + soff, 16);
+    return v;
+}
 template <int P>
 static inline void gg_setprio() {}
 template <typename T>
