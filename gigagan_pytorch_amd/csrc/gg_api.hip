@@ -150,8 +150,7 @@ bool gg_v2_eligible(const gg_gemm_desc* d) {
         if (d->CV != d->C && (d->C & 63)) return false;     // a 64-wide k-tile must not wrap around the physical channels
     }
     // ROWK operands are read through 32-bit buffer offsets (gg_gemm2.h): keep a margin below 4 GiB
-    if (d->a_layout == GG_ROWK && gg_a_bytes(d) + (1ll << 24) >= (1ll << 32)) return false;
-    if (d->b_layout == GG_ROWK && gg_b_bytes(d) >= (1ll << 32)) return false;
+    if (gg_a_bytes(d) + (1ll << 24) >= (1ll << 32) || gg_b_bytes(d) >= (1ll << 32)) return false;
     return gg_v2_has_variant(d);
 }
 
@@ -469,6 +468,8 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     p.partial = (float*)workspace;
     p.b_img_stride = d->b_image_stride;
     p.a_bytes = gg_a_bytes(d); p.b_bytes = gg_b_bytes(d);
+    p.krow_fast = d->a_conv && d->a_layout == GG_KROW && d->conv_stride == 1 && p.OH == d->H && p.OW == d->W && p.w_shift >= 0 &&
+                  p.hw_shift >= 0 && !d->in_scale && (d->CV == d->C || !(d->C & 7));
 #ifdef GG2_PROBE
     if (pl.tile > 3) p.xcd_slices = getenv("GG2_DBG") ? atoi(getenv("GG2_DBG")) : 0;   // probe builds: k-loop phase mask
 #endif

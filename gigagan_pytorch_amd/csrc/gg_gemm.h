@@ -79,6 +79,7 @@ struct GgGemmParams {
     long long b_img_stride;    // conv forward only: > 0: image i's weights start at B + i * b_img_stride (per-sample weights)
     // byte extents of the A / B operands as seen from their base pointers (buffer descriptors of the 8-wave kernel's ROWK loaders)
     long long a_bytes, b_bytes;
+    int krow_fast;     // weight-gradient conv gather: stride-1 'same' windows, power-of-two image sides, no input scale
 };
 
 GG_DEVICE float gg_apply_act(float v, int act, float slope) {

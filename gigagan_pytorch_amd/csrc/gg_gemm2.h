@@ -277,6 +277,69 @@ GG_DEVICE void gg2_load_krow_conv(u16x8* regs, const GgConvCol& cc, const GgGemm
     }
 }
 
+// ---- buffer-addressed KROW loaders (weight gradients: both operands are indexed by the output pixel) -------------------------
+// dense (dy [pixel][co]): lane offset (k-row within the tile, column group) is loop invariant, the tile adds one scalar.
+template <int COLS>
+GG_DEVICE void gg2_bkrow_init(unsigned* voff, int ld, int ncols, int c0) {
+    const int cg = threadIdx.x % Gg2KRow<COLS>::CG, kr = threadIdx.x / Gg2KRow<COLS>::CG;
+#pragma unroll
+    for (int i = 0; i < Gg2KRow<COLS>::NV; ++i)
+        voff[i] = (c0 + cg * 8 + 8 <= ncols) ? (unsigned)(((long long)(kr + Gg2KRow<COLS>::KSTEP * i) * ld + cg * 8) * 2) : 0xFFFFFFFFu;
+}
+
+template <int COLS>
+GG_DEVICE void gg2_bload_krow_dense(u16x8* regs, GgBuf buf, const unsigned* voff, int ld, int c0, int kend, int k0) {
+    const unsigned soff = (unsigned)(((long long)k0 * ld + c0) * 2);
+    const int rem = kend - k0, kr = threadIdx.x / Gg2KRow<COLS>::CG;
+#pragma unroll
+    for (int i = 0; i < Gg2KRow<COLS>::NV; ++i) {
+        const unsigned ok = (kr + Gg2KRow<COLS>::KSTEP * i < rem) ? 1u : 0u;
+        regs[i] = gg_buf_load16(buf, voff[i] | (ok - 1u), soff);
+    }
+}
+
+// conv gather for stride-1 'same' windows (OH == H, OW == W: every 3x3 / 1x1 layer) with power-of-two image sides: the input
+// pixel of output pixel `pix` and tap (kh, kw) is pix + (kh - pad) * W + (kw - pad), so a lane's byte offset is
+// (k-row * C + tap shift + channel group) -- loop invariant -- plus the scalar k0 * C; only the inside-the-image test needs the
+// pixel's (oh, ow), two shifts and two unsigned compares per vector (the generic form spent ~110 vector instructions per load)
+struct Gg2ConvColB {
+    int dkh, dkw, valid;
+};
+
+template <int COLS>
+GG_DEVICE Gg2ConvColB gg2_conv_col_init_b(unsigned* voff, const GgGemmParams& p, int c0, long long bias) {
+    const int cg = threadIdx.x % Gg2KRow<COLS>::CG, kr = threadIdx.x / Gg2KRow<COLS>::CG;
+    const int c = c0 + cg * 8;
+    Gg2ConvColB cc;
+    cc.valid = c < p.M;
+    const int tap = cc.valid ? c / p.CV : 0;
+    const int cv = cc.valid ? c - tap * p.CV : 0;
+    const int kh = tap / p.S, kw = tap - kh * p.S;
+    const int ci = (p.CV == p.C) ? cv : cv % p.C;
+    cc.dkh = kh - p.pad;
+    cc.dkw = kw - p.pad;
+    const long long shift = ((long long)cc.dkh * p.W + cc.dkw) * p.C + ci + bias;
+#pragma unroll
+    for (int i = 0; i < Gg2KRow<COLS>::NV; ++i)
+        voff[i] = cc.valid ? (unsigned)(((long long)(kr + Gg2KRow<COLS>::KSTEP * i) * p.C + shift) * 2) : 0xFFFFFFFFu;
+    return cc;
+}
+
+template <int COLS>
+GG_DEVICE void gg2_bload_krow_conv(u16x8* regs, GgBuf buf, const unsigned* voff, const Gg2ConvColB& cc, const GgGemmParams& p,
+                                   int kend, int k0) {
+    const unsigned soff = (unsigned)((long long)k0 * p.C * 2);
+    const int kr = threadIdx.x / Gg2KRow<COLS>::CG;
+#pragma unroll
+    for (int i = 0; i < Gg2KRow<COLS>::NV; ++i) {
+        const int pix = k0 + kr + Gg2KRow<COLS>::KSTEP * i;
+        const int ow = pix & (p.OW - 1), oh = (pix >> p.w_shift) & (p.OH - 1);
+        const bool in = (unsigned)(oh + cc.dkh) < (unsigned)p.H && (unsigned)(ow + cc.dkw) < (unsigned)p.W && pix < kend;
+        const unsigned ok = in ? 1u : 0u;
+        regs[i] = gg_buf_load16(buf, voff[i] | (ok - 1u), soff);
+    }
+}
+
 // ---- epilogue -----------------------------------------------------------------------------------------------
 // Every accumulator index below is a compile-time constant by construction (template recursion, one (i, j, g)
 // register quad per step). A `#pragma unroll` nest over the full epilogue body exceeds clang's pragma-unroll budget
@@ -437,14 +500,22 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_gemm2_kernel(GgGemmParams p) {
 
     // ROWK operands go through buffer descriptors (gg2_bload_*); the conv window corners are made non-negative by a base that
     // sits (pad * W + pad) * C elements before the tensor
-    const long long abias = (A_CONV && !A_KROW) ? ((long long)p.pad * p.W + p.pad) * p.C : 0;
+    const long long abias = A_CONV ? ((long long)p.pad * p.W + p.pad) * p.C : 0;
     Gg2ConvRowB crow[A_CONV && !A_KROW ? ANV : 1];
     if (A_CONV && !A_KROW) gg2_conv_rows_init_b<BM>(crow, p, m0, abias);
-    unsigned avoff[!A_CONV && !A_KROW ? ANV : 1], bvoff[!B_KROW ? BNV : 1];
+    unsigned avoff[(!A_CONV || A_KROW) ? ANV : 1], bvoff[BNV];
+    // reduction-major (weight-gradient) operands: buffer path for 8-aligned column counts; the conv gather additionally needs
+    // stride-1 'same' windows on power-of-two images without an input scale (p.krow_fast, set by the host)
+    const bool a_kfast = A_KROW && (A_CONV ? p.krow_fast != 0 : (p.M & 7) == 0);
+    const bool b_kfast = B_KROW && (p.N & 7) == 0;
+    Gg2ConvColB ccb;
+    ccb.dkh = ccb.dkw = ccb.valid = 0;
     if (!A_CONV && !A_KROW) gg2_brows_init<BM>(avoff, p.lda, p.M, m0);
+    if (!A_CONV && A_KROW) gg2_bkrow_init<BM>(avoff, p.lda, p.M, m0);
+    if (A_CONV && A_KROW && a_kfast) ccb = gg2_conv_col_init_b<BM>(avoff, p, m0, abias);
     if (!B_KROW) gg2_brows_init<BN>(bvoff, p.ldb, p.N, n0);
-    GgBuf bufA = gg_make_buf(!A_KROW ? (const void*)(Ab - abias) : (const void*)Ab,
-                             (unsigned long long)(p.a_bytes - (long long)b * p.a_bs * 2 + abias * 2));
+    else gg2_bkrow_init<BN>(bvoff, p.ldb, p.N, n0);
+    GgBuf bufA = gg_make_buf((const void*)(Ab - abias), (unsigned long long)(p.a_bytes - (long long)b * p.a_bs * 2 + abias * 2));
     GgBuf bufB = gg_make_buf((const void*)Bb, (unsigned long long)(p.b_bytes - (Bb - p.B) * 2));
     GgConvCol ccol;
     ccol.kh = ccol.kw = ccol.ci = ccol.cv = ccol.valid = 0;
@@ -457,15 +528,21 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_gemm2_kernel(GgGemmParams p) {
     auto load_tiles = [&](int k0) {
         const bool full = kend - k0 >= GG2_BK;          // workgroup-uniform; ragged tails keep the pointer-arithmetic loaders
         if (A_CONV) {
-            if (A_KROW) gg2_load_krow_conv<BM>(ra, ccol, p, kend, k0);
-            else gg2_bload_rowk_conv<BM>(ra, crow, bufA, p, kend, k0, ccur);
+            if (A_KROW) {
+                if (a_kfast) gg2_bload_krow_conv<BM>(ra, bufA, avoff, ccb, p, kend, k0);
+                else gg2_load_krow_conv<BM>(ra, ccol, p, kend, k0);
+            } else gg2_bload_rowk_conv<BM>(ra, crow, bufA, p, kend, k0, ccur);
         } else {
-            if (A_KROW) gg2_load_krow_dense<BM>(ra, Ab, p.lda, p.M, m0, kend, k0);
-            else if (full) gg2_bload_rowk_dense<BM>(ra, bufA, avoff, (long long)m0 * p.lda, k0);
+            if (A_KROW) {
+                if (a_kfast) gg2_bload_krow_dense<BM>(ra, bufA, avoff, p.lda, m0, kend, k0);
+                else gg2_load_krow_dense<BM>(ra, Ab, p.lda, p.M, m0, kend, k0);
+            } else if (full) gg2_bload_rowk_dense<BM>(ra, bufA, avoff, (long long)m0 * p.lda, k0);
             else gg2_load_rowk_dense<BM>(ra, Ab, p.lda, p.M, m0, kend, k0);
         }
-        if (B_KROW) gg2_load_krow_dense<BN>(rb, Bb, p.ldb, p.N, n0, kend, k0);
-        else if (full) gg2_bload_rowk_dense<BN>(rb, bufB, bvoff, (long long)n0 * p.ldb, k0);
+        if (B_KROW) {
+            if (b_kfast) gg2_bload_krow_dense<BN>(rb, bufB, bvoff, p.ldb, n0, kend, k0);
+            else gg2_load_krow_dense<BN>(rb, Bb, p.ldb, p.N, n0, kend, k0);
+        } else if (full) gg2_bload_rowk_dense<BN>(rb, bufB, bvoff, (long long)n0 * p.ldb, k0);
         else gg2_load_rowk_dense<BN>(rb, Bb, p.ldb, p.N, n0, kend, k0);
     };
     auto store_tiles = [&](int buf, int k0) {
