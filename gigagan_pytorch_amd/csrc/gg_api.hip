@@ -468,6 +468,7 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     p.partial = (float*)workspace;
     p.b_img_stride = d->b_image_stride;
     p.a_bytes = gg_a_bytes(d); p.b_bytes = gg_b_bytes(d);
+    p.buf_ok = (p.a_bytes + (1ll << 24) < (1ll << 32) && p.b_bytes < (1ll << 32)) ? 31 : 0;
     p.krow_fast = d->a_conv && d->a_layout == GG_KROW && d->conv_stride == 1 && p.OH == d->H && p.OW == d->W && p.w_shift >= 0 &&
                   p.hw_shift >= 0 && !d->in_scale && (d->CV == d->C || !(d->C & 7));
 #ifdef GG2_PROBE

@@ -80,6 +80,8 @@ struct GgGemmParams {
     // byte extents of the A / B operands as seen from their base pointers (buffer descriptors of the 8-wave kernel's ROWK loaders)
     long long a_bytes, b_bytes;
     int krow_fast;     // weight-gradient conv gather: stride-1 'same' windows, power-of-two image sides, no input scale
+    int buf_ok;        // 31 when both operands' byte extents fit the 32-bit offsets of a buffer descriptor, else 0 (bits: A conv rows,
+                       // A dense rows, A reduction-major, B dense rows, B reduction-major)
 };
 
 GG_DEVICE float gg_apply_act(float v, int act, float slope) {
@@ -374,6 +376,179 @@ GG_DEVICE void gg_load_krow_conv(u16x8* regs, const GgConvCol* cols, const GgGem
     }
 }
 
+
+// ---- buffer-addressed loaders (see gg_device.h GgBuf and gg_gemm2.h): loop-invariant per-lane byte offsets, one scalar offset per
+// k-tile, zero fill by the descriptor's bounds check. Used when the operand's byte extent fits 32-bit offsets (p.buf_ok); the
+// pointer-arithmetic loaders above stay for larger tensors, ragged tails and taps that change inside a k-tile (CV % 32 != 0).
+template <int ROWS>
+GG_DEVICE void gg_brows_init(unsigned* voff, int ld, int nrows, int r0) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < GgRowKLayout<ROWS>::NV; ++i) {
+        const int v = t + 256 * i;
+        const int row = v >> 2, kv = v & 3;
+        voff[i] = (row < ROWS && r0 + row < nrows) ? (unsigned)(((long long)row * ld + kv * 8) * 2) : 0xFFFFFFFFu;
+    }
+}
+
+template <int ROWS>
+GG_DEVICE void gg_bload_rowk_dense(u16x8* regs, GgBuf buf, const unsigned* voff, long long r0_ld, int k0) {
+    const unsigned soff = (unsigned)((r0_ld + k0) * 2);
+#pragma unroll
+    for (int i = 0; i < GgRowKLayout<ROWS>::NV; ++i) regs[i] = gg_buf_load16(buf, voff[i], soff);
+}
+
+struct GgConvRowB {
+    unsigned voff, mask;
+    int img;
+};
+
+template <int ROWS>
+GG_DEVICE void gg_conv_rows_init_b(GgConvRowB* rows, const GgGemmParams& p, int m0, long long bias) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < GgRowKLayout<ROWS>::NV; ++i) {
+        const int v = t + 256 * i;
+        const int row = v >> 2, kv = v & 3, m = m0 + row;
+        GgConvRowB r;
+        r.voff = 0xFFFFFFFFu; r.mask = 0; r.img = 0;
+        if (row < ROWS && m < p.M) {
+            const int hw = p.OH * p.OW;
+            const int img = m / hw, rem = m - img * hw;
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+            r.img = img;
+            r.voff = (unsigned)(((((long long)img * p.H + ih0) * p.W + iw0) * p.C + bias + kv * 8) * 2);
+            unsigned int mask = 0;
+            for (int kh = 0; kh < p.R; ++kh)
+                for (int kw = 0; kw < p.S; ++kw) {
+                    const int ih = ih0 + kh, iw = iw0 + kw;
+                    if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) mask |= 1u << (kh * p.S + kw);
+                }
+            r.mask = mask;
+        }
+        rows[i] = r;
+    }
+}
+
+struct GgConvCursor {
+    int tap, cv0, ci0, kh, kw;
+};
+
+GG_DEVICE GgConvCursor gg_conv_cursor(const GgGemmParams& p, int k0) {
+    GgConvCursor c;
+    c.tap = k0 / p.CV;
+    c.cv0 = k0 - c.tap * p.CV;
+    c.ci0 = (p.CV == p.C) ? c.cv0 : c.cv0 % p.C;
+    c.kh = c.tap / p.S;
+    c.kw = c.tap - c.kh * p.S;
+    return c;
+}
+
+// k-tiles of GG_BK (32) visited in order; needs CV % 32 == 0 (one tap per tile) and, for stacked inputs, C % 32 == 0
+template <int ROWS>
+GG_DEVICE void gg_bload_rowk_conv(u16x8* regs, const GgConvRowB* rows, GgBuf buf, const GgGemmParams& p, int kend, int k0,
+                                  GgConvCursor& cur) {
+    const unsigned soff = (unsigned)((((long long)cur.kh * p.W + cur.kw) * p.C + cur.ci0) * 2);
+    const int rem = kend - k0;
+    const unsigned lane_live = ((int)((threadIdx.x & 3) * 8) < rem) ? 1u : 0u;
+    const int tap = cur.tap;
+#pragma unroll
+    for (int i = 0; i < GgRowKLayout<ROWS>::NV; ++i) {
+        const unsigned ok = (rows[i].mask >> tap) & lane_live;
+        regs[i] = gg_buf_load16(buf, rows[i].voff | (ok - 1u), soff);
+    }
+    cur.cv0 += GG_BK;
+    cur.ci0 += GG_BK;
+    if (cur.ci0 >= p.C) cur.ci0 -= p.C;
+    if (cur.cv0 >= p.CV) {
+        cur.cv0 = 0;
+        cur.ci0 = 0;
+        ++cur.tap;
+        if (++cur.kw == p.S) { cur.kw = 0; ++cur.kh; }
+    }
+}
+
+template <int ROWS>
+GG_DEVICE void gg_scale_rowk_conv(u16x8* regs, const GgConvRowB* rows, const GgGemmParams& p, int k0) {
+    const int tap = k0 / p.CV;
+    const int cv = k0 - tap * p.CV + (threadIdx.x & 3) * 8;
+#pragma unroll
+    for (int i = 0; i < GgRowKLayout<ROWS>::NV; ++i) regs[i] = gg_scale8(regs[i], p.in_scale + (long long)rows[i].img * p.CV + cv);
+}
+
+// reduction-major operands (weight gradients): item = (k-pair kp, column group cg), two vectors (pixels k0 + 2 kp, + 1) each
+template <int ROWS>
+GG_DEVICE void gg_bkrow_init(unsigned* voff, int ld, int ncols, int c0) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < GgKRowLayout<ROWS>::NI; ++i) {
+        const int item = t + 256 * i;
+        const int kp = item & 15, cg = item >> 4;
+        const bool ok = item < GgKRowLayout<ROWS>::ITEMS && c0 + cg * 8 + 8 <= ncols;
+        voff[2 * i] = ok ? (unsigned)(((long long)(2 * kp) * ld + cg * 8) * 2) : 0xFFFFFFFFu;
+        voff[2 * i + 1] = ok ? (unsigned)(((long long)(2 * kp + 1) * ld + cg * 8) * 2) : 0xFFFFFFFFu;
+    }
+}
+
+template <int ROWS>
+GG_DEVICE void gg_bload_krow_dense(u16x8* regs, GgBuf buf, const unsigned* voff, int ld, int c0, int kend, int k0) {
+    const unsigned soff = (unsigned)(((long long)k0 * ld + c0) * 2);
+    const int rem = kend - k0, t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < GgKRowLayout<ROWS>::NI; ++i) {
+        const int kp = (t + 256 * i) & 15;
+        const unsigned ok0 = (2 * kp < rem) ? 1u : 0u, ok1 = (2 * kp + 1 < rem) ? 1u : 0u;
+        regs[2 * i] = gg_buf_load16(buf, voff[2 * i] | (ok0 - 1u), soff);
+        regs[2 * i + 1] = gg_buf_load16(buf, voff[2 * i + 1] | (ok1 - 1u), soff);
+    }
+}
+
+// stride-1 'same' windows on power-of-two images, no input scale (p.krow_fast): see gg2_bload_krow_conv
+struct GgConvColB {
+    int dkh, dkw;
+};
+
+template <int ROWS>
+GG_DEVICE void gg_conv_cols_init_b(GgConvColB* cols, unsigned* voff, const GgGemmParams& p, int c0, long long bias) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < GgKRowLayout<ROWS>::NI; ++i) {
+        const int item = t + 256 * i;
+        const int kp = item & 15, cg = item >> 4;
+        const int c = c0 + cg * 8;
+        const bool valid = (item < GgKRowLayout<ROWS>::ITEMS) && (c < p.M);
+        const int tap = valid ? c / p.CV : 0;
+        const int cv = valid ? c - tap * p.CV : 0;
+        const int kh = tap / p.S, kw = tap - kh * p.S;
+        const int ci = (p.CV == p.C) ? cv : cv % p.C;
+        cols[i].dkh = kh - p.pad;
+        cols[i].dkw = kw - p.pad;
+        const long long shift = ((long long)cols[i].dkh * p.W + cols[i].dkw) * p.C + ci + bias;
+        voff[2 * i] = valid ? (unsigned)(((long long)(2 * kp) * p.C + shift) * 2) : 0xFFFFFFFFu;
+        voff[2 * i + 1] = valid ? (unsigned)(((long long)(2 * kp + 1) * p.C + shift) * 2) : 0xFFFFFFFFu;
+    }
+}
+
+template <int ROWS>
+GG_DEVICE void gg_bload_krow_conv(u16x8* regs, GgBuf buf, const unsigned* voff, const GgConvColB* cols, const GgGemmParams& p,
+                                  int kend, int k0) {
+    const unsigned soff = (unsigned)((long long)k0 * p.C * 2);
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < GgKRowLayout<ROWS>::NI; ++i) {
+        const int kp = (t + 256 * i) & 15;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pix = k0 + 2 * kp + h;
+            const int ow = pix & (p.OW - 1), oh = (pix >> p.w_shift) & (p.OH - 1);
+            const bool in = (unsigned)(oh + cols[i].dkh) < (unsigned)p.H && (unsigned)(ow + cols[i].dkw) < (unsigned)p.W && pix < kend;
+            const unsigned ok = in ? 1u : 0u;
+            regs[2 * i + h] = gg_buf_load16(buf, voff[2 * i + h] | (ok - 1u), soff);
+        }
+    }
+}
+
 // ---- the kernel ---------------------------------------------------------------------------------
 
 template <int BM, int BN, int WM, int WN, bool A_KROW, bool B_KROW, bool A_CONV, bool FULL_EPI>
@@ -412,25 +587,68 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_gemm_kernel(GgGemmParams p) {
     // per-image weight operand (per-sample weights of the adaptive conv): a tile never straddles two images (planner)
     const bf16_t* Bb = p.B + (long long)b * p.b_bs + ((A_CONV && !A_KROW && p.b_img_stride) ? (long long)(m0 / (p.OH * p.OW)) * p.b_img_stride : 0);
 
+    // which operands go through buffer descriptors (workgroup-uniform; see the loaders above)
+    const bool a_rconv = A_CONV && !A_KROW && (p.buf_ok & 1) && (p.CV & 31) == 0 && (p.CV == p.C || (p.C & 31) == 0) &&
+                         p.R * p.S <= 32;                        // the tap-validity mask is one 32-bit word
+    const bool a_rdense = !A_CONV && !A_KROW && (p.buf_ok & 2);
+    const bool a_kfast = A_KROW && (p.buf_ok & 4) && (A_CONV ? p.krow_fast != 0 : (p.M & 7) == 0);
+    const bool b_rdense = !B_KROW && (p.buf_ok & 8);
+    const bool b_kfast = B_KROW && (p.buf_ok & 16) && (p.N & 7) == 0;
+    const long long abias = A_CONV ? ((long long)p.pad * p.W + p.pad) * p.C : 0;
+
     GgConvRow crow[A_CONV && !A_KROW ? ANV : 1];
-    if (A_CONV && !A_KROW) gg_conv_rows_init<BM>(crow, p, m0);
+    GgConvRowB crowb[A_CONV && !A_KROW ? ANV : 1];
+    if (A_CONV && !A_KROW) {
+        if (a_rconv) gg_conv_rows_init_b<BM>(crowb, p, m0, abias);
+        else gg_conv_rows_init<BM>(crow, p, m0);
+    }
     GgConvCol ccol[A_CONV && A_KROW ? GgKRowLayout<BM>::NI : 1];
-    if (A_CONV && A_KROW) gg_conv_cols_init<BM>(ccol, p, m0);
+    GgConvColB ccolb[A_CONV && A_KROW ? GgKRowLayout<BM>::NI : 1];
+    unsigned avoff[ANV], bvoff[BNV];
+    if (A_CONV && A_KROW) {
+        if (a_kfast) gg_conv_cols_init_b<BM>(ccolb, avoff, p, m0, abias);
+        else gg_conv_cols_init<BM>(ccol, p, m0);
+    }
+    if (!A_CONV && A_KROW && a_kfast) gg_bkrow_init<BM>(avoff, p.lda, p.M, m0);
+    if (a_rdense) gg_brows_init<BM>(avoff, p.lda, p.M, m0);
+    if (b_rdense) gg_brows_init<BN>(bvoff, p.ldb, p.N, n0);
+    if (b_kfast) gg_bkrow_init<BN>(bvoff, p.ldb, p.N, n0);
+    GgBuf bufA = gg_make_buf((const void*)(Ab - abias), (unsigned long long)(p.a_bytes - (long long)b * p.a_bs * 2 + abias * 2));
+    GgBuf bufB = gg_make_buf((const void*)Bb, (unsigned long long)(p.b_bytes - (Bb - p.B) * 2));
+    GgConvCursor ccur = {0, 0, 0, 0, 0};
+    if (a_rconv) ccur = gg_conv_cursor(p, kbeg);          // load_tiles visits kbeg, kbeg + 32, ... in order
 
     u16x8 ra[ANV], rb[BNV];
 
     auto load_tiles = [&](int k0) {
+        const bool full = kend - k0 >= GG_BK;
         if (A_CONV) {
-            if (A_KROW) gg_load_krow_conv<BM>(ra, ccol, p, kend, k0);
-            else gg_load_rowk_conv<BM>(ra, crow, p, kend, k0);
+            if (A_KROW) {
+                if (a_kfast) gg_bload_krow_conv<BM>(ra, bufA, avoff, ccolb, p, kend, k0);
+                else gg_load_krow_conv<BM>(ra, ccol, p, kend, k0);
+            } else {
+                if (a_rconv) gg_bload_rowk_conv<BM>(ra, crowb, bufA, p, kend, k0, ccur);
+                else gg_load_rowk_conv<BM>(ra, crow, p, kend, k0);
+            }
         } else {
-            if (A_KROW) gg_load_krow_dense<BM>(ra, Ab, p.lda, p.M, m0, kend, k0);
-            else gg_load_rowk_dense<BM>(ra, Ab, p.lda, p.M, m0, p.K, kend, k0);
+            if (A_KROW) {
+                if (a_kfast) gg_bload_krow_dense<BM>(ra, bufA, avoff, p.lda, m0, kend, k0);
+                else gg_load_krow_dense<BM>(ra, Ab, p.lda, p.M, m0, kend, k0);
+            } else {
+                if (a_rdense && full) gg_bload_rowk_dense<BM>(ra, bufA, avoff, (long long)m0 * p.lda, k0);
+                else gg_load_rowk_dense<BM>(ra, Ab, p.lda, p.M, m0, p.K, kend, k0);
+            }
         }
-        if (B_KROW) gg_load_krow_dense<BN>(rb, Bb, p.ldb, p.N, n0, kend, k0);
-        else gg_load_rowk_dense<BN>(rb, Bb, p.ldb, p.N, n0, p.K, kend, k0);
+        if (B_KROW) {
+            if (b_kfast) gg_bload_krow_dense<BN>(rb, bufB, bvoff, p.ldb, n0, kend, k0);
+            else gg_load_krow_dense<BN>(rb, Bb, p.ldb, p.N, n0, kend, k0);
+        } else {
+            if (b_rdense && full) gg_bload_rowk_dense<BN>(rb, bufB, bvoff, (long long)n0 * p.ldb, k0);
+            else gg_load_rowk_dense<BN>(rb, Bb, p.ldb, p.N, n0, p.K, kend, k0);
+        }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, int k0) {
+        if (a_rconv && p.in_scale && k0 < kend) gg_scale_rowk_conv<BM>(ra, crowb, p, k0);
         if (A_KROW) gg_store_krow<BM>(sA[buf], ra);
         else gg_store_rowk<BM>(sA[buf], ra);
         if (B_KROW) gg_store_krow<BN>(sB[buf], rb);
@@ -448,7 +666,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_gemm_kernel(GgGemmParams p) {
     const int nk = (kend > kbeg) ? (kend - kbeg + GG_BK - 1) / GG_BK : 0;
     if (nk > 0) {
         load_tiles(kbeg);
-        store_tiles(0);
+        store_tiles(0, kbeg);
     }
     gg_sync();
 
@@ -473,7 +691,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_gemm_kernel(GgGemmParams p) {
                     // swapped operands: D[n_local][m_local], so a lane's registers run along n
                     acc[i][j] = gg_mfma_32x32x16_bf16(fb[j], fa[i], acc[i][j]);
         }
-        if (has_next) store_tiles(buf ^ 1);
+        if (has_next) store_tiles(buf ^ 1, kbeg + (kt + 1) * GG_BK);
         gg_sync();
     }
 
