@@ -215,6 +215,7 @@ static bool gg_dconv_eligible(const gg_gemm_desc* d) {
     if (d->N > 64 || (d->N & 7) || d->batch != 1 || d->d2s || d->c_is_f32) return false;
     if ((d->W % GG_DC_TW) || (d->H % GG_DC_TH) || (d->ldc & 7) || d->K != 9 * d->C) return false;
     if (d->M % (d->H * d->W)) return false;
+    if ((long long)d->M * d->C * 2 + (1ll << 24) >= (1ll << 32)) return false;      // 32-bit buffer offsets into the activation
     return true;
 }
 

@@ -62,25 +62,33 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_dconv_kernel(GgGemmParams p) {
     const int tiles_img = tiles_w * tiles_h;
     const int total = (p.M / (p.H * p.W)) * tiles_img;
 
+    // the halo tile through a buffer descriptor (gg_device.h GgBuf): a lane's byte offset inside the tile ((r * W + c) * C + chunk)
+    // is fixed for the kernel's lifetime, the tile origin is one scalar, pixels outside the image get offset 0xFFFFFFFF and come
+    // back as zeros (the pointer form spent ~45 vector instructions and a branch per 16-byte load)
+    const long long xbias = ((long long)p.W + 1) * C;              // origin of tile (0, 0) is one row and one pixel before the image
+    GgBuf bufX = gg_make_buf((const void*)(p.A - xbias), (unsigned long long)(p.a_bytes + xbias * 2));
+    unsigned xoff[NVX];
+    int xr[NVX], xc[NVX];
+#pragma unroll
+    for (int i = 0; i < NVX; ++i) {
+        const int v = tid + 256 * i;
+        const int pix = v / CV8, c8 = v - pix * CV8;
+        xr[i] = pix / HW;
+        xc[i] = pix - xr[i] * HW;
+        xoff[i] = (v < NPIX * CV8) ? (unsigned)((((long long)xr[i] * p.W + xc[i]) * C + c8 * 8) * 2) : 0xFFFFFFFFu;
+    }
     u16x8 rx[NVX];
+    int rx_img = 0;                 // image of the tile held in rx (for the style modulation applied when it is parked in LDS)
     auto load_tile = [&](int tile) {
         const int img = tile / tiles_img, rem = tile - img * tiles_img;
         const int th = rem / tiles_w, tw = rem - th * tiles_w;
         const int h0 = th * TH - 1, w0 = tw * TW - 1;
+        const unsigned soff = (unsigned)(((((long long)img * p.H + h0) * p.W + w0) * C + xbias) * 2);
+        rx_img = img;
 #pragma unroll
         for (int i = 0; i < NVX; ++i) {
-            const int v = tid + 256 * i;
-            u16x8 x = gg_zero8();
-            if (v < NPIX * CV8) {
-                const int pix = v / CV8, c8 = v - pix * CV8;
-                const int r = pix / HW, c = pix - r * HW;
-                const int ih = h0 + r, iw = w0 + c;
-                if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
-                    x = *(const u16x8*)(p.A + (((long long)img * p.H + ih) * p.W + iw) * C + c8 * 8);
-                    if (p.in_scale) x = gg_scale8(x, p.in_scale + (long long)img * C + c8 * 8);   // style modulation on load
-                }
-            }
-            rx[i] = x;
+            const unsigned ok = ((unsigned)(h0 + xr[i]) < (unsigned)p.H && (unsigned)(w0 + xc[i]) < (unsigned)p.W) ? 1u : 0u;
+            rx[i] = gg_buf_load16(bufX, xoff[i] | (ok - 1u), soff);
         }
     };
     auto store_tile = [&]() {
@@ -89,7 +97,9 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_dconv_kernel(GgGemmParams p) {
             const int v = tid + 256 * i;
             if (v < NPIX * CV8) {
                 const int pix = v / CV8, c8 = v - pix * CV8;
-                *(u16x8*)&sX[pix * XP + c8 * 8] = rx[i];
+                u16x8 x = rx[i];
+                if (p.in_scale) x = gg_scale8(x, p.in_scale + (long long)rx_img * C + c8 * 8);   // style modulation (zeros stay zeros)
+                *(u16x8*)&sX[pix * XP + c8 * 8] = x;
             }
         }
     };
