@@ -143,11 +143,32 @@ def native_comm() -> NativeComm | None:
     return _native
 
 
-def enable_native_comm(device) -> NativeComm:
-    """create the gg_comm_* communicator for this process (collective: every rank calls it). Falls back to nothing on CPU."""
+def enable_native_comm(device):
+    """create the gg_comm_* communicator for this process (collective: every rank calls it). The ranks then agree (a MIN
+    all-reduce over the bootstrap process group) on whether EVERY rank succeeded; if one did not (no librccl to bind, a refused
+    communicator), all of them drop the native communicator and the gradient exchange stays on torch.distributed's RCCL backend —
+    a replica must never wait in a collective its peers do not issue. Returns the communicator or None."""
     global _native
-    if _native is None:
-        _native = NativeComm().init(device)
+    if _native is not None:
+        return _native
+    comm, err = None, None
+    try:
+        comm = NativeComm().init(device)
+    except Exception as e:     # noqa: BLE001 - any failure means "use the process group instead", decided collectively below
+        err = e
+    if is_distributed():
+        ok = torch.tensor([1 if comm is not None else 0], device=device, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if comm is not None:
+                comm.destroy()
+            if dist.get_rank() == 0:
+                print(f'gigagan_pytorch_amd: native RCCL communicator unavailable on some rank ({err}); '
+                      'gradient exchange through torch.distributed', flush=True)
+            return None
+    elif comm is None:
+        raise err
+    _native = comm
     return _native
 
 
