@@ -3,6 +3,7 @@
 #include "gg_device.h"
 #include "gg_gemm.h"
 #include "gg_gemm2.h"
+#include "gg_conv3.h"
 #include "gg_elementwise.h"
 #include "gg_modconv.h"
 #include "gg_attention.h"
@@ -248,6 +249,9 @@ static void gg_launch_dconv(const GgGemmParams& p, hipStream_t s) {
     else GG_LAUNCH((gg_dconv_kernel<C, TN, false>), dim3((unsigned)blocks), dim3(256), s, p);
 }
 
+static bool gg_conv3_eligible(const gg_gemm_desc* d);
+static GemmPlan gg_conv3_plan(const gg_gemm_desc* d, int tile);
+
 // ---- tuning cache: measured-best (tile, split-K) per exact geometry (gg_gemm_plan_table) ----------------------------------
 struct GgPlanChoice { int tile, splitk; };
 static std::unordered_map<std::string, GgPlanChoice> g_plan_table;
@@ -274,6 +278,11 @@ static bool gg_table_plan(const gg_gemm_desc* d, GemmPlan& pl) {
         pl.splitk = 1; pl.k_per_split = d->K; pl.blocks_mn = d->M / pl.bm;
         return true;
     }
+    if (tile == 7 || tile == 8) {
+        if (!gg_conv3_eligible(d)) return false;
+        pl = gg_conv3_plan(d, tile);
+        return true;
+    }
     if (tile < 1 || tile > 6) return false;
     if (tile >= 4 && !gg_v2_eligible(d)) return false;
     const GgTileModel& tm = kTileModels[tile - 1];
@@ -289,9 +298,53 @@ static bool gg_table_plan(const gg_gemm_desc* d, GemmPlan& pl) {
     return true;
 }
 
+// the halo-staged 3x3 convolution (gg_conv3.h, plan tile 7): stride 1 / pad 1 on 64-channel-multiple inputs whose 256-pixel tiles are
+// whole image rows or whole images; 7: 256 output channels per workgroup, 8: 128). It takes over every unsplit 256-row implicit-GEMM
+// choice of the planner on eligible layers (measured +17-36 % per layer, profiles/r02_conv3_ab.log); GG_CONV3=0 disables that
+// (A/B runs); force_tile 7 / 8 selects it wherever eligible.
+static int gg_conv3_policy() {
+    static int policy = -1;
+    if (policy < 0) {
+        const char* e = getenv("GG_CONV3");
+        policy = e ? atoi(e) : 1;
+        if (policy < 0) policy = 1;
+    }
+    return policy;
+}
+
+static bool gg_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+static bool gg_conv3_eligible(const gg_gemm_desc* d) {
+    if (!d->a_conv || d->a_layout != GG_ROWK || d->b_layout != GG_ROWK) return false;
+    if (d->R != 3 || d->S != 3 || d->conv_stride != 1 || d->conv_pad != 1) return false;
+    if (d->C != d->CV || (d->C & 63) || d->K != 9 * d->C || (d->ldb & 7)) return false;
+    if (d->in_scale || d->b_image_stride || d->batch != 1 || d->d2s) return false;
+    if (!gg_pow2(d->H) || !gg_pow2(d->W) || d->W < 8 || d->W > 64 || d->H * d->W < 64) return false;
+    if (d->M % (d->H * d->W)) return false;
+    if (gg_a_bytes(d) >= (1ll << 32) || gg_b_bytes(d) >= (1ll << 32)) return false;
+    // the tile's halo (PH + 2 rows of W + 2 slots for each of its TI images) must fit the LDS area reserved for it
+    const int hw = d->H * d->W, ph = hw >= 256 ? 256 / d->W : d->H, ti = hw >= 256 ? 1 : 256 / hw;
+    if (ti * (ph + 2) * (d->W + 2) > GG_C3_MAX_SLOTS || ti * (ph + 2) > GG_C3_MAX_ROWS) return false;
+    return true;
+}
+
+static GemmPlan gg_conv3_plan(const gg_gemm_desc* d, int tile) {
+    GemmPlan pl;
+    pl.tile = tile; pl.bm = 256; pl.bn = tile == 7 ? 256 : 128; pl.splitk = 1; pl.k_per_split = d->K;
+    pl.blocks_mn = (long long)((d->M + 255) / 256) * ((d->N + pl.bn - 1) / pl.bn);
+    return pl;
+}
+
+// the planner (table or cost model) thinks in implicit-GEMM tiles; an unsplit 256-row choice on an eligible layer runs halo-staged
+static GemmPlan gg_conv3_substitute(const gg_gemm_desc* d, const GemmPlan& pl) {
+    if ((pl.tile != 4 && pl.tile != 5) || pl.splitk != 1 || d->force_tile != 0 || !gg_conv3_policy() || !gg_conv3_eligible(d)) return pl;
+    return gg_conv3_plan(d, pl.tile == 4 ? 7 : 8);
+}
+
 GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     GemmPlan pl;
-    if (gg_table_plan(d, pl)) return pl;
+    if ((d->force_tile == 7 || d->force_tile == 8) && gg_conv3_eligible(d)) return gg_conv3_plan(d, d->force_tile);
+    if (gg_table_plan(d, pl)) return gg_conv3_substitute(d, pl);
     if (gg_use_dconv(d)) {
         pl.tile = 9; pl.bm = GG_DC_TH * GG_DC_TW; pl.bn = d->N <= 32 ? 32 : 64;
         pl.splitk = 1; pl.k_per_split = d->K; pl.blocks_mn = d->M / pl.bm;
@@ -343,7 +396,7 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     const int per = (ktiles + pl.splitk - 1) / pl.splitk;
     pl.splitk = (ktiles + per - 1) / per;
     pl.k_per_split = per * tm.bk;
-    return pl;
+    return gg_conv3_substitute(d, pl);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -490,6 +543,16 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
         if (d->C == 16) { if (wide) gg_launch_dconv<16, 2>(p, s); else gg_launch_dconv<16, 1>(p, s); }
         else if (d->C == 32) { if (wide) gg_launch_dconv<32, 2>(p, s); else gg_launch_dconv<32, 1>(p, s); }
         else { if (wide) gg_launch_dconv<64, 2>(p, s); else gg_launch_dconv<64, 1>(p, s); }
+    }
+    else if (pl.tile == 7 || pl.tile == 8) {
+        const bool full = p.bias || p.out_scale || p.noise || p.residual || p.act != GG_ACT_NONE;
+        if (pl.tile == 7) {
+            if (full) GG_LAUNCH((gg_conv3_kernel<256, 2, 4, true>), grid2, dim3(GG2_NT), s, p);
+            else GG_LAUNCH((gg_conv3_kernel<256, 2, 4, false>), grid2, dim3(GG2_NT), s, p);
+        } else {
+            if (full) GG_LAUNCH((gg_conv3_kernel<128, 4, 2, true>), grid2, dim3(GG2_NT), s, p);
+            else GG_LAUNCH((gg_conv3_kernel<128, 4, 2, false>), grid2, dim3(GG2_NT), s, p);
+        }
     }
     else if (pl.tile == 4) gg_launch_gemm2_tile<256, 256, 2, 4>(p, akrow, bkrow, aconv, grid2, s);
     else if (pl.tile == 5) gg_launch_gemm2_tile<256, 128, 2, 4>(p, akrow, bkrow, aconv, grid2, s);

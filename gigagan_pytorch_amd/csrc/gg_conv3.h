@@ -1,0 +1,195 @@
+// 3x3 / stride 1 / pad 1 convolution (forward and data gradient of the discriminator's and the plain generator convolutions,
+// reference gigagan_pytorch.py:1597-1618 block convs, :1661-1668 predictor convs) on 64-channel-multiple inputs, 256 pixels x 256
+// output channels per workgroup, with the activation staged ONCE per 64-channel chunk for all nine taps.
+//
+// Why: the implicit GEMM (gg_gemm2.h) reloads the 256 x 64 activation tile for every tap — 64 KB per workgroup and k-tile
+// through L2 -> LDS. At 256 workgroups that is 8.6-10.9 TB/s when the kernel runs at 1100 TFLOP/s, which is what the L2 delivers
+// (the 256x128 tile tops out at 930 TFLOP/s = the same byte rate; register staging vs. LDS-DMA staging measured the same,
+// profiles/r02_dma_ab.log): the tile is fed at the L2's rate, not the matrix pipe's. Here the workgroup's 256 pixels are whole
+// image rows (or whole images), their one-pixel halo is parked in LDS per channel chunk (<= 400 slots x 128 bytes instead of
+// 9 x 256 x 128), and the nine taps read their fragments from it at a tap-uniform offset; only the weight tiles stream per
+// tap (LDS-DMA, XOR-swizzled rows as in gg_gemm2d_kernel). L2 -> LDS bytes per 9 k-tiles: 339 KB instead of 576 KB.
+//
+// Reduction order: (channel chunk, tap, channel) instead of (tap, channel): fp32 sums differ from the implicit GEMM in the last
+// bits.
+#pragma once
+#include "gg_gemm2.h"
+
+#define GG_C3_MAX_SLOTS 400
+#define GG_C3_MAX_ROWS 40                                  // halo rows of a tile (host-checked with the slot count)
+#define GG_C3_PITCH 144                                   // bytes per halo slot: 64 channels + 16 bytes pad (consecutive slots: conflict-free)
+// Every halo row is followed by 224 bytes: a fragment's 32 lanes are 32 consecutive pixels, which on 8- and 16-wide images wrap
+// into the next image row, W + 2 slots further. (W + 2) * 144 + 224 = 144 W mod 256, so the wrapped lanes continue the bank
+// sequence of the lanes before them as if the slots were consecutive.
+#define GG_C3_ROWPAD 224
+#define GG_C3_HBYTES 67584                                // largest halo (8x8 images: 400 slots, 40 rows) rounded up to 1 KB
+#define GG_C3_NVH ((GG_C3_MAX_SLOTS * 8 + GG2_NT - 1) / GG2_NT)    // 16-byte halo vectors per thread: 7
+
+template <int BN, int WM, int WN, bool FULL_EPI>
+GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_conv3_kernel(GgGemmParams p) {
+    static_assert(WM * WN == 8, "8 wavefronts per workgroup");
+    constexpr int BM = 256;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int BNV = Gg2Dma<BN>::NV, BBYTES = Gg2Dma<BN>::BYTES;
+    constexpr int SP = WTN * 2 + 8;
+    constexpr int TILE_BYTES = GG_C3_HBYTES + 2 * BBYTES, STAGE_BYTES = 8 * WTM * SP;
+    static_assert(GG_C3_MAX_SLOTS * GG_C3_PITCH + GG_C3_MAX_ROWS * GG_C3_ROWPAD <= GG_C3_HBYTES, "halo area");
+
+    GG_SHARED __attribute__((aligned(1024))) char smem[TILE_BYTES > STAGE_BYTES ? TILE_BYTES : STAGE_BYTES];
+    char* const halo = smem;
+    auto tileB = [&](int buf) { return smem + GG_C3_HBYTES + buf * BBYTES; };
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware tile order: as gg_gemm2_kernel (no batch, no split-K here)
+    const int nwg = gridDim.x;
+    const int xq = nwg >> 3, xr = nwg & 7;
+    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+    const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + pos;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tile_m = wg / tiles_n, tile_n = wg % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // tile geometry: PH full-width rows of TI images (H, W powers of two, 8 <= W <= 64: host)
+    const int W = p.W, H = p.H, ws = p.w_shift, hs = p.hw_shift;
+    const int HW = H * W;
+    const int PH = HW >= BM ? BM >> ws : H;
+    const int TI = HW >= BM ? 1 : BM >> hs;
+    const int HWp = W + 2, SPI = (PH + 2) * HWp;                 // halo row length, halo slots per image
+    const int NS = TI * SPI;
+    const int RSB = HWp * GG_C3_PITCH + GG_C3_ROWPAD;            // bytes from one halo row to the next
+    const int img0 = m0 >> hs, row0 = HW >= BM ? (m0 & (HW - 1)) >> ws : 0;
+    const int n_img = p.M >> hs;
+
+    GgBuf bufA = gg_make_buf((const void*)p.A, (unsigned long long)p.a_bytes);
+    GgBuf bufB = gg_make_buf((const void*)p.B, (unsigned long long)p.b_bytes);
+
+    // halo loader: vector v = t + 512 i -> slot v / 8, 8-channel piece v % 8 (loop invariant; 0xFFFFFFFF = padding -> zero fill)
+    unsigned hvoff[GG_C3_NVH];
+#pragma unroll
+    for (int i = 0; i < GG_C3_NVH; ++i) {
+        const int v = tid + GG2_NT * i;
+        const int slot = v >> 3, ch = v & 7;
+        hvoff[i] = 0xFFFFFFFFu;
+        if (slot < NS) {
+            const int il = slot / SPI, rem = slot - il * SPI;
+            const int hy = rem / HWp, hx = rem - hy * HWp;
+            const int ih = row0 + hy - 1, iw = hx - 1, img = img0 + il;
+            if (ih >= 0 && ih < H && iw >= 0 && iw < W && img < n_img)
+                hvoff[i] = (unsigned)(((((long long)img * H + ih) * W + iw) * p.C + ch * 8) * 2);
+        }
+    }
+    u16x8 hreg[GG_C3_NVH];
+    auto load_halo = [&](int c) {
+        const unsigned soff = (unsigned)(c * GG2_BK * 2);
+#pragma unroll
+        for (int i = 0; i < GG_C3_NVH; ++i) hreg[i] = gg_buf_load16(bufA, hvoff[i], soff);
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int i = 0; i < GG_C3_NVH; ++i) {
+            const int v = tid + GG2_NT * i;
+            const int slot = v >> 3, hrow = slot / HWp;         // (halo rows run on across the tile's images)
+            if (slot < NS) *(u16x8*)(halo + hrow * RSB + (slot - hrow * HWp) * GG_C3_PITCH + (v & 7) * 16) = hreg[i];
+        }
+    };
+
+    // weight tiles: LDS-DMA into XOR-swizzled 128-byte rows (see gg_gemm2d_kernel)
+    unsigned bvoff[BNV];
+#pragma unroll
+    for (int i = 0; i < BNV; ++i) {
+        const int row = gg2d_row<BN>(i), kc = gg2d_chunk(i);
+        bvoff[i] = (n0 + row < p.N) ? (unsigned)(((long long)row * p.ldb + kc * 8) * 2) : 0xFFFFFFFFu;
+    }
+    auto dma_b = [&](int buf, int tap, int c) {
+        const unsigned soff = (unsigned)(((long long)n0 * p.ldb + tap * p.C + c * GG2_BK) * 2);
+        char* lb = tileB(buf) + wave * (BNV * 1024);
+#pragma unroll
+        for (int i = 0; i < BNV; ++i) gg_buf_load_lds16(bufB, bvoff[i], soff, lb + i * 1024);
+    };
+
+    // fragment addressing. A: pixel row r of the tile -> its halo slot at tap (0, 0); a tap adds kh halo rows and kw slots
+    const int frow = lane & 31, fhi = lane >> 5;
+    int a_addr[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * WTM + i * 32 + frow;
+        const int il = HW >= BM ? 0 : r >> hs;
+        const int rr = HW >= BM ? r : r & (HW - 1);
+        a_addr[i] = (il * (PH + 2) + (rr >> ws)) * RSB + (rr & (W - 1)) * GG_C3_PITCH + fhi * 16;
+    }
+    const int fx = (fhi ^ ((frow >> 1) & 7)) * 16;
+    const int b_lane = (wn * WTN + frow) * 128;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunks = p.C / GG2_BK;
+    load_halo(0);
+    dma_b(0, 0, 0);
+    store_halo();
+    gg_wait_vm<0>();
+    gg_sync();
+
+    int step = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) load_halo(c + 1);              // lands in registers while this chunk's nine taps run
+        int toff = 0;                                        // byte offset of the tap inside the halo
+        for (int kh = 0; kh < 3; ++kh) {
+            for (int kw = 0; kw < 3; ++kw, ++step) {
+                const int buf = step & 1;
+                const int tap = kh * 3 + kw;
+                // the other weight buffer was released by the barrier that ended the previous tap
+                if (tap < 8) dma_b(buf ^ 1, tap + 1, c);
+                else if (c + 1 < nchunks) dma_b(buf ^ 1, 0, c + 1);
+                const char* ta = halo + toff;
+                const char* tb = tileB(buf) + b_lane;
+#pragma unroll
+                for (int kk = 0; kk < GG2_BK / 16; ++kk) {
+                    u16x8 fa[TM], fb[TN];
+                    const int fo = fx ^ (kk * 32);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[i] = *(const u16x8*)(ta + a_addr[i] + kk * 32);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[j] = *(const u16x8*)(tb + j * 32 * 128 + fo);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = gg_mfma_32x32x16_bf16(fb[j], fa[i], acc[i][j]);
+                }
+                gg_wait_vm<0>();
+                gg_sync();
+                toff += GG_C3_PITCH;
+            }
+            toff += RSB - 3 * GG_C3_PITCH;
+        }
+        if (c + 1 < nchunks) {      // every wave is past its last read of this chunk's halo (barrier above)
+            store_halo();
+            gg_sync();
+        }
+    }
+
+    const GgGemmParams e = *gg_late_params(p);
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const int m_wave = m0 + wm * WTM, n_wave = n0 + wn * WTN;
+    const bool staged = !e.c_f32 && !e.d2s && (e.N & 3) == 0 && (e.ldc & 3) == 0 && (!e.residual || (e.ldr & 3) == 0);
+    if (staged) {
+        char* stage = smem + wave * (WTM * SP);
+        gg2_epilogue_step<0, TM, TN, FULL_EPI, true>(acc, e, 0, 0, m_wave + (lane & 31), n_wave + 4 * (lane >> 5), stage, SP, lane,
+                                                     z4, z4);
+        gg_sync();
+        gg2_stage_writeback<WTM, WTN>(e, 0, stage, SP, m_wave, n_wave, lane);
+    } else {
+        gg2_epilogue_step<0, TM, TN, FULL_EPI, false>(acc, e, 0, 0, m_wave + (lane & 31), n_wave + 4 * (lane >> 5), nullptr, 0, lane,
+                                                      z4, z4);
+    }
+}

@@ -105,6 +105,13 @@ GG_DEVICE u16x8 gg_buf_load16(GgBuf r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(u16x8, v);
 }
 
+// buffer-addressed LDS-DMA (buffer_load_dwordx4 ... lds): lane i's 16 bytes land at lds_wave_base + 16 i (wave-uniform base, it
+// travels in M0); out-of-range lanes deposit zeros. Counts on vmcnt; NOT ordered with ds_* operations: a reader needs
+// gg_wait_vm<0>() in the issuing wave and a barrier.
+GG_DEVICE void gg_buf_load_lds16(GgBuf r, unsigned voff, unsigned soff, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (void __attribute__((address_space(3)))*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
+
 template <int P>
 GG_DEVICE void gg_setprio() { __builtin_amdgcn_s_setprio(P); }    // wave issue priority (arbitration between the waves of a SIMD)
 

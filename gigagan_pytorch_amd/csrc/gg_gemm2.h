@@ -110,32 +110,35 @@ struct Gg2ConvRowB {
 };
 
 // `bias` (elements): the descriptor base sits that far BEFORE the tensor so that corners of padded windows stay non-negative
+GG_DEVICE Gg2ConvRowB gg2_conv_row_b(const GgGemmParams& p, int m, int kc, long long bias) {
+    Gg2ConvRowB r;
+    r.voff = 0xFFFFFFFFu; r.mask = 0; r.img = 0;
+    if (m < p.M) {
+        const int hw = p.OH * p.OW;
+        const int img = m / hw, rem = m - img * hw;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+        r.img = img;
+        const long long corner = (((long long)img * p.H + ih0) * p.W + iw0) * p.C;
+        r.voff = (unsigned)((corner + bias + kc * 8) * 2);
+        unsigned int mask = 0;
+        for (int kh = 0; kh < p.R; ++kh)
+            for (int kw = 0; kw < p.S; ++kw) {
+                const int ih = ih0 + kh, iw = iw0 + kw;
+                if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) mask |= 1u << (kh * p.S + kw);
+            }
+        r.mask = mask;
+    }
+    return r;
+}
+
 template <int ROWS>
 GG_DEVICE void gg2_conv_rows_init_b(Gg2ConvRowB* rows, const GgGemmParams& p, int m0, long long bias) {
     const int t = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < Gg2RowK<ROWS>::NV; ++i) {
         const int v = t + GG2_NT * i;
-        const int m = m0 + (v >> 3), kc = v & 7;
-        Gg2ConvRowB r;
-        r.voff = 0xFFFFFFFFu; r.mask = 0; r.img = 0;
-        if (m < p.M) {
-            const int hw = p.OH * p.OW;
-            const int img = m / hw, rem = m - img * hw;
-            const int oh = rem / p.OW, ow = rem - oh * p.OW;
-            const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
-            r.img = img;
-            const long long corner = (((long long)img * p.H + ih0) * p.W + iw0) * p.C;
-            r.voff = (unsigned)((corner + bias + kc * 8) * 2);
-            unsigned int mask = 0;
-            for (int kh = 0; kh < p.R; ++kh)
-                for (int kw = 0; kw < p.S; ++kw) {
-                    const int ih = ih0 + kh, iw = iw0 + kw;
-                    if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) mask |= 1u << (kh * p.S + kw);
-                }
-            r.mask = mask;
-        }
-        rows[i] = r;
+        rows[i] = gg2_conv_row_b(p, m0 + (v >> 3), v & 7, bias);
     }
 }
 
@@ -654,3 +657,25 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_gemm2_kernel(GgGemmParams p) {
                                                       lane, z4, z4);
     }
 }
+
+// ---- LDS-DMA staged row-major tiles (used by gg_conv3.h for its weight tiles) ------------------------------------------------
+// A wave's DMA instruction (buffer_load_dwordx4 ... lds) deposits 64 x 16 contiguous bytes, so rows cannot be padded; the tile is
+// stored as 128-byte rows with its eight 16-byte chunks XOR-swizzled: chunk c of row r sits in slot c ^ ((r >> 1) & 7). The
+// fragment reads (32 rows x one chunk per half wave) are conflict-free under the ds_read_b128 lane grouping: rows two apart share
+// banks and get different slots.
+// (A whole-kernel variant of gg_gemm2_kernel staged this way — no staging registers, no ds_write phase — measured within +-2 % of
+// the register-staged kernel on every config-2 layer and 0.0 % on the step, profiles/r02_dma_ab_{off,on}.log: the 256x256 tile is
+// fed at the L2's delivery rate either way. It was deleted; gg_conv3.h attacks the bytes instead.)
+template <int ROWS>
+struct Gg2Dma {
+    static constexpr int NV = ROWS / 64;          // DMA instructions per thread and k-tile (8 rows x 128 bytes per wave each)
+    static constexpr int BYTES = ROWS * 128;
+    static_assert(NV >= 2 && (NV & 1) == 0, "row -> slot shortcut below assumes an even count");
+};
+
+// the thread's i-th DMA vector: row 8 * (wave * NV + i) + lane / 8 of the tile, LDS slot lane % 8
+template <int ROWS>
+GG_DEVICE int gg2d_row(int i) { return 8 * ((threadIdx.x >> 6) * Gg2Dma<ROWS>::NV + i) + ((threadIdx.x & 63) >> 3); }
+// ... which holds chunk slot ^ ((row >> 1) & 7) = (lane % 8) ^ (lane / 16) ^ (4 if i is odd)
+GG_DEVICE int gg2d_chunk(int i) { return (int)((threadIdx.x & 7) ^ ((threadIdx.x & 63) >> 4) ^ ((i & 1) << 2)); }
+

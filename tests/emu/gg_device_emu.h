@@ -77,6 +77,11 @@ static inline u16x8 gg_buf_load16(GgBuf r, unsigned voff, unsigned soff) {
     if ((unsigned long long)voff + 16 <= r.bytes) memcpy(&v, r.base + voff + soff, 16);
     return v;
 }
+static inline void gg_buf_load_lds16(GgBuf r, unsigned voff, unsigned soff, void* lds_wave_base) {
+    static const char zeros[16] = {0};
+    const void* src = ((unsigned long long)voff + 16 <= r.bytes) ? (const void*)(r.base + voff + soff) : (const void*)zeros;
+    gg_emu_dma_issue(src, (char*)lds_wave_base + 16 * (threadIdx.x & 63u));
+}
 template <int P>
 static inline void gg_setprio() {}
 template <typename T>

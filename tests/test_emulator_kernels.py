@@ -532,6 +532,41 @@ def test_direct_conv_matches_implicit_gemm(cfg):
     assert rel_err(K.conv2d_nhwc(x, w, ksize=3, in_scale=s_in, force_tile=9), K.conv2d_nhwc(x, w, ksize=3, in_scale=s_in, force_tile=1)) < 2e-3
 
 
+@pytest.mark.parametrize('cfg', [(1, 16, 16, 64, 256, 7), (5, 8, 8, 128, 264, 7), (1, 8, 32, 64, 128, 8), (3, 16, 8, 64, 136, 8),
+                                 (1, 64, 64, 64, 128, 7)])
+def test_halo_staged_conv3_matches_fp32_convolution(cfg):
+    """gg_conv3 (activation halo staged once per 64-channel chunk, nine taps read it at a tap-uniform offset, weight tiles by
+    LDS-DMA into swizzled rows) against fp32 convolution of the same bf16 operands: whole-image tiles (H*W < 256, ragged
+    image count), row tiles (H*W >= 256, non-square), ragged N, several channel chunks; plain, bias + activation and residual
+    epilogues; and the planner hands ineligible geometries to the implicit GEMM."""
+    n, H, W, ci, co, tile = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(n, H, W, ci)); w = bf(torch.randn(co, 9 * ci) * 0.1)
+    bias = torch.randn(co); res = bf(torch.randn(n, H, W, co))
+    exact = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().view(co, 3, 3, ci).permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    K.plan_log = []
+    got = K.conv2d_nhwc(x, w, ksize=3, out_dtype=torch.float32, force_tile=tile)
+    assert K.plan_log == [(tile, 1)]
+    K.plan_log = None
+    assert rel_err(got, exact) < 1e-5
+    got = K.conv2d_nhwc(x, w, ksize=3, bias=bias, act='lrelu', alpha=0.5, bias_scale=0.5, force_tile=tile)
+    assert rel_err(got, F.leaky_relu(0.5 * exact + 0.5 * bias, 0.2)) < 4e-3
+    got = K.conv2d_nhwc(x, w, ksize=3, residual=res, res_scale=0.5, force_tile=tile)
+    assert rel_err(got, exact + 0.5 * res.float()) < 4e-3
+
+
+def test_halo_staged_conv3_is_not_planned_for_ineligible_geometries():
+    torch.manual_seed(0)
+    K.plan_log = []
+    for (H, W, ci, ks, kw) in [(4, 4, 64, 3, {}), (16, 16, 32, 3, {}), (12, 16, 64, 3, {}), (16, 16, 64, 1, {}),
+                               (16, 16, 64, 3, dict(in_scale=torch.rand(2, 64) + 0.5))]:
+        x = bf(torch.randn(2, H, W, ci)); w = bf(torch.randn(128, ks * ks * ci) * 0.1)
+        got = K.conv2d_nhwc(x, w, ksize=ks, force_tile=7, **kw)
+        assert rel_err(got, K.conv2d_nhwc(x, w, ksize=ks, force_tile=1, **kw)) < 2e-3
+    assert all(t not in (7, 8) for t, _ in K.plan_log[::2]), K.plan_log
+    K.plan_log = None
+
+
 @pytest.mark.parametrize('cfg', [(5, 2, 10, 12, 3), (18, 1, 8, 16, 1), (3, 4, 6, 20, 3)])
 def test_fused_adaptive_conv_coefficients_match_tensor_algebra(cfg):
     from helpers import check_modcoef

@@ -398,6 +398,27 @@ def test_direct_conv_vs_implicit_gemm_and_cpu(cfg):
     assert rel_err(K.conv2d_nhwc(xd, wd, force_tile=9, **kw), K.conv2d_nhwc(xd, wd, force_tile=1, **kw)) < BF16_TOL
 
 
+@pytest.mark.parametrize('cfg', [(8, 16, 16, 512, 512, 7), (13, 8, 8, 256, 520, 7), (2, 64, 64, 128, 128, 8), (4, 32, 16, 64, 200, 8),
+                                 (4, 32, 32, 256, 256, 7)])
+def test_halo_staged_conv3_vs_implicit_gemm_and_cpu(cfg):
+    """gg_conv3 (halo staged once per channel chunk) against the implicit-GEMM kernel on the same operands and against fp32 CPU
+    convolution, forward and data-gradient form, plain and full epilogue."""
+    n, H, W, ci, co, tile = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(n, H, W, ci)); w = bf(torch.randn(co, 9 * ci) * 0.05)
+    bias = torch.randn(co); res = bf(torch.randn(n, H, W, co))
+    xd, wd, bd, rd = x.to(dev()), w.to(dev()), bias.to(dev()), res.to(dev())
+    K.plan_log = []
+    got = K.conv2d_nhwc(xd, wd, ksize=3, out_dtype=torch.float32, force_tile=tile)
+    assert K.plan_log == [(tile, 1)]
+    K.plan_log = None
+    exact = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().view(co, 3, 3, ci).permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    assert rel_err(got.cpu(), exact) < F32_TOL
+    assert rel_err(got, K.conv2d_nhwc(xd, wd, ksize=3, out_dtype=torch.float32, force_tile=1)) < F32_TOL
+    kw = dict(ksize=3, bias=bd, act='lrelu', alpha=0.5, bias_scale=0.5, residual=rd)
+    assert rel_err(K.conv2d_nhwc(xd, wd, force_tile=tile, **kw), K.conv2d_nhwc(xd, wd, force_tile=1, **kw)) < BF16_TOL
+
+
 @pytest.mark.parametrize('cfg', [(5, 2, 10, 12, 3), (32, 2, 512, 512, 3), (32, 2, 32, 64, 3), (32, 1, 3, 32, 1)])
 def test_fused_adaptive_conv_coefficients_match_tensor_algebra(cfg):
     from helpers import check_modcoef
