@@ -135,7 +135,7 @@ def main():
         best = (t_plan, tile.value, sk.value)
         if t_plan >= args.min_us:
             ktiles = (d.K + 31) // 32
-            for ft in (1, 2, 3, 4, 5, 6, 9):
+            for ft in (1, 2, 3, 4, 5, 6, 7, 8, 9):
                 seen = set()
                 for fs in ladder:
                     if fs > ktiles:
@@ -148,8 +148,8 @@ def main():
                     t = time_plan(L, d, ws)
                     if t is not None and t < best[0]:
                         best = (t, ft, s2.value)
-                    if ft == 9:
-                        break
+                    if ft in (7, 8, 9):
+                        break               # the halo-staged and direct convolutions do not split K
                     if t is not None and t > 3 * best[0] and fs >= 8:
                         break                   # far off already: deeper splits only add reduction traffic
         d.force_tile = d.force_splitk = 0
