@@ -648,8 +648,7 @@ extern "C" int gg_wgrad_finish(const float* g, float* dst, int32_t O, int32_t I,
     if (O <= 0 || I <= 0 || T <= 0 || C8 < I || O8 < O) return gg_fail(-2, "gg_wgrad_finish: bad extents");
     GgWgradFinishParams p;
     p.g = g; p.dst = dst; p.O = O; p.I = I; p.T = T; p.C8 = C8; p.O8 = O8; p.accumulate = accumulate; p.alpha = alpha;
-    p.splits = 1; p.split_stride = 0;
-    GG_LAUNCH(gg_wgrad_finish_kernel, dim3((unsigned)((O + 31) / 32), (unsigned)((I + 31) / 32)), dim3(256),
+    GG_LAUNCH(gg_wgrad_finish_kernel, dim3((unsigned)((O + 31) / 32), (unsigned)((I + GG_WF_IB - 1) / GG_WF_IB)), dim3(256),
               (hipStream_t)stream, p);
     return gg_check_launch();
 }
