@@ -566,7 +566,25 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
         long long total = (long long)d->M * d->N * d->batch;
         long long nb = pl.splitk <= 8 ? (total + 255) / 256 : (total + 63) / 64;
         if (nb > 8192) nb = 8192;
-        GG_LAUNCH(gg_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), s, p);
+        // 2..8 slices of a 4-column-aligned plain [m][n] result: the vectorised finish (all slice loads in flight)
+        const bool vec = pl.splitk <= 8 && !(d->N & 3) && !d->d2s && !(d->ldc & 3) && !(d->c_batch_stride & 3) &&
+                         !(((uintptr_t)d->C_out) & 15) && !(((uintptr_t)workspace) & 15);
+        if (vec) {
+            long long nb4 = (total / 4 + 255) / 256;
+            if (nb4 > 8192) nb4 = 8192;
+            const dim3 g4((unsigned)nb4), blk(256);
+            switch (pl.splitk) {
+                case 2: GG_LAUNCH((gg_splitk_reduce4_kernel<2>), g4, blk, s, p); break;
+                case 3: GG_LAUNCH((gg_splitk_reduce4_kernel<3>), g4, blk, s, p); break;
+                case 4: GG_LAUNCH((gg_splitk_reduce4_kernel<4>), g4, blk, s, p); break;
+                case 5: GG_LAUNCH((gg_splitk_reduce4_kernel<5>), g4, blk, s, p); break;
+                case 6: GG_LAUNCH((gg_splitk_reduce4_kernel<6>), g4, blk, s, p); break;
+                case 7: GG_LAUNCH((gg_splitk_reduce4_kernel<7>), g4, blk, s, p); break;
+                default: GG_LAUNCH((gg_splitk_reduce4_kernel<8>), g4, blk, s, p); break;
+            }
+        } else {
+            GG_LAUNCH(gg_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), s, p);
+        }
         rc = gg_check_launch();
     }
     return rc;

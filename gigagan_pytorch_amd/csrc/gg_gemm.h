@@ -727,6 +727,42 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_gemm_kernel(GgGemmParams p) {
     }
 }
 
+// split-K finish for 2..8 slices of a [M][N] result with N % 4 == 0: a thread owns four consecutive columns and issues the 16-byte
+// loads of ALL slices before the first add (the generic kernel below walks the slices in a run-time loop: one exposed round trip
+// per slice). Slices are added in index order, as there.
+template <int SK>
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_splitk_reduce4_kernel(GgGemmParams p) {
+    const long long per = (long long)p.M * p.N;
+    const long long total4 = per * p.batch / 4;
+    for (long long v4 = (long long)blockIdx.x * 256 + threadIdx.x; v4 < total4; v4 += (long long)gridDim.x * 256) {
+        const long long idx = v4 * 4;
+        int b = 0;
+        long long rem = idx;
+        if (p.batch > 1) {
+            b = (int)(idx / per);
+            rem = idx - (long long)b * per;
+        }
+        const float* src = p.partial + (long long)b * SK * per + rem;
+        f32x4 v[SK];
+#pragma unroll
+        for (int ks = 0; ks < SK; ++ks) v[ks] = *(const f32x4*)(src + (long long)ks * per);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < SK; ++ks) s += v[ks];
+        const int m = (int)(rem / p.N), n = (int)(rem - (long long)m * p.N);
+        float o[4];
+        for (int e = 0; e < 4; ++e) o[e] = gg_epilogue(p, s[e], m, n + e);
+        const long long off = (long long)b * p.c_bs + (long long)m * p.ldc + n;
+        if (p.c_f32) {
+            const f32x4 w = {o[0], o[1], o[2], o[3]};
+            *(f32x4*)((float*)p.Cout + off) = w;
+        } else {
+            const u16x4 w = {gg_f2bf(o[0]), gg_f2bf(o[1]), gg_f2bf(o[2]), gg_f2bf(o[3])};
+            *(u16x4*)((bf16_t*)p.Cout + off) = w;
+        }
+    }
+}
+
 // finishes a split-K launch: sums the fp32 partials and applies the epilogue. Few splits: one thread per output
 // element. Many splits (narrow weight gradients: a few thousand outputs, hundreds to thousands of slices): a wave per 64
 // consecutive outputs (256-byte coalesced rows of the partial buffer), the 4 waves of the workgroup interleave over the
