@@ -1,6 +1,6 @@
 """GPU probe of the HBM-bound helper kernels around the contractions at config-2 sizes: achieved bytes/s of bias/activation
 backward, split-K reduce (inside conv2d_wgrad_nhwc), weight-gradient finish and the weight re-pack.
-Run on the GPU box:  python tests/gpu_stream_probe.py   (test infrastructure: not part of the product path)."""
+Run on the GPU box:  python tests/gpu_stream_probe.py [other_library.so]   (test infrastructure: not part of the product path)."""
 import sys
 from pathlib import Path
 
@@ -8,6 +8,9 @@ import torch
 
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
+from gigagan_pytorch_amd import _C   # noqa: E402
+if len(sys.argv) > 1:
+    _C.bind(sys.argv[1])           # another build of the library (same-box A/B)
 from gigagan_pytorch_amd import kernels as K   # noqa: E402
 
 
@@ -57,6 +60,14 @@ def main():
         for _ in range(reps):
             w = torch.randn(co, ci, 9, device=dev)
             tab.register(w, co, ci, 9, 'fwd'); tab.register(w, co, ci, 9, 'bwd')
+            tot += w.numel()
+    us = time_us(tab.refresh)
+    print(f'{tot / 1e6:.1f} M weights, {tab.n} entries: {us:7.1f} us  {tot * 12 / us / 1e6:5.2f} TB/s', flush=True)
+    tab, tot = K.PackTable(dev, capacity=256), 0           # the 1x1 part of the discriminator: attention projections, feed-forwards
+    for co, ci, reps in [(2048, 512, 4), (512, 2048, 4), (512, 512, 16), (1024, 256, 4), (256, 1024, 4), (256, 256, 16)]:
+        for _ in range(reps):
+            w = torch.randn(co, ci, 1, device=dev)
+            tab.register(w, co, ci, 1, 'fwd'); tab.register(w, co, ci, 1, 'bwd')
             tot += w.numel()
     us = time_us(tab.refresh)
     print(f'{tot / 1e6:.1f} M weights, {tab.n} entries: {us:7.1f} us  {tot * 12 / us / 1e6:5.2f} TB/s', flush=True)
