@@ -10,6 +10,9 @@ import torch
 
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
+from gigagan_pytorch_amd import _C   # noqa: E402
+if len(sys.argv) > 1:
+    _C.bind(sys.argv[1])           # another build of the library (same-box A/B)
 from gigagan_pytorch_amd import kernels as K   # noqa: E402
 
 
@@ -41,7 +44,7 @@ def main():
         w = (torch.randn(co, ks * ks * ci, device=dev) * 0.05).to(torch.bfloat16)
         ref = K.conv2d_nhwc(x, w, ksize=ks, force_tile=1).float()
         row = [name]
-        for tile in (0, 4, 5, 7, 8):
+        for tile in (0, 7, 8):
             out = K.conv2d_nhwc(x, w, ksize=ks, force_tile=tile).float()
             err = ((out - ref).norm() / ref.norm()).item()
             ms = time_ms(lambda: K.conv2d_nhwc(x, w, ksize=ks, force_tile=tile))
