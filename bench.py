@@ -343,14 +343,13 @@ def main():
             # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
             # gfx950 correction + WRITE_SIZE, KiB -> bytes), when the summary for this kernel is present
             traffic = traffic_shape = None
-            pmc = ROOT / 'profiles' / 'r01_pmc_traffic.json'
-            if pmc.exists():
+            for pmc in sorted((ROOT / 'profiles').glob('r0*_pmc_traffic*.json')):
                 try:
                     rec = json.loads(pmc.read_text())
                     if rec.get('kernel') == name:
                         traffic, traffic_shape = rec.get('bytes_per_launch'), rec.get('shape')
                 except Exception:
-                    traffic = None
+                    pass
             roofline = dict(bound='mfma', kernel=name, achieved=achieved, peak=MFMA_PEAK_TF, unit='TFLOP/s',
                             frac=achieved / MFMA_PEAK_TF, traffic=traffic, traffic_shape=traffic_shape,
                             avg_launch_us=a['ms'] / a['launches'] * 1e3, launches_per_step=a['launches'] / 4,
