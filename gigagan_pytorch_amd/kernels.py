@@ -154,7 +154,7 @@ def _epilogue(d: GemmDesc, alpha, bias, out_scale, rows_per_group, noise, noise_
 
 def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=True, out_dtype=torch.bfloat16,
          alpha=1.0, bias=None, act=None, act_slope=0.2, out_scale=None, rows_per_group=0,
-         k_valid=None, m_valid=None, n_valid=None, out=None, force_splitk=0, force_tile=0):
+         k_valid=None, m_valid=None, n_valid=None, out=None, force_splitk=0, force_tile=0, bias_scale=1.0):
     """C[b] = act(alpha * op(A[b]) @ op(B[b])^T ...) for bf16 operands of shape ([batch,] rows, cols).
 
     `trans_a=False`: A is stored (M, K) (k contiguous) -> ROWK; `trans_a=True`: stored (K, M) -> KROW.
@@ -189,7 +189,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=True, out_d
     d.C_out, d.ldc, d.c_is_f32 = ptr(out), out.stride(-2), int(out.dtype == torch.float32)
     d.c_batch_stride = out.stride(0) if out.dim() == 3 else 0
     d.force_splitk, d.force_tile = force_splitk, force_tile
-    _epilogue(d, alpha, bias, out_scale, rows_per_group, None, None, act, act_slope, keep)
+    _epilogue(d, alpha, bias, out_scale, rows_per_group, None, None, act, act_slope, keep, bias_scale=bias_scale)
     _run_gemm(d, a)
     return out
 

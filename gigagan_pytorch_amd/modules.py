@@ -421,8 +421,8 @@ class EqualLinear(nn.Module):
             self.bias = nn.Parameter(torch.zeros(dim_out))
         self.lr_mul = lr_mul
 
-    def forward(self, x):
-        return ops.impl.linear(x, self.weight * self.lr_mul, self.bias * self.lr_mul)
+    def forward(self, x, act=None):
+        return ops.impl.equal_linear(x, self.weight, getattr(self, 'bias', None), self.lr_mul, act)
 
 
 class StyleNetwork(nn.Module):
@@ -441,7 +441,10 @@ class StyleNetwork(nn.Module):
         if self.dim_text_latent > 0:
             assert exists(text_latent)
             x = torch.cat((x, text_latent.float()), dim=-1)
-        return self.net(x)
+        mods = list(self.net)           # [EqualLinear, LeakyReLU] pairs: the activation rides on the linear layer's epilogue
+        for lin in mods[0::2]:
+            x = lin(x, act='lrelu')
+        return x
 
 
 class Noise(nn.Module):

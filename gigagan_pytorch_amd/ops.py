@@ -150,6 +150,8 @@ def _table_pack(w, kind: str):
             shp = (shp[0] * shp[1],) + shp[2:]
         if kind == 's2d':                   # (O, 4C, 1, 1) over channels (c, s1, s2) == (O, C, 2*2) taps
             O, I, T, tk = shp[0], shp[1] // 4, 4, 'fwd'
+        elif len(shp) == 2:                 # linear weight (O, I): a one-tap kernel
+            O, I, T, tk = shp[0], shp[1], 1, kind
         else:
             O, I, T, tk = shp[0], shp[1], shp[2] * shp[3], kind
         src = w.detach()
@@ -764,6 +766,56 @@ def matmul_nt(x: torch.Tensor, w: torch.Tensor, bias=None, act=None, out_f32=Fal
     return out.reshape(*lead, n)
 
 
+class LinearFn(Function):
+    """y = act(scale * (x @ W^T + bias)) for a 2-D weight parameter owned by a FlatAdamW (EqualLinear of the style network,
+    gp.py:871-888, :909-921): the bf16 operand comes from the pack table (no per-call scale / cast / pad launches), the learning-rate
+    multiplier rides on the GEMM's alpha / bias_scale and the leaky-relu on its epilogue. Backward: one mask + column-sum pass,
+    two GEMMs, and the parameter gradients go straight into the flat .grad views when the trainer's grad sink is on. First
+    order only (the style network is never under the gradient penalty)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, scale, act):
+        O, I = w.shape
+        wb = packed_weight(w, 'fwd')                              # (O, I) bf16 (O, I multiples of 8: checked by the caller)
+        xb = x.reshape(-1, I)
+        xb = xb.to(ACT_DTYPE) if xb.dtype != ACT_DTYPE else xb
+        xb = xb.contiguous()
+        out = K.gemm(xb, wb, trans_b=True, alpha=scale, bias=bias, bias_scale=scale, act=act, act_slope=LRELU_SLOPE)[0]
+        ctx.cfg = (scale, act, tuple(x.shape), x.dtype)
+        ctx.save_for_backward(xb, w, bias, out if act else None)
+        return out.reshape(*x.shape[:-1], O)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        xb, w, bias, out = ctx.saved_tensors
+        scale, act, xshape, xdtype = ctx.cfg
+        O, I = w.shape
+        wb = packed_weight(w, 'fwd')
+        g = dout.reshape(-1, O)
+        g = (g.to(ACT_DTYPE) if g.dtype != ACT_DTYPE else g).contiguous()
+        want_db = bias is not None and ctx.needs_input_grad[2]
+        db = dw = dx = None
+        if act == 'lrelu' or want_db:
+            g, part = K.bias_act_bwd(g, out if act == 'lrelu' else None, want_db, LRELU_SLOPE, partials=True)
+            if want_db:
+                bsink = _grad_sink_of(bias)
+                if bsink is not None:
+                    K.colsum_finish(part, O, scale, out=bsink, accumulate=True)
+                else:
+                    db = K.colsum_finish(part, O, scale)
+        if ctx.needs_input_grad[0]:     # dx(r, i) = scale * sum_o g(r, o) W(o, i)
+            dx = K.gemm(g, wb, trans_b=False, alpha=scale)[0].reshape(xshape).to(xdtype)
+        if ctx.needs_input_grad[1]:     # dW(o, i) = scale * sum_r g(r, o) x(r, i)
+            gw = K.gemm(g, xb, trans_a=True, trans_b=False, alpha=scale, out_dtype=torch.float32)[0]
+            sink = _grad_sink_of(w)
+            if sink is not None:
+                sink.add_(gw)
+            else:
+                dw = gw
+        return dx, dw, db, None, None
+
+
 class GlobalMeanFn(Function):
     """(b, C, H, W) bf16 channels_last -> (b, C) fp32 mean over the pixels (SqueezeExcite's pool, gp.py:300): a two-stage HIP
     reduction over the bf16 tensor (gg_pool_mean_fwd). `fork=True` returns (mean, x): the trunk continues with the alias and
@@ -1048,6 +1100,19 @@ class HipOps:
 
     def linear(self, x, weight, bias=None, act=None):
         return matmul_nt(x, weight, None if bias is None else bias.float().contiguous(), act)
+
+    def equal_linear(self, x, weight, bias, lr_mul, act=None):
+        """EqualLinear (gp.py:871-888): act(linear(x, weight * lr_mul, bias * lr_mul)). Parameters of a FlatAdamW-owned model with
+        8-aligned extents run as LinearFn (operand from the pack table, multiplier and activation in the GEMM epilogue)."""
+        if (not second_order and isinstance(weight, torch.nn.Parameter) and getattr(weight, '_gg_pack_table', None) is not None
+                and not _DEBUG_NO_TABLE and weight.dim() == 2 and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0
+                and weight.dtype == torch.float32 and (bias is None or bias.dtype == torch.float32)
+                and act in (None, 'lrelu') and x.shape[-1] == weight.shape[1]
+                and not (weight.device.type == 'cuda' and torch.cuda.is_current_stream_capturing()
+                         and '_gg_tpacks' not in weight.__dict__)):
+            return LinearFn.apply(x, weight, bias, float(lr_mul), act)
+        y = self.linear(x, weight * lr_mul, None if bias is None else bias * lr_mul)
+        return F.leaky_relu(y, LRELU_SLOPE) if act == 'lrelu' else y
 
     # -- skip-layer excitation multiply (gp.py:1023-1024, :1812-1813) ----------------------------
     def channel_scale(self, x, s):

@@ -80,7 +80,7 @@ class FlatAdamW(torch.optim.Optimizer):
         from . import ops
         ops._pack_tables.add(self.pack_table)
         for p in self._all:
-            if p.ndim >= 4:
+            if p.ndim >= 4 or p.ndim == 2:      # conv weights / kernel banks; linear weights (ops.LinearFn)
                 p._gg_pack_table = self.pack_table
 
     def zero_grad(self, set_to_none=False):

@@ -94,6 +94,50 @@ def check_flat_optimizer_packs_and_grad_sink(device):
             assert torch.equal(fresh, w.detach().permute(0, 2, 3, 1).reshape(16, -1).to(torch.bfloat16))
 
 
+def check_style_network_on_linear_fn(device):
+    """StyleNetwork owned by a FlatAdamW: every EqualLinear + LeakyReLU pair runs as ops.LinearFn (bf16 operand from the pack
+    table, lr multiplier and activation in the GEMM epilogue; gradients through one mask / column-sum pass and two GEMMs, into
+    the flat gradient buffer with the grad sink). Output and every parameter / input gradient against the oracle formulation of
+    gp.py:871-921; operands stay current after an optimizer step."""
+    from gigagan_pytorch_amd import ops
+    from gigagan_pytorch_amd.modules import StyleNetwork
+    from gigagan_pytorch_amd.optimizer import FlatAdamW
+    from oracle.torch_ops import OracleOps
+    torch.manual_seed(0)
+    net = StyleNetwork(64, 3, lr_mul=0.1).to(device)
+    for m in net.net[0::2]:
+        torch.nn.init.normal_(m.bias, std=0.5)
+    opt = FlatAdamW(list(net.parameters()), lr=1e-2)
+    z = torch.randn(6, 64).to(device).requires_grad_()
+    probe = torch.randn(6, 64).to(device)
+
+    def run(sink):
+        opt.zero_grad()
+        z.grad = None
+        y = net(z)
+        ops.grad_sink = sink
+        try:
+            (y.float() * probe).sum().backward()
+        finally:
+            ops.grad_sink = False
+        return y.detach().float().cpu(), opt.flat_g.clone().cpu(), z.grad.clone().cpu()
+    with ops.use_impl(OracleOps(bf16_operands=True)):
+        y_ref, g_ref, dz_ref = run(False)
+    with ops.use_impl(ops.HipOps()):
+        y, g, dz = run(False)
+        assert '_gg_tpacks' in net.net[0].weight.__dict__, 'the pack-table path was not taken'
+        y2, g2, dz2 = run(True)
+        assert rel_err(y, y_ref) < 1e-2 and rel_err(g, g_ref) < 2e-2 and rel_err(dz, dz_ref) < 2e-2, (rel_err(y, y_ref), rel_err(g, g_ref), rel_err(dz, dz_ref))
+        assert rel_err(g2, g) < 1e-6 and torch.equal(y2, y) and torch.equal(dz2, dz)
+        opt.step()
+        w = net.net[0].weight
+        assert torch.equal(ops.packed_weight(w, 'fwd'), w.detach().to(torch.bfloat16))
+        with torch.no_grad():
+            y3 = net(z).float().cpu()
+    with ops.use_impl(OracleOps(bf16_operands=True)), torch.no_grad():
+        assert rel_err(y3, net(z).float().cpu()) < 1e-2
+
+
 def check_modcoef(cfg, device):
     """gg_modcoef (s, a, d in one launch; gradients w.r.t. mod, kernel_mod and the kernel bank in two) against the
     tensor-algebra formulation of gp.py:378-400, values and gradients."""

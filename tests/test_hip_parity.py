@@ -323,6 +323,11 @@ def test_fused_modconv_uses_bank_operand_from_pack_table():
     check_fused_modconv_uses_bank_operand_from_pack_table(dev())
 
 
+def test_style_network_runs_on_linear_fn_and_matches_oracle():
+    from helpers import check_style_network_on_linear_fn
+    check_style_network_on_linear_fn(dev())
+
+
 def test_flat_optimizer_packs_and_grad_sink_match_autograd():
     from helpers import check_flat_optimizer_packs_and_grad_sink
     check_flat_optimizer_packs_and_grad_sink(dev())
