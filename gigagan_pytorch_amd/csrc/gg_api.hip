@@ -4,6 +4,7 @@
 #include "gg_gemm.h"
 #include "gg_gemm2.h"
 #include "gg_conv3.h"
+#include "gg_wgrad9.h"
 #include "gg_elementwise.h"
 #include "gg_modconv.h"
 #include "gg_attention.h"
@@ -251,6 +252,8 @@ static void gg_launch_dconv(const GgGemmParams& p, hipStream_t s) {
 
 static bool gg_conv3_eligible(const gg_gemm_desc* d);
 static GemmPlan gg_conv3_plan(const gg_gemm_desc* d, int tile);
+static bool gg_wgrad9_eligible(const gg_gemm_desc* d);
+static GemmPlan gg_wgrad9_plan(const gg_gemm_desc* d, int splitk);
 
 // ---- tuning cache: measured-best (tile, split-K) per exact geometry (gg_gemm_plan_table) ----------------------------------
 struct GgPlanChoice { int tile, splitk; };
@@ -281,6 +284,11 @@ static bool gg_table_plan(const gg_gemm_desc* d, GemmPlan& pl) {
     if (tile == 7 || tile == 8) {
         if (!gg_conv3_eligible(d)) return false;
         pl = gg_conv3_plan(d, tile);
+        return true;
+    }
+    if (tile == 10) {
+        if (!gg_wgrad9_eligible(d)) return false;
+        pl = gg_wgrad9_plan(d, it->second.splitk);
         return true;
     }
     if (tile < 1 || tile > 6) return false;
@@ -335,6 +343,66 @@ static GemmPlan gg_conv3_plan(const gg_gemm_desc* d, int tile) {
     return pl;
 }
 
+// the nine-tap weight gradient (gg_wgrad9.h, plan tile 10): 3x3 / stride 1 / pad 1 on 32-channel-multiple inputs, 8..64-wide power-of-
+// two images. It takes over the 8-wave implicit-GEMM weight gradient wherever the planner chose a 256-row tile on an eligible layer
+// (measured +16-35 % per layer on the 256/512-channel layers, +1.9 % on the step: profiles/r02_wgrad9_ab.log); GG_WGRAD9=0 disables
+// that (A/B runs); force_tile 10 selects it wherever eligible.
+static int gg_wgrad9_policy() {
+    static int policy = -1;
+    if (policy < 0) {
+        const char* e = getenv("GG_WGRAD9");
+        policy = e ? atoi(e) : 1;
+        if (policy < 0) policy = 1;
+    }
+    return policy;
+}
+
+static bool gg_wgrad9_eligible(const gg_gemm_desc* d) {
+    if (!d->a_conv || d->a_layout != GG_KROW || d->b_layout != GG_KROW) return false;
+    if (d->R != 3 || d->S != 3 || d->conv_stride != 1 || d->conv_pad != 1) return false;
+    if (d->C != d->CV || (d->C & 31) || d->M != 9 * d->C || (d->N & 7) || (d->ldb & 7) || (d->ldc & 3)) return false;
+    if (d->in_scale || d->b_image_stride || d->batch != 1 || d->d2s || !d->c_is_f32) return false;
+    if (d->bias || d->out_scale || d->noise || d->residual || d->act != GG_ACT_NONE) return false;
+    if (!gg_pow2(d->H) || !gg_pow2(d->W) || d->W < 8 || d->W > 64 || d->H * d->W < 64 || (d->K & 63)) return false;
+    if (d->K % (d->H * d->W)) return false;
+    if (gg_a_bytes(d) + (1ll << 24) >= (1ll << 32) || gg_b_bytes(d) >= (1ll << 32)) return false;
+    return true;
+}
+
+// split-K for the nine-tap kernel: one 99 KB workgroup per CU; the same cost form as gg_plan_cost (rounds x k-tiles + partial traffic)
+static GemmPlan gg_wgrad9_plan(const gg_gemm_desc* d, int splitk) {
+    GemmPlan pl;
+    pl.tile = 10; pl.bm = 288; pl.bn = 256;
+    pl.blocks_mn = (long long)(d->C / 32) * ((d->N + 255) / 256);
+    const int ktiles = d->K / 64;
+    int sk = splitk;
+    if (sk <= 0) {
+        double best = 1e30;
+        sk = 1;
+        int max_sk = ktiles / 4;
+        if (max_sk < 1) max_sk = 1;
+        if (max_sk > 256) max_sk = 256;
+        for (int c = 1; c <= max_sk; ++c) {
+            const int per = (ktiles + c - 1) / c;
+            if ((ktiles + per - 1) / per != c) continue;
+            const long long rounds = (pl.blocks_mn * c + 255) / 256;
+            double t = (double)rounds * (per * 1.9 + 3.0);
+            if (c > 1) t += 3.0 + (double)d->M * d->N * 4.0 * (c + 1) / 4.0e6;
+            if (t < best) { best = t; sk = c; }
+        }
+    }
+    if (sk > ktiles) sk = ktiles;
+    const int per = (ktiles + sk - 1) / sk;
+    pl.splitk = (ktiles + per - 1) / per;
+    pl.k_per_split = per * 64;
+    return pl;
+}
+
+static GemmPlan gg_wgrad9_substitute(const gg_gemm_desc* d, const GemmPlan& pl) {
+    if ((pl.tile != 4 && pl.tile != 5) || d->force_tile != 0 || d->force_splitk != 0 || !gg_wgrad9_policy() || !gg_wgrad9_eligible(d)) return pl;
+    return gg_wgrad9_plan(d, 0);
+}
+
 // the planner (table or cost model) thinks in implicit-GEMM tiles; an unsplit 256-row choice on an eligible layer runs halo-staged
 static GemmPlan gg_conv3_substitute(const gg_gemm_desc* d, const GemmPlan& pl) {
     if ((pl.tile != 4 && pl.tile != 5) || pl.splitk != 1 || d->force_tile != 0 || !gg_conv3_policy() || !gg_conv3_eligible(d)) return pl;
@@ -344,7 +412,8 @@ static GemmPlan gg_conv3_substitute(const gg_gemm_desc* d, const GemmPlan& pl) {
 GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     GemmPlan pl;
     if ((d->force_tile == 7 || d->force_tile == 8) && gg_conv3_eligible(d)) return gg_conv3_plan(d, d->force_tile);
-    if (gg_table_plan(d, pl)) return gg_conv3_substitute(d, pl);
+    if (d->force_tile == 10 && gg_wgrad9_eligible(d)) return gg_wgrad9_plan(d, d->force_splitk);
+    if (gg_table_plan(d, pl)) return gg_wgrad9_substitute(d, gg_conv3_substitute(d, pl));
     if (gg_use_dconv(d)) {
         pl.tile = 9; pl.bm = GG_DC_TH * GG_DC_TW; pl.bn = d->N <= 32 ? 32 : 64;
         pl.splitk = 1; pl.k_per_split = d->K; pl.blocks_mn = d->M / pl.bm;
@@ -396,7 +465,7 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     const int per = (ktiles + pl.splitk - 1) / pl.splitk;
     pl.splitk = (ktiles + per - 1) / per;
     pl.k_per_split = per * tm.bk;
-    return gg_conv3_substitute(d, pl);
+    return gg_wgrad9_substitute(d, gg_conv3_substitute(d, pl));
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -461,7 +530,7 @@ extern "C" int gg_gemm_plan_table(const gg_plan_entry* entries, int32_t n) {
     g_plan_table.clear();
     for (int i = 0; i < n; ++i) {
         const gg_plan_entry& e = entries[i];
-        if (e.tile < 1 || e.tile > 9 || e.splitk < 1) return gg_fail(-2, "gg_gemm_plan_table: entry %d has tile %d split-K %d", i, e.tile, e.splitk);
+        if (e.tile < 1 || e.tile > 10 || e.splitk < 1) return gg_fail(-2, "gg_gemm_plan_table: entry %d has tile %d split-K %d", i, e.tile, e.splitk);
         g_plan_table[gg_plan_key(&e.M)] = GgPlanChoice{e.tile, e.splitk};
     }
     return 0;
@@ -544,6 +613,7 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
         else if (d->C == 32) { if (wide) gg_launch_dconv<32, 2>(p, s); else gg_launch_dconv<32, 1>(p, s); }
         else { if (wide) gg_launch_dconv<64, 2>(p, s); else gg_launch_dconv<64, 1>(p, s); }
     }
+    else if (pl.tile == 10) GG_LAUNCH(gg_wgrad9_kernel, grid2, dim3(GG2_NT), s, p);
     else if (pl.tile == 7 || pl.tile == 8) {
         const bool full = p.bias || p.out_scale || p.noise || p.residual || p.act != GG_ACT_NONE;
         if (pl.tile == 7) {

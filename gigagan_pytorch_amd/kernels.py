@@ -94,6 +94,8 @@ def _kernel_key(d: GemmDesc, L) -> str:
     L.lib.gg_gemm_plan(C.byref(d), C.byref(tile), C.byref(sk))
     if tile.value == 9:
         name = f'gg_dconv_kernel<C={d.C},TN={1 if d.N <= 32 else 2}>'
+    elif tile.value == 10:
+        name = 'gg_wgrad9_kernel'
     elif tile.value in (7, 8):
         name = f'gg_conv3_kernel<{256 if tile.value == 7 else 128}>'
     elif tile.value >= 4:

@@ -135,7 +135,7 @@ def main():
         best = (t_plan, tile.value, sk.value)
         if t_plan >= args.min_us:
             ktiles = (d.K + 31) // 32
-            for ft in (1, 2, 3, 4, 5, 6, 7, 8, 9):
+            for ft in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
                 seen = set()
                 for fs in ladder:
                     if fs > ktiles:

@@ -560,6 +560,31 @@ def test_halo_staged_conv3_matches_fp32_convolution(cfg):
     assert rel_err(got, exact + 0.5 * res.float()) < 4e-3
 
 
+@pytest.mark.parametrize('cfg', [(1, 16, 16, 32, 256, 0), (3, 8, 8, 64, 264, 2), (1, 32, 32, 32, 128, 4), (1, 8, 64, 32, 40, 0),
+                                 (2, 16, 8, 96, 256, 1)])
+def test_nine_tap_weight_gradient_matches_autograd(cfg):
+    """gg_wgrad9 (all nine taps of a 32-channel slice per workgroup: dy tile shared, x operand = the k-tile's halo read through
+    transpose reads at a tap-uniform offset) against autograd's conv weight gradient on the same bf16 operands: whole-image and
+    row k-tiles, several channel slices, ragged output-channel tiles, automatic and forced split-K."""
+    n, H, W, ci, co, sk = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(n, H, W, ci)); dy = bf(torch.randn(n, H, W, co))
+    w = torch.zeros(co, ci, 3, 3, requires_grad=True)
+    F.conv2d(x.float().permute(0, 3, 1, 2), w, padding=1).backward(dy.float().permute(0, 3, 1, 2))
+    want = w.grad.permute(2, 3, 1, 0).reshape(-1, co)
+    K.plan_log = []
+    got = K.conv2d_wgrad_nhwc(x, dy, ksize=3, force_tile=10, force_splitk=sk)
+    assert K.plan_log[-1][0] == 10 and (sk == 0 or K.plan_log[-1][1] == sk), K.plan_log
+    K.plan_log = None
+    assert rel_err(got, want) < 1e-5
+    # ineligible geometries (4x4 images, 24 channels, stride 2) are planned on the implicit GEMM
+    K.plan_log = []
+    K.conv2d_wgrad_nhwc(bf(torch.randn(2, 4, 4, 32)), bf(torch.randn(2, 4, 4, 64)), ksize=3, force_tile=10)
+    K.conv2d_wgrad_nhwc(bf(torch.randn(1, 8, 8, 24)), bf(torch.randn(1, 8, 8, 64)), ksize=3, force_tile=10)
+    assert all(t != 10 for t, _ in K.plan_log), K.plan_log
+    K.plan_log = None
+
+
 def test_halo_staged_conv3_is_not_planned_for_ineligible_geometries():
     torch.manual_seed(0)
     K.plan_log = []

@@ -424,6 +424,23 @@ def test_halo_staged_conv3_vs_implicit_gemm_and_cpu(cfg):
     assert rel_err(K.conv2d_nhwc(xd, wd, force_tile=tile, **kw), K.conv2d_nhwc(xd, wd, force_tile=1, **kw)) < BF16_TOL
 
 
+@pytest.mark.parametrize('cfg', [(64, 16, 16, 512, 512, 0), (40, 8, 8, 256, 520, 3), (8, 32, 32, 128, 256, 0), (2, 64, 64, 64, 128, 16)])
+def test_nine_tap_weight_gradient_vs_implicit_gemm_and_cpu(cfg):
+    """gg_wgrad9 against the 4-wave implicit-GEMM weight gradient on the same operands and against fp32 CPU autograd."""
+    n, H, W, ci, co, sk = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(n, H, W, ci)); dy = bf(torch.randn(n, H, W, co))
+    xd, dyd = x.to(dev()), dy.to(dev())
+    K.plan_log = []
+    got = K.conv2d_wgrad_nhwc(xd, dyd, ksize=3, force_tile=10, force_splitk=sk)
+    assert K.plan_log[-1][0] == 10
+    K.plan_log = None
+    assert rel_err(got, K.conv2d_wgrad_nhwc(xd, dyd, ksize=3, force_tile=1)) < F32_TOL
+    w = torch.zeros(co, ci, 3, 3, requires_grad=True)
+    F.conv2d(x.float().permute(0, 3, 1, 2), w, padding=1).backward(dy.float().permute(0, 3, 1, 2))
+    assert rel_err(got.cpu(), w.grad.permute(2, 3, 1, 0).reshape(-1, co)) < F32_TOL
+
+
 @pytest.mark.parametrize('cfg', [(5, 2, 10, 12, 3), (32, 2, 512, 512, 3), (32, 2, 32, 64, 3), (32, 1, 3, 32, 1)])
 def test_fused_adaptive_conv_coefficients_match_tensor_algebra(cfg):
     from helpers import check_modcoef
