@@ -40,6 +40,14 @@ def main():
                 continue
             us = time_us(lambda: K.bias_act_bwd(dy, y, True, partials=True))
             print(f'rows {n * R * R:8d} C {Cc:4d}: {us:7.1f} us  {dy.numel() * 6 / us / 1e6:6.2f} TB/s', flush=True)
+    print('--- exact GELU of the attention feed-forwards: forward 4 B, backward 6 B, second order 10 B per element')
+    for rows, Cc in [(128 * 1024, 1024), (256 * 256, 2048), (32 * 1024, 1024)]:
+        x = torch.randn(rows, Cc, device=dev).to(torch.bfloat16)
+        dy = torch.randn(rows, Cc, device=dev).to(torch.bfloat16)
+        g = torch.randn(rows, Cc, device=dev).to(torch.bfloat16)
+        us = [time_us(lambda: K.gelu(x)), time_us(lambda: K.gelu(x, dy)), time_us(lambda: K.gelu(x, dy, g))]
+        print(f'{rows:7d} x {Cc:5d}: ' + '  '.join(f'{nm} {u:7.1f} us {x.numel() * bpe / u / 1e6:5.2f} TB/s'
+                                                    for nm, u, bpe in zip(('fwd', 'bwd', 'bwd2'), us, (4, 6, 10))), flush=True)
     print('--- weight gradient: GEMM + split-K reduce, then finish (fp32 (9C, O) -> (O, C, 9) accumulate)')
     for n, R, ci, co in [(8 * b, 16, 512, 512), (4 * b, 32, 256, 256), (16 * b, 8, 512, 512), (2 * b, 64, 128, 128), (b, 128, 64, 64)]:
         x = torch.randn(n, R, R, ci, device=dev).to(torch.bfloat16)
