@@ -33,7 +33,7 @@ struct GgPackEntry {
 #define GG_PK_P1 66       // kind 1 LDS pitch (bf16): 64 + 2 -> 33-word row shift, conflict-free transposed writes
 
 // header[0] = number of entries, header[1] = total work items
-// A workgroup walks a CONTIGUOUS range of items (one table search, then linear advance) and issues all fp32 loads of an item
+// A workgroup searches the table once, then only advances, and issues all fp32 loads of an item
 // before the first use (kind 0: up to 16 in flight per thread, kind 1: batches of 12): the first version searched the table per
 // item and looped load -> convert -> LDS store, i.e. ~12 us of exposed round trips per 9 KB item (1.8 TB/s on the D model).
 #define GG_PK_B1 12       // kind 1 loads in flight per thread
@@ -45,11 +45,11 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_pack_weights_kernel(const GgPackEntry* t
     const int n = (int)header[0];
     const long long total = header[1];
     const int tid = threadIdx.x;
-    const long long per_block = (total + gridDim.x - 1) / gridDim.x;
-    long long item = (long long)blockIdx.x * per_block;
-    long long item_end = item + per_block;
-    if (item_end > total) item_end = total;
-    if (item >= item_end) return;
+    // items are dealt round-robin (block b takes b, b + G, b + 2G, ...: heavy and light entries spread evenly over the workgroups;
+    // contiguous ranges left the blocks that drew the 9 KB transposing items running 2x longer than the launch's mean); a block's
+    // items increase, so the table position only ever advances
+    long long item = blockIdx.x;
+    if (item >= total) return;
     int lo = 0, hi = n - 1;                           // last entry with first_item <= item
     while (lo < hi) {
         int mid = (lo + hi + 1) >> 1;
@@ -57,11 +57,11 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_pack_weights_kernel(const GgPackEntry* t
     }
     GgPackEntry e = table[lo];
     long long next_first = lo + 1 < n ? table[lo + 1].first_item : total;
-    for (; item < item_end; ++item) {
-        while (item >= next_first) {                  // (entries without items are skipped)
+    for (; item < total; item += gridDim.x) {
+        while (item >= next_first) {
             ++lo;
-            e = table[lo];
             next_first = lo + 1 < n ? table[lo + 1].first_item : total;
+            if (item < next_first) e = table[lo];
         }
         const long long local = item - e.first_item;
         const int T = e.T;
