@@ -27,7 +27,8 @@ struct GgPackEntry {
 //   T <= 16: kind 0: one output row o x 256 input channels      -> O8 * ceil(I8 / 256) items
 //            kind 1: 64 output channels x 16 input channels     -> ceil(O8 / 64) * ceil(I8 / 16) items
 //            both stream contiguous fp32 runs in, transpose through LDS, and write contiguous bf16 rows out
-//   T  > 16: 256 eight-channel units per item, one per thread (strided scalar gathers; 7x7 stems only)
+//   T  > 16: 256 (eight-channel unit, tap) pairs per item, one per thread (strided scalar gathers; 7x7 stems only)
+//            -> ceil(O8 * I8 / 8 * T / 256) items
 #define GG_PK_TMAX 16
 #define GG_PK_P0 264      // kind 0 LDS pitch (bf16): 256 + 8
 #define GG_PK_P1 66       // kind 1 LDS pitch (bf16): 64 + 2 -> 33-word row shift, conflict-free transposed writes
@@ -68,32 +69,28 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_pack_weights_kernel(const GgPackEntry* t
         const int tinv = 65536 / T + 1;
         const long long drow = e.dst_row ? e.dst_row : (long long)T * e.I8;    // kind 0 destination pitches
         const long long dtap = e.dst_tap ? e.dst_tap : e.I8;
-        if (T > GG_PK_TMAX) {
-            const long long unit = local * 256 + tid;
+        if (T > GG_PK_TMAX) {      // one (8-channel unit, tap) per thread: 8 strided scalar loads, one 16-byte store
+            const long long w = local * 256 + tid;
+            const long long unit = w / T;
+            const int t = (int)(w - unit * T);
             if (e.kind == 0) {
                 const int chunks = e.I8 >> 3;
                 if (unit >= (long long)e.O8 * chunks) continue;
                 const int o = (int)(unit / chunks), i0 = (int)(unit % chunks) * 8;
-                const float* s = e.src + ((long long)o * e.I + i0) * T;
-                bf16_t* d = e.dst + (long long)o * drow + i0;
+                const float* s = e.src + ((long long)o * e.I + i0) * T + t;
                 const int valid = (o < e.O) ? (e.I - i0 < 8 ? e.I - i0 : 8) : 0;
-                for (int t = 0; t < T; ++t) {
-                    u16x8 v;
-                    for (int j = 0; j < 8; ++j) v[j] = gg_f2bf(j < valid ? s[(long long)j * T + t] : 0.f);
-                    *(u16x8*)(d + (long long)t * dtap) = v;
-                }
+                u16x8 v;
+                for (int j = 0; j < 8; ++j) v[j] = gg_f2bf(j < valid ? s[(long long)j * T] : 0.f);
+                *(u16x8*)(e.dst + (long long)o * drow + i0 + (long long)t * dtap) = v;
             } else {
                 if (unit >= (long long)e.I8 * (e.O8 >> 3)) continue;
                 const int i = (int)(unit % e.I8), o0 = (int)(unit / e.I8) * 8;
-                const float* s = e.src + ((long long)o0 * e.I + i) * T;
-                bf16_t* d = e.dst + (long long)i * T * e.O8 + o0;
+                const float* s = e.src + ((long long)o0 * e.I + i) * T + t;
                 const int valid = (i < e.I) ? (e.O - o0 < 8 ? e.O - o0 : 8) : 0;
                 const long long ostride = (long long)e.I * T;
-                for (int t = 0; t < T; ++t) {
-                    u16x8 v;
-                    for (int j = 0; j < 8; ++j) v[j] = gg_f2bf(j < valid ? s[j * ostride + t] : 0.f);
-                    *(u16x8*)(d + (long long)(T - 1 - t) * e.O8) = v;
-                }
+                u16x8 v;
+                for (int j = 0; j < 8; ++j) v[j] = gg_f2bf(j < valid ? s[j * ostride] : 0.f);
+                *(u16x8*)(e.dst + (long long)i * T * e.O8 + o0 + (long long)(T - 1 - t) * e.O8) = v;
             }
             continue;
         }

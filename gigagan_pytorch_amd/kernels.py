@@ -975,7 +975,7 @@ class PackTable:
         if T <= 16:     # work items per entry: the formulas of gg_weights.h
             self.items += o8 * ((i8 + 255) // 256) if k == 0 else ((o8 + 63) // 64) * ((i8 + 15) // 16)
         else:
-            self.items += (o8 * i8 // 8 + 255) // 256
+            self.items += (o8 * i8 // 8 * T + 255) // 256
         self.header.copy_(torch.tensor([self.n, self.items], dtype=torch.int64))
         self.keep.append((src, dst))
         return dst
