@@ -585,6 +585,32 @@ def test_nine_tap_weight_gradient_matches_autograd(cfg):
     K.plan_log = None
 
 
+def test_committed_plan_table_loads_and_is_honoured_by_the_planner():
+    """plans/gfx950.json (tests/gpu_plan_sweep.py output) is accepted entry by entry by gg_gemm_plan_table, every tile it names is
+    one the planner knows, and an installed entry (here: the nine-tap weight gradient with a measured split) overrides the cost
+    model for exactly its geometry; ineligible entries are ignored."""
+    import json
+    from gigagan_pytorch_amd import _C
+    L = _C.lib()
+    entries = json.loads(_C.PLAN_TABLE.read_text())['entries']
+    assert len(entries) > 50 and all(1 <= e['tile'] <= 10 and e['splitk'] >= 1 for e in entries)
+    try:
+        L.load_plan_table(entries)
+        assert L.plan_entries == len(entries)
+        x = bf(torch.randn(1, 16, 16, 32)); dy = bf(torch.randn(1, 16, 16, 64))
+        key = dict(M=288, N=64, K=256, batch=1, a_layout=1, b_layout=1, a_conv=1, H=16, W=16, C=32, CV=32, R=3, conv_stride=1,
+                   conv_pad=1, c_is_f32=1, d2s=0, epi=0, scaled=0)
+        L.load_plan_table([dict(key, tile=10, splitk=2), dict(key, N=72, tile=7, splitk=1)])
+        K.plan_log = []
+        got = K.conv2d_wgrad_nhwc(x, dy, ksize=3)
+        K.conv2d_wgrad_nhwc(x, bf(torch.randn(1, 16, 16, 72)), ksize=3)     # tile 7 is not a weight-gradient kernel: entry ignored
+        assert K.plan_log[0] == (10, 2) and K.plan_log[1][0] not in (7, 8), K.plan_log
+        assert rel_err(got, K.conv2d_wgrad_nhwc(x, dy, ksize=3, force_tile=1)) < 1e-5
+    finally:
+        K.plan_log = None
+        L.load_plan_table([])
+
+
 def test_halo_staged_conv3_is_not_planned_for_ineligible_geometries():
     torch.manual_seed(0)
     K.plan_log = []
