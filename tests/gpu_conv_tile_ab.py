@@ -1,6 +1,7 @@
-"""GPU A/B of the LDS-DMA staged contraction kernel (GG_GEMM_DMA=1) against the register-staged one on the config-2 row-major
-launches (conv forward / data gradient shapes, batch 32), each checked against the 4-wave 128x128 tile.
-Run twice on one box:  GG_GEMM_DMA=0 python tests/gpu_dma_ab.py; GG_GEMM_DMA=1 python tests/gpu_dma_ab.py
+"""GPU micro A/B of the row-major convolution kernels on the config-2 shapes (batch 32): the planned kernel (tile 0) against forced
+tiles (7 / 8: the halo-staged 3x3 convolution; 4 / 5 / 6: the 8-wave implicit GEMM), each checked against the 4-wave 128x128 tile.
+An optional argument binds another build of the library, for same-box comparisons of two builds:
+    python tests/gpu_conv_tile_ab.py [other_library.so]
 (test infrastructure: not part of the product path)."""
 import os
 import sys
@@ -53,7 +54,7 @@ def main():
             if tile == 0:
                 tot += ms
         print(' | '.join(row), flush=True)
-    print('GG_GEMM_DMA', os.environ.get('GG_GEMM_DMA', '0'), 'planned total', round(tot, 3), 'ms', flush=True)
+    print('planned total', round(tot, 3), 'ms', flush=True)
 
 
 if __name__ == '__main__':
