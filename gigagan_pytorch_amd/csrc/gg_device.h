@@ -68,24 +68,10 @@ GG_DEVICE u16x4 gg_lds_read_tr16(const bf16_t* p) {
     return __builtin_bit_cast(u16x4, r);
 }
 
-// direct global -> LDS load (LDS-DMA, global_load_lds_dwordx4): lane i's 16 bytes land at lds_wave_base + 16 i; the base
-// must be wave-uniform (it travels in M0). Counts on vmcnt like any vector-memory load; NOT ordered with ds_* operations.
-GG_DEVICE void gg_load_lds16(const void* g, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
-                                     (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
-}
 template <int N>
 GG_DEVICE void gg_wait_vm() {           // s_waitcnt vmcnt(N): at most N vector-memory operations of this wave outstanding
-    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    static_assert(N == 0 || N == 4 || N == 8, "add the literal");
-}
-// workgroup barrier WITHOUT the vmcnt(0) drain __syncthreads carries: LDS traffic of this wave retired, loads stay in flight
-GG_DEVICE void gg_barrier_raw() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    static_assert(N == 0, "add the literal");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // Buffer addressing (SRSRC): a wave-uniform 128-bit descriptor {base, bytes} plus a 32-bit per-lane byte offset and a scalar byte
@@ -111,9 +97,6 @@ GG_DEVICE u16x8 gg_buf_load16(GgBuf r, unsigned voff, unsigned soff) {
 GG_DEVICE void gg_buf_load_lds16(GgBuf r, unsigned voff, unsigned soff, void* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (void __attribute__((address_space(3)))*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
 }
-
-template <int P>
-GG_DEVICE void gg_setprio() { __builtin_amdgcn_s_setprio(P); }    // wave issue priority (arbitration between the waves of a SIMD)
 
 GG_DEVICE float gg_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 GG_DEVICE float gg_shfl(float v, int src) { return __shfl(v, src, 64); }

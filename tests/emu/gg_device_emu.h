@@ -60,12 +60,8 @@ u16x4 gg_emu_lds_read_tr16(const bf16_t* p);
 void gg_emu_dma_issue(const void* g, void* dst);
 void gg_emu_dma_wait(int keep_newest);
 static inline void gg_sync() { gg_emu_dma_wait(0); gg_emu_syncthreads(); }
-static inline void gg_load_lds16(const void* g, void* lds_wave_base) {
-    gg_emu_dma_issue(g, (char*)lds_wave_base + 16 * (threadIdx.x & 63u));
-}
 template <int N>
 static inline void gg_wait_vm() { gg_emu_dma_wait(N); }
-static inline void gg_barrier_raw() { gg_emu_syncthreads(); }
 // buffer addressing stand-in: the hardware range-checks the per-lane offset (not the scalar one) and returns zeros beyond `bytes`
 struct GgBuf { const char* base; unsigned long long bytes; };
 static inline GgBuf gg_make_buf(const void* base, unsigned long long bytes) {
@@ -82,8 +78,6 @@ static inline void gg_buf_load_lds16(GgBuf r, unsigned voff, unsigned soff, void
     const void* src = ((unsigned long long)voff + 16 <= r.bytes) ? (const void*)(r.base + voff + soff) : (const void*)zeros;
     gg_emu_dma_issue(src, (char*)lds_wave_base + 16 * (threadIdx.x & 63u));
 }
-template <int P>
-static inline void gg_setprio() {}
 template <typename T>
 static inline const T* gg_late_params(const T& by_value) { return &by_value; }
 static inline f32x16 gg_mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c) {
