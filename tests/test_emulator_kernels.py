@@ -585,6 +585,21 @@ def test_nine_tap_weight_gradient_matches_autograd(cfg):
     K.plan_log = None
 
 
+@pytest.mark.parametrize('sk', [2, 5, 8, 12])
+def test_splitk_finish_paths_bf16_batched_and_epilogue(sk):
+    """the vectorised finish (2..8 slices, four columns per thread) and the many-slice finish give the unsplit result: bf16 and
+    fp32 outputs, a batched launch, bias + leaky-relu applied after the slices are summed."""
+    torch.manual_seed(0)
+    A = bf(torch.randn(2, 40, 32 * sk)); B = bf(torch.randn(2, 24, 32 * sk)); bias = torch.randn(24)
+    for kw in (dict(out_dtype=torch.float32), dict(), dict(bias=bias, act='lrelu', alpha=0.25)):
+        want = K.gemm(A, B, force_tile=1, force_splitk=1, **kw)
+        K.plan_log = []
+        got = K.gemm(A, B, force_tile=1, force_splitk=sk, **kw)
+        assert K.plan_log[-1] == (1, sk), K.plan_log
+        K.plan_log = None
+        assert rel_err(got, want) < (1e-5 if kw.get('out_dtype') is torch.float32 else 4e-3), (sk, kw.keys())
+
+
 def test_committed_plan_table_loads_and_is_honoured_by_the_planner():
     """plans/gfx950.json (tests/gpu_plan_sweep.py output) is accepted entry by entry by gg_gemm_plan_table, every tile it names is
     one the planner knows, and an installed entry (here: the nine-tap weight gradient with a measured split) overrides the cost
