@@ -8,7 +8,7 @@
 // profiles/r02_dma_ab.log): the tile is fed at the L2's rate, not the matrix pipe's. Here the workgroup's 256 pixels are whole
 // image rows (or whole images), their one-pixel halo is parked in LDS per channel chunk (<= 400 slots x 128 bytes instead of
 // 9 x 256 x 128), and the nine taps read their fragments from it at a tap-uniform offset; only the weight tiles stream per
-// tap (LDS-DMA, XOR-swizzled rows as in gg_gemm2d_kernel). L2 -> LDS bytes per 9 k-tiles: 339 KB instead of 576 KB.
+// tap (LDS-DMA into XOR-swizzled rows: Gg2Dma in gg_gemm2.h). L2 -> LDS bytes per 9 k-tiles: 339 KB instead of 576 KB.
 //
 // Reduction order: (channel chunk, tap, channel) instead of (tap, channel): fp32 sums differ from the implicit GEMM in the last
 // bits.
@@ -97,7 +97,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_conv3_kernel(GgGemmParams p) {
         }
     };
 
-    // weight tiles: LDS-DMA into XOR-swizzled 128-byte rows (see gg_gemm2d_kernel)
+    // weight tiles: LDS-DMA into XOR-swizzled 128-byte rows (Gg2Dma, gg_gemm2.h)
     unsigned bvoff[BNV];
 #pragma unroll
     for (int i = 0; i < BNV; ++i) {
