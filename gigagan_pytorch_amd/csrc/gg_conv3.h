@@ -5,7 +5,7 @@
 // Why: the implicit GEMM (gg_gemm2.h) reloads the 256 x 64 activation tile for every tap — 64 KB per workgroup and k-tile
 // through L2 -> LDS. At 256 workgroups that is 8.6-10.9 TB/s when the kernel runs at 1100 TFLOP/s, which is what the L2 delivers
 // (the 256x128 tile tops out at 930 TFLOP/s = the same byte rate; register staging vs. LDS-DMA staging measured the same,
-// profiles/r02_dma_ab.log): the tile is fed at the L2's rate, not the matrix pipe's. Here the workgroup's 256 pixels are whole
+// profiles/r02_dma_ab_{off,on}.log): the tile is fed at the L2's rate, not the matrix pipe's. Here the workgroup's 256 pixels are whole
 // image rows (or whole images), their one-pixel halo is parked in LDS per channel chunk (<= 400 slots x 128 bytes instead of
 // 9 x 256 x 128), and the nine taps read their fragments from it at a tap-uniform offset; only the weight tiles stream per
 // tap (LDS-DMA into XOR-swizzled rows: Gg2Dma in gg_gemm2.h). L2 -> LDS bytes per 9 k-tiles: 339 KB instead of 576 KB.
