@@ -238,6 +238,19 @@ def main():
                     help='let the trajectory run on (it diverges on synthetic uniform images, here as in the reference)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher (replaces `accelerate launch`, reference README.md:168-182) -
+        # one rank per GPU under torch.distributed.run on this node; rank 0 of the children prints the JSON line
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        sys.exit(subprocess.call(cmd, env=env))
+
     from gigagan_pytorch_amd import distributed as gdist, kernels as K
     from gigagan_pytorch_amd.data import SyntheticImages
     from gigagan_pytorch_amd.gigagan import cycle
@@ -245,7 +258,8 @@ def main():
 
     rank, local, world = gdist.init_from_env('cuda')
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
-    assert world == args.gpus or world == 1, (world, args.gpus)
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE is {world}: launch one rank per GPU (or let bench.py do it)'
+    assert torch.cuda.device_count() > local, f'rank {rank}: no GPU {local} on this node ({torch.cuda.device_count()} visible)'
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
 
@@ -289,7 +303,11 @@ def main():
         run_steps(1)
         warmup += 1
     comm = gdist.native_comm()
-    if comm is not None:
+    graphs_on = bool(gan._graphable(1))
+    # exposed share of the gradient exchange = how long the compute stream waits at the join behind the in-backward slices.
+    # HIP events cannot be recorded inside a hipGraph replay, so with graphs on it is taken from the eager cycle further down.
+    time_comm_here = comm is not None and world > 1 and not graphs_on
+    if time_comm_here:
         comm.timing, comm.exposed_ms = True, []
     barrier()
     t0 = time.perf_counter()
@@ -298,18 +316,15 @@ def main():
     dt_local = time.perf_counter() - t0         # this rank's own clock, before the closing barrier
     barrier()
     dt = time.perf_counter() - t0
-    per_rank = None
+    mine = dict(rank=rank, ms_per_step=dt_local / steps * 1e3, exposed_comm_ms_per_step=None)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        exposed = 0.
-        if comm is not None:
-            comm.timing = False
-            exposed = sum(a.elapsed_time(b) for a, b in comm.exposed_ms) / steps
-        mine = dict(rank=rank, ms_per_step=dt_local / steps * 1e3, exposed_comm_ms_per_step=exposed)
-        per_rank = [None] * world
-        dist.all_gather_object(per_rank, mine)
+    if time_comm_here:
+        comm.timing = False
+        mine.update(exposed_comm_ms_per_step=sum(a.elapsed_time(b) for a, b in comm.exposed_ms) / steps,
+                    exposed_comm_measured='timed region (eager launches)')
     finite = bool(torch.isfinite(gan.G_opt.flat_p).all() and torch.isfinite(gan.D_opt.flat_p).all()
                   and torch.isfinite(gan.G_opt.flat_g).all() and torch.isfinite(gan.D_opt.flat_g).all())
     loss_vals = [float(v) for v in (*d_losses, *g_losses) if v is not None]
@@ -325,7 +340,15 @@ def main():
         graphs_were_on, gan.use_hip_graphs = gan.use_hip_graphs, False   # HIP events cannot be recorded inside a replay
         if rank == 0:
             K.profiler = K.GemmProfiler()
+        time_comm_cycle = comm is not None and world > 1 and mine['exposed_comm_ms_per_step'] is None
+        if time_comm_cycle:
+            comm.timing, comm.exposed_ms = True, []
         run_steps(4)
+        if time_comm_cycle:
+            comm.timing = False
+            torch.cuda.synchronize()
+            mine.update(exposed_comm_ms_per_step=sum(a.elapsed_time(b) for a, b in comm.exposed_ms) / 4,
+                        exposed_comm_measured='eager 4-step cycle after the timed region (the timed steps are hipGraph replays)')
         agg = shapes = None
         if rank == 0:
             agg = K.profiler.summary()
@@ -365,6 +388,11 @@ def main():
         except Exception as e:    # noqa: BLE001 - a secondary measurement must not take the bench line down
             roofline['modconv_forward'] = dict(error=f'{type(e).__name__}: {e}')
 
+    per_rank = None
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'uncond':
         cpu = cpu_baseline()
@@ -384,7 +412,10 @@ def main():
             steps=steps, warmup=warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling='weak',
             vs_baseline=None, dtype='bf16', data='synthetic',
             config=dict(workload=f'{what} bf16 bs={args.batch}/GPU, GP every 4th step', global_batch=args.batch * world,
-                        parallelism=f'dp{world}', hip_graphs=bool(gan._graphable(1))),
+                        parallelism=f'dp{world}', hip_graphs=bool(gan._graphable(1)), comm=gdist.comm_backend(),
+                        comm_world=(comm.world if comm is not None else (world if world > 1 else 0)),
+                        comm_overlap=('in-backward slices: D %d, G %d' % (gan.D_red.n, gan.G_red.n)
+                                      if (gan.D_red is not None and gan.overlap_grad_reduce) else 'none')),
             roofline=roofline, cpu_baseline=cpu,
             finite=finite, state_restored_every_cycle=snap is not None, per_rank=per_rank,
             last_losses=dict(d=float(d_losses.divergence), g=float(g_losses.divergence),

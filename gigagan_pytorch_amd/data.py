@@ -105,11 +105,35 @@ def shard_dataloader(dl, rank: int, world: int, seed: int = 0):
     if world <= 1 or not isinstance(dl, DataLoader) or not hasattr(dl.dataset, '__len__') or dl.batch_size is None:
         return dl
     from torch.utils.data.distributed import DistributedSampler
+    stock = (torch.utils.data.SequentialSampler, torch.utils.data.RandomSampler)
+    if not isinstance(dl.sampler, stock):
+        raise ValueError('shard_dataloader: the loader carries a custom sampler / batch_sampler; shard it yourself (e.g. a '
+                         'DistributedSampler over your sampling scheme) and pass the per-rank loader - it would be silently '
+                         'replaced otherwise')
     shuffle = not isinstance(dl.sampler, torch.utils.data.SequentialSampler)
     sampler = DistributedSampler(dl.dataset, num_replicas=world, rank=rank, shuffle=shuffle, seed=seed, drop_last=True)
-    return DataLoader(dl.dataset, batch_size=dl.batch_size, sampler=sampler, num_workers=dl.num_workers,
-                      collate_fn=dl.collate_fn, pin_memory=dl.pin_memory, drop_last=True,
-                      persistent_workers=getattr(dl, 'persistent_workers', False) and dl.num_workers > 0)
+    inner = DataLoader(dl.dataset, batch_size=dl.batch_size, sampler=sampler, num_workers=dl.num_workers,
+                       collate_fn=dl.collate_fn, pin_memory=dl.pin_memory, drop_last=True,
+                       persistent_workers=getattr(dl, 'persistent_workers', False) and dl.num_workers > 0)
+    return EpochShardedLoader(inner, sampler)
+
+
+class EpochShardedLoader:
+    """a per-rank DataLoader whose DistributedSampler is re-seeded at the start of every pass (`sampler.set_epoch`): the trainer
+    iterates through `cycle(dl)`, and without this every epoch would replay the first epoch's permutation on every rank
+    (accelerate's prepared loader reseeds per epoch, gp.py:2150-2159)."""
+
+    def __init__(self, loader, sampler):
+        self.loader, self.sampler, self.epoch = loader, sampler, 0
+        self.batch_size, self.dataset = loader.batch_size, loader.dataset
+
+    def __iter__(self):
+        self.sampler.set_epoch(self.epoch)
+        self.epoch += 1
+        return iter(self.loader)
+
+    def __len__(self):
+        return len(self.loader)
 
 
 def _record_stream(item, stream):

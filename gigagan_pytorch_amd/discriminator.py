@@ -274,6 +274,11 @@ class Discriminator(nn.Module):
         t2c = getattr(self, 'text_to_conv_conditioning', None)
         if t2c is not None:
             out.extend(t2c.parameters())
+        # the text encoder's tokens only reach the logits through that conditioning (gp.py:1717-1723): without the multi-scale
+        # outputs the whole encoder (transformer, learned_global_token, project_in) is left without gradients in the reference
+        te = getattr(self, 'text_encoder', None)
+        if te is not None and not self.unconditional:
+            out.extend(p for p in te.parameters() if p.requires_grad)
         return out
 
     def aux_parameters(self):

@@ -143,33 +143,77 @@ def native_comm() -> NativeComm | None:
     return _native
 
 
+def _all_ok(ok: bool, device) -> bool:
+    """MIN over the bootstrap process group of a per-rank success flag (collective; every rank calls it at the same point)."""
+    if not is_distributed():
+        return ok
+    t = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
 def enable_native_comm(device):
-    """create the gg_comm_* communicator for this process (collective: every rank calls it). The ranks then agree (a MIN
-    all-reduce over the bootstrap process group) on whether EVERY rank succeeded; if one did not (no librccl to bind, a refused
-    communicator), all of them drop the native communicator and the gradient exchange stays on torch.distributed's RCCL backend —
-    a replica must never wait in a collective its peers do not issue. Returns the communicator or None."""
+    """create the gg_comm_* communicator for this process (collective: every rank calls it). The bring-up runs in phases and the
+    ranks agree (a MIN all-reduce over the bootstrap process group) after EACH phase before any of them enters the next
+    collective: (1) bind librccl / rank 0 draws the unique id; (2) the id is broadcast - an empty id if rank 0 failed, so peers
+    can bail out; (3) ncclCommInitRank. A rank that failed in phase 1 therefore never leaves its peers waiting in the broadcast
+    or inside ncclCommInitRank. If any phase fails anywhere, every rank drops the native communicator, says so (each rank prints
+    its own reason) and the gradient exchange stays on torch.distributed's RCCL backend; `comm_backend()` reports which one
+    carries the gradients (bench.py prints it). Returns the communicator or None."""
     global _native
     if _native is not None:
         return _native
-    comm, err = None, None
-    try:
-        comm = NativeComm().init(device)
-    except Exception as e:     # noqa: BLE001 - any failure means "use the process group instead", decided collectively below
+    import ctypes as C
+    comm, err = NativeComm(), None
+    dist_on = is_distributed()
+    rank_, world_ = (dist.get_rank(), dist.get_world_size()) if dist_on else (0, 1)
+    uid = (C.c_char * 128)()
+    L = None
+    try:                                                    # phase 1: local only
+        from . import _C
+        L = _C.lib()
+        if L.is_emulator:
+            raise RuntimeError('gg_comm needs the gfx950 build (RCCL runs on GPUs)')
+        rccl = [q for q in (torch.__path__[0] + '/lib/librccl.so',) if os.path.exists(q)]
+        L.check(L.lib.gg_comm_load(rccl[0].encode() if rccl else None), 'gg_comm_load')
+        if rank_ == 0:
+            L.check(L.lib.gg_comm_unique_id(uid), 'gg_comm_unique_id')
+    except Exception as e:     # noqa: BLE001
         err = e
-    if is_distributed():
-        ok = torch.tensor([1 if comm is not None else 0], device=device, dtype=torch.int32)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
-            if comm is not None:
-                comm.destroy()
-            if dist.get_rank() == 0:
-                print(f'gigagan_pytorch_amd: native RCCL communicator unavailable on some rank ({err}); '
-                      'gradient exchange through torch.distributed', flush=True)
-            return None
-    elif comm is None:
-        raise err
+    ok = _all_ok(err is None, device)
+    if ok and dist_on:                                      # phase 2: every rank is here, so the broadcast is safe
+        box = [bytes(uid)]
+        dist.broadcast_object_list(box, src=0)
+        uid = (C.c_char * 128).from_buffer_copy(box[0])
+    if ok:                                                  # phase 3: every rank enters ncclCommInitRank
+        try:
+            torch.cuda.set_device(device)
+            L.check(L.lib.gg_comm_init(rank_, world_, uid), 'gg_comm_init')
+            assert L.lib.gg_comm_world() == world_, (L.lib.gg_comm_world(), world_)
+            comm.lib, comm.world = L, world_
+            comm.stream = torch.cuda.Stream(device=device)
+        except Exception as e:     # noqa: BLE001
+            err = e
+        ok = _all_ok(err is None, device)
+    if not ok:
+        if comm.lib is not None:
+            comm.destroy()
+        if not dist_on:
+            raise err
+        print(f'gigagan_pytorch_amd[rank {rank_}]: native RCCL communicator unavailable '
+              f'({err if err is not None else "a peer failed"}); gradient exchange through torch.distributed', flush=True)
+        return None
     _native = comm
     return _native
+
+
+def comm_backend() -> str:
+    """which transport carries the gradient exchange of this process."""
+    if _native is not None:
+        return 'gg_comm/rccl'
+    if is_distributed():
+        return f'torch.distributed/{dist.get_backend()}'
+    return 'none'
 
 
 def shutdown():
@@ -199,6 +243,126 @@ def all_reduce_flat_grads(flat_grad: torch.Tensor, n_slices: int = 4):
 def wait_all(works):
     for w in works:
         w.wait()
+
+
+# ---- in-backward sliced all-reduce (DDP's bucket hooks, gp.py:1902 / :1987) -------------------------------------------------
+class GradReducer:
+    """Overlaps the gradient exchange of ONE model (one FlatAdamW) with its backward pass. The flat gradient buffer is cut at
+    parameter boundaries into `n_slices` contiguous slices; parameters were laid out in forward order, so the LAST slice's
+    gradients are complete first. Every gradient write-back reports in (`fired`: autograd's post-accumulate hook, and the
+    weight-gradient finish kernels that write into the flat buffer directly, ops.grad_ready); when a slice has seen as many
+    reports as it did in the first (learning) pass of the same step kind, its all-reduce is enqueued - on the library's RCCL
+    side stream behind an event of the compute stream (GPU), or as an async torch.distributed collective (gloo / fallback).
+    Slices are always issued from the last to the first: the order is the same on every rank whatever order the hooks fire in,
+    and a slice whose count is never reached (it would not be: counts are learned from the same graph) goes out at `finish()`.
+    `finish()` flushes the rest and makes the compute stream wait for the exchange; inside a hipGraph capture both the fork
+    (event wait) and the join become graph edges, so the replayed step carries its own overlapped collectives."""
+
+    def __init__(self, opt, n_slices: int = 6):
+        self.opt = opt
+        target = max(opt.total // max(n_slices, 1), 1)
+        bounds = [0]
+        for off in opt.offsets[1:]:
+            if off - bounds[-1] >= target and len(bounds) < n_slices:
+                bounds.append(off)
+        bounds.append(opt.total)
+        self.bounds = bounds
+        self.n = len(bounds) - 1
+        self.slice_of = {}
+        k = 0
+        for p, off in zip(opt._all, opt.offsets):
+            while off >= bounds[k + 1]:
+                k += 1
+            self.slice_of[id(p)] = k
+            p._gg_reducer = self
+            p.register_post_accumulate_grad_hook(self._hook)
+        self.expected: dict = {}
+        self.sig = None
+        self.count = None
+        self.learning = False
+        self.next = -1
+        self.works = []
+        self.launched = 0
+        self.in_backward_launches = 0      # statistics of the last armed pass: slices that went out before finish()
+
+    @staticmethod
+    def active(flat) -> bool:
+        return (is_distributed() and (not flat.is_cuda or _native is not None)) or (_native is not None and flat.is_cuda)
+
+    def arm(self, sig):
+        """start of a step whose ONE backward pass produces all gradients of this model."""
+        self.sig = sig
+        self.count = [0] * self.n
+        self.learning = sig not in self.expected
+        self.next = self.n - 1
+        self.works = []
+        self.launched = 0
+        self.in_backward_launches = 0
+        if not self.learning:
+            self._advance()            # trailing slices nobody writes (unused parameters) go out first
+
+    def _hook(self, p):
+        self.fired(p)
+
+    def fired(self, p):
+        if self.sig is None:
+            return
+        k = self.slice_of[id(p)]
+        self.count[k] += 1
+        if not self.learning and k > self.next:
+            raise RuntimeError(f'GradReducer: a gradient of slice {k} was written after its all-reduce had been issued (step kind '
+                               f'{self.sig}: this backward differs from the one its slice counts were learned on)')
+        if not self.learning and k == self.next:
+            self._advance()
+            self.in_backward_launches = self.launched
+
+    def _advance(self):
+        exp = self.expected[self.sig]
+        while self.next >= 0 and self.count[self.next] >= exp[self.next]:
+            self._launch(self.next)
+            self.next -= 1
+
+    def _launch(self, k):
+        lo, hi = self.bounds[k], self.bounds[k + 1]
+        g = self.opt.flat_g
+        self.launched += 1
+        if _native is not None and g.is_cuda:
+            cur = torch.cuda.current_stream(g.device)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            _native.stream.wait_event(ev)
+            _native.lib.check(_native.lib.lib.gg_comm_allreduce(g.data_ptr() + lo * 4, hi - lo, 0, _native.stream.cuda_stream),
+                              'gg_comm_allreduce')
+        else:
+            self.works.append(dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        """after the backward: send what is left (last to first), then fence the compute stream / wait for the handles."""
+        if self.sig is None:
+            return
+        g = self.opt.flat_g
+        native = _native is not None and g.is_cuda
+        t0 = None
+        if native and _native.timing and not torch.cuda.is_current_stream_capturing():
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record(torch.cuda.current_stream(g.device))
+        if self.learning:
+            self.expected[self.sig] = list(self.count)
+        while self.next >= 0:
+            self._launch(self.next)
+            self.next -= 1
+        if native:
+            cur = torch.cuda.current_stream(g.device)
+            cur.wait_stream(_native.stream)
+            if t0 is not None:
+                t1 = torch.cuda.Event(enable_timing=True)
+                t1.record(cur)
+                _native.exposed_ms.append((t0, t1))
+        else:
+            for w in self.works:
+                w.wait()
+        self.works = []
+        self.sig = None
 
 
 def broadcast_flat_params(flat_p: torch.Tensor, src: int = 0):

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 from collections import namedtuple
 from math import sqrt
+import os
 from pathlib import Path
 
 import torch
@@ -212,6 +213,11 @@ class GigaGAN(nn.Module):
                                    inactive=self.D.unused_parameters())
         gdist.broadcast_flat_params(self.G_opt.flat_p)
         gdist.broadcast_flat_params(self.D_opt.flat_p)
+        # data parallel: the gradient all-reduce runs INSIDE the backward pass, slice by slice (DDP's bucket hooks, gp.py:1902);
+        # `overlap_grad_reduce = False` restores one exchange after the backward
+        self.overlap_grad_reduce = not os.environ.get('GG_NO_COMM_OVERLAP')
+        self.G_red = gdist.GradReducer(self.G_opt) if gdist.GradReducer.active(self.G_opt.flat_g) else None
+        self.D_red = gdist.GradReducer(self.D_opt) if gdist.GradReducer.active(self.D_opt.flat_g) else None
 
         self.has_ema_generator = False
         if self.is_main and create_ema_generator_at_init:
@@ -369,7 +375,8 @@ class GigaGAN(nn.Module):
         batch_size = dl.batch_size
         dl = shard_dataloader(dl, gdist.rank(), gdist.world_size())
         if prefetch_to_device is None:
-            prefetch_to_device = self._device.type == 'cuda' and isinstance(dl, torch.utils.data.DataLoader)
+            from .data import EpochShardedLoader
+            prefetch_to_device = self._device.type == 'cuda' and isinstance(dl, (torch.utils.data.DataLoader, EpochShardedLoader))
         if prefetch_to_device:
             dl = DevicePrefetcher(dl, self._device)
         self.train_dl = dl
@@ -454,13 +461,10 @@ class GigaGAN(nn.Module):
         """upsampler mode under hipGraphs: the generator's low-resolution conditioning comes from a loader batch of its own
         (gp.py:2196, :2208-2212); copy it into the static buffer the captured step reads."""
         if not self.train_upsampler:
-            return
+            return None
         src = next(dl_iter)
-        buf = self._graphs.get(('src', tuple(src.shape)))
-        if buf is None:
-            buf = self._graphs[('src', tuple(src.shape))] = torch.empty_like(src, device=self.device)
-        buf.copy_(src, non_blocking=True)
-        self._static_G_src = buf
+        self._static_G_src = self._stage('src', src)
+        return (tuple(src.shape), src.dtype)
 
     def _run_graphed(self, key, fn, static_inputs=()):
         """replay (capturing on first use) the hipGraph of `fn`, a closure over static input buffers that returns a
@@ -604,26 +608,37 @@ class GigaGAN(nn.Module):
         self.D.train()
 
         graphed = self._graphable(grad_accum_every)
+        # one backward pass produces every discriminator gradient of this step -> its all-reduce can ride inside that pass
+        red = self.D_red if (self.overlap_grad_reduce and grad_accum_every == 1 and not has_matching_awareness) else None
+        red_sig = ('D', bool(apply_gradient_penalty), bool(calc_multiscale_loss))
         staged = None
         if graphed and not self.unconditional:
             # a text-conditional D step draws two loader batches: the real pairs and the generator's conditioning (gp.py:2269, :2196)
             staged, dl_iter = self._take_graphable_batches(dl_iter, 2)
             graphed = staged is not None
         if graphed:
+            # every staged tensor's (shape, dtype) is part of the graph key: `_stage` hands out one static buffer per signature,
+            # and a captured graph keeps reading the buffers it was captured with - a loader that yields another shape (e.g.
+            # token encodings of another length, which the reference accepts) must capture its own graph, not replay this one
             if self.unconditional:
                 real = next(dl_iter)
-                self._stage_upsampler_source(dl_iter)
+                sig = self._stage_upsampler_source(dl_iter)
             else:
                 (real, _), (g_img, g_enc) = staged
                 self._static_G_src = (self._stage('g_img', g_img), self._stage('g_enc', g_enc))
-            key = ('D', bool(apply_gradient_penalty), bool(calc_multiscale_loss), tuple(real.shape))
+                sig = (tuple(g_img.shape), g_img.dtype, tuple(g_enc.shape), g_enc.dtype)
+            key = ('D', bool(apply_gradient_penalty), bool(calc_multiscale_loss), tuple(real.shape), real.dtype, sig)
             static_real = self._stage('d_real', real)
 
             def fn():
                 self.D_opt.zero_grad()
+                if red is not None:
+                    red.arm(red_sig)
                 col = [] if has_matching_awareness else None
                 out = self._d_micro(static_real, None, None, 1, apply_gradient_penalty, calc_multiscale_loss, collect=col)
                 mal = self._matching_aware_pass(col, 1) if has_matching_awareness else torch.zeros((), device=dev)
+                if red is not None:
+                    red.finish()
                 return (*out, mal)
 
             (total_divergence, total_multiscale_divergence, total_gp_loss, total_aux_loss,
@@ -635,6 +650,8 @@ class GigaGAN(nn.Module):
             total_divergence, total_gp_loss, total_aux_loss = zero.clone(), zero.clone(), zero.clone()
             total_multiscale_divergence = zero.clone() if calc_multiscale_loss else None
             self.D_opt.zero_grad()
+            if red is not None:
+                red.arm(red_sig)
             for _ in range(grad_accum_every):
                 if self.unconditional:
                     real_images = next(dl_iter)
@@ -651,12 +668,15 @@ class GigaGAN(nn.Module):
                     total_multiscale_divergence += ms / grad_accum_every
                 total_gp_loss += gp / grad_accum_every
                 total_aux_loss += aux / grad_accum_every
+            if red is not None:
+                red.finish()
 
         if has_matching_awareness and collected is not None:
             total_matching_aware_loss = self._matching_aware_pass(collected, grad_accum_every)
 
-        works = gdist.all_reduce_flat_grads(self.D_opt.flat_g)
-        gdist.wait_all(works)
+        if red is None:
+            works = gdist.all_reduce_flat_grads(self.D_opt.flat_g)
+            gdist.wait_all(works)
         # parameters whose gradient is None in the reference this step are skipped entirely (no decay, no moment update)
         skip = []
         if not calc_multiscale_loss:
@@ -735,19 +755,29 @@ class GigaGAN(nn.Module):
             p.requires_grad_(False)
         try:
             graphed = self._graphable(grad_accum_every) and not exists(clip)
+            red = self.G_red if (self.overlap_grad_reduce and grad_accum_every == 1 and not exists(clip)) else None
+            red_sig = ('G', bool(calc_multiscale_loss))
+            sig = None
             if graphed and not self.unconditional:
                 staged, dl_iter = self._take_graphable_batches(dl_iter, 1)
                 graphed = staged is not None
                 if graphed:
-                    self._static_G_src = (self._stage('g_img', staged[0][0]), self._stage('g_enc', staged[0][1]))
+                    g_img, g_enc = staged[0]
+                    self._static_G_src = (self._stage('g_img', g_img), self._stage('g_enc', g_enc))
+                    sig = (tuple(g_img.shape), g_img.dtype, tuple(g_enc.shape), g_enc.dtype)
             if graphed:
-                key = ('G', int(batch_size), bool(calc_multiscale_loss))
                 if self.unconditional:
-                    self._stage_upsampler_source(dl_iter)
+                    sig = self._stage_upsampler_source(dl_iter)
+                key = ('G', int(batch_size), bool(calc_multiscale_loss), sig)       # staged signatures: see the D step
 
                 def fn():
                     self.G_opt.zero_grad()
-                    return self._g_micro(batch_size, None, 1, calc_multiscale_loss)
+                    if red is not None:
+                        red.arm(red_sig)
+                    out = self._g_micro(batch_size, None, 1, calc_multiscale_loss)
+                    if red is not None:
+                        red.finish()
+                    return out
 
                 total_divergence, total_multiscale_divergence = self._run_graphed(key, fn)
                 if not calc_multiscale_loss:
@@ -756,11 +786,15 @@ class GigaGAN(nn.Module):
                 total_divergence = zero.clone()
                 total_multiscale_divergence = zero.clone() if calc_multiscale_loss else None
                 self.G_opt.zero_grad()
+                if red is not None:
+                    red.arm(red_sig)
                 for _ in range(grad_accum_every):
                     d, ms = self._g_micro(batch_size, dl_iter, grad_accum_every, calc_multiscale_loss, collect=collected)
                     total_divergence += d / grad_accum_every
                     if calc_multiscale_loss:
                         total_multiscale_divergence += ms / grad_accum_every
+                if red is not None:
+                    red.finish()
                 if exists(clip):
                     # gather every micro-batch's images and captions (over the ranks too) and score them with CLIP (gp.py:2578-2592)
                     loss = aux_clip_loss(clip=clip, texts=collected[1], images=torch.cat(collected[0], dim=0).float())
@@ -770,8 +804,9 @@ class GigaGAN(nn.Module):
             for p in self.D.parameters():
                 p.requires_grad_(True)
 
-        works = gdist.all_reduce_flat_grads(self.G_opt.flat_g)
-        gdist.wait_all(works)
+        if red is None:
+            works = gdist.all_reduce_flat_grads(self.G_opt.flat_g)
+            gdist.wait_all(works)
         self.G_opt.step(grad_scale=1. / gdist.world_size())
 
         if self.is_main and self.has_ema_generator:

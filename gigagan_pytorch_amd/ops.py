@@ -252,6 +252,20 @@ def _grad_sink_of(w):
     return g
 
 
+def grad_ready(w):
+    """a finish kernel has just been enqueued that writes w's gradient into the flat buffer behind autograd's back (no
+    AccumulateGrad node runs for it): tell the model's in-backward gradient exchange (distributed.GradReducer), if any."""
+    r = w.__dict__.get('_gg_reducer')
+    if r is not None:
+        r.fired(w)
+
+
+def _check_act_residual(act, residual, *tensors):
+    if act and residual is not None and torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise RuntimeError('conv2d: an activation and a residual cannot share one epilogue under autograd (the backward recovers '
+                           'the leaky-relu mask from the sign of the stored output); apply the residual in a separate op')
+
+
 class ConvFn(Function):
     """y = act(alpha * (conv(x * in_scale, w) + bias)) + res_scale * residual ;  x: (b,H,W,C8) bf16, w: float parameter layout."""
 
@@ -260,8 +274,8 @@ class ConvFn(Function):
         """`fork=True` returns (y, x): x's OTHER consumer takes the returned alias; its gradient then arrives here and is
         added in the data-gradient GEMM's epilogue (no separate accumulation pass over the activation gradient)."""
         ksize, stride, pad, wkind = geom
-        # the backward recovers the leaky-relu mask from the sign of the stored output: not with a residual added after it
-        assert not (act and residual is not None and torch.is_grad_enabled()), 'ConvFn: activation + residual epilogue is forward-only'
+        # (activation + residual in one epilogue is forward-only - the backward recovers the leaky-relu mask from the sign of the
+        # stored output: checked in `_check_act_residual` by the callers, where the grad mode is still the caller's)
         wmat = packed_weight(w, 's2d' if wkind == 's2d' else 'fwd')
         o8 = wmat.shape[0]
         b8 = bias
@@ -292,6 +306,7 @@ class ConvFn(Function):
         if bsink is not None:       # bias gradient: partial column sums -> one finish launch into the flat .grad
             dz, part = K.bias_act_bwd(dy, y if ctx.act == 'lrelu' else None, True, LRELU_SLOPE, partials=True)
             K.colsum_finish(part, ctx.n_bias, alpha, out=bsink, accumulate=True)
+            grad_ready(bias)
         elif ctx.act == 'lrelu' or want_db:
             dz, db = BiasActBwdFn.apply(dy, y if ctx.act == 'lrelu' else None, want_db)
             if want_db:
@@ -320,6 +335,7 @@ class ConvFn(Function):
             sink = _grad_sink_of(w)
             if sink is not None:
                 WgradFn.compute(x, dz, in_scale, geom, alpha, tuple(w.shape), sink)
+                grad_ready(w)
             else:
                 dw = WgradFn.apply(x, dz, in_scale, geom, alpha, tuple(w.shape)).to(w.dtype)
         dres = None
@@ -364,6 +380,7 @@ class DgradFn(Function):
             sink = _grad_sink_of(w)
             if sink is not None:
                 WgradFn.compute(g, dz, None, geom, alpha, tuple(w.shape), sink)
+                grad_ready(w)
             else:
                 dw = WgradFn.apply(g, dz, None, geom, alpha, tuple(w.shape)).to(w.dtype)
         return ddz, dw, None, None, None, None, (g if ctx.needs_input_grad[6] else None)
@@ -489,6 +506,8 @@ class ModCoefFn(Function):
                 gk = a * (ga - (a * ga).sum(-1, keepdim=True))
             return gmod, gk, None, None, None, None
         gmod, gk = K.modcoef_bwd(weights.detach(), kmod, s, d, gs, ga, gd, gw, ctx.eps)
+        if sink is not None:
+            grad_ready(weights)
         return gmod, gk, (gw if (gw is not None and sink is None) else None), None, None, None
 
 
@@ -802,6 +821,7 @@ class LinearFn(Function):
                 bsink = _grad_sink_of(bias)
                 if bsink is not None:
                     K.colsum_finish(part, O, scale, out=bsink, accumulate=True)
+                    grad_ready(bias)
                 else:
                     db = K.colsum_finish(part, O, scale)
         if ctx.needs_input_grad[0]:     # dx(r, i) = scale * sum_o g(r, o) W(o, i)
@@ -811,6 +831,7 @@ class LinearFn(Function):
             sink = _grad_sink_of(w)
             if sink is not None:
                 sink.add_(gw)
+                grad_ready(w)
             else:
                 dw = gw
         return dx, dw, db, None, None
@@ -1076,6 +1097,7 @@ class HipOps:
         if residual is not None:
             if o % 8:        # ragged channel count: add outside the kernel
                 return self.conv2d(x, weight, bias, act, stride, scale) + residual.to(ACT_DTYPE) * res_scale
+            _check_act_residual(act, residual, x, weight, bias, residual)
             res = nhwc(to_act(residual))
         if fork:
             y, xa = ConvFn.apply(xh, weight, None if bias is None else bias.float().contiguous(), None, act, geom,

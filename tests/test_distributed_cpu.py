@@ -91,7 +91,9 @@ def test_data_parallel_equals_large_batch_gradient():
             assert torch.allclose(f, (x + y) / 2, rtol=1e-3, atol=1e-5)
 
 
-def _train_worker(rank, world, port, ret, tmp):
+def _train_worker(rank, world, port, ret, tmp, overlap=True):
+    if not overlap:
+        os.environ['GG_NO_COMM_OVERLAP'] = '1'
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     import sys
     from pathlib import Path
@@ -110,14 +112,21 @@ def _train_worker(rank, world, port, ret, tmp):
     torch.manual_seed(10 + rank)             # per-rank latents / noise / data
     it = cycle(SyntheticImages(2, 16, seed=rank))
     d0 = gan.D_opt.flat_p.clone()
-    for _ in range(2):
+    in_bwd = []
+    for _ in range(4):                       # steps 2 and 4 carry the gradient penalty; 3 and 4 re-use learned slice counts
         gan.train_step(it, 2)
+        if gan.D_red is not None:
+            in_bwd.append((gan.D_red.in_backward_launches, gan.G_red.in_backward_launches))
+    assert (gan.D_red is not None) == overlap or not overlap
     flat = torch.cat([gan.D_opt.flat_p, gan.G_opt.flat_p])
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
     same = all(torch.equal(gathered[0], g) for g in gathered)
     moved = not torch.equal(d0, gan.D_opt.flat_p)
-    ret[rank] = bool(same and moved and torch.isfinite(flat).all())
+    import hashlib
+    ret[rank] = dict(ok=bool(same and moved and torch.isfinite(flat).all()), in_bwd=in_bwd, slices=(gan.D_red.n if gan.D_red else 0),
+                     overlap_on=bool(gan.overlap_grad_reduce),
+                     digest=hashlib.sha256(flat.numpy().tobytes()).hexdigest())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -130,4 +139,14 @@ def test_two_rank_training_keeps_replicas_identical(tmp_path):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_train_worker, args=(world, port, ret, str(tmp_path)), nprocs=world, join=True)
-    assert all(ret.get(r) for r in range(world)), dict(ret)
+    assert all(ret.get(r) and ret[r]['ok'] for r in range(world)), dict(ret)
+    # the gradient exchange ran INSIDE the backward passes once the slice counts were learned (steps 3 and 4): most slices of both
+    # models went out before the backward returned ...
+    r0 = ret[0]
+    assert r0['overlap_on'] and r0['slices'] >= 3, r0
+    assert r0['in_bwd'][0] == (0, 0), r0                   # learning pass: everything flushed after the backward
+    assert all(d >= r0['slices'] - 1 and g >= 1 for d, g in r0['in_bwd'][2:]), r0
+    # ... and gives bit-identical parameters to one exchange after the backward (summation order inside a slice is the same)
+    ret2 = mgr.dict()
+    mp.spawn(_train_worker, args=(world, _free_port(), ret2, str(tmp_path / 'b'), False), nprocs=world, join=True)
+    assert ret2[0]['ok'] and not ret2[0]['overlap_on'] and ret2[0]['digest'] == r0['digest'], (dict(ret2), r0)

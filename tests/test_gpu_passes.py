@@ -225,6 +225,46 @@ def test_native_rccl_communicator_on_one_gpu():
     assert _C.lib().lib.gg_comm_world() == 0
 
 
+def test_in_backward_gradient_exchange_is_captured_with_the_step(tmp_path):
+    """data-parallel step plumbing on the one GPU this box has: with a (one-rank) gg_comm communicator up, the trainer's
+    GradReducer issues the sliced all-reduce from inside the backward pass - forked onto the communicator's side stream behind
+    an event, joined before the optimizer - and the whole thing is captured into the step's hipGraph (distributed.GradReducer,
+    gigagan.py `_run_graphed`). Checks: the captures succeed, slices did go out during the backward, and four steps (plain and
+    gradient-penalty, replayed) leave exactly the parameters of the same run with the exchange issued after the backward."""
+    from gigagan_pytorch_amd import GigaGAN, distributed as gdist
+    from gigagan_pytorch_amd.data import SyntheticImages
+    from gigagan_pytorch_amd.gigagan import cycle
+    from helpers import C1_G, C1_D
+    d = dev()
+    comm = gdist.enable_native_comm(d)
+    assert comm is not None and gdist.comm_backend() == 'gg_comm/rccl'
+    try:
+        digests = []
+        for overlap in (True, False):
+            torch.manual_seed(0)
+            gan = GigaGAN(generator=dict(C1_G), discriminator=dict(C1_D), apply_gradient_penalty_every=2, device=d,
+                          create_ema_generator_at_init=False, model_folder=str(tmp_path / f'm{overlap}'),
+                          results_folder=str(tmp_path / f'r{overlap}'))
+            assert gan.D_red is not None and gan.G_red is not None
+            gan.overlap_grad_reduce = overlap
+            torch.manual_seed(10)
+            it = cycle(SyntheticImages(2, 64, device=d, seed=3))
+            for _ in range(4):
+                gan.train_step(it, 2)
+            torch.cuda.synchronize()
+            assert gan.use_hip_graphs, 'a capture with the gradient exchange inside was refused'
+            flat = torch.cat([gan.D_opt.flat_p, gan.G_opt.flat_p])
+            assert torch.isfinite(flat).all()
+            if overlap:     # the capture pass of each step kind ran with learned slice counts: slices left during the backward
+                assert gan.D_red.in_backward_launches >= gan.D_red.n - 1 and gan.G_red.in_backward_launches >= 1, \
+                    (gan.D_red.in_backward_launches, gan.G_red.in_backward_launches, gan.D_red.n, gan.G_red.n)
+            digests.append(flat.clone())
+            del gan
+        assert torch.equal(digests[0], digests[1])
+    finally:
+        gdist.shutdown()
+
+
 @pytest.mark.parametrize('cfg', [(512, 512, 4, 32), (512, 256, 16, 32), (128, 64, 64, 8), (64, 32, 128, 8), (32, 32, 128, 8),
                                  (32, 16, 256, 4), (16, 16, 256, 4)])
 def test_no_grad_adaptive_conv_at_config2_layer_shapes(cfg):
