@@ -140,13 +140,14 @@ def cpu_baseline(budget_s=45.0):
 
 def modconv_forward_roofline(gan, batch, dev):
     """north-star sub-target: the style-modulated (demodulated 3x3) adaptive convolutions of ONE generator forward at the
-    bench batch, no-grad path (what the D-step runs). HIP events on the launch stream around EVERY kernel the op launches
-    (coefficient / per-sample-weight kernel, modulation pass, convolution; kernels.LaunchProfiler), executed eagerly;
-    `achieved` = algorithmic flops 2*b*O*I*9*H*W per layer (171.5 GF at batch 32) / the sum of those kernel
-    times. call_ms additionally contains the eager launch gaps between them."""
+    bench batch, no-grad path (what the D-step runs): the forward's ONE batched modulation launch (gg_modw_multi_fwd: softmax over
+    the kernels, demodulation coefficients, per-sample weights of every layer that is not behind a skip-layer excitation) plus
+    everything the 15 layer calls launch (excited layers' own weight launch, the convolution, split-K finish). HIP events on the
+    launch stream around EVERY C-ABI launch (kernels.LaunchProfiler), executed eagerly; `achieved` = algorithmic flops
+    2*b*O*I*9*H*W per layer (171.5 GF at batch 32) / the time of one hipGraph replay of exactly these launches."""
     from gigagan_pytorch_amd import ops, kernels as K
-    rec, calls = [], []
-    orig = ops.HipOps.modconv2d
+    rec, calls, prep = [], [], []
+    orig, orig_prep = ops.HipOps.modconv2d, ops.HipOps.modconv_prepare
 
     with K.LaunchProfiler() as prof:
         def timed(self, x, weights, mod, kernel_mod=None, demod=True, **kw):
@@ -162,25 +163,38 @@ def modconv_forward_roofline(gan, batch, dev):
             rec.append((e0, e1, 2.0 * b * O * I * 9 * H * W, f'{I}->{O}@{H}x{W}', n0, len(prof.records)))
             calls.append((x, weights, mod, kernel_mod, dict(kw, demod=demod)))
             return y
-        ops.HipOps.modconv2d = timed
+
+        def timed_prep(self, specs):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n0 = len(prof.records)
+            e0.record()
+            n = orig_prep(self, specs)
+            e1.record()
+            prep.append((specs, e0, e1, n0, len(prof.records), n))
+            return n
+        ops.HipOps.modconv2d, ops.HipOps.modconv_prepare = timed, timed_prep
         try:
             with torch.no_grad():
                 for _ in range(3):
                     rec.clear()
                     calls.clear()
+                    prep.clear()
                     gan.G(noise=torch.randn(batch, gan.G.style_network_dim, device=dev))
             torch.cuda.synchronize()
         finally:
-            ops.HipOps.modconv2d = orig
-    # the same 15 calls, on the inputs they saw, replayed as ONE hipGraph: their GPU time as the training step executes them
+            ops.HipOps.modconv2d, ops.HipOps.modconv_prepare = orig, orig_prep
+    # the same launches, on the inputs they saw, replayed as ONE hipGraph: their GPU time as the training step executes them
     # (back to back, kernel boundaries included, no host launch gaps - an eager split-K launch pair is ~10 us apart)
     graph_ms = None
     try:
         impl = ops.HipOps()
 
         def run_all():
+            for specs, *_ in prep:
+                orig_prep(impl, specs)
             for x, w, m, km, kw in calls:
                 orig(impl, x, w, m, km, **kw)
+            impl.modconv_release()
         with torch.no_grad():
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -205,21 +219,28 @@ def modconv_forward_roofline(gan, batch, dev):
         graph_ms = None
         graph_err = f'{type(e).__name__}: {e}'
     layers, call_ms, kern_ms, fl = [], 0., 0., 0.
+    for specs, e0, e1, n0, n1, n in prep:
+        launches = [(nm, a.elapsed_time(b)) for nm, a, b in prof.records[n0:n1]]
+        t_kern = sum(t for _, t in launches)
+        layers.append(dict(layer=f'batched modulation of {n} layers', call_us=e0.elapsed_time(e1) * 1e3, kernel_us=t_kern * 1e3,
+                           launches={nm: round(t * 1e3, 1) for nm, t in launches}))
+        call_ms, kern_ms = call_ms + e0.elapsed_time(e1), kern_ms + t_kern
     for e0, e1, f, name, n0, n1 in rec:
         t_call = e0.elapsed_time(e1)
         launches = [(nm, a.elapsed_time(b)) for nm, a, b in prof.records[n0:n1]]
         t_kern = sum(t for _, t in launches)
-        layers.append(dict(layer=name, call_us=t_call * 1e3, kernel_us=t_kern * 1e3, kernel_tflops=f / t_kern / 1e9,
+        layers.append(dict(layer=name, call_us=t_call * 1e3, kernel_us=t_kern * 1e3, kernel_tflops=f / max(t_kern, 1e-9) / 1e9,
                            launches={nm: round(t * 1e3, 1) for nm, t in launches}))
         call_ms, kern_ms, fl = call_ms + t_call, kern_ms + t_kern, fl + f
     t_ms = graph_ms if graph_ms else kern_ms
     return dict(achieved=fl / t_ms / 1e9, peak=MFMA_PEAK_TF, unit='TFLOP/s', frac=fl / t_ms / 1e9 / MFMA_PEAK_TF,
                 graph_ms=graph_ms, kernel_ms=kern_ms, call_ms=call_ms, gflop=fl / 1e9, batch=batch, layers=layers,
                 note='the 15 demodulated 3x3 adaptive convs of one no-grad generator forward: `achieved` = algorithmic flops '
-                     '(2*b*O*I*9*H*W) / graph_ms, the time of one hipGraph replay of exactly these 15 calls (every kernel they '
-                     'launch: per-sample-weight / coefficient kernel, modulation pass, convolution, split-K reduction; kernel '
-                     'boundaries included). kernel_ms / the per-layer table = HIP events around every C-ABI launch issued eagerly '
-                     '(a launch that enqueues two kernels includes the host gap between them); call_ms brackets the eager calls')
+                     '(2*b*O*I*9*H*W) / graph_ms, the time of one hipGraph replay of exactly these launches (the batched modulation '
+                     'launch + every kernel the 15 calls launch: excited layers\' per-sample-weight kernel, convolution, split-K '
+                     'reduction; kernel boundaries included). kernel_ms / the per-layer table = HIP events around every C-ABI launch '
+                     'issued eagerly (a launch that enqueues two kernels includes the host gap between them); call_ms brackets the '
+                     'eager calls')
 
 
 def main():

@@ -251,7 +251,7 @@ static void gg_launch_dconv(const GgGemmParams& p, hipStream_t s) {
 }
 
 static bool gg_conv3_eligible(const gg_gemm_desc* d);
-static GemmPlan gg_conv3_plan(const gg_gemm_desc* d, int tile);
+static GemmPlan gg_conv3_plan(const gg_gemm_desc* d, int tile, int splitk);
 static bool gg_wgrad9_eligible(const gg_gemm_desc* d);
 static GemmPlan gg_wgrad9_plan(const gg_gemm_desc* d, int splitk);
 
@@ -283,7 +283,7 @@ static bool gg_table_plan(const gg_gemm_desc* d, GemmPlan& pl) {
     }
     if (tile == 7 || tile == 8) {
         if (!gg_conv3_eligible(d)) return false;
-        pl = gg_conv3_plan(d, tile);
+        pl = gg_conv3_plan(d, tile, it->second.splitk);
         return true;
     }
     if (tile == 10) {
@@ -325,10 +325,13 @@ static bool gg_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static bool gg_conv3_eligible(const gg_gemm_desc* d) {
     if (!d->a_conv || d->a_layout != GG_ROWK || d->b_layout != GG_ROWK) return false;
     if (d->R != 3 || d->S != 3 || d->conv_stride != 1 || d->conv_pad != 1) return false;
-    if (d->C != d->CV || (d->C & 63) || d->K != 9 * d->C || (d->ldb & 7)) return false;
-    if (d->in_scale || d->b_image_stride || d->batch != 1 || d->d2s) return false;
+    // CV = C, or N * C: a kernel bank stacked along the reduction (weights [co][tap][n][ci]); chunks of 64 never wrap around C
+    if ((d->C & 63) || d->CV % d->C || d->K != 9 * d->CV || (d->ldb & 7)) return false;
+    if (d->CV != d->C && !d->in_scale) return false;      // (an unscaled stacked bank would just double the work)
+    if (d->batch != 1 || d->d2s) return false;
     if (!gg_pow2(d->H) || !gg_pow2(d->W) || d->W < 8 || d->W > 64 || d->H * d->W < 64) return false;
     if (d->M % (d->H * d->W)) return false;
+    if (d->b_image_stride && ((d->H * d->W) & 255)) return false;        // per-image weights: a 256-pixel tile inside one image
     if (gg_a_bytes(d) >= (1ll << 32) || gg_b_bytes(d) >= (1ll << 32)) return false;
     // the tile's halo (PH + 2 rows of W + 2 slots for each of its TI images) must fit the LDS area reserved for it
     const int hw = d->H * d->W, ph = hw >= 256 ? 256 / d->W : d->H, ti = hw >= 256 ? 1 : 256 / hw;
@@ -336,10 +339,49 @@ static bool gg_conv3_eligible(const gg_gemm_desc* d) {
     return true;
 }
 
-static GemmPlan gg_conv3_plan(const gg_gemm_desc* d, int tile) {
+// tile 7: 256 x 256, tile 8: 256 x 128. splitk <= 0: chosen by the cost form of gg_plan_cost (rounds of 256 resident workgroups x
+// taps of the slice + the fp32 partial round trip); per-tap times from the round-2 layer measurements (1200 / 1100 TFLOP/s).
+static double gg_conv3_cost(const gg_gemm_desc* d, int tile, int sk, int* per_out) {
+    const int bn = tile == 7 ? 256 : 128;
+    const long long blocks = (long long)((d->M + 255) / 256) * ((d->N + bn - 1) / bn);
+    const int nchunks = d->CV / 64;
+    const int per = (nchunks + sk - 1) / sk;
+    if (per_out) *per_out = per;
+    const long long rounds = (blocks * sk + 255) / 256;
+    double t = (double)rounds * (per * 9 * (tile == 7 ? 1.8 : 1.0) + 4.0);
+    if (sk > 1) t += 3.0 + (double)d->M * d->N * 4.0 * (sk + 1) / 4.0e6;
+    return t;
+}
+
+static GemmPlan gg_conv3_plan(const gg_gemm_desc* d, int tile, int splitk) {
     GemmPlan pl;
-    pl.tile = tile; pl.bm = 256; pl.bn = tile == 7 ? 256 : 128; pl.splitk = 1; pl.k_per_split = d->K;
+    pl.tile = tile; pl.bm = 256; pl.bn = tile == 7 ? 256 : 128;
     pl.blocks_mn = (long long)((d->M + 255) / 256) * ((d->N + pl.bn - 1) / pl.bn);
+    const int nchunks = d->CV / 64;
+    // SCALED: the scale values of (images of a tile) x (channels of a k-slice) live in LDS (GG_C3_SC_FLOATS)
+    const int hw = d->H * d->W, ti = hw >= 256 ? 1 : 256 / hw;
+    int min_sk = 1;
+    if (d->in_scale) {
+        const int max_per = GG_C3_SC_FLOATS / (ti * 64);
+        min_sk = (nchunks + max_per - 1) / max_per;
+    }
+    int sk = splitk;
+    if (sk <= 0) {
+        double best = 1e30;
+        sk = min_sk;
+        const int max_sk = nchunks < 64 ? nchunks : 64;
+        for (int c = min_sk; c <= max_sk; ++c) {
+            int per;
+            const double t = gg_conv3_cost(d, tile, c, &per);
+            if ((nchunks + per - 1) / per != c) continue;          // split counts that leave empty slices
+            if (t < best) { best = t; sk = c; }
+        }
+    }
+    if (sk < min_sk) sk = min_sk;
+    if (sk > nchunks) sk = nchunks;
+    const int per = (nchunks + sk - 1) / sk;
+    pl.splitk = (nchunks + per - 1) / per;
+    pl.k_per_split = per * 64;            // CHANNELS per slice (each with its nine taps): what gg_conv3_kernel reads
     return pl;
 }
 
@@ -403,17 +445,32 @@ static GemmPlan gg_wgrad9_substitute(const gg_gemm_desc* d, const GemmPlan& pl) 
     return gg_wgrad9_plan(d, 0);
 }
 
-// the planner (table or cost model) thinks in implicit-GEMM tiles; an unsplit 256-row choice on an eligible layer runs halo-staged
-static GemmPlan gg_conv3_substitute(const gg_gemm_desc* d, const GemmPlan& pl) {
-    if ((pl.tile != 4 && pl.tile != 5) || pl.splitk != 1 || d->force_tile != 0 || !gg_conv3_policy() || !gg_conv3_eligible(d)) return pl;
-    return gg_conv3_plan(d, pl.tile == 4 ? 7 : 8);
+// the planner (table or cost model) thinks in implicit-GEMM tiles; an unsplit 256-row choice on an eligible layer runs halo-staged.
+// `modelled`: the plan came from the cost model (not from the measured table): the halo-staged kernel with its own split-K is then
+// compared with it by modelled cost (small-M layers: the generator's 8x8 .. 32x32 adaptive convs at batch 32)
+static GemmPlan gg_conv3_substitute(const gg_gemm_desc* d, const GemmPlan& pl, bool modelled) {
+    if (d->force_tile != 0 || !gg_conv3_policy() || !gg_conv3_eligible(d)) return pl;
+    if (!modelled) {        // a measured choice: only the unsplit 256-row tiles are known to lose against the halo-staged kernel
+        if ((pl.tile == 4 || pl.tile == 5) && pl.splitk == 1 && !d->in_scale) return gg_conv3_plan(d, pl.tile == 4 ? 7 : 8, 1);
+        return pl;
+    }
+    if (pl.tile < 1 || pl.tile > 6 || d->force_splitk != 0) return pl;
+    GemmPlan best = pl;
+    double best_t = gg_plan_cost(d, kTileModels[pl.tile - 1], pl.splitk, nullptr);
+    for (int tile = 7; tile <= 8; ++tile) {
+        if (tile == 7 && d->N < 192) continue;
+        const GemmPlan c = gg_conv3_plan(d, tile, 0);
+        const double t = gg_conv3_cost(d, tile, c.splitk, nullptr);
+        if (t < best_t) { best_t = t; best = c; }
+    }
+    return best;
 }
 
 GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     GemmPlan pl;
-    if ((d->force_tile == 7 || d->force_tile == 8) && gg_conv3_eligible(d)) return gg_conv3_plan(d, d->force_tile);
+    if ((d->force_tile == 7 || d->force_tile == 8) && gg_conv3_eligible(d)) return gg_conv3_plan(d, d->force_tile, d->force_splitk);
     if (d->force_tile == 10 && gg_wgrad9_eligible(d)) return gg_wgrad9_plan(d, d->force_splitk);
-    if (gg_table_plan(d, pl)) return gg_wgrad9_substitute(d, gg_conv3_substitute(d, pl));
+    if (gg_table_plan(d, pl)) return gg_wgrad9_substitute(d, gg_conv3_substitute(d, pl, false));
     if (gg_use_dconv(d)) {
         pl.tile = 9; pl.bm = GG_DC_TH * GG_DC_TW; pl.bn = d->N <= 32 ? 32 : 64;
         pl.splitk = 1; pl.k_per_split = d->K; pl.blocks_mn = d->M / pl.bm;
@@ -465,7 +522,7 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     const int per = (ktiles + pl.splitk - 1) / pl.splitk;
     pl.splitk = (ktiles + per - 1) / per;
     pl.k_per_split = per * tm.bk;
-    return gg_wgrad9_substitute(d, gg_conv3_substitute(d, pl));
+    return gg_wgrad9_substitute(d, gg_conv3_substitute(d, pl, true));
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -615,14 +672,22 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     }
     else if (pl.tile == 10) GG_LAUNCH(gg_wgrad9_kernel, grid2, dim3(GG2_NT), s, p);
     else if (pl.tile == 7 || pl.tile == 8) {
-        const bool full = p.bias || p.out_scale || p.noise || p.residual || p.act != GG_ACT_NONE;
-        if (pl.tile == 7) {
-            if (full) GG_LAUNCH((gg_conv3_kernel<256, 2, 4, true>), grid2, dim3(GG2_NT), s, p);
-            else GG_LAUNCH((gg_conv3_kernel<256, 2, 4, false>), grid2, dim3(GG2_NT), s, p);
-        } else {
-            if (full) GG_LAUNCH((gg_conv3_kernel<128, 4, 2, true>), grid2, dim3(GG2_NT), s, p);
-            else GG_LAUNCH((gg_conv3_kernel<128, 4, 2, false>), grid2, dim3(GG2_NT), s, p);
-        }
+        // (a split launch writes fp32 partials: its epilogue runs in the reduce pass, so it takes the plain instantiation)
+        const bool full = pl.splitk == 1 && (p.bias || p.out_scale || p.noise || p.residual || p.act != GG_ACT_NONE);
+        const bool scaled = p.in_scale != nullptr;
+#define GG_C3(BN, WM, WN)                                                                                       \
+        do {                                                                                                    \
+            if (scaled) {                                                                                       \
+                if (full) GG_LAUNCH((gg_conv3_kernel<BN, WM, WN, true, true>), grid2, dim3(GG2_NT), s, p);      \
+                else GG_LAUNCH((gg_conv3_kernel<BN, WM, WN, false, true>), grid2, dim3(GG2_NT), s, p);          \
+            } else {                                                                                            \
+                if (full) GG_LAUNCH((gg_conv3_kernel<BN, WM, WN, true, false>), grid2, dim3(GG2_NT), s, p);     \
+                else GG_LAUNCH((gg_conv3_kernel<BN, WM, WN, false, false>), grid2, dim3(GG2_NT), s, p);         \
+            }                                                                                                   \
+        } while (0)
+        if (pl.tile == 7) GG_C3(256, 2, 4);
+        else GG_C3(128, 4, 2);
+#undef GG_C3
     }
     else if (pl.tile == 4) gg_launch_gemm2_tile<256, 256, 2, 4>(p, akrow, bkrow, aconv, grid2, s);
     else if (pl.tile == 5) gg_launch_gemm2_tile<256, 128, 2, 4>(p, akrow, bkrow, aconv, grid2, s);
@@ -1052,9 +1117,9 @@ extern "C" int gg_pool_mean_bwd(const void* g, const float* gs, void* y, int32_t
     return gg_check_launch();
 }
 
-extern "C" int gg_modw_fwd(const float* w, const float* mod, int32_t mod_ld, const float* kmod, int32_t kmod_ld, const float* xs,
-                           int32_t xs_ld, float* s, float* a, float* d, void* wmix, int32_t layout, int32_t b, int32_t N, int32_t O,
-                           int32_t I, int32_t T, int32_t Ip, int32_t Op, int32_t demod, float eps, void* stream) {
+static int gg_modw_fill(GgModWParams& p, const float* w, const float* mod, int32_t mod_ld, const float* kmod, int32_t kmod_ld,
+                        const float* xs, int32_t xs_ld, float* s, float* a, float* d, float* insc, void* wmix, int32_t layout, int32_t b,
+                        int32_t N, int32_t O, int32_t I, int32_t T, int32_t Ip, int32_t Op, int32_t demod, float eps) {
     if (!w || !mod) return gg_fail(-1, "gg_modw_fwd: null pointer");
     if (b <= 0 || b > GG_MW_BMAX || N <= 0 || N > GG_MW_NMAX || O <= 0 || I <= 0 || (I & 3) || T <= 0 || Ip < I || Op < O)
         return gg_fail(-2, "gg_modw_fwd: bad extents (b=%d N=%d O=%d I=%d T=%d)", b, N, O, I, T);
@@ -1067,9 +1132,8 @@ extern "C" int gg_modw_fwd(const float* w, const float* mod, int32_t mod_ld, con
         if (layout == 2 && ((I & 15) || O > 32)) return gg_fail(-4, "gg_modw_fwd: layout 2 needs I %% 16 == 0 and O <= 32");
         if (((uintptr_t)wmix) & 15) return gg_fail(-4, "gg_modw_fwd: wmix must be 16-byte aligned");
     }
-    GgModWParams p;
     memset(&p, 0, sizeof(p));
-    p.w = w; p.mod = mod; p.kmod = kmod; p.s = s; p.a = a; p.d = d; p.wmix = (bf16_t*)wmix; p.layout = layout;
+    p.w = w; p.mod = mod; p.kmod = kmod; p.s = s; p.a = a; p.d = d; p.insc = insc; p.wmix = (bf16_t*)wmix; p.layout = layout;
     p.b = b; p.N = N; p.O = O; p.I = I; p.T = T; p.Ip = Ip; p.Op = Op; p.demod = demod; p.eps = eps;
     p.mod_ld = mod_ld; p.kmod_ld = kmod_ld; p.xs = xs; p.xs_ld = xs_ld;
     // coefficient-only launches: one workgroup per channel handles every sample; with per-sample weights the samples are spread
@@ -1081,12 +1145,44 @@ extern "C" int gg_modw_fwd(const float* w, const float* mod, int32_t mod_ld, con
         if (bc > b) bc = b;
     }
     p.bc = bc;
-    const dim3 grid((unsigned)O, (unsigned)((b + bc - 1) / bc));
+    return 0;
+}
+
+extern "C" int gg_modw_fwd(const float* w, const float* mod, int32_t mod_ld, const float* kmod, int32_t kmod_ld, const float* xs,
+                           int32_t xs_ld, float* s, float* a, float* d, void* wmix, int32_t layout, int32_t b, int32_t N, int32_t O,
+                           int32_t I, int32_t T, int32_t Ip, int32_t Op, int32_t demod, float eps, void* stream) {
+    GgModWParams p;
+    int rc = gg_modw_fill(p, w, mod, mod_ld, kmod, kmod_ld, xs, xs_ld, s, a, d, nullptr, wmix, layout, b, N, O, I, T, Ip, Op, demod, eps);
+    if (rc) return rc;
+    const dim3 grid((unsigned)O, (unsigned)((b + p.bc - 1) / p.bc));
     if (N == 1) GG_LAUNCH((gg_modw_kernel<1>), grid, dim3(256), (hipStream_t)stream, p);
     else if (N == 2) GG_LAUNCH((gg_modw_kernel<2>), grid, dim3(256), (hipStream_t)stream, p);
     else if (N == 3) GG_LAUNCH((gg_modw_kernel<3>), grid, dim3(256), (hipStream_t)stream, p);
     else GG_LAUNCH((gg_modw_kernel<4>), grid, dim3(256), (hipStream_t)stream, p);
     return gg_check_launch();
+}
+
+extern "C" int gg_modw_multi_fwd(const gg_modw_item* items, int32_t n_items, void* stream) {
+    if (!items || n_items <= 0) return gg_fail(-1, "gg_modw_multi_fwd: no items");
+    for (int i0 = 0; i0 < n_items; i0 += GG_MW_MAX_ITEMS) {
+        GgModWMulti m;
+        memset(&m, 0, sizeof(m));
+        m.n = n_items - i0 < GG_MW_MAX_ITEMS ? n_items - i0 : GG_MW_MAX_ITEMS;
+        int blocks = 0;
+        for (int j = 0; j < m.n; ++j) {
+            const gg_modw_item& it = items[i0 + j];
+            int rc = gg_modw_fill(m.item[j], it.w, it.mod, it.mod_ld, it.kmod, it.kmod_ld, it.xs, it.xs_ld, it.s, it.a, it.d, it.insc,
+                                  it.wmix, it.layout, it.b, it.N, it.O, it.I, it.T, it.Ip, it.Op, it.demod, it.eps);
+            if (rc) return rc;
+            m.first_block[j] = blocks;
+            blocks += it.O * ((it.b + m.item[j].bc - 1) / m.item[j].bc);
+        }
+        for (int j = m.n; j <= GG_MW_MAX_ITEMS; ++j) m.first_block[j] = blocks;
+        GG_LAUNCH(gg_modw_multi_kernel, dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, m);
+        int rc = gg_check_launch();
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 extern "C" int gg_sconv_fwd(const void* x, const void* w, int64_t w_bs, void* y, const float* noise, const float* noise_w,

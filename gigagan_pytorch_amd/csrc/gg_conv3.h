@@ -12,6 +12,15 @@
 //
 // Reduction order: (channel chunk, tap, channel) instead of (tap, channel): fp32 sums differ from the implicit GEMM in the last
 // bits.
+//
+// Round 3 — what the generator's no-grad adaptive convolutions (gp.py:344-409) need from it:
+//  * split-K over the channel chunks (p.splitk slices of p.k_per_split channels, fp32 partials finished by gg_splitk_reduce*):
+//    at batch 32 the 8x8 / 16x16 layers have 8 / 32 row tiles - a chip of 256 CUs needs the reduction spread as well;
+//  * a virtual channel axis CV = N * C (the N kernels of the bank stacked along the reduction, weights [co][tap][n][ci]) with a
+//    per-(image, virtual channel) scale a[b,n] * s[b,i] applied ONCE per staged halo chunk (SCALED): the style modulation and
+//    kernel mix ride on the operand load instead of a separate pass that writes the N-fold modulated activation (the implicit
+//    GEMM applies such a scale per tap - nine times the work, measured slower than the separate pass; here it is 1/9 of that);
+//  * per-image weight operands (p.b_img_stride: the reference's per-sample weights) when a tile lies inside one image.
 #pragma once
 #include "gg_gemm2.h"
 
@@ -24,8 +33,9 @@
 #define GG_C3_ROWPAD 224
 #define GG_C3_HBYTES 67584                                // largest halo (8x8 images: 400 slots, 40 rows) rounded up to 1 KB
 #define GG_C3_NVH ((GG_C3_MAX_SLOTS * 8 + GG2_NT - 1) / GG2_NT)    // 16-byte halo vectors per thread: 7
+#define GG_C3_SC_FLOATS 4096                              // SCALED: (images of a tile) x (channels of a k-slice) scale values in LDS
 
-template <int BN, int WM, int WN, bool FULL_EPI>
+template <int BN, int WM, int WN, bool FULL_EPI, bool SCALED = false>
 GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_conv3_kernel(GgGemmParams p) {
     static_assert(WM * WN == 8, "8 wavefronts per workgroup");
     constexpr int BM = 256;
@@ -33,25 +43,34 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_conv3_kernel(GgGemmParams p) {
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int BNV = Gg2Dma<BN>::NV, BBYTES = Gg2Dma<BN>::BYTES;
     constexpr int SP = WTN * 2 + 8;
-    constexpr int TILE_BYTES = GG_C3_HBYTES + 2 * BBYTES, STAGE_BYTES = 8 * WTM * SP;
+    constexpr int SC_BYTES = SCALED ? GG_C3_SC_FLOATS * 4 : 0;
+    constexpr int TILE_BYTES = GG_C3_HBYTES + 2 * BBYTES + SC_BYTES, STAGE_BYTES = 8 * WTM * SP;
     static_assert(GG_C3_MAX_SLOTS * GG_C3_PITCH + GG_C3_MAX_ROWS * GG_C3_ROWPAD <= GG_C3_HBYTES, "halo area");
 
     GG_SHARED __attribute__((aligned(1024))) char smem[TILE_BYTES > STAGE_BYTES ? TILE_BYTES : STAGE_BYTES];
     char* const halo = smem;
     auto tileB = [&](int buf) { return smem + GG_C3_HBYTES + buf * BBYTES; };
+    float* const scl = (float*)(smem + GG_C3_HBYTES + 2 * BBYTES);      // SCALED only
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
-    // XCD-aware tile order: as gg_gemm2_kernel (no batch, no split-K here)
+    // XCD-aware tile order: as gg_gemm2_kernel (flattened grid, output tile fastest, then the k-slice)
     const int nwg = gridDim.x;
     const int xq = nwg >> 3, xr = nwg & 7;
     const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
     const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + pos;
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int tile_m = wg / tiles_n, tile_n = wg % tiles_n;
+    const int tiles_mn = tiles_n * ((p.M + BM - 1) / BM);
+    const int ks = wg / tiles_mn, tile = wg - ks * tiles_mn;
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    // k-slice: channel chunks [c_lo, c_hi) of the virtual channel axis (CV = C, or N * C for a stacked bank)
+    const int nchunks_all = p.CV / GG2_BK;
+    const int cps = p.splitk > 1 ? p.k_per_split / GG2_BK : nchunks_all;
+    const int c_lo = ks * cps;
+    const int c_hi = c_lo + cps < nchunks_all ? c_lo + cps : nchunks_all;
 
     // tile geometry: PH full-width rows of TI images (H, W powers of two, 8 <= W <= 64: host)
     const int W = p.W, H = p.H, ws = p.w_shift, hs = p.hw_shift;
@@ -83,17 +102,48 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_conv3_kernel(GgGemmParams p) {
         }
     }
     u16x8 hreg[GG_C3_NVH];
+    // the physical channel of virtual channel cv is cv % C: a 64-wide chunk never wraps (C % 64 == 0, host)
     auto load_halo = [&](int c) {
-        const unsigned soff = (unsigned)(c * GG2_BK * 2);
+        const int cv0 = c * GG2_BK;
+        const unsigned soff = (unsigned)((p.CV == p.C ? cv0 : cv0 % p.C) * 2);
 #pragma unroll
         for (int i = 0; i < GG_C3_NVH; ++i) hreg[i] = gg_buf_load16(bufA, hvoff[i], soff);
     };
-    auto store_halo = [&]() {
+    // SCALED: offset of the vector's 8 scale values inside `scl` for chunk c_lo (image-in-tile * channels of the slice + piece)
+    const int nsc = (c_hi - c_lo) * GG2_BK;
+    int hsc[SCALED ? GG_C3_NVH : 1];
+    if constexpr (SCALED) {
+#pragma unroll
+        for (int i = 0; i < GG_C3_NVH; ++i) {
+            const int v = tid + GG2_NT * i;
+            const int slot = v >> 3;
+            hsc[i] = (slot < NS ? (slot / SPI) * nsc : 0) + (v & 7) * 8;
+        }
+        for (int idx = tid; idx < TI * nsc; idx += GG2_NT) {
+            const int il = idx / nsc, j = idx - il * nsc;
+            const int img = img0 + il;
+            scl[idx] = img < n_img ? p.in_scale[(long long)img * p.CV + c_lo * GG2_BK + j] : 0.f;
+        }
+        gg_sync();
+    }
+    auto store_halo = [&](int c) {
 #pragma unroll
         for (int i = 0; i < GG_C3_NVH; ++i) {
             const int v = tid + GG2_NT * i;
             const int slot = v >> 3, hrow = slot / HWp;         // (halo rows run on across the tile's images)
-            if (slot < NS) *(u16x8*)(halo + hrow * RSB + (slot - hrow * HWp) * GG_C3_PITCH + (v & 7) * 16) = hreg[i];
+            if (slot < NS) {
+                u16x8 h = hreg[i];
+                if constexpr (SCALED) {
+                    const float* sp = scl + hsc[i] + (c - c_lo) * GG2_BK;
+                    const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        h[e] = gg_f2bf(gg_bf2f(h[e]) * s0[e]);
+                        h[e + 4] = gg_f2bf(gg_bf2f(h[e + 4]) * s1[e]);
+                    }
+                }
+                *(u16x8*)(halo + hrow * RSB + (slot - hrow * HWp) * GG_C3_PITCH + (v & 7) * 16) = h;
+            }
         }
     };
 
@@ -104,8 +154,10 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_conv3_kernel(GgGemmParams p) {
         const int row = gg2d_row<BN>(i), kc = gg2d_chunk(i);
         bvoff[i] = (n0 + row < p.N) ? (unsigned)(((long long)row * p.ldb + kc * 8) * 2) : 0xFFFFFFFFu;
     }
+    // per-image weight operand (the adaptive conv's per-sample weights): a tile lies inside one image then (TI == 1, host)
+    const long long b_img = p.b_img_stride ? (long long)img0 * p.b_img_stride : 0;
     auto dma_b = [&](int buf, int tap, int c) {
-        const unsigned soff = (unsigned)(((long long)n0 * p.ldb + tap * p.C + c * GG2_BK) * 2);
+        const unsigned soff = (unsigned)((b_img + (long long)n0 * p.ldb + tap * p.CV + c * GG2_BK) * 2);
         char* lb = tileB(buf) + wave * (BNV * 1024);
 #pragma unroll
         for (int i = 0; i < BNV; ++i) gg_buf_load_lds16(bufB, bvoff[i], soff, lb + i * 1024);
@@ -132,15 +184,15 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_conv3_kernel(GgGemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nchunks = p.C / GG2_BK;
-    load_halo(0);
-    dma_b(0, 0, 0);
-    store_halo();
+    const int nchunks = c_hi;
+    load_halo(c_lo);
+    dma_b(0, 0, c_lo);
+    store_halo(c_lo);
     gg_wait_vm<0>();
     gg_sync();
 
     int step = 0;
-    for (int c = 0; c < nchunks; ++c) {
+    for (int c = c_lo; c < nchunks; ++c) {
         if (c + 1 < nchunks) load_halo(c + 1);              // lands in registers while this chunk's nine taps run
         int toff = 0;                                        // byte offset of the tap inside the halo
         for (int kh = 0; kh < 3; ++kh) {
@@ -173,7 +225,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_conv3_kernel(GgGemmParams p) {
             toff += RSB - 3 * GG_C3_PITCH;
         }
         if (c + 1 < nchunks) {      // every wave is past its last read of this chunk's halo (barrier above)
-            store_halo();
+            store_halo(c + 1);
             gg_sync();
         }
     }
@@ -181,15 +233,16 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_conv3_kernel(GgGemmParams p) {
     const GgGemmParams e = *gg_late_params(p);
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     const int m_wave = m0 + wm * WTM, n_wave = n0 + wn * WTN;
-    const bool staged = !e.c_f32 && !e.d2s && (e.N & 3) == 0 && (e.ldc & 3) == 0 && (!e.residual || (e.ldr & 3) == 0);
+    const bool staged = e.splitk == 1 && !e.c_f32 && !e.d2s && (e.N & 3) == 0 && (e.ldc & 3) == 0 &&
+                        (!e.residual || (e.ldr & 3) == 0);
     if (staged) {
         char* stage = smem + wave * (WTM * SP);
         gg2_epilogue_step<0, TM, TN, FULL_EPI, true>(acc, e, 0, 0, m_wave + (lane & 31), n_wave + 4 * (lane >> 5), stage, SP, lane,
                                                      z4, z4);
         gg_sync();
         gg2_stage_writeback<WTM, WTN>(e, 0, stage, SP, m_wave, n_wave, lane);
-    } else {
-        gg2_epilogue_step<0, TM, TN, FULL_EPI, false>(acc, e, 0, 0, m_wave + (lane & 31), n_wave + 4 * (lane >> 5), nullptr, 0, lane,
+    } else {      // fp32 outputs and split-K partials (slice ks of [splitk][M][N]): direct quad stores
+        gg2_epilogue_step<0, TM, TN, FULL_EPI, false>(acc, e, 0, ks, m_wave + (lane & 31), n_wave + 4 * (lane >> 5), nullptr, 0, lane,
                                                       z4, z4);
     }
 }

@@ -38,6 +38,18 @@ struct GgModWParams {
     const float* xs;       // optional (b, I) extra scale of the INPUT activation (skip-layer excitation, gp.py:1023-1024) folded into
     int xs_ld;             // s and the per-sample weights - not into the demodulation, which the reference computes from mod + 1 alone
     int bc;                // samples per workgroup: grid = (O, ceil(b / bc)); every workgroup re-derives the Gram rows of its channel
+    float* insc;           // optional (b, N * Ip) out: a[b,n] * s[b,i] - the per-(sample, stacked channel) input scale of the shared-
+                           // bank convolution with the N kernels stacked along the reduction (gg_conv3_kernel SCALED)
+};
+
+// one launch for MANY layers (the generator's no-grad forward: every layer's modulation comes out of ONE style vector, gp.py:1160-
+// 1175, so all coefficient / per-sample-weight work of a forward is known before its first convolution): workgroup -> (item, channel,
+// sample chunk) through the prefix table
+#define GG_MW_MAX_ITEMS 16
+struct GgModWMulti {
+    int n;
+    int first_block[GG_MW_MAX_ITEMS + 1];
+    GgModWParams item[GG_MW_MAX_ITEMS];
 };
 
 GG_DEVICE float gg_mw_wave_sum(float v) {
@@ -51,16 +63,11 @@ GG_DEVICE float gg_mw_wave_sum(float v) {
 // 0 / 1): with run-time loop bounds and loads under conditions the compiler emitted one branch + `s_waitcnt vmcnt(0)` per load,
 // i.e. a chain of ~60 dependent memory round trips per workgroup (50 us for a 512-channel layer; measured, profiles/).
 template <int N>
-GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modw_kernel(GgModWParams p) {
+GG_DEVICE void gg_modw_body(const GgModWParams& p, int o, int chunk, float* wl, float* gram, float (*a_s)[GG_MW_NMAX], float* d_s) {
     constexpr int NP = N * (N + 1) / 2;
-    GG_SHARED __attribute__((aligned(16))) float wl[GG_MW_WMAX];   // [n][i*T + t]
-    GG_SHARED float gram[GG_MW_GMAX];                     // [pair][i], pair = (n, m >= n) in row-major upper-triangle order
-    GG_SHARED float a_s[GG_MW_BMAX][GG_MW_NMAX];
-    GG_SHARED float d_s[GG_MW_BMAX];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int o = blockIdx.x;
     const int IT = p.I * p.T;
-    const int b_lo = blockIdx.y * p.bc;
+    const int b_lo = chunk * p.bc;
     const int b_hi = b_lo + p.bc < p.b ? b_lo + p.bc : p.b;
     // s / the zero padding of d of this chunk's samples: written by the workgroups of channel 0
     if (o == 0)
@@ -71,6 +78,24 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modw_kernel(GgModWParams p) {
                     const float v = (p.mod[(long long)row * p.mod_ld + ic] + 1.f) * (p.xs ? p.xs[(long long)row * p.xs_ld + ic] : 1.f);
                     p.s[(long long)row * p.Ip + i] = i < p.I ? v : 0.f;
                 }
+            if (p.insc) {       // a[row, n] * s[row, i] over the stacked channel axis (n, i): the softmax is re-derived here
+                float av[GG_MW_NMAX] = {1.f, 0.f, 0.f, 0.f};
+                if (N > 1) {
+                    float kv[N], mx = -3.0e38f, sum = 0.f;
+#pragma unroll
+                    for (int n = 0; n < N; ++n) { kv[n] = p.kmod[(long long)row * p.kmod_ld + n]; mx = kv[n] > mx ? kv[n] : mx; }
+#pragma unroll
+                    for (int n = 0; n < N; ++n) { kv[n] = gg_expf(kv[n] - mx); sum += kv[n]; }
+#pragma unroll
+                    for (int n = 0; n < N; ++n) av[n] = kv[n] / sum;
+                }
+                for (int i = tid; i < p.Ip; i += 256) {
+                    const int ic = i < p.I ? i : p.I - 1;
+                    const float v = (p.mod[(long long)row * p.mod_ld + ic] + 1.f) * (p.xs ? p.xs[(long long)row * p.xs_ld + ic] : 1.f);
+#pragma unroll
+                    for (int n = 0; n < N; ++n) p.insc[((long long)row * N + n) * p.Ip + i] = i < p.I ? av[n] * v : 0.f;
+                }
+            }
             if (p.d)
                 for (int c = p.O + tid; c < p.Op; c += 256) p.d[(long long)row * p.Op + c] = 0.f;
         }
@@ -199,6 +224,33 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modw_kernel(GgModWParams p) {
             p.wmix[off] = gg_f2bf(v);
         }
     }
+}
+
+template <int N>
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modw_kernel(GgModWParams p) {
+    GG_SHARED __attribute__((aligned(16))) float wl[GG_MW_WMAX];   // [n][i*T + t]
+    GG_SHARED float gram[GG_MW_GMAX];                     // [pair][i], pair = (n, m >= n) in row-major upper-triangle order
+    GG_SHARED float a_s[GG_MW_BMAX][GG_MW_NMAX];
+    GG_SHARED float d_s[GG_MW_BMAX];
+    gg_modw_body<N>(p, blockIdx.x, blockIdx.y, wl, gram, a_s, d_s);
+}
+
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modw_multi_kernel(GgModWMulti m) {
+    GG_SHARED __attribute__((aligned(16))) float wl[GG_MW_WMAX];
+    GG_SHARED float gram[GG_MW_GMAX];
+    GG_SHARED float a_s[GG_MW_BMAX][GG_MW_NMAX];
+    GG_SHARED float d_s[GG_MW_BMAX];
+    // (the table is read through the kernarg pointer: run-time indexing of the by-value struct would copy it to scratch)
+    const GgModWMulti* mp = gg_late_params(m);
+    int it = 0;
+    while (it + 1 < mp->n && (int)blockIdx.x >= mp->first_block[it + 1]) ++it;
+    const GgModWParams p = mp->item[it];
+    const int rel = blockIdx.x - mp->first_block[it];
+    const int o = rel % p.O, chunk = rel / p.O;
+    if (p.N == 1) gg_modw_body<1>(p, o, chunk, wl, gram, a_s, d_s);
+    else if (p.N == 2) gg_modw_body<2>(p, o, chunk, wl, gram, a_s, d_s);
+    else if (p.N == 3) gg_modw_body<3>(p, o, chunk, wl, gram, a_s, d_s);
+    else gg_modw_body<4>(p, o, chunk, wl, gram, a_s, d_s);
 }
 
 // ---- streaming direct convolution on per-sample weights ------------------------------------------------------------------

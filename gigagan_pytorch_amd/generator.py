@@ -165,9 +165,37 @@ class Generator(BaseGenerator):
                 noise = torch.randn((batch_size, self.style_network_dim), device=self.device)
             styles = self.style_network(noise, global_text_tokens)
 
-        conv_mods = iter(self.style_to_conv_modulations(styles).split(self.style_embed_split_dims, dim=-1))
+        conv_mods = self.style_to_conv_modulations(styles).split(self.style_embed_split_dims, dim=-1)
         batch = styles.shape[0]
         device = styles.device
+        prepared = self._announce_adaptive_convs(conv_mods, batch)
+        try:
+            return self._synthesise(iter(conv_mods), batch, device, fine_text_tokens, text_mask, return_all_rgbs)
+        finally:
+            if prepared:
+                ops.impl.modconv_release()
+
+    def _announce_adaptive_convs(self, conv_mods, batch):
+        """no-grad forward on an op set that batches the style-dependent work (ops.HipOps.modconv_prepare): hand over every demodulated
+        3x3 adaptive conv with its modulation slices - all of them come out of the one projection above (gp.py:1160-1175) - so that
+        their coefficients / per-sample weights are computed by ONE launch before the first convolution."""
+        if torch.is_grad_enabled() or not hasattr(ops.impl, 'modconv_prepare'):
+            return 0
+        res = 4
+        specs = [(self.init_conv.weights, conv_mods[0], conv_mods[1], res, res, False, self.init_conv.demod, self.init_conv.eps)]
+        for ind, (squeeze_excite, block, *_rest) in enumerate(self.layers):
+            upsample = _rest[3]
+            if exists(upsample):
+                res *= 2
+            excited = self.num_skip_layers_excite > 0 and ind >= self.num_skip_layers_excite
+            conv1, conv2 = block[0], block[3]
+            m = conv_mods[2 + 6 * ind: 8 + 6 * ind]
+            specs.append((conv1.weights, m[0], m[1], res, res, excited, conv1.demod, conv1.eps))
+            specs.append((conv2.weights, m[2], m[3], res, res, False, conv2.demod, conv2.eps))
+        specs = [sp for sp in specs if sp[1].shape[0] == batch]
+        return ops.impl.modconv_prepare(specs)
+
+    def _synthesise(self, conv_mods, batch, device, fine_text_tokens, text_mask, return_all_rgbs):
 
         x = self.init_block[None].expand(batch, -1, -1, -1)
         x = self.init_conv(x, mod=next(conv_mods), kernel_mod=next(conv_mods))

@@ -602,6 +602,50 @@ def modw_fwd(w: torch.Tensor, mod: torch.Tensor, kmod, demod: bool, eps: float, 
     return s, a, d
 
 
+class ModwItem(C.Structure):         # mirrors gg_modw_item (include/gigagan_amd.h)
+    _fields_ = ([(f, C.c_void_p) for f in ('w', 'mod', 'kmod', 'xs', 's', 'a', 'd', 'insc', 'wmix')] +
+                [(f, C.c_int32) for f in ('mod_ld', 'kmod_ld', 'xs_ld', 'layout', 'b', 'N', 'O', 'I', 'T', 'Ip', 'Op', 'demod')] +
+                [('eps', C.c_float), ('reserved', C.c_int32)])
+
+
+def modw_multi(layers):
+    """gg_modw_multi_fwd: the coefficient / per-sample-weight work of MANY adaptive-conv layers in one launch (per 16 layers).
+    `layers`: dicts with w (N, O, I, k, k) fp32, mod (b, I), kmod (b, N) | None, demod, eps, Ip, Op and the wanted outputs:
+    coef=True -> s (b, Ip), a (b, N), d (b, Op), insc (b, N*Ip) are allocated and returned; wmix / layout as in modw_fwd. Returns a
+    list of dicts(s, a, d, insc) (None where not requested)."""
+    L = _C.lib()
+    arr = (ModwItem * len(layers))()
+    outs, keep = [], []
+    for it, ly in zip(arr, layers):
+        w, mod, kmod, wmix = ly['w'], ly['mod'], ly.get('kmod'), ly.get('wmix')
+        L.require(w, mod, kmod, wmix)
+        N, O, I = w.shape[:3]
+        T = w.shape[3] * w.shape[4]
+        b = mod.shape[0]
+        assert w.dtype == torch.float32 and w.is_contiguous() and mod.dtype == torch.float32 and mod.stride(1) == 1
+        assert mod.shape == (b, I) and (kmod is None or (kmod.shape == (b, N) and kmod.dtype == torch.float32 and kmod.stride(1) == 1))
+        Ip, Op = ly['Ip'], ly['Op']
+        o = dict(s=None, a=None, d=None, insc=None)
+        if ly.get('coef', True):
+            o['s'] = torch.empty((b, Ip), dtype=torch.float32, device=w.device)
+            o['a'] = torch.empty((b, N), dtype=torch.float32, device=w.device)
+            o['d'] = torch.empty((b, Op), dtype=torch.float32, device=w.device)
+            o['insc'] = torch.empty((b, N * Ip), dtype=torch.float32, device=w.device)
+        if wmix is not None:
+            assert wmix.dtype == torch.bfloat16 and wmix.is_contiguous()
+        it.w, it.mod, it.kmod, it.xs = ptr(w), ptr(mod), ptr(kmod), None
+        it.s, it.a, it.d, it.insc, it.wmix = ptr(o['s']), ptr(o['a']), ptr(o['d']), ptr(o['insc']), ptr(wmix)
+        it.mod_ld, it.kmod_ld, it.xs_ld = mod.stride(0), (0 if kmod is None else kmod.stride(0)), 0
+        it.layout = int(ly.get('layout', 0))
+        it.b, it.N, it.O, it.I, it.T, it.Ip, it.Op = b, N, O, I, T, Ip, Op
+        it.demod, it.eps = int(bool(ly.get('demod', True))), float(ly.get('eps', 1e-8))
+        outs.append(o)
+        keep.append((w, mod, kmod, wmix))
+    rc = L.lib.gg_modw_multi_fwd(C.cast(arr, C.c_void_p), len(layers), L.stream(layers[0]['w']))
+    L.check(rc, 'gg_modw_multi_fwd')
+    return outs
+
+
 def sconv(x: torch.Tensor, wmix: torch.Tensor, O: int, noise=None, noise_w=None, act=None, slope: float = 0.2) -> torch.Tensor:
     """streaming 3x3 convolution with per-image filter banks (gg_sconv_fwd): x (b, H, W, C) bf16, wmix (b, 9, C/16, 32, 16) bf16
     (or (1, ...) shared) -> (b, H, W, O) bf16 = act(conv + noise * noise_w)."""

@@ -1065,6 +1065,8 @@ class ResampleFn(Function):
 # --------------------------------------------------------------------------------------------------
 # the op set
 # --------------------------------------------------------------------------------------------------
+_prepared: dict = {}        # id(weights) -> coefficients / per-sample weights computed by HipOps.modconv_prepare for the running forward
+_BANK_IN_SCALE = not os.environ.get('GG_NO_BANK_IN_SCALE')      # A/B switch: modulation on the conv's operand staging vs a separate pass
 
 class HipOps:
     """MI355X implementation: HIP kernels for contractions/resampling, torch glue for pointwise pieces."""
@@ -1206,6 +1208,51 @@ class HipOps:
         return GlobalMeanFn.apply(x, True) if fork else GlobalMeanFn.apply(x)
 
     # -- adaptive / modulated conv (gp.py:315-409) -----------------------------------------------
+    @staticmethod
+    def _modconv_path(b, N, O, I, H, W):
+        """which no-grad formulation a demodulated 3x3 adaptive conv runs in (see modconv2d)."""
+        if I in (16, 32, 64) and O <= 32 and W % 32 == 0 and b * H * W >= 32768:
+            return 'sconv'
+        if H * W % 128 == 0 and H * W >= 1024 and b * O * I * 9 <= (16 << 20):
+            return 'pimg'
+        return 'bank'
+
+    def modconv_prepare(self, specs):
+        """ONE launch for the style-dependent part of every announced adaptive conv of a no-grad generator forward (gg_modw_multi_fwd):
+        all of a forward's modulations are column slices of one style projection (gp.py:1160-1175), so softmax(kernel_mod), the
+        demodulation coefficients and - where the layer runs on per-sample weights - the weights themselves are computed before the
+        first convolution instead of by one launch in front of each (15 on config 2: ~330 us of a 1.1 ms forward). `specs`: tuples
+        (weights, mod, kernel_mod, H, W, excited, demod, eps); layers behind a skip-layer excitation are left to their own launch.
+        The results wait in a registry keyed by the weight tensor until that layer's modconv2d call picks them up."""
+        _prepared.clear()
+        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for sp in specs for t in sp[:3]):
+            return 0
+        layers, metas = [], []
+        for weights, mod, kmod, H, W, excited, demod, eps in specs:
+            N, O, I, k, _ = weights.shape
+            b = mod.shape[0]
+            if (k != 3 or not demod or excited or weights.dtype != torch.float32 or not weights.is_contiguous() or I % 8 or O % 8
+                    or not K.modw_eligible(b, N, I, k * k) or weights.device.type != mod.device.type):
+                continue
+            path = self._modconv_path(b, N, O, I, H, W)
+            ly = dict(w=weights.detach(), mod=_rows_f32(mod), kmod=_rows_f32(kmod) if N > 1 else None, demod=demod, eps=eps,
+                      Ip=I, Op=O)
+            if path == 'sconv':
+                ly.update(coef=False, wmix=_wmix_buffer(weights, b, I), layout=2)
+            elif path == 'pimg':
+                ly.update(coef=False, wmix=_wmix_rows(weights, b, O, 9 * I), layout=1)
+            layers.append(ly)
+            metas.append((weights, mod, path, b))
+        if not layers:
+            return 0
+        outs = K.modw_multi(layers)
+        for (weights, mod, path, b), o in zip(metas, outs):
+            _prepared[id(weights)] = dict(o, mod_ptr=mod.data_ptr(), path=path, b=b)
+        return len(layers)
+
+    def modconv_release(self):
+        _prepared.clear()
+
     def modconv2d(self, x, weights, mod, kernel_mod=None, demod=True, eps=1e-8, noise=None, noise_weight=None,
                   act=None, in_excite=None):
         """`in_excite` (b, I[, 1, 1]): a per-sample scale of the input activation (the skip-layer excitation the generator applies
@@ -1218,40 +1265,62 @@ class HipOps:
             t is not None and t.requires_grad for t in (x, weights, mod, kernel_mod, noise_weight, in_excite))
         w_ok = weights.dtype == torch.float32 and weights.is_contiguous()
         if not needs_grad and k == 3 and w_ok and K.modw_eligible(b, N, I, k * k) and Ip == I and Op == O:
-            # no-grad forward (the discriminator step's generator pass, generate()): csrc/gg_modfwd.h
-            km = _rows_f32(kernel_mod) if N > 1 else None       # column slices of the style network's output: read in place
-            md = _rows_f32(mod)
-            xs = None if in_excite is None else _rows_f32(in_excite.reshape(b, I))
-            wd = weights.detach()
+            # no-grad forward (the discriminator step's generator pass, generate()): csrc/gg_modfwd.h. The coefficients / per-sample
+            # weights come from the forward's ONE batched launch when the generator announced its layers (modconv_prepare),
+            # otherwise (and for layers behind a skip-layer excitation, whose scale is not known up front) from a launch here.
+            path = self._modconv_path(b, N, O, I, H, W)
+            rec = _prepared.pop(id(weights), None)
+            if rec is not None and (in_excite is not None or rec['mod_ptr'] != mod.data_ptr() or rec['path'] != path
+                                    or rec['b'] != b):
+                rec = None
             nz = nw = None
             if noise is not None:
                 nz = noise.reshape(-1).float().contiguous()
                 nw = noise_weight.detach().reshape(-1).float().contiguous()
-            if I in (16, 32, 64) and O <= 32 and W % 32 == 0 and b * H * W >= 32768:
+            wd = weights.detach()
+            if rec is None:
+                km = _rows_f32(kernel_mod) if N > 1 else None       # column slices of the style network's output: read in place
+                md = _rows_f32(mod)
+                xs = None if in_excite is None else _rows_f32(in_excite.reshape(b, I))
+            if path == 'sconv':
                 # narrow high-resolution layers: the reference's per-sample weights (a few KiB each) + the streaming convolution
                 wm = _wmix_buffer(weights, b, I)
-                K.modw_fwd(wd, md, km, demod, eps, Ip, Op, coef=False, wmix=wm, layout=2, xs=xs)
+                if rec is None:
+                    K.modw_fwd(wd, md, km, demod, eps, Ip, Op, coef=False, wmix=wm, layout=2, xs=xs)
                 return nchw(K.sconv(nhwc(x), wm, O, nz, nw, act, LRELU_SLOPE))
-            if H * W % 128 == 0 and H * W >= 1024 and b * O * I * 9 <= (16 << 20):
+            if path == 'pimg':
                 # mid resolutions: the per-sample weights are still small next to the activation (<= 32 MiB of bf16), so the
                 # reference's formulation (one kernel per sample, algorithmic flops) beats the shared bank's doubled reduction:
-                # implicit GEMM with a per-image weight operand, modulation / demodulation folded into the weights
+                # per-image weight operand, modulation / demodulation folded into the weights
                 wm = _wmix_rows(weights, b, O, 9 * I)
-                K.modw_fwd(wd, md, km, demod, eps, Ip, Op, coef=False, wmix=wm, layout=1, xs=xs)
+                if rec is None:
+                    K.modw_fwd(wd, md, km, demod, eps, Ip, Op, coef=False, wmix=wm, layout=1, xs=xs)
                 y = K.conv2d_nhwc(nhwc(x), wm, ksize=3, noise=nz, noise_w=nw, act=act, act_slope=LRELU_SLOPE,
                                   per_image_weights=True)
                 return nchw(y)
-            # wide layers: shared bank, the N kernels stacked along the reduction on a pre-modulated activation
-            s, a, d = K.modw_fwd(wd, md, km, demod, eps, Ip, Op, xs=xs)
-            x2 = K.modulate_bank(nhwc(x), s, a)
+            # wide low-resolution layers (weights >> activations): shared bank, the N kernels stacked along the reduction
+            if rec is None:
+                s, a, d = K.modw_fwd(wd, md, km, demod, eps, Ip, Op, xs=xs)
+                insc = None
+            else:
+                s, a, d, insc = rec['s'], rec['a'], rec['d'], rec['insc']
             wk = None
             if (isinstance(weights, torch.nn.Parameter) and getattr(weights, '_gg_pack_table', None) is not None
                     and not _DEBUG_NO_TABLE):
                 wk = _table_pack(weights, 'modk')
             if wk is None:
                 wk = wd.permute(1, 3, 4, 0, 2).reshape(O, k * k * N * I).to(ACT_DTYPE).contiguous()
-            y = K.conv2d_nhwc(x2, wk, ksize=k, out_scale=d if demod else None, noise=nz, noise_w=nw, act=act,
-                              act_slope=LRELU_SLOPE)
+            if W >= 8 and H * W >= 64 and I % 64 == 0 and _BANK_IN_SCALE:
+                # the per-(sample, stacked channel) scale a_n * s_i rides on the convolution's operand staging (gg_conv3 SCALED: applied
+                # once per staged 64-channel halo chunk, shared by the nine taps): no modulated copy of the activation is written
+                if insc is None:
+                    insc = (a[:, :, None] * s[:, None, :]).reshape(b, N * Ip).contiguous()
+                y = K.conv2d_nhwc(nhwc(x), wk, ksize=k, cv=N * Ip, in_scale=insc, out_scale=d if demod else None, noise=nz,
+                                  noise_w=nw, act=act, act_slope=LRELU_SLOPE)
+            else:   # 4x4 images: the N-fold pre-modulated activation is 0.5 MB; one pointwise pass + the plain gather
+                x2 = K.modulate_bank(nhwc(x), s, a)
+                y = K.conv2d_nhwc(x2, wk, ksize=k, out_scale=d if demod else None, noise=nz, noise_w=nw, act=act,
+                                  act_slope=LRELU_SLOPE)
             return nchw(y)
         if in_excite is not None:        # every other path: the plain multiply (with its fused backward when gradients flow)
             x = self.channel_scale(x, in_excite)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 5
+#define GG_ABI_VERSION 6
 
 int gg_version(void);
 const char* gg_last_error(void);
@@ -318,6 +318,21 @@ int gg_attn_bwd2(const void* q, const void* k, const void* v, const void* k0, co
 int gg_modw_fwd(const float* w, const float* mod, int32_t mod_ld, const float* kmod, int32_t kmod_ld, const float* xs, int32_t xs_ld,
                 float* s, float* a, float* d, void* wmix, int32_t layout, int32_t b, int32_t N, int32_t O, int32_t I, int32_t T,
                 int32_t Ip, int32_t Op, int32_t demod, float eps, void* stream);
+/* gg_modw_multi_fwd: the same work for up to 16 layers in ONE launch. Every adaptive conv of a generator forward is modulated by a
+ * column slice of ONE style projection (`style_to_conv_modulations(styles).split(...)`, gp.py:1160-1175, unet_upsampler.py:700-
+ * 706), so all coefficients / per-sample weights of a forward are known before its first convolution: one launch at the top of the
+ * forward replaces one per layer (15 on config 2). `insc` (optional, (b, N*Ip) fp32 out): a[b,n] * s[b,i] over the stacked channel
+ * axis (n, i) - the input scale of the shared-bank convolution with the N kernels stacked along the reduction (gg_gemm_bf16 with
+ * in_scale, CV = N*C). Same limits per item as gg_modw_fwd. */
+typedef struct gg_modw_item {
+    const float* w; const float* mod; const float* kmod; const float* xs;
+    float* s; float* a; float* d; float* insc; void* wmix;
+    int32_t mod_ld, kmod_ld, xs_ld, layout;
+    int32_t b, N, O, I, T, Ip, Op, demod;
+    float eps;
+    int32_t reserved;
+} gg_modw_item;
+int gg_modw_multi_fwd(const gg_modw_item* items, int32_t n_items, void* stream);
 int gg_sconv_fwd(const void* x, const void* w, int64_t w_bs, void* y, const float* noise, const float* noise_w, int32_t b,
                  int32_t H, int32_t W, int32_t C, int32_t O, int32_t act, float slope, void* stream);
 int gg_modulate_bank_fwd(const void* x, const float* s, const float* a, void* out, int32_t b, int32_t P, int32_t Cin, int32_t Cout,

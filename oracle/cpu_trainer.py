@@ -9,12 +9,12 @@ import torch
 
 def install_cpu_adamw(opt):
     """replace `opt.step` (the fused HIP launch) of a FlatAdamW whose buffers live on the CPU by the same update in torch."""
-    flags = opt.flags.repeat_interleave(256)
-    active = (flags & 1).bool()
-    decay = ((flags & 2) != 0) & active
-
     @torch.no_grad()
     def step(grad_scale: float = 1.0, skip=()):
+        # parameters in `skip` got no gradient this step: neither stepped nor decayed (torch optimizers skip None grads)
+        flags = opt.flags_without(skip).repeat_interleave(256)
+        active = (flags & 1).bool()
+        decay = ((flags & 2) != 0) & active
         g0 = opt.param_groups[0]
         lr, (b1, b2), eps = g0['lr'], g0['betas'], g0['eps']
         opt.step_count += 1

@@ -550,14 +550,75 @@ def test_halo_staged_conv3_matches_fp32_convolution(cfg):
     bias = torch.randn(co); res = bf(torch.randn(n, H, W, co))
     exact = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().view(co, 3, 3, ci).permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
     K.plan_log = []
-    got = K.conv2d_nhwc(x, w, ksize=3, out_dtype=torch.float32, force_tile=tile)
+    got = K.conv2d_nhwc(x, w, ksize=3, out_dtype=torch.float32, force_tile=tile, force_splitk=1)
     assert K.plan_log == [(tile, 1)]
     K.plan_log = None
     assert rel_err(got, exact) < 1e-5
-    got = K.conv2d_nhwc(x, w, ksize=3, bias=bias, act='lrelu', alpha=0.5, bias_scale=0.5, force_tile=tile)
+    got = K.conv2d_nhwc(x, w, ksize=3, bias=bias, act='lrelu', alpha=0.5, bias_scale=0.5, force_tile=tile, force_splitk=1)
     assert rel_err(got, F.leaky_relu(0.5 * exact + 0.5 * bias, 0.2)) < 4e-3
-    got = K.conv2d_nhwc(x, w, ksize=3, residual=res, res_scale=0.5, force_tile=tile)
+    got = K.conv2d_nhwc(x, w, ksize=3, residual=res, res_scale=0.5, force_tile=tile, force_splitk=1)
     assert rel_err(got, exact + 0.5 * res.float()) < 4e-3
+
+
+@pytest.mark.parametrize('cfg', [(3, 8, 8, 128, 264, 7, 2), (1, 16, 16, 192, 128, 8, 3), (2, 32, 32, 64, 128, 8, 0)])
+def test_halo_staged_conv3_split_over_channel_chunks(cfg):
+    """gg_conv3 with the reduction split over its 64-channel chunks (the generator's 8x8 / 16x16 layers at batch 32 have too few
+    row tiles for 256 CUs): fp32 partials + the split-K finish give the unsplit result, with the full epilogue (per-sample
+    output scale, noise, leaky-relu) applied by the finish; forced and automatic split counts."""
+    n, H, W, ci, co, tile, sk = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(n, H, W, ci)); w = bf(torch.randn(co, 9 * ci) * 0.1)
+    exact = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().view(co, 3, 3, ci).permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    K.plan_log = []
+    got = K.conv2d_nhwc(x, w, ksize=3, out_dtype=torch.float32, force_tile=tile, force_splitk=sk)
+    assert K.plan_log[-1][0] == tile and (sk == 0 or K.plan_log[-1][1] == sk), K.plan_log
+    K.plan_log = None
+    assert rel_err(got, exact) < 1e-5
+    d = torch.rand(n, co) + 0.5; nz = torch.randn(n * H * W); nw = torch.randn(co)
+    got = K.conv2d_nhwc(x, w, ksize=3, out_scale=d, noise=nz, noise_w=nw, act='lrelu', force_tile=tile, force_splitk=max(sk, 2))
+    want = F.leaky_relu(exact * d[:, None, None, :] + nz.view(n, H, W, 1) * nw, 0.2)
+    assert rel_err(got, want) < 4e-3
+
+
+@pytest.mark.parametrize('cfg', [(5, 8, 8, 64, 2, 264, 7, 0), (2, 16, 16, 128, 2, 128, 8, 2), (1, 32, 32, 64, 3, 128, 8, 1)])
+def test_halo_staged_conv3_applies_the_bank_modulation_on_its_operand_staging(cfg):
+    """the shared-bank adaptive conv (gp.py:378-409) as ONE contraction: N kernels stacked along the reduction (weights
+    [co][tap][n][ci], CV = N * C virtual channels over C physical ones) with the per-(sample, stacked channel) scale a[b,n] * s[b,i]
+    applied when the halo chunk is parked in LDS (gg_conv3 SCALED) == the convolution of the explicitly modulated N-fold
+    activation; whole-image tiles with several images per tile (8x8), split and unsplit."""
+    n, H, W, ci, N, co, tile, sk = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(n, H, W, ci)); w = bf(torch.randn(co, 9 * N * ci) * 0.1)
+    insc = (torch.rand(n, N * ci) + 0.5)
+    x2 = bf(torch.cat([x.float() * insc[:, None, None, j * ci:(j + 1) * ci] for j in range(N)], dim=-1))     # (n, H, W, N*ci)
+    want = K.conv2d_nhwc(x2, w, ksize=3, out_dtype=torch.float32, force_tile=1)
+    K.plan_log = []
+    got = K.conv2d_nhwc(x, w, ksize=3, cv=N * ci, in_scale=insc, out_dtype=torch.float32, force_tile=tile, force_splitk=sk)
+    assert K.plan_log[-1][0] == tile, K.plan_log
+    K.plan_log = None
+    assert rel_err(got, want) < 1e-5
+    # unforced: the planner may pick it by modelled cost; whatever runs must agree
+    got = K.conv2d_nhwc(x, w, ksize=3, cv=N * ci, in_scale=insc, out_dtype=torch.float32)
+    assert rel_err(got, want) < 1e-5
+
+
+@pytest.mark.parametrize('cfg', [(3, 16, 16, 64, 128, 8, 1), (2, 32, 32, 128, 256, 7, 2), (2, 16, 32, 64, 72, 8, 0)])
+def test_halo_staged_conv3_with_per_image_weights(cfg):
+    """per-sample weights (the reference's own formulation of the adaptive conv, gp.py:390-409): image i is convolved with w[i];
+    row tiles lie inside one image (H * W >= 256)."""
+    n, H, W, ci, co, tile, sk = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(n, H, W, ci)); w = bf(torch.randn(n, co, 9 * ci) * 0.1)
+    want = torch.stack([F.conv2d(x[i:i + 1].float().permute(0, 3, 1, 2), w[i].float().view(co, 3, 3, ci).permute(0, 3, 1, 2),
+                                 padding=1)[0].permute(1, 2, 0) for i in range(n)])
+    K.plan_log = []
+    got = K.conv2d_nhwc(x, w, ksize=3, per_image_weights=True, out_dtype=torch.float32, force_tile=tile, force_splitk=sk)
+    assert K.plan_log[-1][0] == tile, K.plan_log
+    K.plan_log = None
+    assert rel_err(got, want) < 1e-5
+    nz = torch.randn(n * H * W); nw = torch.randn(co)
+    got = K.conv2d_nhwc(x, w, ksize=3, per_image_weights=True, noise=nz, noise_w=nw, act='lrelu', force_tile=tile, force_splitk=sk)
+    assert rel_err(got, F.leaky_relu(want + nz.view(n, H, W, 1) * nw, 0.2)) < 4e-3
 
 
 @pytest.mark.parametrize('cfg', [(1, 16, 16, 32, 256, 0), (3, 8, 8, 64, 264, 2), (1, 32, 32, 32, 128, 4), (1, 8, 64, 32, 40, 0),
@@ -629,8 +690,7 @@ def test_committed_plan_table_loads_and_is_honoured_by_the_planner():
 def test_halo_staged_conv3_is_not_planned_for_ineligible_geometries():
     torch.manual_seed(0)
     K.plan_log = []
-    for (H, W, ci, ks, kw) in [(4, 4, 64, 3, {}), (16, 16, 32, 3, {}), (12, 16, 64, 3, {}), (16, 16, 64, 1, {}),
-                               (16, 16, 64, 3, dict(in_scale=torch.rand(2, 64) + 0.5))]:
+    for (H, W, ci, ks, kw) in [(4, 4, 64, 3, {}), (16, 16, 32, 3, {}), (12, 16, 64, 3, {}), (16, 16, 64, 1, {})]:
         x = bf(torch.randn(2, H, W, ci)); w = bf(torch.randn(128, ks * ks * ci) * 0.1)
         got = K.conv2d_nhwc(x, w, ksize=ks, force_tile=7, **kw)
         assert rel_err(got, K.conv2d_nhwc(x, w, ksize=ks, force_tile=1, **kw)) < 2e-3
@@ -665,25 +725,32 @@ def test_narrow_modconv_layers_take_the_streaming_convolution():
     assert rel_err(y1, y0) < 1e-2
 
 
-def test_premodulated_modconv_path_matches_oracle():
-    """low / mid-resolution no-grad adaptive conv: activation scaled per kernel of the bank by a pointwise pass, then the plain
-    conv gather over (n, ci) channels with the demodulation / noise / activation in the epilogue."""
+def test_shared_bank_modconv_paths_match_oracle():
+    """wide low-resolution no-grad adaptive conv (shared bank, the N kernels stacked along the reduction): from 8x8 up the
+    per-(sample, stacked channel) scale rides on the convolution's operand staging (in_scale, no modulated copy of the activation);
+    4x4 images keep one pointwise pass for both kernels of the bank + the plain gather. Demodulation / noise / activation in the
+    epilogue; both against the oracle."""
     from gigagan_pytorch_amd.modules import AdaptiveConv2DMod
     torch.manual_seed(0)
     conv = AdaptiveConv2DMod(64, 72, 3, num_conv_kernels=2)
-    x, mod, km = torch.randn(2, 64, 8, 8), torch.randn(2, 64) * 0.3, torch.randn(2, 2)
-    nz, nw = torch.randn(2, 1, 8, 8), torch.randn(72, 1, 1) * 0.1
-    calls, orig = [], K.modulate_bank
-    try:
-        K.modulate_bank = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
-        with torch.no_grad():
-            y1 = conv(x, mod, km, noise=nz, noise_weight=nw, act='lrelu')
-            assert len(calls) == 1                      # one pointwise pass for both kernels of the bank
-    finally:
-        K.modulate_bank = orig
-    with torch.no_grad(), ops.use_impl(OracleOps(bf16_operands=True)):
-        y0 = conv(x, mod, km, noise=nz, noise_weight=nw, act='lrelu')
-    assert rel_err(y1, y0) < 1e-2
+    for res, want_calls in ((8, 0), (4, 1)):
+        x, mod, km = torch.randn(2, 64, res, res), torch.randn(2, 64) * 0.3, torch.randn(2, 2)
+        nz, nw = torch.randn(2, 1, res, res), torch.randn(72, 1, 1) * 0.1
+        calls, orig = [], K.modulate_bank
+        K.desc_log = []
+        try:
+            K.modulate_bank = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+            with torch.no_grad():
+                y1 = conv(x, mod, km, noise=nz, noise_weight=nw, act='lrelu')
+            assert len(calls) == want_calls, (res, calls)
+            from gigagan_pytorch_amd._C import GemmDesc
+            d = GemmDesc.from_buffer_copy(K.desc_log[-1])
+            assert bool(d.in_scale) == (want_calls == 0) and d.CV == (128 if want_calls == 0 else d.C)
+        finally:
+            K.modulate_bank, K.desc_log = orig, None
+        with torch.no_grad(), ops.use_impl(OracleOps(bf16_operands=True)):
+            y0 = conv(x, mod, km, noise=nz, noise_weight=nw, act='lrelu')
+        assert rel_err(y1, y0) < 1e-2, res
 
 
 # ---- no-grad forward of the adaptive convolution (gg_modfwd.h) -----------------------------------------------------------
@@ -714,6 +781,85 @@ def test_modw_coefficients_and_per_sample_weights_match_the_reference_formulatio
         assert rel_err(got[:, :O], ref_w.reshape(b, O, I, 9)) < 4e-3 and float(got[:, O:].abs().max() if O < 32 else 0.) == 0.
     _, _, d0 = K.modw_fwd(w, mod, kmod, False, 1e-8, r8(I), r8(O))
     assert torch.equal(d0[:, :O], torch.ones(b, O))
+
+
+def test_multi_layer_modulation_launch_equals_the_per_layer_launches():
+    """gg_modw_multi_fwd (every layer's coefficients / per-sample weights in one launch) == one gg_modw_fwd per layer, bit for
+    bit: a coefficient-only layer (+ the stacked input scale a[b,n] * s[b,i]), a per-image-weight layer (layout 1), a streaming
+    layer (layout 2), a single-kernel layer (N = 1), with modulation rows that are column slices of one wide matrix."""
+    torch.manual_seed(0)
+    b = 5
+    cfgs = [(2, 24, 32, 'coef'), (2, 16, 24, 'rows'), (2, 16, 32, 'bank'), (1, 8, 16, 'coef'), (3, 8, 8, 'coef')]
+    wide = torch.randn(b, sum(I + N for N, O, I, _ in cfgs)) * 0.5            # the style projection all slices come from
+    layers, want, col = [], [], 0
+    for N, O, I, kind in cfgs:
+        w = torch.randn(N, O, I, 3, 3) * 0.2
+        mod, kmod = wide[:, col:col + I], (wide[:, col + I:col + I + N] if N > 1 else None)
+        col += I + N
+        ly = dict(w=w, mod=mod, kmod=kmod, demod=True, eps=1e-8, Ip=I, Op=O)
+        if kind == 'coef':
+            s, a, d = K.modw_fwd(w, mod, kmod, True, 1e-8, I, O)
+            want.append(dict(s=s, a=a, d=d, insc=(a[:, :, None] * s[:, None, :]).reshape(b, N * I)))
+        elif kind == 'rows':
+            wm = torch.zeros(b, O, 9 * I, dtype=torch.bfloat16)
+            K.modw_fwd(w, mod, kmod, True, 1e-8, I, O, coef=False, wmix=wm, layout=1)
+            want.append(dict(wmix=wm))
+            ly.update(coef=False, wmix=torch.zeros_like(wm), layout=1)
+        else:
+            wm = torch.zeros(b, 9, I // 16, 32, 16, dtype=torch.bfloat16)
+            K.modw_fwd(w, mod, kmod, True, 1e-8, I, O, coef=False, wmix=wm, layout=2)
+            want.append(dict(wmix=wm))
+            ly.update(coef=False, wmix=torch.zeros_like(wm), layout=2)
+        layers.append(ly)
+    outs = K.modw_multi(layers)
+    for ly, o, w_ in zip(layers, outs, want):
+        if 'wmix' in w_:
+            assert torch.equal(ly['wmix'], w_['wmix']) and o['d'] is None
+        else:
+            assert torch.equal(o['s'], w_['s']) and torch.equal(o['a'], w_['a']) and torch.equal(o['d'], w_['d'])
+            assert torch.allclose(o['insc'], w_['insc'], rtol=1e-6, atol=1e-7)
+    # more layers than one launch holds (16): split transparently
+    many = [dict(w=layers[0]['w'], mod=layers[0]['mod'], kmod=layers[0]['kmod'], demod=True, eps=1e-8, Ip=32, Op=24) for _ in range(19)]
+    outs = K.modw_multi(many)
+    assert len(outs) == 19 and all(torch.equal(o['d'], want[0]['d']) for o in outs)
+
+
+def test_generator_announces_its_adaptive_convs_and_every_layer_uses_the_batched_modulation():
+    """no-grad Generator.forward on the kernels: ONE gg_modw_multi_fwd launch at the top (all 3x3 demodulated layers that are not
+    behind a skip-layer excitation), no per-layer gg_modw_fwd for them, the registry is empty afterwards, and the images equal
+    the per-layer-launch path (prepare disabled) bit for bit and the oracle within bf16 tolerance."""
+    from gigagan_pytorch_amd.generator import Generator
+    from helpers import SMALL_G
+    torch.manual_seed(0)
+    G = Generator(**SMALL_G).eval()
+    z = torch.randn(2, 32)
+    calls = []
+    real_multi, real_single = K.modw_multi, K.modw_fwd
+    K.modw_multi = lambda layers: (calls.append(('multi', len(layers))), real_multi(layers))[1]
+    K.modw_fwd = lambda *a, **k: (calls.append(('single',)), real_single(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            torch.manual_seed(1)
+            img = G(noise=z)
+            n_multi = [c for c in calls if c[0] == 'multi']
+            n_single = [c for c in calls if c[0] == 'single']
+            assert len(n_multi) == 1 and not ops._prepared, (calls, list(ops._prepared))
+            excited = max(G.num_layers - G.num_skip_layers_excite, 0) if G.num_skip_layers_excite else 0
+            assert n_multi[0][1] == 1 + 2 * G.num_layers - excited and len(n_single) == excited, (calls, excited)
+            calls.clear()
+            prep, ops.HipOps.modconv_prepare = ops.HipOps.modconv_prepare, lambda self, specs: 0
+            try:
+                torch.manual_seed(1)
+                img0 = G(noise=z)
+            finally:
+                ops.HipOps.modconv_prepare = prep
+            assert not [c for c in calls if c[0] == 'multi'] and torch.equal(img, img0)
+            with ops.use_impl(OracleOps(bf16_operands=True)):
+                torch.manual_seed(1)
+                ref = G(noise=z)
+        assert rel_err(img, ref) < 2e-2
+    finally:
+        K.modw_multi, K.modw_fwd = real_multi, real_single
 
 
 @pytest.mark.parametrize('cfg', [(2, 16, 64, 16, 16), (1, 8, 32, 32, 32), (3, 8, 64, 64, 24), (2, 5, 32, 32, 8)])
