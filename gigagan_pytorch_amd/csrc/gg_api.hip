@@ -1117,8 +1117,39 @@ extern "C" int gg_pool_mean_bwd(const void* g, const float* gs, void* y, int32_t
     return gg_check_launch();
 }
 
-static int gg_modw_fill(GgModWParams& p, const float* w, const float* mod, int32_t mod_ld, const float* kmod, int32_t kmod_ld,
-                        const float* xs, int32_t xs_ld, float* s, float* a, float* d, float* insc, void* wmix, int32_t layout, int32_t b,
+static int gg_poolhf_check(const char* who, int32_t b, int32_t H, int32_t W, int32_t C) {
+    if (b <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) || C <= 0 || (C & 7))
+        return gg_fail(-2, "%s: needs even H, W >= 2 and C %% 8 == 0 (b=%d H=%d W=%d C=%d)", who, b, H, W, C);
+    return 0;
+}
+
+extern "C" int gg_poolhf_fwd(const void* x, void* pool, void* hf, int32_t b, int32_t H, int32_t W, int32_t C, void* stream) {
+    if (!x || !pool || !hf) return gg_fail(-1, "gg_poolhf_fwd: null pointer");
+    int rc = gg_poolhf_check("gg_poolhf_fwd", b, H, W, C);
+    if (rc) return rc;
+    GgPoolHfParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)x; p.pool = (bf16_t*)pool; p.hf = (bf16_t*)hf; p.b = b; p.H = H; p.W = W; p.C = C;
+    GG_LAUNCH(gg_poolhf_fwd_kernel, dim3(gg_grid_for((long long)b * (H / 2) * (W / 2) * (C / 8))), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+extern "C" int gg_poolhf_bwd(const void* x, const void* g_pool, const void* g_hf, void* dx, int32_t b, int32_t H, int32_t W, int32_t C,
+                             void* stream) {
+    if (!x || !dx || (!g_pool && !g_hf)) return gg_fail(-1, "gg_poolhf_bwd: null pointer");
+    int rc = gg_poolhf_check("gg_poolhf_bwd", b, H, W, C);
+    if (rc) return rc;
+    GgPoolHfParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)x; p.g_pool = (const bf16_t*)g_pool; p.g_hf = (const bf16_t*)g_hf; p.dx = (bf16_t*)dx;
+    p.b = b; p.H = H; p.W = W; p.C = C;
+    GG_LAUNCH(gg_poolhf_bwd_kernel, dim3(gg_grid_for((long long)b * (H / 2) * (W / 2) * (C / 8))), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+static int gg_modw_fill(GgModWParams& p, const float* w, const float* gram, const float* mod, int32_t mod_ld, const float* kmod,
+                        int32_t kmod_ld, const float* xs, int32_t xs_ld, float* s, float* a, float* d, float* insc, void* wmix,
+                        int32_t layout, int32_t b,
                         int32_t N, int32_t O, int32_t I, int32_t T, int32_t Ip, int32_t Op, int32_t demod, float eps) {
     if (!w || !mod) return gg_fail(-1, "gg_modw_fwd: null pointer");
     if (b <= 0 || b > GG_MW_BMAX || N <= 0 || N > GG_MW_NMAX || O <= 0 || I <= 0 || (I & 3) || T <= 0 || Ip < I || Op < O)
@@ -1133,7 +1164,8 @@ static int gg_modw_fill(GgModWParams& p, const float* w, const float* mod, int32
         if (((uintptr_t)wmix) & 15) return gg_fail(-4, "gg_modw_fwd: wmix must be 16-byte aligned");
     }
     memset(&p, 0, sizeof(p));
-    p.w = w; p.mod = mod; p.kmod = kmod; p.s = s; p.a = a; p.d = d; p.insc = insc; p.wmix = (bf16_t*)wmix; p.layout = layout;
+    p.w = w; p.gram = gram; p.mod = mod; p.kmod = kmod; p.s = s; p.a = a; p.d = d; p.insc = insc; p.wmix = (bf16_t*)wmix;
+    p.layout = layout;
     p.b = b; p.N = N; p.O = O; p.I = I; p.T = T; p.Ip = Ip; p.Op = Op; p.demod = demod; p.eps = eps;
     p.mod_ld = mod_ld; p.kmod_ld = kmod_ld; p.xs = xs; p.xs_ld = xs_ld;
     // coefficient-only launches: one workgroup per channel handles every sample; with per-sample weights the samples are spread
@@ -1152,7 +1184,8 @@ extern "C" int gg_modw_fwd(const float* w, const float* mod, int32_t mod_ld, con
                            int32_t xs_ld, float* s, float* a, float* d, void* wmix, int32_t layout, int32_t b, int32_t N, int32_t O,
                            int32_t I, int32_t T, int32_t Ip, int32_t Op, int32_t demod, float eps, void* stream) {
     GgModWParams p;
-    int rc = gg_modw_fill(p, w, mod, mod_ld, kmod, kmod_ld, xs, xs_ld, s, a, d, nullptr, wmix, layout, b, N, O, I, T, Ip, Op, demod, eps);
+    int rc = gg_modw_fill(p, w, nullptr, mod, mod_ld, kmod, kmod_ld, xs, xs_ld, s, a, d, nullptr, wmix, layout, b, N, O, I, T, Ip, Op,
+                          demod, eps);
     if (rc) return rc;
     const dim3 grid((unsigned)O, (unsigned)((b + p.bc - 1) / p.bc));
     if (N == 1) GG_LAUNCH((gg_modw_kernel<1>), grid, dim3(256), (hipStream_t)stream, p);
@@ -1164,38 +1197,56 @@ extern "C" int gg_modw_fwd(const float* w, const float* mod, int32_t mod_ld, con
 
 extern "C" int gg_modw_multi_fwd(const gg_modw_item* items, int32_t n_items, void* stream) {
     if (!items || n_items <= 0) return gg_fail(-1, "gg_modw_multi_fwd: no items");
-    for (int i0 = 0; i0 < n_items; i0 += GG_MW_MAX_ITEMS) {
-        GgModWMulti m;
-        memset(&m, 0, sizeof(m));
-        m.n = n_items - i0 < GG_MW_MAX_ITEMS ? n_items - i0 : GG_MW_MAX_ITEMS;
-        int blocks = 0;
-        for (int j = 0; j < m.n; ++j) {
-            const gg_modw_item& it = items[i0 + j];
-            int rc = gg_modw_fill(m.item[j], it.w, it.mod, it.mod_ld, it.kmod, it.kmod_ld, it.xs, it.xs_ld, it.s, it.a, it.d, it.insc,
-                                  it.wmix, it.layout, it.b, it.N, it.O, it.I, it.T, it.Ip, it.Op, it.demod, it.eps);
-            if (rc) return rc;
-            m.first_block[j] = blocks;
-            blocks += it.O * ((it.b + m.item[j].bc - 1) / m.item[j].bc);
-        }
-        for (int j = m.n; j <= GG_MW_MAX_ITEMS; ++j) m.first_block[j] = blocks;
-        GG_LAUNCH(gg_modw_multi_kernel, dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, m);
-        int rc = gg_check_launch();
+    GgModWMulti tab;
+    int blocks = 0;
+    auto flush = [&]() -> int {
+        if (tab.n == 0) return 0;
+        for (int j = tab.n; j <= GG_MW_MAX_ITEMS; ++j) tab.first_block[j] = blocks;
+        GG_LAUNCH(gg_modw_multi_kernel, dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, tab);
+        tab.n = 0;
+        blocks = 0;
+        return gg_check_launch();
+    };
+    memset(&tab, 0, sizeof(tab));
+    for (int i = 0; i < n_items; ++i) {
+        const gg_modw_item& it = items[i];
+        GgModWParams q;
+        int rc = gg_modw_fill(q, it.w, it.gram, it.mod, it.mod_ld, it.kmod, it.kmod_ld, it.xs, it.xs_ld, it.s, it.a, it.d, it.insc,
+                              it.wmix, it.layout, it.b, it.N, it.O, it.I, it.T, it.Ip, it.Op, it.demod, it.eps);
         if (rc) return rc;
+        if (it.N > 2) {         // rare: its own launch (the single-layer kernel)
+            const dim3 grid((unsigned)it.O, (unsigned)((it.b + q.bc - 1) / q.bc));
+            if (it.N == 3) GG_LAUNCH((gg_modw_kernel<3>), grid, dim3(256), (hipStream_t)stream, q);
+            else GG_LAUNCH((gg_modw_kernel<4>), grid, dim3(256), (hipStream_t)stream, q);
+            if ((rc = gg_check_launch())) return rc;
+            continue;
+        }
+        // one launch carries hundreds of workgroups already: every workgroup takes all samples of its channel (the per-workgroup
+        // prologue - bank rows, Gram rows, barriers - is the cost, not the samples); coefficient-only items with cached Gram rows
+        // run a workgroup per channel pair without LDS (gg_modw_coef_body)
+        q.bc = it.b;
+        q.fast = (it.gram && !it.wmix && it.I <= 512) ? 1 : 0;
+        if (tab.n == GG_MW_MAX_ITEMS && (rc = flush())) return rc;
+        tab.item[tab.n] = q;
+        tab.first_block[tab.n] = blocks;
+        blocks += q.fast ? (it.O + 1) / 2 : it.O * ((it.b + q.bc - 1) / q.bc);
+        ++tab.n;
     }
-    return 0;
+    return flush();
 }
 
 extern "C" int gg_sconv_fwd(const void* x, const void* w, int64_t w_bs, void* y, const float* noise, const float* noise_w,
-                            int32_t b, int32_t H, int32_t W, int32_t C, int32_t O, int32_t act, float slope, void* stream) {
+                            const float* xs, int32_t b, int32_t H, int32_t W, int32_t C, int32_t O, int32_t act, float slope,
+                            void* stream) {
     if (!x || !w || !y) return gg_fail(-1, "gg_sconv_fwd: null pointer");
     if (b <= 0 || H <= 0 || W <= 0 || (W & 31) || !(C == 16 || C == 32 || C == 64) || O <= 0 || O > 32 || (O & 7))
         return gg_fail(-2, "gg_sconv_fwd: needs W %% 32 == 0, C in {16, 32, 64}, O <= 32 and O %% 8 == 0 (W=%d C=%d O=%d)", W, C, O);
     if ((noise != nullptr) != (noise_w != nullptr)) return gg_fail(-1, "gg_sconv_fwd: noise and noise_w go together");
     if (act < 0 || act > 1) return gg_fail(-3, "gg_sconv_fwd: activation must be none (0) or leaky-relu (1)");
-    if ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y)) & 15) return gg_fail(-4, "gg_sconv_fwd: 16-byte alignment required");
+    if ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)xs)) & 15) return gg_fail(-4, "gg_sconv_fwd: 16-byte alignment required");
     GgSconvParams p;
     memset(&p, 0, sizeof(p));
-    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.w_bs = w_bs; p.y = (bf16_t*)y; p.noise = noise; p.noise_w = noise_w;
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.w_bs = w_bs; p.y = (bf16_t*)y; p.noise = noise; p.noise_w = noise_w; p.xs = xs;
     p.b = b; p.H = H; p.W = W; p.O = O; p.act = act; p.slope = slope;
     // work item of a wavefront: a 32-pixel-wide strip of `rows` rows (+ one halo row above and below: 2 / rows extra reads);
     // a workgroup = 4 wavefronts inside one image sharing that image's filter bank in LDS

@@ -100,6 +100,26 @@ GG_DEVICE void gg_buf_load_lds16(GgBuf r, unsigned voff, unsigned soff, void* ld
 
 GG_DEVICE float gg_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 GG_DEVICE float gg_shfl(float v, int src) { return __shfl(v, src, 64); }
+// the value lane `src` holds, for a WAVE-UNIFORM src (v_readlane_b32: a few cycles; gg_shfl is a ds_bpermute round trip)
+GG_DEVICE float gg_readlane(float v, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), __builtin_amdgcn_readfirstlane(src)));
+}
+// sum over the 64 lanes, returned to every lane (wave-uniform): four DPP adds inside the 16-lane rows (quad swaps, half-row and row
+// mirrors: ~4 cycles each, no LDS crossbar) and one readlane per row. The butterfly of gg_shfl_xor costs six ds_bpermute round trips
+// (~100 cycles each) - the adaptive-conv coefficient kernel does one reduction per (sample, channel).
+GG_DEVICE float gg_wave_sum_all(float v) {
+    int x = __builtin_bit_cast(int, v);
+#define GG_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+    (void)x;
+    GG_DPP_ADD(0xB1);        // quad_perm [1,0,3,2]
+    GG_DPP_ADD(0x4E);        // quad_perm [2,3,0,1]
+    GG_DPP_ADD(0x141);       // row_half_mirror
+    GG_DPP_ADD(0x140);       // row_mirror
+#undef GG_DPP_ADD
+    const int vi = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48)));
+}
 GG_DEVICE void gg_atomic_add(float* p, float v) { atomicAdd(p, v); }
 GG_DEVICE float gg_expf(float x) { return __expf(x); }
 GG_DEVICE float gg_exp2f(float x) { return __builtin_amdgcn_exp2f(x); }     // bare v_exp_f32 (no range fix-ups: x <= 128 here)

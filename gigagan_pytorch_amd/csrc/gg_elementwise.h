@@ -953,3 +953,174 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_linattn_kapply_kernel(GgLinAttnParams p)
         *(u16x8*)(p.y + row * p.ld_y + cv * 8) = o;
     }
 }
+
+// ---- unet Downsample tail (reference unet_upsampler.py:134-160): pooled = max_pool2d(x, 2) and the high-frequency map
+// hf = x - blur(x) (blur = kornia filter2d, normalised [1,2,1]^2 / 16, border 'reflect') that rides the skip connection -------
+// forward: one thread per (2x2 output cell, 8-channel vector): the cell's 4x4 neighbourhood (16-byte loads, reflected at the image
+// border; the overlap between neighbouring cells is served by the vector L1 / L2) -> four hf vectors + one pooled vector.
+// HBM: x read once, hf + pooled written once (the stock formulation: max-pool pass + blur pass + two fp32 casts + a subtraction).
+// backward: dx = scatter(g_pool to the window's arg-max, first maximum in row-major window order as torch) + g_hf - blur^T(g_hf);
+// blur^T is the exact adjoint of the reflect-padded stencil (border rows / columns collect the reflected taps).
+struct GgPoolHfParams {
+    const bf16_t* x;        // [b][H][W][C]
+    bf16_t* pool;           // fwd out [b][H/2][W/2][C]
+    bf16_t* hf;             // fwd out [b][H][W][C]
+    const bf16_t* g_pool;   // bwd in (may be null)
+    const bf16_t* g_hf;     // bwd in (may be null)
+    bf16_t* dx;             // bwd out [b][H][W][C]
+    int b, H, W, C;
+};
+
+GG_DEVICE int gg_reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_poolhf_fwd_kernel(GgPoolHfParams p) {
+    const int cvs = p.C >> 3, OH = p.H >> 1, OW = p.W >> 1;
+    const long long n = (long long)p.b * OH * OW * cvs;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % cvs);
+        long long cell = i / cvs;
+        const int ox = (int)(cell % OW);
+        cell /= OW;
+        const int oy = (int)(cell % OH), img = (int)(cell / OH);
+        const bf16_t* xi = p.x + ((long long)img * p.H * p.W) * p.C + cv * 8;
+        u16x8 v[4][4];                       // rows 2oy-1 .. 2oy+2, columns 2ox-1 .. 2ox+2 (all loads issued before the first use)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int yy = gg_reflect(2 * oy - 1 + r, p.H);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int xx = gg_reflect(2 * ox - 1 + c, p.W);
+                v[r][c] = *(const u16x8*)(xi + ((long long)yy * p.W + xx) * p.C);
+            }
+        }
+        u16x8 mx;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float f[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) f[r][c] = gg_bf2f(v[r][c][e]);
+            float m = f[1][1];
+            m = f[1][2] > m ? f[1][2] : m;
+            m = f[2][1] > m ? f[2][1] : m;
+            m = f[2][2] > m ? f[2][2] : m;
+            mx[e] = gg_f2bf(m);
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int r = 1 + dy, c = 1 + dx;
+                    const float blur = (f[r - 1][c - 1] + 2.f * f[r - 1][c] + f[r - 1][c + 1] + 2.f * f[r][c - 1] + 4.f * f[r][c] +
+                                        2.f * f[r][c + 1] + f[r + 1][c - 1] + 2.f * f[r + 1][c] + f[r + 1][c + 1]) * 0.0625f;
+                    v[r][c][e] = gg_f2bf(f[r][c] - blur);
+                }
+        }
+        *(u16x8*)(p.pool + (((long long)img * OH + oy) * OW + ox) * p.C + cv * 8) = mx;
+        bf16_t* hi = p.hf + ((long long)img * p.H * p.W) * p.C + cv * 8;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx)
+                *(u16x8*)(hi + ((long long)(2 * oy + dy) * p.W + 2 * ox + dx) * p.C) = v[1 + dy][1 + dx];
+    }
+}
+
+// weight of g[y] in dx[u] along one axis: sum of the taps w_k = {1, 2, 1} / 4 of output y that read input u (reflected)
+GG_DEVICE float gg_blur_adj(int u, int y, int n) {
+    float c = 0.f;
+    if (y < 0 || y >= n) return 0.f;
+    if (gg_reflect(y - 1, n) == u) c += 0.25f;
+    if (y == u) c += 0.5f;
+    if (gg_reflect(y + 1, n) == u) c += 0.25f;
+    return c;
+}
+
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_poolhf_bwd_kernel(GgPoolHfParams p) {
+    const int cvs = p.C >> 3, OH = p.H >> 1, OW = p.W >> 1;
+    const long long n = (long long)p.b * OH * OW * cvs;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % cvs);
+        long long cell = i / cvs;
+        const int ox = (int)(cell % OW);
+        cell /= OW;
+        const int oy = (int)(cell % OH), img = (int)(cell / OH);
+        const long long ibase = ((long long)img * p.H * p.W) * p.C + cv * 8;
+        float acc[2][2][8];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[dy][dx][e] = 0.f;
+        if (p.g_hf) {
+            // g_hf at rows 2oy-1 .. 2oy+2 / columns 2ox-1 .. 2ox+2 (clamped loads; out-of-image rows get weight 0 below)
+            u16x8 g[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int yy = 2 * oy - 1 + r, yc = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int xx = 2 * ox - 1 + c, xc = xx < 0 ? 0 : (xx >= p.W ? p.W - 1 : xx);
+                    g[r][c] = *(const u16x8*)(p.g_hf + ibase + ((long long)yc * p.W + xc) * p.C);
+                }
+            }
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int u = 2 * oy + dy, w = 2 * ox + dx;
+                    float wy[3], wx[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        wy[k] = gg_blur_adj(u, u - 1 + k, p.H);
+                        wx[k] = gg_blur_adj(w, w - 1 + k, p.W);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) s += wy[ky] * wx[kx] * gg_bf2f(g[dy + ky][dx + kx][e]);
+                        acc[dy][dx][e] = gg_bf2f(g[1 + dy][1 + dx][e]) - s;
+                    }
+                }
+        }
+        if (p.g_pool) {
+            const u16x8 gp = *(const u16x8*)(p.g_pool + (((long long)img * OH + oy) * OW + ox) * p.C + cv * 8);
+            u16x8 xv[2][2];
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx)
+                    xv[dy][dx] = *(const u16x8*)(p.x + ibase + ((long long)(2 * oy + dy) * p.W + 2 * ox + dx) * p.C);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int by = 0, bx = 0;
+                float m = gg_bf2f(xv[0][0][e]);
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const float f = gg_bf2f(xv[dy][dx][e]);
+                        if (f > m) { m = f; by = dy; bx = dx; }
+                    }
+                const float gv = gg_bf2f(gp[e]);
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) acc[dy][dx][e] += (dy == by && dx == bx) ? gv : 0.f;
+            }
+        }
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                u16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = gg_f2bf(acc[dy][dx][e]);
+                *(u16x8*)(p.dx + ibase + ((long long)(2 * oy + dy) * p.W + 2 * ox + dx) * p.C) = o;
+            }
+    }
+}

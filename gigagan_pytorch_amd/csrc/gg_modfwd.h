@@ -21,6 +21,7 @@
 #define GG_MW_BMAX 64          // samples per launch
 #define GG_MW_WMAX 9216        // N * I * T floats staged per workgroup (36 KiB: two 512-channel 3x3 kernels)
 #define GG_MW_GMAX 1536        // pairs * I floats (Gram rows)
+#define GG_MW_SMAX 4608        // samples * I floats of weight scales staged per pass (the upper half of the bank's LDS area)
 
 struct GgModWParams {
     const float* w;        // (N, O, I, T) fp32 parameter layout
@@ -38,6 +39,10 @@ struct GgModWParams {
     const float* xs;       // optional (b, I) extra scale of the INPUT activation (skip-layer excitation, gp.py:1023-1024) folded into
     int xs_ld;             // s and the per-sample weights - not into the demodulation, which the reference computes from mod + 1 alone
     int bc;                // samples per workgroup: grid = (O, ceil(b / bc)); every workgroup re-derives the Gram rows of its channel
+    const float* gram;     // optional [pair][O][I]: the bank's Gram rows, refreshed with the packed operands after each optimizer step
+                           // (gg_weights.h kind 2); a coefficient-only workgroup then never touches the bank itself
+    int fast;              // set by the host: coefficient-only item with cached Gram rows and I <= 512 -> gg_modw_coef_body (a workgroup per
+                           // channel pair, Gram rows in registers, no LDS, no workgroup barriers): grid ceil(O / 2) workgroups
     float* insc;           // optional (b, N * Ip) out: a[b,n] * s[b,i] - the per-(sample, stacked channel) input scale of the shared-
                            // bank convolution with the N kernels stacked along the reduction (gg_conv3_kernel SCALED)
 };
@@ -63,15 +68,17 @@ GG_DEVICE float gg_mw_wave_sum(float v) {
 // 0 / 1): with run-time loop bounds and loads under conditions the compiler emitted one branch + `s_waitcnt vmcnt(0)` per load,
 // i.e. a chain of ~60 dependent memory round trips per workgroup (50 us for a 512-channel layer; measured, profiles/).
 template <int N>
-GG_DEVICE void gg_modw_body(const GgModWParams& p, int o, int chunk, float* wl, float* gram, float (*a_s)[GG_MW_NMAX], float* d_s) {
+GG_DEVICE void gg_modw_body(const GgModWParams& p, int o, int chunk, float* wl, float* gram, float (*a_s)[GG_MW_NMAX], float* d_s,
+                            float* ssc = nullptr) {
     constexpr int NP = N * (N + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int IT = p.I * p.T;
     const int b_lo = chunk * p.bc;
     const int b_hi = b_lo + p.bc < p.b ? b_lo + p.bc : p.b;
-    // s / the zero padding of d of this chunk's samples: written by the workgroups of channel 0
-    if (o == 0)
-        for (int row = b_lo; row < b_hi; ++row) {
+    // s / insc / the zero padding of d of this chunk's samples: workgroup o writes the rows b_lo + o, b_lo + o + O, ... (spread over
+    // the channels' workgroups: one workgroup writing all rows was a 32-deep chain of dependent round trips - the launch's tail)
+    if (p.s || p.insc || (p.d && p.Op > p.O))
+        for (int row = b_lo + o; row < b_hi; row += p.O) {
             if (p.s)
                 for (int i = tid; i < p.Ip; i += 256) {
                     const int ic = i < p.I ? i : p.I - 1;
@@ -99,8 +106,9 @@ GG_DEVICE void gg_modw_body(const GgModWParams& p, int o, int chunk, float* wl, 
             if (p.d)
                 for (int c = p.O + tid; c < p.Op; c += 256) p.d[(long long)row * p.Op + c] = 0.f;
         }
-    // the bank rows of this channel: 16-byte loads, four in flight per thread (I % 4 == 0: rows are 16-byte aligned)
-    {
+    // the bank rows of this channel: 16-byte loads, four in flight per thread (I % 4 == 0: rows are 16-byte aligned). Not needed
+    // when the Gram rows are cached and no per-sample weights are asked for (workgroup-uniform)
+    if (p.wmix || !p.gram) {
         const int ivn = IT >> 2;
 #pragma unroll
         for (int n = 0; n < N; ++n) {
@@ -137,7 +145,11 @@ GG_DEVICE void gg_modw_body(const GgModWParams& p, int o, int chunk, float* wl, 
     }
     gg_sync();
     if (p.demod) {
-        {
+        if (p.gram) {
+#pragma unroll
+            for (int pair = 0; pair < NP; ++pair)
+                for (int i = tid; i < p.I; i += 256) gram[pair * p.I + i] = p.gram[((long long)pair * p.O + o) * p.I + i];
+        } else {
             int pair = 0;
 #pragma unroll
             for (int n = 0; n < N; ++n)
@@ -207,22 +219,212 @@ GG_DEVICE void gg_modw_body(const GgModWParams& p, int o, int chunk, float* wl, 
     }
     if (!p.wmix) return;
     gg_sync();
-    // per-sample weights: threads run along (t, i) with i fastest, so the bf16 stores of a wave are contiguous
-    for (int bb = b_lo; bb < b_hi; ++bb) {
-        const float dv = d_s[bb];
-        const float* mrow = p.mod + (long long)bb * p.mod_ld;
-        const float* xrow = p.xs ? p.xs + (long long)bb * p.xs_ld : nullptr;
-        for (int e = tid; e < IT; e += 256) {
-            const int t = e / p.I, i = e - t * p.I;
-            float m = 0.f;
+    // per-sample weights. The scalar form (one bf16 store and ~40 instructions per element: division, 64-bit offset, two LDS
+    // broadcasts, a global load) was INSTRUCTION-bound: 19 M elements x 40 / 64 lanes = 12 M wave instructions = 45 us for config 2's
+    // four per-image-weight layers. Vector form: a thread owns 8 consecutive input channels of one tap (one 16-byte store per
+    // sample), the samples' scales (mod + 1) * xs are staged in LDS in passes of SB samples (one batch of independent loads per
+    // pass: no global load inside the loop), the bank values of the unit are read once for all samples.
+    const bool vec = ssc && (p.I & 7) == 0 && N * IT <= GG_MW_WMAX - GG_MW_SMAX && p.I <= GG_MW_SMAX;
+    if (vec) {
+        const int i8n = p.I >> 3, units = p.T * i8n;
+        const int SB = GG_MW_SMAX / p.I;                                   // samples per staging pass
+        for (int s0 = b_lo; s0 < b_hi; s0 += SB) {
+            const int s1 = s0 + SB < b_hi ? s0 + SB : b_hi;
+            gg_sync();                                                    // (the previous pass is done with ssc)
+            const int cnt = (s1 - s0) * p.I;
+            for (int e0 = tid; e0 < cnt; e0 += 256 * 8) {
+                float v[8];
 #pragma unroll
-            for (int n = 0; n < N; ++n) m += a_s[bb][n] * wl[n * IT + i * p.T + t];
-            const float v = dv * (mrow[i] + 1.f) * (xrow ? xrow[i] : 1.f) * m;
-            long long off;
-            if (p.layout == 1) off = (((long long)bb * p.O + o) * p.T + t) * p.I + i;
-            else off = ((((long long)bb * p.T + t) * (p.I >> 4) + (i >> 4)) * 32 + o) * 16 + (i & 15);
-            p.wmix[off] = gg_f2bf(v);
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + 256 * u < cnt ? e0 + 256 * u : cnt - 1;
+                    const int bb = s0 + e / p.I, i = e % p.I;
+                    v[u] = (p.mod[(long long)bb * p.mod_ld + i] + 1.f) * (p.xs ? p.xs[(long long)bb * p.xs_ld + i] : 1.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (e0 + 256 * u < cnt) ssc[e0 + 256 * u] = v[u];
+            }
+            gg_sync();
+            for (int un = tid; un < units; un += 256) {
+                const int t = un / i8n, i0 = (un - t * i8n) * 8;
+                float wv[N][8];
+#pragma unroll
+                for (int n = 0; n < N; ++n)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) wv[n][e] = wl[n * IT + (i0 + e) * p.T + t];
+                for (int bb = s0; bb < s1; ++bb) {
+                    const float* sp = ssc + (bb - s0) * p.I + i0;
+                    const f32x4 sa = *(const f32x4*)sp, sb = *(const f32x4*)(sp + 4);
+                    const float dv = d_s[bb];
+                    u16x8 o8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float m = 0.f;
+#pragma unroll
+                        for (int n = 0; n < N; ++n) m += a_s[bb][n] * wv[n][e];
+                        o8[e] = gg_f2bf(dv * (e < 4 ? sa[e] : sb[e - 4]) * m);
+                    }
+                    long long off;
+                    if (p.layout == 1) off = (((long long)bb * p.O + o) * p.T + t) * p.I + i0;
+                    else off = ((((long long)bb * p.T + t) * (p.I >> 4) + (i0 >> 4)) * 32 + o) * 16 + (i0 & 15);
+                    *(u16x8*)(p.wmix + off) = o8;
+                }
+            }
         }
+        return;
+    }
+    for (int e = tid; e < IT; e += 256) {
+        const int t = e / p.I, i = e - t * p.I;
+        float wv[N];
+#pragma unroll
+        for (int n = 0; n < N; ++n) wv[n] = wl[n * IT + i * p.T + t];
+        for (int bb0 = b_lo; bb0 < b_hi; bb0 += 8) {
+            float sc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int bc = bb0 + u < b_hi ? bb0 + u : b_hi - 1;
+                sc[u] = p.mod[(long long)bc * p.mod_ld + i] + 1.f;
+            }
+            if (p.xs) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int bc = bb0 + u < b_hi ? bb0 + u : b_hi - 1;
+                    sc[u] *= p.xs[(long long)bc * p.xs_ld + i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int bb = bb0 + u;
+                if (bb < b_hi) {
+                    float m = 0.f;
+#pragma unroll
+                    for (int n = 0; n < N; ++n) m += a_s[bb][n] * wv[n];
+                    const float v = d_s[bb] * sc[u] * m;
+                    long long off;
+                    if (p.layout == 1) off = (((long long)bb * p.O + o) * p.T + t) * p.I + i;
+                    else off = ((((long long)bb * p.T + t) * (p.I >> 4) + (i >> 4)) * 32 + o) * 16 + (i & 15);
+                    p.wmix[off] = gg_f2bf(v);
+                }
+            }
+        }
+    }
+}
+
+// Coefficient-only items with cached Gram rows: one WAVE per output channel. The per-workgroup chain of gg_modw_body (Gram rows ->
+// LDS -> barrier -> samples) ran ~6 us per channel and a 512-channel layer is 512 workgroups: 54 us for config 2's seven wide
+// layers even with the Gram rows cached. Here a lane keeps the 3 x 8 Gram values of its channel in registers (i = lane + 64 j,
+// I <= 512), broadcasts a sample's softmax weights with readlane, and the wave walks the samples four at a time (their modulation
+// rows fetched back to back). Workgroup wg of the item's nwg also writes the rows wg, wg + nwg, ... of s / a / insc.
+template <int N>
+GG_DEVICE void gg_modw_coef_body(const GgModWParams& p, int wg, int nwg) {
+    constexpr int NP = N * (N + 1) / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int row = wg; row < p.b; row += nwg) {
+        float av[GG_MW_NMAX] = {1.f, 0.f, 0.f, 0.f};
+        if (N > 1) {
+            float kv[N], mx = -3.0e38f, sum = 0.f;
+#pragma unroll
+            for (int n = 0; n < N; ++n) { kv[n] = p.kmod[(long long)row * p.kmod_ld + n]; mx = kv[n] > mx ? kv[n] : mx; }
+#pragma unroll
+            for (int n = 0; n < N; ++n) { kv[n] = gg_expf(kv[n] - mx); sum += kv[n]; }
+#pragma unroll
+            for (int n = 0; n < N; ++n) av[n] = kv[n] / sum;
+        }
+        if (p.a && tid < N) p.a[row * N + tid] = av[tid < GG_MW_NMAX ? tid : 0];
+        for (int i = tid; i < p.Ip; i += 256) {
+            const int ic = i < p.I ? i : p.I - 1;
+            const float v = (p.mod[(long long)row * p.mod_ld + ic] + 1.f) * (p.xs ? p.xs[(long long)row * p.xs_ld + ic] : 1.f);
+            if (p.s) p.s[(long long)row * p.Ip + i] = i < p.I ? v : 0.f;
+            if (p.insc) {
+#pragma unroll
+                for (int n = 0; n < N; ++n) p.insc[((long long)row * N + n) * p.Ip + i] = i < p.I ? av[n] * v : 0.f;
+            }
+        }
+        if (p.d)
+            for (int c = p.O + tid; c < p.Op; c += 256) p.d[(long long)row * p.Op + c] = 0.f;
+    }
+    // the workgroup owns the channel pair (2 wg, 2 wg + 1); its four waves split the samples (a wave walking all 32 samples of a
+    // channel was a ~30 us serial chain). The pair shares every modulation value and rides on packed fp32 FMAs (v_pk_fma_f32).
+    const int o0 = wg * 2;
+    if (o0 >= p.O || !p.d) return;
+    const bool two = o0 + 1 < p.O;
+    const int per = ((p.b + 3) / 4 + 3) & ~3;                  // samples per wave, a multiple of the batch of four
+    const int s_lo = wave * per, s_hi = s_lo + per < p.b ? s_lo + per : p.b;
+    if (s_lo >= p.b) return;
+    if (!p.demod) {
+        for (int bb = s_lo + lane; bb < s_hi; bb += 64) {
+            p.d[(long long)bb * p.Op + o0] = 1.f;
+            if (two) p.d[(long long)bb * p.Op + o0 + 1] = 1.f;
+        }
+        return;
+    }
+    // this lane's sample (lane < b <= 64): softmax over the kernels; other lanes' values are fetched with readlane below
+    float av[GG_MW_NMAX] = {1.f, 0.f, 0.f, 0.f};
+    if (N > 1) {
+        const int sb = lane < p.b ? lane : p.b - 1;
+        float kv[N], mx = -3.0e38f, sum = 0.f;
+#pragma unroll
+        for (int n = 0; n < N; ++n) { kv[n] = p.kmod[(long long)sb * p.kmod_ld + n]; mx = kv[n] > mx ? kv[n] : mx; }
+#pragma unroll
+        for (int n = 0; n < N; ++n) { kv[n] = gg_expf(kv[n] - mx); sum += kv[n]; }
+#pragma unroll
+        for (int n = 0; n < N; ++n) av[n] = kv[n] / sum;
+    }
+    f32x2 g[NP][8];                                             // (channel o0, channel o0 + 1) pairs
+#pragma unroll
+    for (int pr = 0; pr < NP; ++pr)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = lane + 64 * j;
+            const long long base = ((long long)pr * p.O + o0) * p.I + (i < p.I ? i : p.I - 1);
+            const float v0 = p.gram[base], v1 = p.gram[base + (two ? p.I : 0)];
+            g[pr][j] = (f32x2){i < p.I ? v0 : 0.f, i < p.I ? v1 : 0.f};
+        }
+    auto load_batch = [&](float (&mv)[4][8], int bb0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int bc = bb0 + u < p.b ? bb0 + u : p.b - 1;
+            const float* mrow = p.mod + (long long)bc * p.mod_ld;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mv[u][j] = mrow[lane + 64 * j < p.I ? lane + 64 * j : p.I - 1];
+        }
+    };
+    float cur[4][8], nxt[4][8];
+    load_batch(cur, s_lo);
+    for (int bb0 = s_lo; bb0 < s_hi; bb0 += 4) {
+        load_batch(nxt, bb0 + 4 < s_hi ? bb0 + 4 : bb0);        // the next four rows fly while these are reduced
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int bc = bb0 + u < p.b ? bb0 + u : p.b - 1;
+            f32x2 cp[NP];
+            int pr = 0;
+#pragma unroll
+            for (int n = 0; n < N; ++n)
+#pragma unroll
+                for (int m = n; m < N; ++m, ++pr) {
+                    const float c = gg_readlane(av[n], bc) * gg_readlane(av[m], bc);
+                    cp[pr] = (f32x2){c, c};
+                }
+            f32x2 acc = {0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float sv = cur[u][j] + 1.f;
+                const float s2 = sv * sv;
+                f32x2 q = {0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < NP; ++k) q += cp[k] * g[k][j];
+                acc += (f32x2){s2, s2} * q;
+            }
+            const float t0 = gg_wave_sum_all(acc[0]), t1 = gg_wave_sum_all(acc[1]);
+            if (lane == 0 && bb0 + u < s_hi) {
+                p.d[(long long)(bb0 + u) * p.Op + o0] = gg_rsqrtf(t0 > p.eps ? t0 : p.eps);
+                if (two) p.d[(long long)(bb0 + u) * p.Op + o0 + 1] = gg_rsqrtf(t1 > p.eps ? t1 : p.eps);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cur[u][j] = nxt[u][j];
     }
 }
 
@@ -235,22 +437,30 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modw_kernel(GgModWParams p) {
     gg_modw_body<N>(p, blockIdx.x, blockIdx.y, wl, gram, a_s, d_s);
 }
 
-GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modw_multi_kernel(GgModWMulti m) {
+// ONE launch for all items (N <= 2 here: the host sends banks of more kernels to gg_modw_kernel, whose instantiations need > 256
+// registers): coefficient-only items with cached Gram rows run gg_modw_coef_body, the items that build per-sample weights
+// gg_modw_body with their scales staged in LDS. Both kinds run side by side in the one grid.
+GG_KERNEL GG_LAUNCH_BOUNDS2(256, 3) void gg_modw_multi_kernel(GgModWMulti m) {
     GG_SHARED __attribute__((aligned(16))) float wl[GG_MW_WMAX];
     GG_SHARED float gram[GG_MW_GMAX];
     GG_SHARED float a_s[GG_MW_BMAX][GG_MW_NMAX];
     GG_SHARED float d_s[GG_MW_BMAX];
+    float* const ssc = wl + (GG_MW_WMAX - GG_MW_SMAX);       // staged weight scales share the bank area (banks <= half of it)
     // (the table is read through the kernarg pointer: run-time indexing of the by-value struct would copy it to scratch)
     const GgModWMulti* mp = gg_late_params(m);
     int it = 0;
     while (it + 1 < mp->n && (int)blockIdx.x >= mp->first_block[it + 1]) ++it;
     const GgModWParams p = mp->item[it];
     const int rel = blockIdx.x - mp->first_block[it];
+    if (p.fast) {           // (item-uniform: every workgroup of the item takes this branch)
+        const int nwg = mp->first_block[it + 1] - mp->first_block[it];
+        if (p.N == 1) gg_modw_coef_body<1>(p, rel, nwg);
+        else gg_modw_coef_body<2>(p, rel, nwg);
+        return;
+    }
     const int o = rel % p.O, chunk = rel / p.O;
-    if (p.N == 1) gg_modw_body<1>(p, o, chunk, wl, gram, a_s, d_s);
-    else if (p.N == 2) gg_modw_body<2>(p, o, chunk, wl, gram, a_s, d_s);
-    else if (p.N == 3) gg_modw_body<3>(p, o, chunk, wl, gram, a_s, d_s);
-    else gg_modw_body<4>(p, o, chunk, wl, gram, a_s, d_s);
+    if (p.N == 1) gg_modw_body<1>(p, o, chunk, wl, gram, a_s, d_s, ssc);
+    else gg_modw_body<2>(p, o, chunk, wl, gram, a_s, d_s, ssc);
 }
 
 // ---- streaming direct convolution on per-sample weights ------------------------------------------------------------------
@@ -265,6 +475,8 @@ struct GgSconvParams {
     int b, H, W, O;
     int act;                // 0 none, 1 leaky relu
     float slope;
+    const float* xs;        // optional [b][C]: a per-sample scale of the INPUT channels (the skip-layer excitation, gp.py:1023-1024),
+                            // applied to the bank as it is parked in LDS - the convolution is linear in (x * xs) = weights * xs
     int rows_per_item;      // a wavefront's work item: a 32-pixel-wide strip of this many rows
     int items_per_wave;     // items a wavefront walks through (a workgroup of 4 wavefronts stays inside one image)
 };
@@ -384,7 +596,20 @@ GG_KERNEL GG_LAUNCH_BOUNDS2(256, (C <= 32 ? 3 : 2)) void gg_sconv_kernel(GgSconv
         for (int u = 0; u < PER; ++u) r[u] = src[tid + 256 * u < NV ? tid + 256 * u : NV - 1];
 #pragma unroll
         for (int u = 0; u < PER; ++u)
-            if (tid + 256 * u < NV) ((u16x8*)wl)[tid + 256 * u] = r[u];
+            if (tid + 256 * u < NV) {
+                u16x8 v = r[u];
+                if (p.xs) {         // vector index -> ((tap * KC + kc) * 32 + o) * 2 + half: input channels kc * 16 + half * 8 + 0..7
+                    const int vi = tid + 256 * u;
+                    const float* sp = p.xs + (long long)img * C + ((vi >> 6) % KC) * 16 + (vi & 1) * 8;
+                    const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = gg_f2bf(gg_bf2f(v[e]) * s0[e]);
+                        v[e + 4] = gg_f2bf(gg_bf2f(v[e + 4]) * s1[e]);
+                    }
+                }
+                ((u16x8*)wl)[tid + 256 * u] = v;
+            }
     }
     gg_sync();
     const int pl = lane & 31, hi = lane >> 5;

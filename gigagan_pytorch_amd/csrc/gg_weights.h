@@ -4,6 +4,10 @@
 //  gg_pack_weights_kernel: ONE launch re-packs every registered conv weight of a model into its bf16 GEMM operand(s)
 //      kind 0 ('fwd'): dst[o][t][i8]        = src[o][i][t]            (forward B operand, [co][kh][kw][ci])
 //      kind 1 ('bwd'): dst[i][T-1-t][o8]    = src[o][i][t]            (data-gradient B operand: flipped, in/out swapped)
+//      kind 2 ('gram'): src is a kernel bank (N, O, I, T); dst (fp32) [pair][o][i] = c * sum_t W_n[o][i][t] W_m[o][i][t] for the
+//                      pairs n <= m (c = 1 on the diagonal, 2 off it): the Gram rows from which the adaptive convolution's
+//                      demodulation d[b,o] = rsqrt(sum_i s_i^2 a^T G[o][i] a) is formed (gp.py:390-400) - they only change when the
+//                      optimizer steps, so they are refreshed here instead of in every forward (gg_modfwd.h reads them)
 //    channel counts zero-padded to multiples of 8. It replaces the per-weight permute / flip / pad / cast chain the
 //    reference gets from cuDNN's internal filter transforms (gp.py:402-409, :1608-1621 F.conv2d call sites) - ~1200
 //    tiny launches per step - by a table walk. The table and its header live in device memory, so a captured hipGraph
@@ -20,7 +24,7 @@ struct GgPackEntry {
     bf16_t* dst;            // kind 0: (O8, T, I8) ; kind 1: (I8, T, O8)
     long long first_item;   // prefix sum of work items over the table
     int O, I, T, O8, I8, kind;
-    int dst_row, dst_tap;   // kind 0: element pitch of a dst row / of a tap within it (0 = dense: T * I8, I8)
+    int dst_row, dst_tap;   // kind 0: element pitch of a dst row / of a tap within it (0 = dense: T * I8, I8); kind 2: dst_row = N
 };
 
 // Work items (one workgroup each; `first_item` is their prefix sum, computed by the host with the same formulas):
@@ -29,6 +33,7 @@ struct GgPackEntry {
 //            both stream contiguous fp32 runs in, transpose through LDS, and write contiguous bf16 rows out
 //   T  > 16: 256 (eight-channel unit, tap) pairs per item, one per thread (strided scalar gathers; 7x7 stems only)
 //            -> ceil(O8 * I8 / 8 * T / 256) items
+//   kind 2:  one output channel of the bank (all pairs, all input channels) -> O items
 #define GG_PK_TMAX 16
 #define GG_PK_P0 264      // kind 0 LDS pitch (bf16): 256 + 8
 #define GG_PK_P1 66       // kind 1 LDS pitch (bf16): 64 + 2 -> 33-word row shift, conflict-free transposed writes
@@ -66,6 +71,22 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_pack_weights_kernel(const GgPackEntry* t
         }
         const long long local = item - e.first_item;
         const int T = e.T;
+        if (e.kind == 2) {          // Gram rows of output channel o = local (threads run along the input channels)
+            const int N = e.dst_row, o = (int)local;
+            float* g = (float*)e.dst;
+            for (int i = tid; i < e.I; i += 256) {
+                int pair = 0;
+                for (int n = 0; n < N; ++n)
+                    for (int m = n; m < N; ++m, ++pair) {
+                        const float* wn = e.src + (((long long)n * e.O + o) * e.I + i) * T;
+                        const float* wm = e.src + (((long long)m * e.O + o) * e.I + i) * T;
+                        float acc = 0.f;
+                        for (int t = 0; t < T; ++t) acc += wn[t] * wm[t];
+                        g[((long long)pair * e.O + o) * e.I + i] = (n == m ? 1.f : 2.f) * acc;
+                    }
+            }
+            continue;
+        }
         const int tinv = 65536 / T + 1;
         const long long drow = e.dst_row ? e.dst_row : (long long)T * e.I8;    // kind 0 destination pitches
         const long long dtap = e.dst_tap ? e.dst_tap : e.I8;

@@ -603,7 +603,7 @@ def modw_fwd(w: torch.Tensor, mod: torch.Tensor, kmod, demod: bool, eps: float, 
 
 
 class ModwItem(C.Structure):         # mirrors gg_modw_item (include/gigagan_amd.h)
-    _fields_ = ([(f, C.c_void_p) for f in ('w', 'mod', 'kmod', 'xs', 's', 'a', 'd', 'insc', 'wmix')] +
+    _fields_ = ([(f, C.c_void_p) for f in ('w', 'mod', 'kmod', 'xs', 'gram', 's', 'a', 'd', 'insc', 'wmix')] +
                 [(f, C.c_int32) for f in ('mod_ld', 'kmod_ld', 'xs_ld', 'layout', 'b', 'N', 'O', 'I', 'T', 'Ip', 'Op', 'demod')] +
                 [('eps', C.c_float), ('reserved', C.c_int32)])
 
@@ -617,8 +617,8 @@ def modw_multi(layers):
     arr = (ModwItem * len(layers))()
     outs, keep = [], []
     for it, ly in zip(arr, layers):
-        w, mod, kmod, wmix = ly['w'], ly['mod'], ly.get('kmod'), ly.get('wmix')
-        L.require(w, mod, kmod, wmix)
+        w, mod, kmod, wmix, gram = ly['w'], ly['mod'], ly.get('kmod'), ly.get('wmix'), ly.get('gram')
+        L.require(w, mod, kmod, wmix, gram)
         N, O, I = w.shape[:3]
         T = w.shape[3] * w.shape[4]
         b = mod.shape[0]
@@ -633,30 +633,34 @@ def modw_multi(layers):
             o['insc'] = torch.empty((b, N * Ip), dtype=torch.float32, device=w.device)
         if wmix is not None:
             assert wmix.dtype == torch.bfloat16 and wmix.is_contiguous()
-        it.w, it.mod, it.kmod, it.xs = ptr(w), ptr(mod), ptr(kmod), None
+        if gram is not None:
+            assert gram.dtype == torch.float32 and gram.is_contiguous() and gram.shape == (N * (N + 1) // 2, O, I)
+        it.w, it.mod, it.kmod, it.xs, it.gram = ptr(w), ptr(mod), ptr(kmod), None, ptr(gram)
         it.s, it.a, it.d, it.insc, it.wmix = ptr(o['s']), ptr(o['a']), ptr(o['d']), ptr(o['insc']), ptr(wmix)
         it.mod_ld, it.kmod_ld, it.xs_ld = mod.stride(0), (0 if kmod is None else kmod.stride(0)), 0
         it.layout = int(ly.get('layout', 0))
         it.b, it.N, it.O, it.I, it.T, it.Ip, it.Op = b, N, O, I, T, Ip, Op
         it.demod, it.eps = int(bool(ly.get('demod', True))), float(ly.get('eps', 1e-8))
         outs.append(o)
-        keep.append((w, mod, kmod, wmix))
+        keep.append((w, mod, kmod, wmix, gram))
     rc = L.lib.gg_modw_multi_fwd(C.cast(arr, C.c_void_p), len(layers), L.stream(layers[0]['w']))
     L.check(rc, 'gg_modw_multi_fwd')
     return outs
 
 
-def sconv(x: torch.Tensor, wmix: torch.Tensor, O: int, noise=None, noise_w=None, act=None, slope: float = 0.2) -> torch.Tensor:
+def sconv(x: torch.Tensor, wmix: torch.Tensor, O: int, noise=None, noise_w=None, act=None, slope: float = 0.2, xs=None) -> torch.Tensor:
     """streaming 3x3 convolution with per-image filter banks (gg_sconv_fwd): x (b, H, W, C) bf16, wmix (b, 9, C/16, 32, 16) bf16
-    (or (1, ...) shared) -> (b, H, W, O) bf16 = act(conv + noise * noise_w)."""
+    (or (1, ...) shared) -> (b, H, W, O) bf16 = act(conv(x * xs) + noise * noise_w); xs (b, C) fp32 optional."""
     L = _C.lib()
-    L.require(x, wmix, noise, noise_w)
+    L.require(x, wmix, noise, noise_w, xs)
+    if xs is not None:
+        assert xs.dtype == torch.float32 and xs.is_contiguous() and xs.shape == (x.shape[0], x.shape[3])
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and wmix.dtype == torch.bfloat16 and wmix.is_contiguous()
     b, H, W, Cc = x.shape
     assert wmix.shape[1:] == (9, Cc // 16, 32, 16) and wmix.shape[0] in (1, b)
     y = torch.empty((b, H, W, O), dtype=torch.bfloat16, device=x.device)
     w_bs = wmix.stride(0) if wmix.shape[0] > 1 else 0
-    rc = L.lib.gg_sconv_fwd(ptr(x), ptr(wmix), w_bs, ptr(y), ptr(noise), ptr(noise_w), b, H, W, Cc, O,
+    rc = L.lib.gg_sconv_fwd(ptr(x), ptr(wmix), w_bs, ptr(y), ptr(noise), ptr(noise_w), ptr(xs), b, H, W, Cc, O,
                             1 if act == 'lrelu' else 0, float(slope), L.stream(x))
     L.check(rc, 'gg_sconv_fwd')
     return y
@@ -904,6 +908,30 @@ def pool_mean_bwd(gs: torch.Tensor, shape, g=None, inplace: bool = False) -> tor
     return y
 
 
+def poolhf_fwd(x: torch.Tensor):
+    """x (b, H, W, C) bf16 NHWC -> (max_pool2d(x, 2) (b, H/2, W/2, C), x - blur(x) (b, H, W, C)) in one pass (gg_poolhf_fwd)."""
+    L = _C.lib()
+    L.require(x)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    b, H, W, Cc = x.shape
+    pool = torch.empty((b, H // 2, W // 2, Cc), dtype=torch.bfloat16, device=x.device)
+    hf = torch.empty_like(x)
+    L.check(L.lib.gg_poolhf_fwd(ptr(x), ptr(pool), ptr(hf), b, H, W, Cc, L.stream(x)), 'gg_poolhf_fwd')
+    return pool, hf
+
+
+def poolhf_bwd(x: torch.Tensor, g_pool, g_hf) -> torch.Tensor:
+    """gradient of poolhf_fwd w.r.t. x from the gradients of its two outputs (either may be None)."""
+    L = _C.lib()
+    L.require(x, g_pool, g_hf)
+    b, H, W, Cc = x.shape
+    for g in (g_pool, g_hf):
+        assert g is None or (g.dtype == torch.bfloat16 and g.is_contiguous())
+    dx = torch.empty_like(x)
+    L.check(L.lib.gg_poolhf_bwd(ptr(x), ptr(g_pool), ptr(g_hf), ptr(dx), b, H, W, Cc, L.stream(x)), 'gg_poolhf_bwd')
+    return dx
+
+
 def rmsnorm_fwd(x: torch.Tensor, gamma: torch.Tensor, silu: bool = False) -> torch.Tensor:
     """x (..., C) bf16 contiguous, gamma (C,) fp32 -> y bf16; `silu`: y = silu(norm(x)) in the same pass."""
     L = _C.lib()
@@ -996,6 +1024,23 @@ class PackTable:
         dst = torch.zeros((o8, T * N * i8), dtype=torch.bfloat16, device=self.device)
         for n in range(N):
             self.register(src[n], O, I, T, 'fwd', into=(dst, n * i8, T * N * i8, N * i8))
+        return dst
+
+    def register_gram(self, src: torch.Tensor, N: int, O: int, I: int, T: int) -> torch.Tensor:
+        """src: fp32 contiguous (N, O, I, T) kernel bank -> persistent fp32 (N(N+1)/2, O, I) Gram rows sum_t W_n W_m (off-diagonal
+        pairs doubled): what the adaptive conv's demodulation needs of the bank (gg_modfwd.h). One table entry (kind 2), one work
+        item per output channel."""
+        assert src.dtype == torch.float32 and src.is_contiguous() and src.numel() == N * O * I * T
+        assert self.n < self.capacity, 'PackTable capacity exceeded'
+        dst = torch.zeros((N * (N + 1) // 2, O, I), dtype=torch.float32, device=self.device)
+        e = PackEntry(src.data_ptr(), dst.data_ptr(), self.items, O, I, T, O, I, 2, N, 0)
+        words = torch.frombuffer(bytearray(bytes(e)), dtype=torch.int64)
+        w = words.numel()
+        self.table[self.n * w:(self.n + 1) * w].copy_(words)
+        self.n += 1
+        self.items += O
+        self.header.copy_(torch.tensor([self.n, self.items], dtype=torch.int64))
+        self.keep.append((src, dst))
         return dst
 
     def register(self, src: torch.Tensor, O: int, I: int, T: int, kind: str, into=None) -> torch.Tensor:

@@ -134,11 +134,12 @@ def _table_pack(w, kind: str):
         if w.device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
             return None                     # table appends are host->device copies: not while a graph is being captured
         shp = tuple(w.shape)
-        if kind == 'modk':                  # (N, O, I, k, k) bank -> [co][tap][n][ci] (fused no-grad adaptive conv)
+        if kind in ('modk', 'gram'):        # (N, O, I, k, k) bank -> [co][tap][n][ci] (fused no-grad adaptive conv) / its Gram rows
             src = w.detach()
             if len(shp) != 5 or not src.is_contiguous():
                 return None
-            dst = tab.register_bank(src, shp[0], shp[1], shp[2], shp[3] * shp[4])
+            reg = tab.register_bank if kind == 'modk' else tab.register_gram
+            dst = reg(src, shp[0], shp[1], shp[2], shp[3] * shp[4])
             if slot is None:
                 slot = w.__dict__.setdefault('_gg_tpacks', {})
             ent = slot[kind] = (dst, w.data_ptr(), w._version)
@@ -1047,6 +1048,28 @@ class RowsForkFn(Function):
         return g_all, None
 
 
+class PoolHighFreqFn(Function):
+    """(max_pool2d(x, 2), x - blur(x)) of an NHWC bf16 tensor in one HIP pass; backward in one pass too (the pooled gradient
+    goes to each window's first maximum, the high-frequency gradient through the exact adjoint of the reflect-padded blur).
+    First order (the unet is the generator: never under the gradient penalty)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        ctx.set_materialize_grads(False)
+        return K.poolhf_fwd(x)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_pool, g_hf):
+        x, = ctx.saved_tensors
+        if g_pool is None and g_hf is None:
+            return None
+        gp = None if g_pool is None else g_pool.to(ACT_DTYPE).contiguous()
+        gh = None if g_hf is None else g_hf.to(ACT_DTYPE).contiguous()
+        return K.poolhf_bwd(x, gp, gh)
+
+
 class ResampleFn(Function):
     """Separable banded linear resampling of an NHWC tensor (bilinear x2 + binomial blur, bilinear resize,
     and their adjoints), closed under differentiation: backward = the same kernel with the transposed
@@ -1222,8 +1245,12 @@ class HipOps:
         all of a forward's modulations are column slices of one style projection (gp.py:1160-1175), so softmax(kernel_mod), the
         demodulation coefficients and - where the layer runs on per-sample weights - the weights themselves are computed before the
         first convolution instead of by one launch in front of each (15 on config 2: ~330 us of a 1.1 ms forward). `specs`: tuples
-        (weights, mod, kernel_mod, H, W, excited, demod, eps); layers behind a skip-layer excitation are left to their own launch.
-        The results wait in a registry keyed by the weight tensor until that layer's modconv2d call picks them up."""
+        (weights, mod, kernel_mod, H, W, excited, demod, eps). A layer behind a skip-layer excitation (gp.py:1023-1024: its input is
+        scaled per sample and channel by a value that only exists once earlier layers have run) gets its per-sample weights WITHOUT
+        that scale here; its convolution applies the scale to the weights as they are staged (gg_sconv_fwd `xs`, gg_conv3 SCALED) -
+        conv(x * e, w) = conv(x, w * e). The bank's Gram rows come from the pack table (refreshed once per optimizer step), so a
+        coefficient-only layer never reads its bank here. The results wait in a registry keyed by the weight tensor until that
+        layer's modconv2d call picks them up."""
         _prepared.clear()
         if torch.is_grad_enabled() and any(t is not None and t.requires_grad for sp in specs for t in sp[:3]):
             return 0
@@ -1231,23 +1258,28 @@ class HipOps:
         for weights, mod, kmod, H, W, excited, demod, eps in specs:
             N, O, I, k, _ = weights.shape
             b = mod.shape[0]
-            if (k != 3 or not demod or excited or weights.dtype != torch.float32 or not weights.is_contiguous() or I % 8 or O % 8
+            if (k != 3 or not demod or weights.dtype != torch.float32 or not weights.is_contiguous() or I % 8 or O % 8
                     or not K.modw_eligible(b, N, I, k * k) or weights.device.type != mod.device.type):
                 continue
             path = self._modconv_path(b, N, O, I, H, W)
+            if excited and (path == 'bank' or (path == 'pimg' and I % 64)):
+                continue            # (no consumer-side scale on these paths: the layer keeps its own launch)
             ly = dict(w=weights.detach(), mod=_rows_f32(mod), kmod=_rows_f32(kmod) if N > 1 else None, demod=demod, eps=eps,
                       Ip=I, Op=O)
+            if (isinstance(weights, torch.nn.Parameter) and getattr(weights, '_gg_pack_table', None) is not None
+                    and not _DEBUG_NO_TABLE):
+                ly['gram'] = _table_pack(weights, 'gram')
             if path == 'sconv':
                 ly.update(coef=False, wmix=_wmix_buffer(weights, b, I), layout=2)
             elif path == 'pimg':
                 ly.update(coef=False, wmix=_wmix_rows(weights, b, O, 9 * I), layout=1)
             layers.append(ly)
-            metas.append((weights, mod, path, b))
+            metas.append((weights, mod, path, b, excited))
         if not layers:
             return 0
         outs = K.modw_multi(layers)
-        for (weights, mod, path, b), o in zip(metas, outs):
-            _prepared[id(weights)] = dict(o, mod_ptr=mod.data_ptr(), path=path, b=b)
+        for (weights, mod, path, b, excited), o in zip(metas, outs):
+            _prepared[id(weights)] = dict(o, mod_ptr=mod.data_ptr(), path=path, b=b, excited=excited)
         return len(layers)
 
     def modconv_release(self):
@@ -1270,9 +1302,12 @@ class HipOps:
             # otherwise (and for layers behind a skip-layer excitation, whose scale is not known up front) from a launch here.
             path = self._modconv_path(b, N, O, I, H, W)
             rec = _prepared.pop(id(weights), None)
-            if rec is not None and (in_excite is not None or rec['mod_ptr'] != mod.data_ptr() or rec['path'] != path
-                                    or rec['b'] != b):
+            if rec is not None and (rec['excited'] != (in_excite is not None) or rec['mod_ptr'] != mod.data_ptr()
+                                    or rec['path'] != path or rec['b'] != b):
                 rec = None
+            xs_late = None          # prepared weights of an excited layer carry no excitation: the convolution applies it
+            if rec is not None and in_excite is not None:
+                xs_late = in_excite.reshape(b, I).detach().float().contiguous()
             nz = nw = None
             if noise is not None:
                 nz = noise.reshape(-1).float().contiguous()
@@ -1287,7 +1322,7 @@ class HipOps:
                 wm = _wmix_buffer(weights, b, I)
                 if rec is None:
                     K.modw_fwd(wd, md, km, demod, eps, Ip, Op, coef=False, wmix=wm, layout=2, xs=xs)
-                return nchw(K.sconv(nhwc(x), wm, O, nz, nw, act, LRELU_SLOPE))
+                return nchw(K.sconv(nhwc(x), wm, O, nz, nw, act, LRELU_SLOPE, xs=xs_late))
             if path == 'pimg':
                 # mid resolutions: the per-sample weights are still small next to the activation (<= 32 MiB of bf16), so the
                 # reference's formulation (one kernel per sample, algorithmic flops) beats the shared bank's doubled reduction:
@@ -1295,7 +1330,7 @@ class HipOps:
                 wm = _wmix_rows(weights, b, O, 9 * I)
                 if rec is None:
                     K.modw_fwd(wd, md, km, demod, eps, Ip, Op, coef=False, wmix=wm, layout=1, xs=xs)
-                y = K.conv2d_nhwc(nhwc(x), wm, ksize=3, noise=nz, noise_w=nw, act=act, act_slope=LRELU_SLOPE,
+                y = K.conv2d_nhwc(nhwc(x), wm, ksize=3, in_scale=xs_late, noise=nz, noise_w=nw, act=act, act_slope=LRELU_SLOPE,
                                   per_image_weights=True)
                 return nchw(y)
             # wide low-resolution layers (weights >> activations): shared bank, the N kernels stacked along the reduction
@@ -1479,8 +1514,12 @@ class HipOps:
         """(max_pool2d(x, 2), x - blur(x)): the unet Downsample's pooled map and the high-frequency map that rides the
         skip connection (unet.py:134-160)."""
         x = to_act(x)
-        hf = (x.float() - self.blur(x).float()).to(ACT_DTYPE)
-        return F.max_pool2d(x, kernel_size=2), hf
+        b, C, H, W = x.shape
+        if C % 8 or H % 2 or W % 2 or second_order:       # ragged shapes / twice-differentiated graphs: the tensor-algebra form
+            hf = (x.float() - self.blur(x).float()).to(ACT_DTYPE)
+            return F.max_pool2d(x, kernel_size=2), hf
+        pool, hf = PoolHighFreqFn.apply(nhwc(x))
+        return nchw(pool), nchw(hf)
 
     def linear_attention_qkv(self, qkv, *, heads, scale):
         """the same on the fused to_qkv output (b, 3C, x, y) (channels: q | k | v): returns (b, C, x, y), or None when the

@@ -300,6 +300,14 @@ int gg_attn_bwd2(const void* q, const void* k, const void* v, const void* k0, co
                  float* mu, float* gi, void* gq, void* gk, void* gv, void* gdo, float* null_part, int32_t B, int32_t n,
                  int32_t h, float alpha, float beta, void* stream);
 
+/* ---- unet Downsample tail (reference unet_upsampler.py:134-160): pool = max_pool2d(x, 2), hf = x - blur(x) with kornia's
+ * normalised [1,2,1]^2/16 filter and 'reflect' border, NHWC bf16, in ONE pass; gg_poolhf_bwd: dx = scatter(g_pool to each window's
+ * first maximum, torch's tie rule) + g_hf - blur^T(g_hf) (exact adjoint of the reflect-padded stencil); either incoming gradient may
+ * be null. Even H, W; C %% 8 == 0. */
+int gg_poolhf_fwd(const void* x, void* pool, void* hf, int32_t b, int32_t H, int32_t W, int32_t C, void* stream);
+int gg_poolhf_bwd(const void* x, const void* g_pool, const void* g_hf, void* dx, int32_t b, int32_t H, int32_t W, int32_t C,
+                  void* stream);
+
 /* ---- no-grad forward of the adaptive convolution (gp.py:344-409; what the discriminator step's generator pass and generate()
  * run), csrc/gg_modfwd.h ----
  * gg_modw_fwd: ONE launch per layer: s = mod + 1 (b, Ip), a = softmax(kernel_mod) (b, N), d (b, Op) = demodulation coefficients
@@ -311,8 +319,9 @@ int gg_attn_bwd2(const void* q, const void* k, const void* v, const void* k0, co
  *   mod (b, I) / kmod (b, N) are fp32 rows `mod_ld` / `kmod_ld` floats apart (column slices of the style network's output).
  *   b <= 64, N <= 4, N*I*T <= 9216, I %% 4 == 0.
  * gg_sconv_fwd: 3x3 / stride 1 / pad 1 convolution of an NHWC bf16 activation with per-image banks (w_bs = elements between
- *   banks, 0 = shared) as a streaming direct convolution: y = act(conv + noise[b][pixel] * noise_w[o]). W %% 32 == 0,
- *   C in {16, 32, 64}, O <= 32, O %% 8 == 0.
+ *   banks, 0 = shared) as a streaming direct convolution: y = act(conv(x * xs) + noise[b][pixel] * noise_w[o]); xs (optional,
+ *   [b][C] fp32): a per-sample input-channel scale (the skip-layer excitation), applied to the bank as it is parked in LDS.
+ *   W %% 32 == 0, C in {16, 32, 64}, O <= 32, O %% 8 == 0.
  * gg_modulate_bank_fwd: out[b][p][n*Cin + i] = x[b][p][i] * s[b][i] * a[b][n] for the N = Cout / Cin kernels of a bank in one pass
  *   (s is [b][Cin], a is [b][N]). */
 int gg_modw_fwd(const float* w, const float* mod, int32_t mod_ld, const float* kmod, int32_t kmod_ld, const float* xs, int32_t xs_ld,
@@ -326,6 +335,7 @@ int gg_modw_fwd(const float* w, const float* mod, int32_t mod_ld, const float* k
  * in_scale, CV = N*C). Same limits per item as gg_modw_fwd. */
 typedef struct gg_modw_item {
     const float* w; const float* mod; const float* kmod; const float* xs;
+    const float* gram;      /* optional [pair][O][I] fp32: the bank's Gram rows as refreshed by gg_pack_weights (kind 2) */
     float* s; float* a; float* d; float* insc; void* wmix;
     int32_t mod_ld, kmod_ld, xs_ld, layout;
     int32_t b, N, O, I, T, Ip, Op, demod;
@@ -333,8 +343,8 @@ typedef struct gg_modw_item {
     int32_t reserved;
 } gg_modw_item;
 int gg_modw_multi_fwd(const gg_modw_item* items, int32_t n_items, void* stream);
-int gg_sconv_fwd(const void* x, const void* w, int64_t w_bs, void* y, const float* noise, const float* noise_w, int32_t b,
-                 int32_t H, int32_t W, int32_t C, int32_t O, int32_t act, float slope, void* stream);
+int gg_sconv_fwd(const void* x, const void* w, int64_t w_bs, void* y, const float* noise, const float* noise_w, const float* xs,
+                 int32_t b, int32_t H, int32_t W, int32_t C, int32_t O, int32_t act, float slope, void* stream);
 int gg_modulate_bank_fwd(const void* x, const float* s, const float* a, void* out, int32_t b, int32_t P, int32_t Cin, int32_t Cout,
                          void* stream);
 

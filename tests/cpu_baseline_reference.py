@@ -9,7 +9,7 @@ port / reference is what bench.py uses to print `cpu_baseline.reference_equivale
 
 Runs only where /root/reference exists (the build container); writes profiles/r03_cpu_baseline_reference.json.
 
-    python tests/cpu_baseline_reference.py [threads]
+    python tests/cpu_baseline_reference.py [threads] [first_core]      # pins itself to `threads` cores from `first_core` on
 """
 import json
 import os
@@ -58,8 +58,11 @@ def timed_cycles(gan):
 
 def main():
     threads = int(sys.argv[1]) if len(sys.argv) > 1 else (os.cpu_count() or 1)
+    if len(sys.argv) > 2:       # keep the measurement on its own cores (the build container is shared with compiles / tests)
+        first = int(sys.argv[2])
+        os.sched_setaffinity(0, set(range(first, first + threads)))
     torch.set_num_threads(threads)
-    rec = dict(host_cores=os.cpu_count(), threads=threads, batch=BATCH, image_size=SIZE, dtype='fp32',
+    rec = dict(host_cores=os.cpu_count(), threads=threads, pinned=len(sys.argv) > 2, batch=BATCH, image_size=SIZE, dtype='fp32',
                protocol='GigaGAN(...)(steps=4) twice: warm-up cycle, then one timed 4-step cycle (3 plain + 1 GP)')
     big = dict(save_and_sample_every=10 ** 9, early_save_and_sample_every=10 ** 9, log_steps_every=10 ** 9)
     with tempfile.TemporaryDirectory() as tmp:

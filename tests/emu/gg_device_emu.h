@@ -89,6 +89,13 @@ static inline float gg_shfl_xor(float v, int mask) {
     return gg_emu_shfl(v, lane ^ mask);
 }
 static inline float gg_shfl(float v, int src) { return gg_emu_shfl(v, src & 63); }
+static inline float gg_readlane(float v, int src) { return gg_emu_shfl(v, src & 63); }
+static inline float gg_wave_sum_all(float v) {     // wave collective; the device version's association: quads, 8, 16, rows
+    v += gg_shfl_xor(v, 1); v += gg_shfl_xor(v, 2);
+    { int lane = (int)(threadIdx.x & 63u); v += gg_emu_shfl(v, (lane & ~7) | (7 - (lane & 7))); }
+    { int lane = (int)(threadIdx.x & 63u); v += gg_emu_shfl(v, (lane & ~15) | (15 - (lane & 15))); }
+    return (gg_emu_shfl(v, 0) + gg_emu_shfl(v, 16)) + (gg_emu_shfl(v, 32) + gg_emu_shfl(v, 48));
+}
 static inline void gg_atomic_add(float* p, float v) { *p += v; }
 
 static inline float gg_expf(float x) { return expf(x); }

@@ -256,3 +256,33 @@ def check_gelu_first_and_second_order(device):
         assert got[0].dtype == torch.bfloat16 and got[0].shape == x0.shape
         for a, b, tol in zip(got, want, (4e-3, 8e-3, 2e-2)):
             assert rel_err(a, b) < tol, (shape, rel_err(a, b))
+
+
+def check_maxpool_highfreq(shape, device):
+    """ops.HipOps.maxpool_highfreq (one HIP pass forward, one backward) against F.max_pool2d and x - blur(x) with the reflect-padded
+    normalised [1,2,1]^2 filter (the oracle's restatement of kornia.filter2d) in fp32 under autograd."""
+    import torch.nn.functional as F
+    from gigagan_pytorch_amd import ops
+    b, H, W, C = shape
+    torch.manual_seed(0)
+    x0 = torch.randn(b, C, H, W).to(torch.bfloat16)
+    c1, c2 = torch.randn(b, C, H // 2, W // 2), torch.randn(b, C, H, W)
+    f = torch.tensor([1., 2., 1.])
+    k = (f[:, None] * f[None, :] / 16.)[None, None].repeat(C, 1, 1, 1)
+
+    def ref(x):
+        xf = x.float()
+        blur = F.conv2d(F.pad(xf, (1, 1, 1, 1), mode='reflect'), k, groups=C)
+        return F.max_pool2d(xf, 2), xf - blur
+    xr = x0.clone().requires_grad_()
+    p0, h0 = ref(xr)
+    g0, = torch.autograd.grad((p0 * c1).sum() + (h0 * c2).sum(), xr)
+    xd = x0.to(device).contiguous(memory_format=torch.channels_last).requires_grad_()
+    p1, h1 = ops.HipOps().maxpool_highfreq(xd)
+    g1, = torch.autograd.grad((p1.float() * c1.to(device)).sum() + (h1.float() * c2.to(device)).sum(), xd)
+    assert p1.dtype == torch.bfloat16 and torch.equal(p1.float().cpu(), p0.detach())          # a max of bf16 values is exact
+    assert rel_err(h1.cpu(), h0.detach()) < 6e-3 and rel_err(g1.cpu(), g0) < 8e-3, (rel_err(h1.cpu(), h0.detach()), rel_err(g1.cpu(), g0))
+    # gradients of one output only
+    ga, = torch.autograd.grad((ops.HipOps().maxpool_highfreq(xd)[0].float() * c1.to(device)).sum(), xd)
+    gb, = torch.autograd.grad((ref(xr)[0] * c1).sum(), xr)
+    assert rel_err(ga.cpu(), gb) < 8e-3

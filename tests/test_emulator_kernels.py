@@ -818,6 +818,18 @@ def test_multi_layer_modulation_launch_equals_the_per_layer_launches():
         else:
             assert torch.equal(o['s'], w_['s']) and torch.equal(o['a'], w_['a']) and torch.equal(o['d'], w_['d'])
             assert torch.allclose(o['insc'], w_['insc'], rtol=1e-6, atol=1e-7)
+    # cached Gram rows (pack table kind 2): coefficient-only layers then run a wave per channel without touching the bank
+    for ly in layers:
+        wf = ly['w'].flatten(3)
+        N = wf.shape[0]
+        ly['gram'] = torch.stack([(1. if n == m else 2.) * (wf[n] * wf[m]).sum(-1) for n in range(N) for m in range(n, N)]).contiguous()
+    outs_g = K.modw_multi(layers)
+    for ly, o, w_ in zip(layers, outs_g, want):
+        if 'wmix' in w_:
+            assert rel_err(ly['wmix'], w_['wmix']) < 1e-6
+        else:
+            assert torch.equal(o['s'], w_['s']) and torch.allclose(o['a'], w_['a'], rtol=1e-6, atol=1e-7)
+            assert torch.allclose(o['d'], w_['d'], rtol=2e-6, atol=1e-7) and torch.allclose(o['insc'], w_['insc'], rtol=1e-6, atol=1e-7)
     # more layers than one launch holds (16): split transparently
     many = [dict(w=layers[0]['w'], mod=layers[0]['mod'], kmod=layers[0]['kmod'], demod=True, eps=1e-8, Ip=32, Op=24) for _ in range(19)]
     outs = K.modw_multi(many)
@@ -825,9 +837,11 @@ def test_multi_layer_modulation_launch_equals_the_per_layer_launches():
 
 
 def test_generator_announces_its_adaptive_convs_and_every_layer_uses_the_batched_modulation():
-    """no-grad Generator.forward on the kernels: ONE gg_modw_multi_fwd launch at the top (all 3x3 demodulated layers that are not
-    behind a skip-layer excitation), no per-layer gg_modw_fwd for them, the registry is empty afterwards, and the images equal
-    the per-layer-launch path (prepare disabled) bit for bit and the oracle within bf16 tolerance."""
+    """no-grad Generator.forward on the kernels: ONE gg_modw_multi_fwd launch at the top for the 3x3 demodulated layers (layers
+    behind a skip-layer excitation included where their convolution can apply the excitation to the staged weights), per-layer
+    gg_modw_fwd only for the rest, Gram rows from the pack table when the parameters are optimizer-owned, the registry is empty
+    afterwards; images equal the per-layer-launch path (prepare disabled; bf16 rounding of the excited layers' weights differs)
+    and the oracle within bf16 tolerance."""
     from gigagan_pytorch_amd.generator import Generator
     from helpers import SMALL_G
     torch.manual_seed(0)
@@ -845,7 +859,7 @@ def test_generator_announces_its_adaptive_convs_and_every_layer_uses_the_batched
             n_single = [c for c in calls if c[0] == 'single']
             assert len(n_multi) == 1 and not ops._prepared, (calls, list(ops._prepared))
             excited = max(G.num_layers - G.num_skip_layers_excite, 0) if G.num_skip_layers_excite else 0
-            assert n_multi[0][1] == 1 + 2 * G.num_layers - excited and len(n_single) == excited, (calls, excited)
+            assert n_multi[0][1] + len(n_single) == 1 + 2 * G.num_layers and len(n_single) <= excited, (calls, excited)
             calls.clear()
             prep, ops.HipOps.modconv_prepare = ops.HipOps.modconv_prepare, lambda self, specs: 0
             try:
@@ -853,11 +867,24 @@ def test_generator_announces_its_adaptive_convs_and_every_layer_uses_the_batched
                 img0 = G(noise=z)
             finally:
                 ops.HipOps.modconv_prepare = prep
-            assert not [c for c in calls if c[0] == 'multi'] and torch.equal(img, img0)
+            assert not [c for c in calls if c[0] == 'multi'] and rel_err(img, img0) < 5e-3
             with ops.use_impl(OracleOps(bf16_operands=True)):
                 torch.manual_seed(1)
                 ref = G(noise=z)
-        assert rel_err(img, ref) < 2e-2
+            assert rel_err(img, ref) < 2e-2
+            # optimizer-owned parameters: the Gram rows come from the pack table and follow an optimizer step
+            from gigagan_pytorch_amd.optimizer import FlatAdamW
+            opt = FlatAdamW(list(G.parameters()), lr=1e-2)
+            torch.manual_seed(1)
+            img1 = G(noise=z)
+            assert '_gg_tpacks' in G.init_conv.weights.__dict__ and 'gram' in G.init_conv.weights._gg_tpacks
+            assert rel_err(img1, img) < 2e-2        # (the style network and the packed operands take their table paths too now)
+            with torch.no_grad():
+                opt.flat_g.normal_()
+            opt.step()
+            wts = G.init_conv.weights.detach().flatten(3)
+            want = torch.stack([(wts[0] * wts[0]).sum(-1), 2 * (wts[0] * wts[1]).sum(-1), (wts[1] * wts[1]).sum(-1)])
+            assert torch.allclose(G.init_conv.weights._gg_tpacks['gram'][0], want, rtol=1e-5, atol=1e-6)
     finally:
         K.modw_multi, K.modw_fwd = real_multi, real_single
 
@@ -1102,3 +1129,9 @@ def test_rmsnorm_with_fused_silu_matches_oracle():
     ya, ga = run(H_); yb, gb = run(O_)
     assert rel_err(ya, yb) < 6e-3
     assert rel_err(ga[0], gb[0]) < 2e-2 and rel_err(ga[1], gb[1]) < 2e-2
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 8, 16), (1, 6, 4, 8), (2, 2, 2, 24)])
+def test_maxpool_highfreq_kernels_vs_torch(shape):
+    from helpers import check_maxpool_highfreq
+    check_maxpool_highfreq(shape, 'cpu')

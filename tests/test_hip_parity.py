@@ -414,14 +414,98 @@ def test_halo_staged_conv3_vs_implicit_gemm_and_cpu(cfg):
     bias = torch.randn(co); res = bf(torch.randn(n, H, W, co))
     xd, wd, bd, rd = x.to(dev()), w.to(dev()), bias.to(dev()), res.to(dev())
     K.plan_log = []
-    got = K.conv2d_nhwc(xd, wd, ksize=3, out_dtype=torch.float32, force_tile=tile)
+    got = K.conv2d_nhwc(xd, wd, ksize=3, out_dtype=torch.float32, force_tile=tile, force_splitk=1)
     assert K.plan_log == [(tile, 1)]
     K.plan_log = None
     exact = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().view(co, 3, 3, ci).permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
     assert rel_err(got.cpu(), exact) < F32_TOL
     assert rel_err(got, K.conv2d_nhwc(xd, wd, ksize=3, out_dtype=torch.float32, force_tile=1)) < F32_TOL
     kw = dict(ksize=3, bias=bd, act='lrelu', alpha=0.5, bias_scale=0.5, residual=rd)
-    assert rel_err(K.conv2d_nhwc(xd, wd, force_tile=tile, **kw), K.conv2d_nhwc(xd, wd, force_tile=1, **kw)) < BF16_TOL
+    assert rel_err(K.conv2d_nhwc(xd, wd, force_tile=tile, force_splitk=1, **kw), K.conv2d_nhwc(xd, wd, force_tile=1, **kw)) < BF16_TOL
+    # split over the channel chunks (automatic and forced): fp32 partials + finish == unsplit
+    for sk in (0, 2, 4):
+        K.plan_log = []
+        got = K.conv2d_nhwc(xd, wd, ksize=3, out_dtype=torch.float32, force_tile=tile, force_splitk=sk)
+        assert K.plan_log[-1][0] == tile and (sk == 0 or K.plan_log[-1][1] == min(sk, ci // 64)), K.plan_log
+        K.plan_log = None
+        assert rel_err(got.cpu(), exact) < F32_TOL
+    assert rel_err(K.conv2d_nhwc(xd, wd, force_tile=tile, force_splitk=2, **kw), K.conv2d_nhwc(xd, wd, force_tile=1, **kw)) < BF16_TOL
+
+
+@pytest.mark.parametrize('cfg', [(32, 8, 8, 512, 2, 512, 8, 8), (32, 16, 16, 256, 2, 256, 8, 4), (5, 8, 8, 64, 3, 264, 7, 0),
+                                 (4, 32, 32, 128, 2, 128, 8, 1)])
+def test_halo_staged_conv3_with_bank_modulation_on_the_operand_staging(cfg):
+    """the generator's shared-bank adaptive conv as ONE contraction at config-2 layer shapes (batch 32): N kernels stacked along
+    the reduction, a[b,n] * s[b,i] applied when the halo chunk is parked in LDS (gg_conv3 SCALED), split over the channel chunks,
+    against the convolution of the explicitly modulated N-fold activation on the implicit GEMM."""
+    n, H, W, ci, N, co, tile, sk = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(n, H, W, ci)).to(dev()); w = bf(torch.randn(co, 9 * N * ci) * 0.05).to(dev())
+    insc = (torch.rand(n, N * ci) + 0.5).to(dev())
+    x2 = bf(torch.cat([x.float() * insc[:, None, None, j * ci:(j + 1) * ci] for j in range(N)], dim=-1))
+    want = K.conv2d_nhwc(x2, w, ksize=3, out_dtype=torch.float32, force_tile=1)
+    K.plan_log = []
+    got = K.conv2d_nhwc(x, w, ksize=3, cv=N * ci, in_scale=insc, out_dtype=torch.float32, force_tile=tile, force_splitk=sk)
+    assert K.plan_log[-1][0] == tile, K.plan_log
+    K.plan_log = None
+    assert rel_err(got, want) < F32_TOL
+    d = (torch.rand(n, co) + 0.5).to(dev()); nz = torch.randn(n * H * W).to(dev()); nw = torch.randn(co).to(dev())
+    epi = dict(out_scale=d, noise=nz, noise_w=nw, act='lrelu')
+    assert rel_err(K.conv2d_nhwc(x, w, ksize=3, cv=N * ci, in_scale=insc, **epi), K.conv2d_nhwc(x2, w, ksize=3, force_tile=1, **epi)) < BF16_TOL
+
+
+@pytest.mark.parametrize('cfg', [(32, 32, 32, 256, 128, 8, 1), (32, 32, 32, 128, 128, 8, 2), (8, 64, 64, 128, 64, 8, 0), (3, 16, 32, 64, 264, 7, 0)])
+def test_halo_staged_conv3_with_per_image_weights_on_gpu(cfg):
+    """per-sample weights (gp.py:390-409) through gg_conv3 at config-2's 32x32 / 64x64 layer shapes vs one F.conv2d per image."""
+    n, H, W, ci, co, tile, sk = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(n, H, W, ci)); w = bf(torch.randn(n, co, 9 * ci) * 0.05)
+    want = torch.stack([F.conv2d(x[i:i + 1].float().permute(0, 3, 1, 2), w[i].float().view(co, 3, 3, ci).permute(0, 3, 1, 2),
+                                 padding=1)[0].permute(1, 2, 0) for i in range(n)])
+    K.plan_log = []
+    got = K.conv2d_nhwc(x.to(dev()), w.to(dev()), ksize=3, per_image_weights=True, out_dtype=torch.float32, force_tile=tile,
+                        force_splitk=sk)
+    assert K.plan_log[-1][0] == tile, K.plan_log
+    K.plan_log = None
+    assert rel_err(got.cpu(), want) < F32_TOL
+
+
+def test_multi_layer_modulation_launch_on_gpu():
+    """gg_modw_multi_fwd at config-2's generator shapes (batch 32): equals one gg_modw_fwd per layer bit for bit."""
+    torch.manual_seed(0)
+    b = 32
+    shapes = [(512, 512, 'coef'), (512, 256, 'coef'), (256, 128, 'rows'), (64, 64, 'rows'), (32, 32, 'bank'), (16, 16, 'bank')]
+    layers, want = [], []
+    for I, O, kind in shapes:
+        w = (torch.randn(2, O, I, 3, 3) * 0.1).to(dev())
+        mod, kmod = (torch.randn(b, I) * 0.5).to(dev()), torch.randn(b, 2).to(dev())
+        ly = dict(w=w, mod=mod, kmod=kmod, demod=True, eps=1e-8, Ip=I, Op=O)
+        if kind == 'coef':
+            want.append(K.modw_fwd(w, mod, kmod, True, 1e-8, I, O))
+        else:
+            shape = (b, O, 9 * I) if kind == 'rows' else (b, 9, I // 16, 32, 16)
+            wm = torch.zeros(shape, dtype=torch.bfloat16, device=dev())
+            K.modw_fwd(w, mod, kmod, True, 1e-8, I, O, coef=False, wmix=wm, layout=1 if kind == 'rows' else 2)
+            want.append(wm)
+            ly.update(coef=False, wmix=torch.zeros_like(wm), layout=1 if kind == 'rows' else 2)
+        layers.append(ly)
+    outs = K.modw_multi(layers)
+    torch.cuda.synchronize()
+    for ly, o, w_ in zip(layers, outs, want):
+        if torch.is_tensor(w_):
+            assert torch.equal(ly['wmix'], w_)
+        else:
+            s, a, d = w_
+            assert torch.equal(o['s'], s) and torch.equal(o['a'], a) and torch.equal(o['d'], d)
+            assert torch.allclose(o['insc'], (a[:, :, None] * s[:, None, :]).reshape(b, -1), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 64, 64), (3, 8, 16, 24), (16, 32, 32, 128)])
+def test_maxpool_highfreq_kernels_vs_torch(shape):
+    """gg_poolhf_fwd / _bwd (unet Downsample tail, unet_upsampler.py:134-160) against max_pool2d + the reflect-padded blur in fp32
+    under autograd: values and the gradient of both outputs."""
+    from helpers import check_maxpool_highfreq
+    check_maxpool_highfreq(shape, dev())
 
 
 @pytest.mark.parametrize('cfg', [(64, 16, 16, 512, 512, 0), (40, 8, 8, 256, 520, 3), (8, 32, 32, 128, 256, 0), (2, 64, 64, 64, 128, 16)])
