@@ -75,14 +75,14 @@ class SyntheticTextImages:
             yield self.images, self.enc
 
 
-def cpu_baseline(budget_s=45.0):
-    """SURVEY.md §8(d) protocol on a bounded sample: OUR trainer (gigagan.py) on the fp32 CPU oracle (kind="port": the
-    reference itself cannot travel to the GPU box; the port/reference ratio measured in the build container is committed in
-    profiles/r02_cpu_baseline_calibration.json and copied into the record), config-2 dims at 256x256, fp32, batch 2, same
-    synthetic uniform images: ONE plain G+D step and ONE gradient-penalty G+D step, both through
-    train_discriminator_step / train_generator_step incl. the optimizer updates; cycle mean = (3 plain + 1 GP) / 4, what a
-    4-step cycle costs. Thread count: best of a 3-point sweep on one discriminator forward. The reference's CPU throughput
-    is nearly batch-independent (0.166 / 0.225 img/s at batch 1 / 2 on 8 cores)."""
+def cpu_baseline(budget_s=150.0):
+    """SURVEY.md §8(d) / BASELINE.md §3 protocol on a bounded sample: config-2 dims at 256x256, fp32, batch 4, same synthetic
+    uniform images, ONE whole 4-step cycle (3 plain + 1 gradient-penalty G+D step incl. optimizer updates and EMA) through
+    `train_step` of OUR trainer on the fp32 CPU oracle (kind="port": the reference itself cannot travel to the GPU box). The
+    unmodified reference was timed by the same protocol - `GigaGAN(...)(steps=4)`, batch 4 - next to this port in the build
+    container (tests/cpu_baseline_reference.py -> profiles/r03_cpu_baseline_reference.json); `reference_equivalent` = value /
+    port_vs_reference is the reference's CPU throughput scaled to this host. Thread count: best of a 3-point sweep on one
+    discriminator forward. Falls back to plain step + gradient-penalty step (cycle mean) if the host is too slow for the budget."""
     from gigagan_pytorch_amd import GigaGAN, ops
     from gigagan_pytorch_amd.data import SyntheticImages
     from gigagan_pytorch_amd.gigagan import cycle
@@ -90,11 +90,11 @@ def cpu_baseline(budget_s=45.0):
     from oracle.cpu_trainer import install_cpu_adamw
     t_start = time.time()
     cores = os.cpu_count() or 1
-    bs, S = 2, 256
+    bs, S = 4, 256
     torch.manual_seed(0)
     with ops.use_impl(OracleOps()):
         gan = GigaGAN(generator=dict(C2_G, image_size=S), discriminator=dict(C2_D, image_size=S), device='cpu',
-                      apply_gradient_penalty_every=4, create_ema_generator_at_init=False, use_hip_graphs=False,
+                      apply_gradient_penalty_every=4, create_ema_generator_at_init=True, use_hip_graphs=False,
                       model_folder='/tmp/gg-bench-cpu-models', results_folder='/tmp/gg-bench-cpu-results')
         install_cpu_adamw(gan.G_opt)
         install_cpu_adamw(gan.D_opt)
@@ -110,28 +110,32 @@ def cpu_baseline(budget_s=45.0):
             sweep[n] = time.time() - t0
         threads = min(sweep, key=sweep.get)
         torch.set_num_threads(threads)
-        times = {}
-        for name, gp in (('plain', False), ('gp', True)):
-            if name == 'gp' and time.time() - t_start + 3.5 * times['plain'] > budget_s * 2:
-                break           # a slow box: report the plain step alone rather than blow the bench's wall time
+        times = []
+        for step in range(4):                       # trainer steps 1..4: step 4 carries the gradient penalty
             t0 = time.time()
-            gan.train_discriminator_step(dl_iter=it, apply_gradient_penalty=gp)
+            gan.train_step(it, bs)
+            times.append(time.time() - t0)
+            if step == 0 and time.time() - t_start + 4.5 * times[0] > budget_s:
+                break           # a slow host: one plain step + one penalty step instead of the whole cycle
+        if len(times) == 4:
+            per_step = sum(times) / 4
+            what = 'one whole 4-step cycle through train_step: ' + ' + '.join(f'{t:.1f}' for t in times) + ' s (the 4th carries the gradient penalty)'
+        else:
+            t0 = time.time()
+            gan.train_discriminator_step(dl_iter=it, apply_gradient_penalty=True)
             gan.train_generator_step(batch_size=bs, dl_iter=it)
-            times[name] = time.time() - t0
-    if 'gp' in times:
-        per_step = (3 * times['plain'] + times['gp']) / 4
-        what = f"plain step {times['plain']:.1f} s + gradient-penalty step {times['gp']:.1f} s, cycle mean (3 plain + 1 GP) / 4"
-    else:
-        per_step = times['plain']
-        what = f"plain step {times['plain']:.1f} s only (gradient-penalty step skipped: time budget)"
+            gp = time.time() - t0
+            per_step = (3 * times[0] + gp) / 4
+            what = f'plain step {times[0]:.1f} s + gradient-penalty step {gp:.1f} s, cycle mean (3 plain + 1 GP) / 4 (time budget)'
     rec = dict(value=bs / per_step, unit='images/sec', cores=threads, kind='port',
                sample=f'our trainer on the fp32 CPU oracle, config-2 dims 256x256, batch {bs}: {what}; {threads} threads = best of '
                       f'the sweep {({k: round(v, 2) for k, v in sweep.items()})} (seconds per D forward) on a {cores}-core host')
-    cal = ROOT / 'profiles' / 'r02_cpu_baseline_calibration.json'
+    cal = ROOT / 'profiles' / 'r03_cpu_baseline_reference.json'
     if cal.exists():
         try:
             c = json.loads(cal.read_text())
             rec['port_vs_reference'] = c.get('port_vs_reference')
+            rec['reference_equivalent'] = rec['value'] / c['port_vs_reference']
             rec['calibration'] = c.get('note')
         except Exception:
             pass

@@ -1324,7 +1324,7 @@ extern "C" int gg_attn_fwd(const void* q, const void* k, const void* v, const vo
     if (rc) return rc;
     if (!o || !lse) return gg_fail(-1, "gg_attn_fwd: null output");
     p.o = (bf16_t*)o; p.lse = lse;
-    GG_LAUNCH(gg_attn_fwd_kernel, dim3((unsigned)(n / 128), (unsigned)(B * h)), dim3(256), (hipStream_t)stream, p);
+    GG_LAUNCH(gg_attn_fwd_kernel<false>, dim3((unsigned)(n / 128), (unsigned)(B * h)), dim3(256), (hipStream_t)stream, p);
     return gg_check_launch();
 }
 
@@ -1338,10 +1338,58 @@ extern "C" int gg_attn_bwd(const void* q, const void* k, const void* v, const vo
     p.o = (bf16_t*)o; p.lse = (float*)lse; p.d_o = (const bf16_t*)d_o; p.dvec = dvec;
     p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.null_part = null_part;
     dim3 grid((unsigned)(n / 128), (unsigned)(B * h));
-    GG_LAUNCH(gg_attn_bwd_dq_kernel, grid, dim3(256), (hipStream_t)stream, p);
+    GG_LAUNCH(gg_attn_bwd_dq_kernel<false>, grid, dim3(256), (hipStream_t)stream, p);
     rc = gg_check_launch();
     if (rc) return rc;
-    GG_LAUNCH(gg_attn_bwd_dkv_kernel, grid, dim3(256), (hipStream_t)stream, p);
+    GG_LAUNCH(gg_attn_bwd_dkv_kernel<false>, grid, dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+// general form: n queries against m keys, strided q / k / v rows, optional null token, optional per-key bias (gg_attention.h GEN)
+static int gg_attn_gen_common(GgAttnParams& p, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                              const void* k0, const void* v0, const float* kbias, int32_t B, int32_t n, int32_t m, int32_t h,
+                              float alpha, float beta) {
+    if (!q || !k || !v || ((k0 == nullptr) != (v0 == nullptr))) return gg_fail(-1, "gg_attn_gen: null pointer");
+    if (B <= 0 || h <= 0 || n <= 0 || m <= 0) return gg_fail(-2, "gg_attn_gen: B, h, n, m must be positive");
+    if ((long long)B * h > 65535) return gg_fail(-2, "gg_attn_gen: B*h exceeds grid.y");
+    if (ldq < h * 64 || ldk < h * 64 || ldv < h * 64 || ((ldq | ldk | ldv) & 7))
+        return gg_fail(-2, "gg_attn_gen: row pitches must be >= h*64 and multiples of 8");
+    if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)k0) | ((uintptr_t)v0)) & 15)
+        return gg_fail(-3, "gg_attn_gen: operands must be 16-byte aligned");
+    memset(&p, 0, sizeof(p));
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.k0 = (const bf16_t*)k0; p.v0 = (const bf16_t*)v0;
+    p.B = B; p.n = n; p.m = m; p.h = h; p.alpha = alpha; p.beta = beta;
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.kbias = kbias; p.has_null = k0 != nullptr;
+    return 0;
+}
+
+extern "C" int gg_attn_gen_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* k0,
+                               const void* v0, const float* kbias, void* o, float* lse, int32_t B, int32_t n, int32_t m, int32_t h,
+                               float alpha, float beta, void* stream) {
+    GgAttnParams p;
+    int rc = gg_attn_gen_common(p, q, ldq, k, ldk, v, ldv, k0, v0, kbias, B, n, m, h, alpha, beta);
+    if (rc) return rc;
+    if (!o || !lse) return gg_fail(-1, "gg_attn_gen_fwd: null output");
+    p.o = (bf16_t*)o; p.lse = lse;
+    GG_LAUNCH(gg_attn_fwd_kernel<true>, dim3((unsigned)((n + 127) / 128), (unsigned)(B * h)), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+extern "C" int gg_attn_gen_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* k0,
+                               const void* v0, const float* kbias, const void* o, const float* lse, const void* d_o, float* dvec,
+                               void* dq, void* dk, void* dv, float* null_part, int32_t B, int32_t n, int32_t m, int32_t h,
+                               float alpha, float beta, void* stream) {
+    GgAttnParams p;
+    int rc = gg_attn_gen_common(p, q, ldq, k, ldk, v, ldv, k0, v0, kbias, B, n, m, h, alpha, beta);
+    if (rc) return rc;
+    if (!o || !lse || !d_o || !dvec || !dq || !dk || !dv || (k0 && !null_part)) return gg_fail(-1, "gg_attn_gen_bwd: null pointer");
+    if (dk == dq) return gg_fail(-4, "gg_attn_gen_bwd: tied projections are the self-attention form (gg_attn_bwd)");
+    p.o = (bf16_t*)o; p.lse = (float*)lse; p.d_o = (const bf16_t*)d_o; p.dvec = dvec;
+    p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.null_part = null_part;
+    GG_LAUNCH(gg_attn_bwd_dq_kernel<true>, dim3((unsigned)((n + 127) / 128), (unsigned)(B * h)), dim3(256), (hipStream_t)stream, p);
+    rc = gg_check_launch();
+    if (rc) return rc;
+    GG_LAUNCH(gg_attn_bwd_dkv_kernel<true>, dim3((unsigned)((m + 127) / 128), (unsigned)(B * h)), dim3(256), (hipStream_t)stream, p);
     return gg_check_launch();
 }
 

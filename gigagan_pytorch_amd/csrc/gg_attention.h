@@ -45,6 +45,14 @@ struct GgAttnParams {
     float* null_part;   // [blocks of the dq kernel][3][64]: partial sums of dk0 (q part), dv0, and [2][0] = dbias0
     int B, n, h;
     float alpha, beta;
+    // general form (GEN instantiations: cross attention gp.py:617-655, the text transformer's attention gp.py:659-722, the unet's
+    // Attend attend.py:64-110): m keys / values per (batch, head) that need not equal the n queries, any n and m (tails are
+    // clamped on load and masked), strided q / k / v rows (channel slices of a fused projection), an optional additive per-key
+    // bias [B][m] (natural-log domain; key-padding masks are -1e30), and the null key / value optional (has_null)
+    int m;
+    long long ldq, ldk, ldv;    // row pitch (elements) of q, k, v; o / dO / dq / dk / dv are dense [B][len][h*64]
+    const float* kbias;
+    int has_null;
 };
 
 // ---- fragment helpers ----------------------------------------------------------------------------------------
@@ -52,6 +60,14 @@ struct GgAttnParams {
 // B-operand fragments straight from global memory: lane l -> token row0 + (l & 31), d = kk*16 + 8*(l >> 5) + 0..7
 GG_DEVICE void gga_load_frags(u16x8* f, const bf16_t* base, long long row_stride, int row0, int lane) {
     const bf16_t* p = base + (long long)(row0 + (lane & 31)) * row_stride + 8 * (lane >> 5);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) f[kk] = *(const u16x8*)(p + kk * 16);
+}
+
+// the same with the token row clamped to nrows - 1 (ragged tails of the general form)
+GG_DEVICE void gga_load_frags_c(u16x8* f, const bf16_t* base, long long row_stride, int row0, int nrows, int lane) {
+    const int r = row0 + (lane & 31);
+    const bf16_t* p = base + (long long)(r < nrows ? r : nrows - 1) * row_stride + 8 * (lane >> 5);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) f[kk] = *(const u16x8*)(p + kk * 16);
 }
@@ -97,6 +113,35 @@ GG_DEVICE GgaTileRegs gga_tile_load(const bf16_t* base, long long row_stride, in
     return r;
 }
 
+GG_DEVICE GgaTileRegs gga_tile_load_c(const bf16_t* base, long long row_stride, int t0, int nrows) {
+    GgaTileRegs r;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int v = t + 256 * it;
+        const int row = t0 + (v >> 3);
+        r.v[it] = *(const u16x8*)(base + (long long)(row < nrows ? row : nrows - 1) * row_stride + (v & 7) * 8);
+    }
+    return r;
+}
+
+// general form: the per-key bias of a staged tile (log2 domain) on top of the |k|^2 term gga_tile_store left in kb[]; rows beyond the
+// last key are switched off. Written by the threads that wrote kb[] (c8 == 0), so no barrier is needed in between.
+GG_DEVICE void gga_tile_bias(float* kb, const float* kbias_row, int t0, int nkeys) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int v = t + 256 * it;
+        const int row = v >> 3;
+        if ((v & 7) == 0) {
+            const int j = t0 + row;
+            float x = kb[row];
+            if (kbias_row) x += kbias_row[j < nkeys ? j : nkeys - 1] * 1.4426950408889634f;
+            kb[row] = j < nkeys ? x : -1.0e30f;
+        }
+    }
+}
+
 GG_DEVICE void gga_tile_store(const GgaTileRegs& r, bf16_t (*rowk)[GGA_KP], char* tr, float* sq, float sq_scale = 1.f) {
     const int t = threadIdx.x;
 #pragma unroll
@@ -138,6 +183,7 @@ GG_DEVICE f32x4 gga_rows4(const float* arr, int blk, int g, int lane) {
 #define GGA_LN2 0.6931471805599453f
 #define GGA_TAU 8.0f
 
+template <bool GEN>
 GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_fwd_kernel(GgAttnParams p) {
     GG_SHARED __attribute__((aligned(16))) bf16_t sK[2][64][GGA_KP];
     GG_SHARED __attribute__((aligned(16))) char sV[2][64 * GGA_TP];
@@ -146,19 +192,45 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_fwd_kernel(GgAttnParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
     const int bh = blockIdx.y, b = bh / p.h, hd = bh % p.h;
     const long long rs = (long long)p.h * GGA_D;
-    const bf16_t* qb = p.q + (long long)b * p.n * rs + hd * GGA_D;
-    const bf16_t* kb = p.k + (long long)b * p.n * rs + hd * GGA_D;
-    const bf16_t* vb = p.v + (long long)b * p.n * rs + hd * GGA_D;
+    const long long rsq = GEN ? p.ldq : rs, rsk = GEN ? p.ldk : rs, rsv = GEN ? p.ldv : rs;
+    const int nk = GEN ? p.m : p.n;                                   // keys per (batch, head)
+    const bf16_t* qb = p.q + (long long)b * p.n * rsq + hd * GGA_D;
+    const bf16_t* kb = p.k + (long long)b * nk * rsk + hd * GGA_D;
+    const bf16_t* vb = p.v + (long long)b * nk * rsv + hd * GGA_D;
+    const float* kbias = (GEN && p.kbias) ? p.kbias + (long long)b * nk : nullptr;
     const int qi0 = blockIdx.x * 128 + wave * 32;
     const float a2 = p.alpha * GGA_LOG2E, b2 = p.beta * GGA_LOG2E, inv_a2 = 1.f / a2;
 
     u16x8 qf[4];
-    gga_load_frags(qf, qb, rs, qi0, lane);
+    if (GEN) gga_load_frags_c(qf, qb, rsq, qi0, p.n, lane);
+    else gga_load_frags(qf, qb, rs, qi0, lane);
 
     // null key / value: initial state of the online softmax (its probability 2^0 = 1 is counted by the hi = 0 lane)
     float m, l = hi ? 0.f : 1.f;
     f32x16 ot[2];
-    {
+    if (GEN && !p.has_null) {
+        // no null token: the reference maximum starts at the (unbiased) score of key 0 - any finite value of the scores' magnitude
+        // will do, the first tiles move it - with nothing counted yet (l = 0, O = 0). (A -inf start would be folded into the score
+        // MFMA's accumulate input below and absorb the scores.)
+        float dot = 0.f, sq = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            u16x8 kv = *(const u16x8*)(kb + kk * 16 + 8 * hi);
+            for (int e = 0; e < 8; ++e) {
+                float kf = gg_bf2f(kv[e]);
+                dot += gg_bf2f(qf[kk][e]) * kf;
+                sq += kf * kf;
+            }
+        }
+        dot += gg_shfl_xor(dot, 32);
+        sq += gg_shfl_xor(sq, 32);
+        m = a2 * dot + b2 * sq;
+        l = 0.f;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[db][r] = 0.f;
+    } else {
         const bf16_t* k0 = p.k0 + hd * GGA_D;
         float dot = 0.f, sq = 0.f;
 #pragma unroll
@@ -180,23 +252,28 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_fwd_kernel(GgAttnParams p) {
             for (int r = 0; r < 16; ++r) ot[db][r] = gg_bf2f(v0[db * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi]);
     }
 
-    GgaTileRegs rk = gga_tile_load(kb, rs, 0), rv = gga_tile_load(vb, rs, 0);
+    auto tload = [&](const bf16_t* base, long long ld, int t0) {
+        return GEN ? gga_tile_load_c(base, ld, t0, nk) : gga_tile_load(base, ld, t0);
+    };
+    GgaTileRegs rk = tload(kb, rsk, 0), rv = tload(vb, rsv, 0);
     gga_tile_store(rk, sK[0], nullptr, sKb[0], b2);
+    if (GEN) gga_tile_bias(sKb[0], kbias, 0, nk);
     gga_tile_store(rv, nullptr, sV[0], nullptr);
-    if (64 < p.n) {
-        rk = gga_tile_load(kb, rs, 64);
-        rv = gga_tile_load(vb, rs, 64);
+    if (64 < nk) {
+        rk = tload(kb, rsk, 64);
+        rv = tload(vb, rsv, 64);
     }
     gg_sync();
-    for (int j0 = 0, buf = 0; j0 < p.n; j0 += 64, buf ^= 1) {
+    for (int j0 = 0, buf = 0; j0 < nk; j0 += 64, buf ^= 1) {
         // tile j0 + 64 sits in the staging registers: park it in the other buffer (free since the barrier that ended the
         // previous iteration) and put tile j0 + 128 in flight
-        if (j0 + 64 < p.n) {
+        if (j0 + 64 < nk) {
             gga_tile_store(rk, sK[buf ^ 1], nullptr, sKb[buf ^ 1], b2);
+            if (GEN) gga_tile_bias(sKb[buf ^ 1], kbias, j0 + 64, nk);
             gga_tile_store(rv, nullptr, sV[buf ^ 1], nullptr);
-            if (j0 + 128 < p.n) {
-                rk = gga_tile_load(kb, rs, j0 + 128);
-                rv = gga_tile_load(vb, rs, j0 + 128);
+            if (j0 + 128 < nk) {
+                rk = tload(kb, rsk, j0 + 128);
+                rv = tload(vb, rsv, j0 + 128);
             }
         }
 
@@ -263,8 +340,10 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_fwd_kernel(GgAttnParams p) {
     }
 
     l += gg_shfl_xor(l, 32);
+    if (GEN) l = fmaxf(l, 1.0e-30f);                     // (every key masked: zeros instead of NaN)
     const float inv = 1.f / l;
     const int qi = qi0 + (lane & 31);
+    if (GEN && qi >= p.n) return;
     bf16_t* orow = p.o + ((long long)b * p.n + qi) * rs + hd * GGA_D;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -279,6 +358,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_fwd_kernel(GgAttnParams p) {
 
 // ---- backward, part 1: dq (+ rowsum(dO*O), + the null key/value partial gradients) ---------------------------------
 // grid: (n / 128, B*h); wave w owns queries q0 + 32w .. +31
+template <bool GEN>
 GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dq_kernel(GgAttnParams p) {
     GG_SHARED __attribute__((aligned(16))) bf16_t sK[2][64][GGA_KP];
     GG_SHARED __attribute__((aligned(16))) bf16_t sV[2][64][GGA_KP];
@@ -289,25 +369,38 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dq_kernel(GgAttnParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
     const int bh = blockIdx.y, b = bh / p.h, hd = bh % p.h;
     const long long rs = (long long)p.h * GGA_D;
-    const long long boff = (long long)b * p.n * rs + hd * GGA_D;
+    const long long boff = (long long)b * p.n * rs + hd * GGA_D;          // dense query-side tensors: o, dO, dq
+    const long long rsq = GEN ? p.ldq : rs, rsk = GEN ? p.ldk : rs, rsv = GEN ? p.ldv : rs;
+    const int nk = GEN ? p.m : p.n;
+    const bf16_t* qb = p.q + (long long)b * p.n * rsq + hd * GGA_D;
+    const bf16_t* kb = p.k + (long long)b * nk * rsk + hd * GGA_D;
+    const bf16_t* vb = p.v + (long long)b * nk * rsv + hd * GGA_D;
+    const float* kbias = (GEN && p.kbias) ? p.kbias + (long long)b * nk : nullptr;
     const int qi0 = blockIdx.x * 128 + wave * 32;
     const int qi = qi0 + (lane & 31);
+    const int qic = (GEN && qi >= p.n) ? p.n - 1 : qi;
     const float a2 = p.alpha * GGA_LOG2E, b2 = p.beta * GGA_LOG2E, inv_a2 = 1.f / a2;
 
     u16x8 qf[4], dof[4];
-    gga_load_frags(qf, p.q + boff, rs, qi0, lane);
-    gga_load_frags(dof, p.d_o + boff, rs, qi0, lane);
+    if (GEN) {
+        gga_load_frags_c(qf, qb, rsq, qi0, p.n, lane);
+        gga_load_frags_c(dof, p.d_o + boff, rs, qi0, p.n, lane);
+    } else {
+        gga_load_frags(qf, p.q + boff, rs, qi0, lane);
+        gga_load_frags(dof, p.d_o + boff, rs, qi0, lane);
+    }
     float dsum = 0.f;   // D_i = sum_d dO_i[d] * O_i[d]
     {
         u16x8 of[4];
-        gga_load_frags(of, p.o + boff, rs, qi0, lane);
+        if (GEN) gga_load_frags_c(of, p.o + boff, rs, qi0, p.n, lane);
+        else gga_load_frags(of, p.o + boff, rs, qi0, lane);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
             for (int e = 0; e < 8; ++e) dsum += gg_bf2f(dof[kk][e]) * gg_bf2f(of[kk][e]);
         dsum += gg_shfl_xor(dsum, 32);
     }
-    const float lse = p.lse[(long long)bh * p.n + qi];
-    if (hi == 0) p.dvec[(long long)bh * p.n + qi] = dsum;
+    const float lse = p.lse[(long long)bh * p.n + qic];
+    if (hi == 0 && qi == qic) p.dvec[(long long)bh * p.n + qi] = dsum;
 
     f32x16 dqt[2];
 #pragma unroll
@@ -316,7 +409,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dq_kernel(GgAttnParams p) {
         for (int r = 0; r < 16; ++r) dqt[db][r] = 0.f;
 
     // null key: ds0 = p0 * (dO_i . v0 - D_i); dq_i += ds0 * k0 (alpha applied at the end); partial sums for dk0 / dv0
-    {
+    if (!GEN || p.has_null) {
         const bf16_t* k0 = p.k0 + hd * GGA_D;
         const bf16_t* v0 = p.v0 + hd * GGA_D;
         float dot = 0.f, sq = 0.f, dp0 = 0.f;
@@ -334,7 +427,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dq_kernel(GgAttnParams p) {
         dot += gg_shfl_xor(dot, 32);
         sq += gg_shfl_xor(sq, 32);
         dp0 += gg_shfl_xor(dp0, 32);
-        const float p0 = gg_expf(p.alpha * dot + p.beta * sq - lse);
+        const float p0 = (GEN && qi != qic) ? 0.f : gg_expf(p.alpha * dot + p.beta * sq - lse);      // (rows past the last query: nothing)
         const float ds0 = p0 * (dp0 - dsum);
 #pragma unroll
         for (int db = 0; db < 2; ++db)
@@ -360,21 +453,26 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dq_kernel(GgAttnParams p) {
     // per score: p = 2^(alpha' s + bias'_j - lse'), dS = p (dP - D): the two subtractions ride on the MFMAs' accumulate
     // inputs (S starts at -lse' / alpha', dP at -D), leaving fma, v_exp_f32, mul and the bf16 pack on the vector ALU
     const float sinit = -lse * GGA_LOG2E * inv_a2, dinit = -dsum;
-    GgaTileRegs rk = gga_tile_load(p.k + boff, rs, 0), rv = gga_tile_load(p.v + boff, rs, 0);
+    auto tload = [&](const bf16_t* base, long long ld, int t0) {
+        return GEN ? gga_tile_load_c(base, ld, t0, nk) : gga_tile_load(base, ld, t0);
+    };
+    GgaTileRegs rk = tload(kb, rsk, 0), rv = tload(vb, rsv, 0);
     gga_tile_store(rk, sK[0], sKt[0], sKb[0], b2);
+    if (GEN) gga_tile_bias(sKb[0], kbias, 0, nk);
     gga_tile_store(rv, sV[0], nullptr, nullptr);
-    if (64 < p.n) {
-        rk = gga_tile_load(p.k + boff, rs, 64);
-        rv = gga_tile_load(p.v + boff, rs, 64);
+    if (64 < nk) {
+        rk = tload(kb, rsk, 64);
+        rv = tload(vb, rsv, 64);
     }
     gg_sync();
-    for (int j0 = 0, buf = 0; j0 < p.n; j0 += 64, buf ^= 1) {
-        if (j0 + 64 < p.n) {
+    for (int j0 = 0, buf = 0; j0 < nk; j0 += 64, buf ^= 1) {
+        if (j0 + 64 < nk) {
             gga_tile_store(rk, sK[buf ^ 1], sKt[buf ^ 1], sKb[buf ^ 1], b2);
+            if (GEN) gga_tile_bias(sKb[buf ^ 1], kbias, j0 + 64, nk);
             gga_tile_store(rv, sV[buf ^ 1], nullptr, nullptr);
-            if (j0 + 128 < p.n) {
-                rk = gga_tile_load(p.k + boff, rs, j0 + 128);
-                rv = gga_tile_load(p.v + boff, rs, j0 + 128);
+            if (j0 + 128 < nk) {
+                rk = tload(kb, rsk, j0 + 128);
+                rv = tload(vb, rsv, j0 + 128);
             }
         }
 #pragma unroll
@@ -407,16 +505,19 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dq_kernel(GgAttnParams p) {
         gg_sync();
     }
 
-    bf16_t* dqrow = p.dq + ((long long)b * p.n + qi) * rs + hd * GGA_D;
+    bf16_t* dqrow = p.dq + ((long long)b * p.n + qic) * rs + hd * GGA_D;
+    if (qi == qic) {
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            u16x4 o4 = {gg_f2bf(dqt[db][4 * g + 0] * p.alpha), gg_f2bf(dqt[db][4 * g + 1] * p.alpha),
-                        gg_f2bf(dqt[db][4 * g + 2] * p.alpha), gg_f2bf(dqt[db][4 * g + 3] * p.alpha)};
-            *(u16x4*)(dqrow + db * 32 + 8 * g + 4 * hi) = o4;
-        }
+            for (int g = 0; g < 4; ++g) {
+                u16x4 o4 = {gg_f2bf(dqt[db][4 * g + 0] * p.alpha), gg_f2bf(dqt[db][4 * g + 1] * p.alpha),
+                            gg_f2bf(dqt[db][4 * g + 2] * p.alpha), gg_f2bf(dqt[db][4 * g + 3] * p.alpha)};
+                *(u16x4*)(dqrow + db * 32 + 8 * g + 4 * hi) = o4;
+            }
+    }
     gg_sync();
+    if (GEN && !p.has_null) return;
     if (threadIdx.x < 192) {
         const int which = threadIdx.x >> 6, d = threadIdx.x & 63;
         float s = 0.f;
@@ -428,6 +529,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dq_kernel(GgAttnParams p) {
 
 // ---- backward, part 2: dk, dv ----------------------------------------------------------------------------------
 // grid: (n / 128, B*h); wave w owns keys j0 + 32w .. +31 and loops over all queries
+template <bool GEN>
 GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dkv_kernel(GgAttnParams p) {
     GG_SHARED __attribute__((aligned(16))) bf16_t sQ[64][GGA_KP];
     GG_SHARED __attribute__((aligned(16))) bf16_t sDO[64][GGA_KP];
@@ -439,20 +541,36 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dkv_kernel(GgAttnParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
     const int bh = blockIdx.y, b = bh / p.h, hd = bh % p.h;
     const long long rs = (long long)p.h * GGA_D;
-    const long long boff = (long long)b * p.n * rs + hd * GGA_D;
+    const long long boff = (long long)b * p.n * rs + hd * GGA_D;           // dense query-side tensors (dO) and, when !GEN, all
+    const long long rsq = GEN ? p.ldq : rs, rsk = GEN ? p.ldk : rs, rsv = GEN ? p.ldv : rs;
+    const int nk = GEN ? p.m : p.n;
+    const bf16_t* qb = p.q + (long long)b * p.n * rsq + hd * GGA_D;
+    const bf16_t* kb = p.k + (long long)b * nk * rsk + hd * GGA_D;
+    const bf16_t* vb = p.v + (long long)b * nk * rsv + hd * GGA_D;
+    const long long koff = (long long)b * nk * rs + hd * GGA_D;            // dense key-side outputs: dk, dv
     const int kj0 = blockIdx.x * 128 + wave * 32;
     const int kj = kj0 + (lane & 31);
+    const int kjc = (GEN && kj >= nk) ? nk - 1 : kj;
 
     u16x8 kf[4], vf[4];
-    gga_load_frags(kf, p.k + boff, rs, kj0, lane);
-    gga_load_frags(vf, p.v + boff, rs, kj0, lane);
+    if (GEN) {
+        gga_load_frags_c(kf, kb, rsk, kj0, nk, lane);
+        gga_load_frags_c(vf, vb, rsv, kj0, nk, lane);
+    } else {
+        gga_load_frags(kf, p.k + boff, rs, kj0, lane);
+        gga_load_frags(vf, p.v + boff, rs, kj0, lane);
+    }
     float ksq = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
         for (int e = 0; e < 8; ++e) { float f = gg_bf2f(kf[kk][e]); ksq += f * f; }
     ksq += gg_shfl_xor(ksq, 32);
     const float a2 = p.alpha * GGA_LOG2E;
-    const float sinit = p.beta * ksq / p.alpha;            // (beta' |k_j|^2) / alpha'
+    float sinit = p.beta * ksq / p.alpha;                  // (beta' |k_j|^2) / alpha'
+    if (GEN) {
+        if (p.kbias) sinit += p.kbias[(long long)b * nk + kjc] / p.alpha;
+        if (kj != kjc) sinit = -1.0e30f;                    // past the last key: probability 0
+    }
 
     f32x16 dkt[2], dvt[2];
 #pragma unroll
@@ -461,12 +579,18 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dkv_kernel(GgAttnParams p) {
         for (int r = 0; r < 16; ++r) { dkt[db][r] = 0.f; dvt[db][r] = 0.f; }
     float dbias = 0.f;
 
-    GgaTileRegs rq = gga_tile_load(p.q + boff, rs, 0), rdo = gga_tile_load(p.d_o + boff, rs, 0);
+    auto qload = [&](const bf16_t* base, long long ld, int t0) {
+        return GEN ? gga_tile_load_c(base, ld, t0, p.n) : gga_tile_load(base, ld, t0);
+    };
+    auto stat_load = [&](int i, float& lse_o, float& d_o_) {          // rows past the last query get lse = +big: probability 0
+        const int ic = (GEN && i >= p.n) ? p.n - 1 : i;
+        lse_o = p.lse[(long long)bh * p.n + ic];
+        d_o_ = p.dvec[(long long)bh * p.n + ic];
+        if (GEN && i >= p.n) lse_o = 1.0e30f;
+    };
+    GgaTileRegs rq = qload(qb, rsq, 0), rdo = qload(p.d_o + boff, rs, 0);
     float r_lse = 0.f, r_d = 0.f;
-    if (threadIdx.x < 64) {
-        r_lse = p.lse[(long long)bh * p.n + threadIdx.x];
-        r_d = p.dvec[(long long)bh * p.n + threadIdx.x];
-    }
+    if (threadIdx.x < 64) stat_load(threadIdx.x, r_lse, r_d);
     for (int i0 = 0; i0 < p.n; i0 += 64) {
         gg_sync();
         gga_tile_store(rq, sQ, sQt, nullptr);
@@ -477,12 +601,9 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dkv_kernel(GgAttnParams p) {
         }
         gg_sync();
         if (i0 + 64 < p.n) {
-            rq = gga_tile_load(p.q + boff, rs, i0 + 64);
-            rdo = gga_tile_load(p.d_o + boff, rs, i0 + 64);
-            if (threadIdx.x < 64) {
-                r_lse = p.lse[(long long)bh * p.n + i0 + 64 + threadIdx.x];
-                r_d = p.dvec[(long long)bh * p.n + i0 + 64 + threadIdx.x];
-            }
+            rq = qload(qb, rsq, i0 + 64);
+            rdo = qload(p.d_o + boff, rs, i0 + 64);
+            if (threadIdx.x < 64) stat_load(i0 + 64 + threadIdx.x, r_lse, r_d);
         }
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib) {
@@ -523,10 +644,11 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dkv_kernel(GgAttnParams p) {
     dbias += gg_shfl_xor(dbias, 32);
 
     // dk_j = alpha * sum_i dS_ij q_i + dbias_j * 2*beta*k_j   (d/dk of beta*|k|^2)
-    const bf16_t* krow = p.k + boff + (long long)kj * rs;
+    if (GEN && kj != kjc) return;
+    const bf16_t* krow = GEN ? kb + (long long)kj * rsk : p.k + boff + (long long)kj * rs;
     const bool tied = p.dk == p.dq;
-    bf16_t* dkrow = p.dk + boff + (long long)kj * rs;
-    bf16_t* dvrow = p.dv + boff + (long long)kj * rs;
+    bf16_t* dkrow = p.dk + (GEN ? koff : boff) + (long long)kj * rs;
+    bf16_t* dvrow = p.dv + (GEN ? koff : boff) + (long long)kj * rs;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll

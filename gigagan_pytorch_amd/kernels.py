@@ -755,6 +755,55 @@ def attn_bwd(q, k, v, k0, v0, o, lse, d_o, heads: int, alpha: float, beta: float
     return dq, dk, dv, s[:, 0] * alpha, s[:, 1], s[:, 2, 0]
 
 
+def _attn_gen_check(q, k, v, heads):
+    for t in (q, k, v):
+        assert t.dtype == torch.bfloat16 and t.dim() == 3 and t.stride(2) == 1 and t.shape[2] == heads * 64
+        assert t.stride(0) == t.shape[1] * t.stride(1) and t.stride(1) % 8 == 0 and t.data_ptr() % 16 == 0
+    assert k.shape[:2] == v.shape[:2] and k.shape[0] == q.shape[0]
+
+
+def attn_gen_fwd(q, k, v, k0, v0, kbias, heads: int, alpha: float, beta: float = 0.0):
+    """general fused attention (gg_attn_gen_fwd): q (B, n, heads*64), k / v (B, m, heads*64) bf16 with a free row pitch (channel
+    slices of a fused projection; stride(0) = len * stride(1)), optional null key / value k0, v0 (heads, 64) bf16, optional
+    per-key bias kbias (B, m) fp32 -> (o (B, n, heads*64) bf16 dense, lse (B*heads, n) fp32)."""
+    L = _C.lib()
+    L.require(q, k, v, k0, v0, kbias)
+    _attn_gen_check(q, k, v, heads)
+    B, n, m = q.shape[0], q.shape[1], k.shape[1]
+    if kbias is not None:
+        assert kbias.dtype == torch.float32 and kbias.is_contiguous() and kbias.shape == (B, m)
+    o = torch.empty((B, n, heads * 64), dtype=torch.bfloat16, device=q.device)
+    lse = torch.empty((B * heads, n), dtype=torch.float32, device=q.device)
+    rc = L.lib.gg_attn_gen_fwd(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(k0), ptr(v0), ptr(kbias), ptr(o),
+                               ptr(lse), B, n, m, heads, alpha, beta, L.stream(q))
+    L.check(rc, 'gg_attn_gen_fwd')
+    return o, lse
+
+
+def attn_gen_bwd(q, k, v, k0, v0, kbias, o, lse, d_o, heads: int, alpha: float, beta: float = 0.0):
+    """-> (dq (B, n, heads*64), dk, dv (B, m, heads*64) bf16 dense; dk0_q, dv0 (heads, 64) fp32 and dbias0 (heads,) fp32 when the null
+    token is present, else None)."""
+    L = _C.lib()
+    L.require(q, k, v, k0, v0, kbias, o, lse, d_o)
+    _attn_gen_check(q, k, v, heads)
+    B, n, m = q.shape[0], q.shape[1], k.shape[1]
+    assert d_o.dtype == torch.bfloat16 and d_o.is_contiguous() and d_o.shape == o.shape and o.is_contiguous()
+    dq = torch.empty_like(o)
+    dk = torch.empty((B, m, heads * 64), dtype=torch.bfloat16, device=q.device)
+    dv = torch.empty_like(dk)
+    dvec = torch.empty_like(lse)
+    nblk = (n + 127) // 128
+    part = torch.empty((B, heads, nblk, 3, 64), dtype=torch.float32, device=q.device) if k0 is not None else None
+    rc = L.lib.gg_attn_gen_bwd(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(k0), ptr(v0), ptr(kbias), ptr(o),
+                               ptr(lse), ptr(d_o), ptr(dvec), ptr(dq), ptr(dk), ptr(dv), ptr(part), B, n, m, heads, alpha, beta,
+                               L.stream(q))
+    L.check(rc, 'gg_attn_gen_bwd')
+    if part is None:
+        return dq, dk, dv, None, None, None
+    s = part.sum(dim=(0, 2))
+    return dq, dk, dv, s[:, 0] * alpha, s[:, 1], s[:, 2, 0]
+
+
 def attn_bwd2(q, k, v, k0, v0, d_o, lse, dvec, aq, ak, av, ak0, av0, heads: int, alpha: float, beta: float):
     """second-order pass: incoming gradients (aq, ak, av like q; ak0, av0 (heads, 64) bf16) w.r.t. attn_bwd's outputs ->
     (gq, gk, gv, gdo bf16 like q; gk0, gv0 (heads, 64) fp32)."""

@@ -651,6 +651,44 @@ class FlashAttnBwdFn(Function):
         return gq, gk, gv, gk0, gv0, None, None, gdo, None, None, None
 
 
+class FlashAttnGenFn(Function):
+    """the general fused attention (gg_attention.h GEN: the unet's Attend attend.py:64-110, CrossAttention gp.py:617-655, the text
+    transformer's attention gp.py:659-722): q (B, n, heads*64), k / v (B, m, heads*64) bf16 views with a free row pitch, optional
+    null key / value (heads, 64), optional per-key bias (B, m) fp32 (key-padding mask as -1e30; a constant: no gradient). No
+    (B*heads, n, m) probability tensor exists in either direction. First order."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, k0, v0, kbias, heads, alpha):
+        k0b = None if k0 is None else k0.to(ACT_DTYPE).contiguous()
+        v0b = None if v0 is None else v0.to(ACT_DTYPE).contiguous()
+        o, lse = K.attn_gen_fwd(q, k, v, k0b, v0b, kbias, heads, alpha)
+        ctx.cfg = (heads, alpha)
+        ctx.save_for_backward(q, k, v, k0, v0, kbias, o, lse)
+        return o
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_o):
+        q, k, v, k0, v0, kbias, o, lse = ctx.saved_tensors
+        heads, alpha = ctx.cfg
+        k0b = None if k0 is None else k0.to(ACT_DTYPE).contiguous()
+        v0b = None if v0 is None else v0.to(ACT_DTYPE).contiguous()
+        dq, dk, dv, dk0, dv0, _ = K.attn_gen_bwd(q, k, v, k0b, v0b, kbias, o, lse, d_o.to(ACT_DTYPE).contiguous(), heads, alpha)
+        if k0 is not None:
+            dk0, dv0 = dk0.to(k0.dtype), dv0.to(v0.dtype)
+        return dq, dk, dv, dk0, dv0, None, None, None
+
+
+def _rows_view(t):
+    """(B, h, len, 64) logical attention operand -> (B, len, h*64) bf16 view with unit feature stride and a batch stride of
+    len * row pitch, without a copy when the operand already is a channel slice of a token-major projection; else a dense copy."""
+    B, h, n, d = t.shape
+    if (t.dtype == ACT_DTYPE and t.stride(3) == 1 and t.stride(1) == d and t.stride(2) % 8 == 0 and t.stride(2) >= h * d
+            and t.stride(0) == n * t.stride(2) and t.data_ptr() % 16 == 0):
+        return t.as_strided((B, n, h * d), (t.stride(0), t.stride(2), 1), t.storage_offset())
+    return t.to(ACT_DTYPE).transpose(1, 2).reshape(B, n, h * d).contiguous()
+
+
 class GemmFn(Function):
     """out[b][r][c] = act(alpha * sum_t X[b](r,t) * Y[b](c,t) + bias[c]).
 
@@ -1446,6 +1484,13 @@ class HipOps:
         """softmax(sim * scale) v with sim = q.k (dot) or -|q-k|^2 (l2). `key_mask` (B, m) bool keeps keys."""
         B, h, n, dh = q.shape
         m = k.shape[2]
+        if dh == 64 and not l2 and B * h <= 65535:
+            # heads of 64 features: the fused kernel family (no probability tensor; key-padding mask as a per-key bias; m, n free)
+            kb = None
+            if key_mask is not None:
+                kb = torch.zeros(key_mask.shape, dtype=torch.float32, device=q.device).masked_fill(~key_mask, -1e30).contiguous()
+            o = FlashAttnGenFn.apply(_rows_view(q), _rows_view(k), _rows_view(v), None, None, kb, h, float(scale))
+            return o.view(B, n, h, dh).transpose(1, 2)
         mp = _round8(m)
         q2 = q.reshape(B * h, n, dh).to(ACT_DTYPE).contiguous()
         k2 = k.reshape(B * h, m, dh).to(ACT_DTYPE)

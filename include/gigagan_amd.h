@@ -232,6 +232,18 @@ int gg_attn_fwd(const void* q, const void* k, const void* v, const void* k0, con
 int gg_attn_bwd(const void* q, const void* k, const void* v, const void* k0, const void* v0, const void* o, const float* lse,
                 const void* d_o, float* dvec, void* dq, void* dk, void* dv, float* null_part, int32_t B, int32_t n, int32_t h,
                 float alpha, float beta, void* stream);
+/* general form of the fused attention (reference attend.py:64-110 `Attend` of the unet, CrossAttention gp.py:617-655, the text
+ * transformer's attention gp.py:659-722): n queries [B][n] against m keys / values [B][m] per head of 64 features, q / k / v rows
+ * `ld*` elements apart (channel slices of a fused projection are read in place), the null key / value optional (k0 = v0 = NULL),
+ * an optional additive per-key bias kbias [B][m] fp32 (key-padding masks: -1e30), any n and m (ragged tails are clamped on load and
+ * masked). o / lse / dO / dq as in gg_attn_fwd; dk / dv dense [B][m][h*64]; null_part [ceil(n/128) blocks ...] as gg_attn_bwd when
+ * the null token is present. First order (these attentions never sit between the images and the gradient penalty). */
+int gg_attn_gen_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* k0, const void* v0,
+                    const float* kbias, void* o, float* lse, int32_t B, int32_t n, int32_t m, int32_t h, float alpha, float beta,
+                    void* stream);
+int gg_attn_gen_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* k0, const void* v0,
+                    const float* kbias, const void* o, const float* lse, const void* d_o, float* dvec, void* dq, void* dk, void* dv,
+                    float* null_part, int32_t B, int32_t n, int32_t m, int32_t h, float alpha, float beta, void* stream);
 /* gg_attn_bwd: `dk` may alias `dq` when the key projection IS the query projection (the L2-distance attention ties them,
  * reference gp.py:566-569): the buffer then receives dq + dk, the gradient of the shared tensor, without a separate add. */
 

@@ -286,3 +286,56 @@ def check_maxpool_highfreq(shape, device):
     ga, = torch.autograd.grad((ops.HipOps().maxpool_highfreq(xd)[0].float() * c1.to(device)).sum(), xd)
     gb, = torch.autograd.grad((ref(xr)[0] * c1).sum(), xr)
     assert rel_err(ga.cpu(), gb) < 8e-3
+
+
+def check_general_attention(cfg, device):
+    """ops.FlashAttnGenFn (gg_attn_gen_fwd / _bwd: n queries x m keys, optional null key / value, optional key-padding mask, ragged
+    n and m, q / k / v as strided channel slices of one fused projection) against softmax(q k^T * scale + mask) v in fp32 autograd
+    on the same bf16 operands: output and the gradients of q, k, v (and the null token)."""
+    from gigagan_pytorch_amd import ops
+    B, h, n, m, null, mask, fused_qkv = cfg
+    torch.manual_seed(0)
+    scale = 64 ** -0.5
+    if fused_qkv:       # self attention on channel slices of one (B, n, 3*h*64) projection (the unet's to_qkv)
+        qkv = torch.randn(B, n, 3 * h * 64).to(torch.bfloat16).to(device).requires_grad_()
+        q, k, v = (qkv[..., i * h * 64:(i + 1) * h * 64].view(B, n, h, 64).transpose(1, 2) for i in range(3))
+        leaves = [qkv]
+    else:
+        q0 = torch.randn(B, n, h * 64).to(torch.bfloat16).to(device).requires_grad_()
+        kv = torch.randn(B, m, 2 * h * 64).to(torch.bfloat16).to(device).requires_grad_()
+        q = q0.view(B, n, h, 64).transpose(1, 2)
+        k, v = (kv[..., i * h * 64:(i + 1) * h * 64].view(B, m, h, 64).transpose(1, 2) for i in range(2))
+        leaves = [q0, kv]
+    nkv = (torch.randn(2, h, 64) * 0.5).to(device).requires_grad_() if null else None
+    km = None
+    if mask:
+        km = torch.ones(B, m, dtype=torch.bool, device=device)
+        for i in range(B):
+            km[i, max(2, m - 5 - 11 * i):] = False        # (at least two keys stay: a fully masked row is uniform attention in the
+                                                          # reference and zeros here - captions always hold a token)
+    probe = torch.randn(B, h, n, 64).to(device)
+
+    def reference():
+        qf, kf, vf = q.float(), k.float(), v.float()
+        bias = torch.zeros(B, 1, 1, kf.shape[2], device=device)
+        if km is not None:
+            bias = bias.masked_fill(~km[:, None, None, :], -1e30)
+        if nkv is not None:
+            nk = nkv[0].to(torch.bfloat16).float()[None, :, None, :].expand(B, -1, -1, -1)
+            nv = nkv[1].to(torch.bfloat16).float()[None, :, None, :].expand(B, -1, -1, -1)
+            kf, vf = torch.cat((nk, kf), 2), torch.cat((nv, vf), 2)
+            bias = torch.nn.functional.pad(bias, (1, 0))
+        att = (qf @ kf.transpose(-1, -2) * scale + bias).softmax(-1)
+        return att @ vf
+    want = reference()
+    gw = torch.autograd.grad((want * probe).sum(), leaves + ([nkv] if null else []))
+    kb = None if km is None else torch.zeros(B, m, device=device).masked_fill(~km, -1e30)
+    got = ops.FlashAttnGenFn.apply(ops._rows_view(q), ops._rows_view(k), ops._rows_view(v), None if nkv is None else nkv[0],
+                                   None if nkv is None else nkv[1], kb, h, scale)
+    got = got.view(B, n, h, 64).transpose(1, 2)
+    gg = torch.autograd.grad((got.float() * probe).sum(), leaves + ([nkv] if null else []))
+    assert rel_err(got, want) < 8e-3, rel_err(got, want)
+    for a, b_ in zip(gg, gw):
+        assert rel_err(a, b_) < 2e-2, (a.shape, rel_err(a, b_))
+    if fused_qkv:       # the channel slices were read in place
+        assert ops._rows_view(q).data_ptr() == qkv.data_ptr()

@@ -1135,3 +1135,10 @@ def test_rmsnorm_with_fused_silu_matches_oracle():
 def test_maxpool_highfreq_kernels_vs_torch(shape):
     from helpers import check_maxpool_highfreq
     check_maxpool_highfreq(shape, 'cpu')
+
+
+@pytest.mark.parametrize('cfg', [(2, 2, 64, 64, False, False, True), (1, 2, 200, 77, False, True, False), (2, 1, 78, 78, True, True, False),
+                                 (1, 1, 130, 130, False, False, True)])
+def test_general_fused_attention_forward_backward_vs_autograd(cfg):
+    from helpers import check_general_attention
+    check_general_attention(cfg, 'cpu')

@@ -471,7 +471,9 @@ def test_halo_staged_conv3_with_per_image_weights_on_gpu(cfg):
 
 
 def test_multi_layer_modulation_launch_on_gpu():
-    """gg_modw_multi_fwd at config-2's generator shapes (batch 32): equals one gg_modw_fwd per layer bit for bit."""
+    """gg_modw_multi_fwd at config-2's generator shapes (batch 32) against one gg_modw_fwd per layer: coefficients to fp32 rounding
+    (the Gram-less path is the same code), per-sample weights to bf16 rounding (the batched launch builds them eight channels per
+    thread: the compiler contracts the fp32 products differently, a last-bit flip on rare elements)."""
     torch.manual_seed(0)
     b = 32
     shapes = [(512, 512, 'coef'), (512, 256, 'coef'), (256, 128, 'rows'), (64, 64, 'rows'), (32, 32, 'bank'), (16, 16, 'bank')]
@@ -493,10 +495,10 @@ def test_multi_layer_modulation_launch_on_gpu():
     torch.cuda.synchronize()
     for ly, o, w_ in zip(layers, outs, want):
         if torch.is_tensor(w_):
-            assert torch.equal(ly['wmix'], w_)
+            assert rel_err(ly['wmix'], w_) < 1e-3 and float((ly['wmix'] != w_).float().mean()) < 0.05
         else:
             s, a, d = w_
-            assert torch.equal(o['s'], s) and torch.equal(o['a'], a) and torch.equal(o['d'], d)
+            assert torch.equal(o['s'], s) and torch.allclose(o['a'], a, rtol=1e-6, atol=1e-7) and torch.allclose(o['d'], d, rtol=2e-6, atol=1e-7)
             assert torch.allclose(o['insc'], (a[:, :, None] * s[:, None, :]).reshape(b, -1), rtol=1e-6, atol=1e-7)
 
 
@@ -529,3 +531,13 @@ def test_nine_tap_weight_gradient_vs_implicit_gemm_and_cpu(cfg):
 def test_fused_adaptive_conv_coefficients_match_tensor_algebra(cfg):
     from helpers import check_modcoef
     check_modcoef(cfg, dev())
+
+
+@pytest.mark.parametrize('cfg', [(16, 8, 256, 256, False, False, True), (16, 8, 64, 64, False, False, True), (16, 8, 1024, 77, False, True, False),
+                                 (16, 8, 78, 78, True, True, False), (3, 2, 130, 50, True, False, False)])
+def test_general_fused_attention_on_gpu(cfg):
+    """gg_attn_gen_* at the shapes configs 4 / 5 run: the unet's Attend at 16x16 and 8x8 (8 heads of 64 on slices of to_qkv), the
+    generator's cross attention at 32x32 over 77 masked text tokens, the text transformer's attention (78 tokens, null key, mask),
+    and a ragged case - forward and backward against fp32 autograd."""
+    from helpers import check_general_attention
+    check_general_attention(cfg, dev())
