@@ -56,6 +56,7 @@ def materialise(d, dev):
     else:
         celems = (d.batch - 1) * d.c_batch_stride + d.M * d.ldc
     d.C_out = buf(celems, f32 if d.c_is_f32 else bf)
+    d._out_tensor = keep[-1]
     if d.bias:
         d.bias = buf(d.N, f32)
     if d.out_scale:
@@ -66,6 +67,16 @@ def materialise(d, dev):
     if d.residual:
         d.residual = buf(d.M * d.ldr, bf)
     return keep
+
+
+def output_of(L, d, ws):
+    """run the plan once and return a copy of what it wrote (the whole C_out allocation)."""
+    stream = torch.cuda.current_stream().cuda_stream
+    rc = L.lib.gg_gemm_bf16(C.byref(d), ws.data_ptr(), ws.numel(), stream)
+    if rc:
+        return None
+    torch.cuda.synchronize()
+    return d._out_tensor.clone()
 
 
 def time_plan(L, d, ws, iters=3):
@@ -133,11 +144,33 @@ def main():
             continue
         planned_total += t_plan * count
         best = (t_plan, tile.value, sk.value)
+        # numerics yardstick: the 4-wave kernel, unsplit (every candidate - and the planner's own choice - must reproduce it:
+        # a fast plan that computes something else does not enter the table)
+        d.force_tile, d.force_splitk = (3 if d.N <= 32 else (2 if d.N <= 64 else 1)), 1
+        d._out_tensor.zero_()
+        ref_out = output_of(L, d, ws)
+        d.force_tile = d.force_splitk = 0
+        tol = 1e-4 if d.c_is_f32 else 2e-2
+
+        def agrees(what):
+            if ref_out is None:
+                return True
+            d._out_tensor.zero_()
+            out = output_of(L, d, ws)
+            if out is None:
+                return False
+            err = float((out.float() - ref_out.float()).norm() / ref_out.float().norm().clamp(min=1e-12))
+            if not (err < tol):
+                print(f'!! WRONG RESULT {what}: rel err {err:.3g} for M={d.M} N={d.N} K={d.K} lay={d.a_layout}{d.b_layout} conv={d.a_conv} '
+                      f'H={d.H} C={d.C} CV={d.CV} R={d.R} s={d.conv_stride} f32={d.c_is_f32} d2s={d.d2s}', flush=True)
+                return False
+            return True
+        agrees(f'planner choice {(tile.value, sk.value)}')
         if t_plan >= args.min_us:
             ktiles = (d.K + 31) // 32
             for ft in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
                 seen = set()
-                for fs in ladder:
+                for fs in (ladder if ft not in (7, 8) else [1, 2, 3, 4, 6, 8, 12, 16]):       # (gg_conv3 splits over 64-channel chunks)
                     if fs > ktiles:
                         break
                     d.force_tile, d.force_splitk = ft, fs
@@ -146,10 +179,10 @@ def main():
                         continue
                     seen.add(s2.value)
                     t = time_plan(L, d, ws)
-                    if t is not None and t < best[0]:
+                    if t is not None and t < best[0] and agrees(f'forced {(ft, s2.value)}'):
                         best = (t, ft, s2.value)
-                    if ft in (7, 8, 9):
-                        break               # the halo-staged and direct convolutions do not split K
+                    if ft == 9:
+                        break               # the direct convolution does not split K
                     if t is not None and t > 3 * best[0] and fs >= 8:
                         break                   # far off already: deeper splits only add reduction traffic
         d.force_tile = d.force_splitk = 0

