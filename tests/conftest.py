@@ -14,6 +14,18 @@ HIP_LIB = ROOT / 'gigagan_pytorch_amd' / 'libgigagan_amd.so'
 REFERENCE = Path('/root/reference')
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """the CPU suite (`-m "not gpu"`) runs the kernels on the host-side emulator: ~75 CPU-minutes serially. When nobody asked for
+    a worker count, spread it over the cores with pytest-xdist (installed in the image): ~12 minutes on 8 cores. GPU runs (`-m gpu`)
+    stay in one process - one GPU, and the driver watches which libraries THAT process maps. GG_TEST_SERIAL=1 switches this off."""
+    if os.environ.get('GG_TEST_SERIAL') or 'not gpu' not in (getattr(config.option, 'markexpr', '') or ''):
+        return None
+    if getattr(config.option, 'numprocesses', 'absent') is None and config.pluginmanager.hasplugin('xdist'):
+        config.option.numprocesses = max(1, min(8, os.cpu_count() or 1))
+    return None
+
+
 def pytest_configure(config):
     if os.environ.get('GG_TEST_POISON'):    # torch.empty() returns NaN-filled memory: reads of never-written elements surface
         torch.use_deterministic_algorithms(True, warn_only=True)
