@@ -4,6 +4,7 @@
 #include "gg_gemm.h"
 #include "gg_gemm2.h"
 #include "gg_conv3.h"
+#include "gg_lrconv.h"
 #include "gg_wgrad9.h"
 #include "gg_elementwise.h"
 #include "gg_modconv.h"
@@ -254,6 +255,8 @@ static bool gg_conv3_eligible(const gg_gemm_desc* d);
 static GemmPlan gg_conv3_plan(const gg_gemm_desc* d, int tile, int splitk);
 static bool gg_wgrad9_eligible(const gg_gemm_desc* d);
 static GemmPlan gg_wgrad9_plan(const gg_gemm_desc* d, int splitk);
+static bool gg_lrconv_eligible(const gg_gemm_desc* d);
+static GemmPlan gg_lrconv_plan(const gg_gemm_desc* d, int splitk);
 
 // ---- tuning cache: measured-best (tile, split-K) per exact geometry (gg_gemm_plan_table) ----------------------------------
 struct GgPlanChoice { int tile, splitk; };
@@ -281,7 +284,7 @@ static bool gg_table_plan(const gg_gemm_desc* d, GemmPlan& pl) {
         pl.splitk = 1; pl.k_per_split = d->K; pl.blocks_mn = d->M / pl.bm;
         return true;
     }
-    if (tile == 7 || tile == 8) {
+    if (tile == 7 || tile == 8 || tile == 12) {
         if (!gg_conv3_eligible(d)) return false;
         pl = gg_conv3_plan(d, tile, it->second.splitk);
         return true;
@@ -289,6 +292,11 @@ static bool gg_table_plan(const gg_gemm_desc* d, GemmPlan& pl) {
     if (tile == 10) {
         if (!gg_wgrad9_eligible(d)) return false;
         pl = gg_wgrad9_plan(d, it->second.splitk);
+        return true;
+    }
+    if (tile == 11) {
+        if (!gg_lrconv_eligible(d)) return false;
+        pl = gg_lrconv_plan(d, it->second.splitk);
         return true;
     }
     if (tile < 1 || tile > 6) return false;
@@ -339,23 +347,24 @@ static bool gg_conv3_eligible(const gg_gemm_desc* d) {
     return true;
 }
 
-// tile 7: 256 x 256, tile 8: 256 x 128. splitk <= 0: chosen by the cost form of gg_plan_cost (rounds of 256 resident workgroups x
+// tile 7: 256 x 256, tile 8: 256 x 128 (one 64-column tile when N <= 64), tile 12: 256 x 64 (layers whose 128-column grid would leave
+// CUs idle: the generator's per-image-weight convolutions at 32x32). splitk <= 0: chosen by the cost form of gg_plan_cost (rounds of 256 resident workgroups x
 // taps of the slice + the fp32 partial round trip); per-tap times from the round-2 layer measurements (1200 / 1100 TFLOP/s).
 static double gg_conv3_cost(const gg_gemm_desc* d, int tile, int sk, int* per_out) {
-    const int bn = tile == 7 ? 256 : 128;
+    const int bn = tile == 7 ? 256 : (tile == 12 ? 64 : 128);
     const long long blocks = (long long)((d->M + 255) / 256) * ((d->N + bn - 1) / bn);
     const int nchunks = d->CV / 64;
     const int per = (nchunks + sk - 1) / sk;
     if (per_out) *per_out = per;
     const long long rounds = (blocks * sk + 255) / 256;
-    double t = (double)rounds * (per * 9 * (tile == 7 ? 1.8 : 1.0) + 4.0);
+    double t = (double)rounds * (per * 9 * (tile == 7 ? 1.8 : (tile == 12 ? 0.65 : 1.0)) + 4.0);
     if (sk > 1) t += 3.0 + (double)d->M * d->N * 4.0 * (sk + 1) / 4.0e6;
     return t;
 }
 
 static GemmPlan gg_conv3_plan(const gg_gemm_desc* d, int tile, int splitk) {
     GemmPlan pl;
-    pl.tile = tile; pl.bm = 256; pl.bn = tile == 7 ? 256 : 128;
+    pl.tile = tile; pl.bm = 256; pl.bn = tile == 7 ? 256 : (tile == 12 ? 64 : 128);
     pl.blocks_mn = (long long)((d->M + 255) / 256) * ((d->N + pl.bn - 1) / pl.bn);
     const int nchunks = d->CV / 64;
     // SCALED: the scale values of (images of a tile) x (channels of a k-slice) live in LDS (GG_C3_SC_FLOATS)
@@ -440,6 +449,50 @@ static GemmPlan gg_wgrad9_plan(const gg_gemm_desc* d, int splitk) {
     return pl;
 }
 
+// the low-resolution 3x3 convolution (gg_lrconv.h, plan tile 11): 4x4 / 8x8 / 16x16 images, 32-channel-multiple inputs, a plain or
+// stacked (CV = N * C, scaled) weight bank; workgroups of 256 pixels (whole images) x 64 output channels x a channel slice, every
+// chunk of 32 channels carrying all nine taps. Chosen by force_tile 11 or a plan-table entry (tests/gpu_modconv_layers.py measures
+// it against the halo-staged kernel and the implicit GEMM on the generator's low-resolution adaptive convolutions).
+static int gg_lrconv_scale_floats(const gg_gemm_desc* d) { return d->W == 4 ? 4096 : 2048; }
+
+static bool gg_lrconv_eligible(const gg_gemm_desc* d) {
+    if (!d->a_conv || d->a_layout != GG_ROWK || d->b_layout != GG_ROWK) return false;
+    if (d->R != 3 || d->S != 3 || d->conv_stride != 1 || d->conv_pad != 1) return false;
+    if ((d->C & 31) || d->CV % d->C || d->K != 9 * d->CV || (d->ldb & 7)) return false;
+    if (d->CV != d->C && !d->in_scale) return false;
+    if (d->batch != 1 || d->d2s || d->b_image_stride) return false;
+    if (d->H != d->W || !(d->W == 4 || d->W == 8 || d->W == 16)) return false;
+    if (d->M % (d->H * d->W)) return false;
+    if (gg_a_bytes(d) >= (1ll << 32) || gg_b_bytes(d) >= (1ll << 32)) return false;
+    return true;
+}
+
+static GemmPlan gg_lrconv_plan(const gg_gemm_desc* d, int splitk) {
+    GemmPlan pl;
+    pl.tile = 11; pl.bm = GG_LR_BM; pl.bn = GG_LR_BN;
+    pl.blocks_mn = (long long)((d->M + GG_LR_BM - 1) / GG_LR_BM) * ((d->N + GG_LR_BN - 1) / GG_LR_BN);
+    const int nchunks = d->CV / GG_LR_KC;
+    // the scale values of (images of a tile) x (channels of a slice) live in LDS
+    const int hw = d->H * d->W, ti = GG_LR_BM / hw;
+    int min_sk = 1;
+    if (d->in_scale) {
+        const int max_per = gg_lrconv_scale_floats(d) / (ti * GG_LR_KC);
+        min_sk = (nchunks + max_per - 1) / max_per;
+    }
+    int sk = splitk;
+    if (sk <= 0) {      // fill the chip once (256 workgroups), at most 16 slices (the vectorised finish)
+        sk = (int)((256 + pl.blocks_mn - 1) / pl.blocks_mn);
+        if (sk > 16) sk = 16;
+        if (sk > 8 && sk < 16) sk = 8;
+    }
+    if (sk < min_sk) sk = min_sk;
+    if (sk > nchunks) sk = nchunks;
+    const int per = (nchunks + sk - 1) / sk;
+    pl.splitk = (nchunks + per - 1) / per;
+    pl.k_per_split = per * GG_LR_KC;       // CHANNELS per slice
+    return pl;
+}
+
 static GemmPlan gg_wgrad9_substitute(const gg_gemm_desc* d, const GemmPlan& pl) {
     if ((pl.tile != 4 && pl.tile != 5) || d->force_tile != 0 || d->force_splitk != 0 || !gg_wgrad9_policy() || !gg_wgrad9_eligible(d)) return pl;
     return gg_wgrad9_plan(d, 0);
@@ -457,8 +510,9 @@ static GemmPlan gg_conv3_substitute(const gg_gemm_desc* d, const GemmPlan& pl, b
     if (pl.tile < 1 || pl.tile > 6 || d->force_splitk != 0) return pl;
     GemmPlan best = pl;
     double best_t = gg_plan_cost(d, kTileModels[pl.tile - 1], pl.splitk, nullptr);
-    for (int tile = 7; tile <= 8; ++tile) {
+    for (int tile : {7, 8, 12}) {
         if (tile == 7 && d->N < 192) continue;
+        if (tile == 12 && (d->N <= 64 || d->N > 256)) continue;      // (N <= 64: tile 8 already runs the 64-column kernel)
         const GemmPlan c = gg_conv3_plan(d, tile, 0);
         const double t = gg_conv3_cost(d, tile, c.splitk, nullptr);
         if (t < best_t) { best_t = t; best = c; }
@@ -466,11 +520,21 @@ static GemmPlan gg_conv3_substitute(const gg_gemm_desc* d, const GemmPlan& pl, b
     return best;
 }
 
+// a stacked, scaled bank on 4x4 images (the generator's first adaptive convolutions): the low-resolution kernel with the modulation on
+// its halo store measured 30.7 us against 38.4 us for modulation pass + implicit GEMM + finish (profiles/r03_lowres_sweep.log); the
+// halo-staged kernel does not take 4-wide images, the implicit GEMM would apply the scale once per tap
+static bool gg_use_lrconv(const gg_gemm_desc* d) {
+    return d->force_tile == 0 && d->a_conv && d->in_scale && d->W == 4 && d->CV != d->C && gg_lrconv_eligible(d);
+}
+
 GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     GemmPlan pl;
-    if ((d->force_tile == 7 || d->force_tile == 8) && gg_conv3_eligible(d)) return gg_conv3_plan(d, d->force_tile, d->force_splitk);
+    if ((d->force_tile == 7 || d->force_tile == 8 || d->force_tile == 12) && gg_conv3_eligible(d))
+        return gg_conv3_plan(d, d->force_tile, d->force_splitk);
     if (d->force_tile == 10 && gg_wgrad9_eligible(d)) return gg_wgrad9_plan(d, d->force_splitk);
+    if (d->force_tile == 11 && gg_lrconv_eligible(d)) return gg_lrconv_plan(d, d->force_splitk);
     if (gg_table_plan(d, pl)) return gg_wgrad9_substitute(d, gg_conv3_substitute(d, pl, false));
+    if (gg_use_lrconv(d)) return gg_lrconv_plan(d, d->force_splitk);
     if (gg_use_dconv(d)) {
         pl.tile = 9; pl.bm = GG_DC_TH * GG_DC_TW; pl.bn = d->N <= 32 ? 32 : 64;
         pl.splitk = 1; pl.k_per_split = d->K; pl.blocks_mn = d->M / pl.bm;
@@ -587,7 +651,7 @@ extern "C" int gg_gemm_plan_table(const gg_plan_entry* entries, int32_t n) {
     g_plan_table.clear();
     for (int i = 0; i < n; ++i) {
         const gg_plan_entry& e = entries[i];
-        if (e.tile < 1 || e.tile > 10 || e.splitk < 1) return gg_fail(-2, "gg_gemm_plan_table: entry %d has tile %d split-K %d", i, e.tile, e.splitk);
+        if (e.tile < 1 || e.tile > 12 || e.splitk < 1) return gg_fail(-2, "gg_gemm_plan_table: entry %d has tile %d split-K %d", i, e.tile, e.splitk);
         g_plan_table[gg_plan_key(&e.M)] = GgPlanChoice{e.tile, e.splitk};
     }
     return 0;
@@ -671,7 +735,17 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
         else { if (wide) gg_launch_dconv<64, 2>(p, s); else gg_launch_dconv<64, 1>(p, s); }
     }
     else if (pl.tile == 10) GG_LAUNCH(gg_wgrad9_kernel, grid2, dim3(GG2_NT), s, p);
-    else if (pl.tile == 7 || pl.tile == 8) {
+    else if (pl.tile == 11) {
+        const bool full = pl.splitk == 1 && (p.bias || p.out_scale || p.noise || p.residual || p.act != GG_ACT_NONE);
+        if (d->W == 4) {
+            if (full) GG_LAUNCH((gg_lrconv_kernel<57344, 4096, true>), grid2, dim3(GG_LR_NT), s, p);
+            else GG_LAUNCH((gg_lrconv_kernel<57344, 4096, false>), grid2, dim3(GG_LR_NT), s, p);
+        } else {
+            if (full) GG_LAUNCH((gg_lrconv_kernel<35840, 2048, true>), grid2, dim3(GG_LR_NT), s, p);
+            else GG_LAUNCH((gg_lrconv_kernel<35840, 2048, false>), grid2, dim3(GG_LR_NT), s, p);
+        }
+    }
+    else if (pl.tile == 7 || pl.tile == 8 || pl.tile == 12) {
         // (a split launch writes fp32 partials: its epilogue runs in the reduce pass, so it takes the plain instantiation)
         const bool full = pl.splitk == 1 && (p.bias || p.out_scale || p.noise || p.residual || p.act != GG_ACT_NONE);
         const bool scaled = p.in_scale != nullptr;
@@ -686,6 +760,7 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
             }                                                                                                   \
         } while (0)
         if (pl.tile == 7) GG_C3(256, 2, 4);
+        else if (pl.tile == 12 || d->N <= 64) GG_C3(64, 8, 1);        // 64-column tiles: all eight waves along the pixels
         else GG_C3(128, 4, 2);
 #undef GG_C3
     }
@@ -702,7 +777,7 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
         long long nb = pl.splitk <= 8 ? (total + 255) / 256 : (total + 63) / 64;
         if (nb > 8192) nb = 8192;
         // 2..8 slices of a 4-column-aligned plain [m][n] result: the vectorised finish (all slice loads in flight)
-        const bool vec = pl.splitk <= 8 && !(d->N & 3) && !d->d2s && !(d->ldc & 3) && !(d->c_batch_stride & 3) &&
+        const bool vec = (pl.splitk <= 8 || pl.splitk == 16) && !(d->N & 3) && !d->d2s && !(d->ldc & 3) && !(d->c_batch_stride & 3) &&
                          !(((uintptr_t)d->C_out) & 15) && !(((uintptr_t)workspace) & 15);
         if (vec) {
             long long nb4 = (total / 4 + 255) / 256;
@@ -715,7 +790,8 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
                 case 5: GG_LAUNCH((gg_splitk_reduce4_kernel<5>), g4, blk, s, p); break;
                 case 6: GG_LAUNCH((gg_splitk_reduce4_kernel<6>), g4, blk, s, p); break;
                 case 7: GG_LAUNCH((gg_splitk_reduce4_kernel<7>), g4, blk, s, p); break;
-                default: GG_LAUNCH((gg_splitk_reduce4_kernel<8>), g4, blk, s, p); break;
+                case 8: GG_LAUNCH((gg_splitk_reduce4_kernel<8>), g4, blk, s, p); break;
+                default: GG_LAUNCH((gg_splitk_reduce4_kernel<16>), g4, blk, s, p); break;
             }
         } else {
             GG_LAUNCH(gg_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), s, p);
@@ -1250,7 +1326,8 @@ extern "C" int gg_sconv_fwd(const void* x, const void* w, int64_t w_bs, void* y,
     p.b = b; p.H = H; p.W = W; p.O = O; p.act = act; p.slope = slope;
     // work item of a wavefront: a 32-pixel-wide strip of `rows` rows (+ one halo row above and below: 2 / rows extra reads);
     // a workgroup = 4 wavefronts inside one image sharing that image's filter bank in LDS
-    const int rows = ((long long)b * H * W >= (2 << 20)) ? 16 : 8;
+    int rows = ((long long)b * H * W >= (2 << 20)) ? 16 : 8;
+    if (const char* e = getenv("GG_SCONV_ROWS")) { const int v = atoi(e); if (v >= 4 && v <= 64 && !(v & 3)) rows = v; }   // sweep aid
     const int items = (W >> 5) * ((H + rows - 1) / rows);
     int ipw = 1;
     while ((long long)b * ((items + 4 * ipw - 1) / (4 * ipw)) > 2048) ++ipw;

@@ -151,7 +151,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_conv3_kernel(GgGemmParams p) {
     unsigned bvoff[BNV];
 #pragma unroll
     for (int i = 0; i < BNV; ++i) {
-        const int row = gg2d_row<BN>(i), kc = gg2d_chunk(i);
+        const int row = gg2d_row<BN>(i), kc = gg2d_chunk<BN>(i);
         bvoff[i] = (n0 + row < p.N) ? (unsigned)(((long long)row * p.ldb + kc * 8) * 2) : 0xFFFFFFFFu;
     }
     // per-image weight operand (the adaptive conv's per-sample weights): a tile lies inside one image then (TI == 1, host)

@@ -670,12 +670,16 @@ template <int ROWS>
 struct Gg2Dma {
     static constexpr int NV = ROWS / 64;          // DMA instructions per thread and k-tile (8 rows x 128 bytes per wave each)
     static constexpr int BYTES = ROWS * 128;
-    static_assert(NV >= 2 && (NV & 1) == 0, "row -> slot shortcut below assumes an even count");
+    static_assert(NV >= 1, "at least eight rows per wave");
 };
 
 // the thread's i-th DMA vector: row 8 * (wave * NV + i) + lane / 8 of the tile, LDS slot lane % 8
 template <int ROWS>
 GG_DEVICE int gg2d_row(int i) { return 8 * ((threadIdx.x >> 6) * Gg2Dma<ROWS>::NV + i) + ((threadIdx.x & 63) >> 3); }
-// ... which holds chunk slot ^ ((row >> 1) & 7) = (lane % 8) ^ (lane / 16) ^ (4 if i is odd)
-GG_DEVICE int gg2d_chunk(int i) { return (int)((threadIdx.x & 7) ^ ((threadIdx.x & 63) >> 4) ^ ((i & 1) << 2)); }
+// ... which holds chunk slot ^ ((row >> 1) & 7) = (lane % 8) ^ (lane / 16) ^ (4 if the 8-row group wave * NV + i is odd)
+template <int ROWS>
+GG_DEVICE int gg2d_chunk(int i) {
+    const int grp = (int)(threadIdx.x >> 6) * Gg2Dma<ROWS>::NV + i;
+    return (int)((threadIdx.x & 7) ^ ((threadIdx.x & 63) >> 4) ^ ((grp & 1) << 2));
+}
 

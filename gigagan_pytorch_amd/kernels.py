@@ -96,8 +96,10 @@ def _kernel_key(d: GemmDesc, L) -> str:
         name = f'gg_dconv_kernel<C={d.C},TN={1 if d.N <= 32 else 2}>'
     elif tile.value == 10:
         name = 'gg_wgrad9_kernel'
-    elif tile.value in (7, 8):
-        name = f'gg_conv3_kernel<{256 if tile.value == 7 else 128}>'
+    elif tile.value == 11:
+        name = 'gg_lrconv_kernel'
+    elif tile.value in (7, 8, 12):
+        name = f'gg_conv3_kernel<{256 if tile.value == 7 else (64 if tile.value == 12 or d.N <= 64 else 128)}>'
     elif tile.value >= 4:
         bm, bn = {4: (256, 256), 5: (256, 128), 6: (128, 128)}[tile.value]
         name = (f'gg_gemm2_kernel<{bm},{bn},2,4,A_KROW={int(d.a_layout == KROW)},B_KROW={int(d.b_layout == KROW)},'

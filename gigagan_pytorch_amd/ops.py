@@ -1383,14 +1383,15 @@ class HipOps:
                 wk = _table_pack(weights, 'modk')
             if wk is None:
                 wk = wd.permute(1, 3, 4, 0, 2).reshape(O, k * k * N * I).to(ACT_DTYPE).contiguous()
-            if W >= 8 and H * W >= 64 and I % 64 == 0 and _BANK_IN_SCALE:
+            if ((W >= 8 and H * W >= 64) or (H == 4 and W == 4)) and I % 64 == 0 and _BANK_IN_SCALE:
                 # the per-(sample, stacked channel) scale a_n * s_i rides on the convolution's operand staging (gg_conv3 SCALED: applied
-                # once per staged 64-channel halo chunk, shared by the nine taps): no modulated copy of the activation is written
+                # once per staged 64-channel halo chunk, shared by the nine taps; 4x4 images: gg_lrconv, plan tile 11): no modulated
+                # copy of the activation is written
                 if insc is None:
                     insc = (a[:, :, None] * s[:, None, :]).reshape(b, N * Ip).contiguous()
                 y = K.conv2d_nhwc(nhwc(x), wk, ksize=k, cv=N * Ip, in_scale=insc, out_scale=d if demod else None, noise=nz,
                                   noise_w=nw, act=act, act_slope=LRELU_SLOPE)
-            else:   # 4x4 images: the N-fold pre-modulated activation is 0.5 MB; one pointwise pass + the plain gather
+            else:   # other shapes: the N-fold pre-modulated activation through one pointwise pass + the plain gather
                 x2 = K.modulate_bank(nhwc(x), s, a)
                 y = K.conv2d_nhwc(x2, wk, ksize=k, out_scale=d if demod else None, noise=nz, noise_w=nw, act=act,
                                   act_slope=LRELU_SLOPE)

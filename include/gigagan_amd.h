@@ -73,7 +73,9 @@ typedef struct gg_gemm_desc {
     int32_t force_tile;   /* 0 = heuristic; 1: 128x128, 2: 128x64, 3: 128x32 (4 waves); 4: 256x256, 5: 256x128, 6: 128x128 (8 waves);
                            * 7: halo-staged 3x3 convolution (stride 1, pad 1, C %% 64 == 0, H and W powers of two, 8 <= W <= 64);
                            * 10: nine-tap 3x3 weight gradient (reduction-major operands, stride 1, pad 1, C %% 32 == 0, 8 <= W <= 64);
-                           * 9: direct 3x3 convolution (C in {16,32,64}, N <= 64, W %% 32 == 0, H %% 8 == 0), else heuristic */
+                           * 9: direct 3x3 convolution (C in {16,32,64}, N <= 64, W %% 32 == 0, H %% 8 == 0);
+                           * 11: low-resolution 3x3 convolution (stride 1, pad 1, C %% 32 == 0, 4x4 / 8x8 / 16x16 images: the first
+                           *     adaptive convolutions of Generator.forward, gp.py:1184-1245), else heuristic */
     int32_t conv_stride;  /* >= 1 */
     int32_t conv_pad;     /* >= 0 */
     float bias_scale;     /* multiplies bias (set 1.0f) */

@@ -21,6 +21,8 @@ def pytest_cmdline_main(config):
     stay in one process - one GPU, and the driver watches which libraries THAT process maps. GG_TEST_SERIAL=1 switches this off."""
     if os.environ.get('GG_TEST_SERIAL') or 'not gpu' not in (getattr(config.option, 'markexpr', '') or ''):
         return None
+    if os.environ.get('PYTEST_XDIST_WORKER') or hasattr(config, 'workerinput'):     # already a worker: never spawn workers of its own
+        return None
     if getattr(config.option, 'numprocesses', 'absent') is None and config.pluginmanager.hasplugin('xdist'):
         config.option.numprocesses = max(1, min(8, os.cpu_count() or 1))
     return None
@@ -31,6 +33,11 @@ def pytest_configure(config):
         torch.use_deterministic_algorithms(True, warn_only=True)
         torch.utils.deterministic.fill_uninitialized_memory = True
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # stale native artefacts are rebuilt ONCE, by the controlling process, before any xdist worker starts (eight workers each
+    # running hipcc into the same .so would race); workers find them fresh
+    gpu_only = (getattr(config.option, 'markexpr', '') or '').strip() == 'gpu'       # the GPU box runs the prebuilt library
+    if not gpu_only and not (os.environ.get('PYTEST_XDIST_WORKER') or hasattr(config, 'workerinput')):
+        _ensure_built()
 
 
 _built = False
@@ -39,7 +46,7 @@ _built = False
 def _ensure_built():
     """(re)build stale native artefacts once per session where a compiler exists (mtime-aware)."""
     global _built
-    if _built:
+    if _built or os.environ.get('PYTEST_XDIST_WORKER'):
         return
     _built = True
     import shutil

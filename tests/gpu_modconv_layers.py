@@ -75,7 +75,10 @@ def try_variant(name, fn, ref, results, flops):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--json', default=str(ROOT / 'gpurun_out' / 'modconv_layers.json'))
+    ap.add_argument('--only', default='', help='comma-separated paths to run (bank, pimg, sconv); default: all')
+    ap.add_argument('--quick', action='store_true', help='bank layers: reference + low-resolution kernel variants only')
     args = ap.parse_args()
+    only = set(filter(None, args.only.split(',')))
     torch.manual_seed(0)
     report = {}
     seen = set()
@@ -90,6 +93,8 @@ def main():
         mod, kmod = torch.randn(B, I, device=DEV) * 0.3, torch.randn(B, N, device=DEV)
         nz, nw = torch.randn(B * R * R, device=DEV), torch.randn(O, device=DEV) * 0.1
         path = ops.HipOps._modconv_path(B, N, O, I, R, R)
+        if only and path not in only:
+            continue
         res = []
         if path == 'bank':
             s, a, d = K.modw_fwd(w, mod, kmod, True, 1e-8, I, O)
@@ -100,9 +105,15 @@ def main():
                               lambda: K.conv2d_nhwc(K.modulate_bank(x, s, a), wk, ksize=3, **epi), None, res, flops)
             try_variant('old: conv only (planner), pre-modulated input', (lambda x2: (lambda: K.conv2d_nhwc(x2, wk, ksize=3, **epi)))(
                 K.modulate_bank(x, s, a)), ref, res, flops)
-            if R >= 8:
+            for sk in (2, 4, 8, 16):
+                try_variant(f'lowres tile 11 sk {sk}',
+                            (lambda k: (lambda: K.conv2d_nhwc(x, wk, ksize=3, cv=N * I, in_scale=insc, force_tile=11, force_splitk=k,
+                                                             **epi)))(sk), ref, res, flops)
+            if args.quick:
+                pass
+            elif R >= 8:
                 try_variant('insc (planner)', lambda: K.conv2d_nhwc(x, wk, ksize=3, cv=N * I, in_scale=insc, **epi), ref, res, flops)
-                for tile in (7, 8, 4, 5, 6):
+                for tile in (7, 8, 12, 4, 5, 6):
                     for sk in ((1, 2, 4, 8, 16, 32) if tile >= 7 else (0,)):
                         if tile == 7 and O < 192:
                             continue
@@ -120,7 +131,7 @@ def main():
             K.modw_fwd(w, mod, kmod, True, 1e-8, I, O, coef=False, wmix=wm, layout=1)
             epi = dict(noise=nz, noise_w=nw, act='lrelu')
             ref = try_variant('pimg (planner)', lambda: K.conv2d_nhwc(x, wm, ksize=3, per_image_weights=True, **epi), None, res, flops)
-            for tile in (7, 8, 5, 6):
+            for tile in (7, 8, 12, 5, 6):
                 for sk in ((1, 2, 4) if tile >= 7 else (0,)):
                     if tile == 7 and O < 192:
                         continue
@@ -151,6 +162,10 @@ def main():
         for r in res:
             print('      ', r, flush=True)
         del x, w
+    if only:
+        Path(args.json).parent.mkdir(exist_ok=True)
+        Path(args.json).write_text(json.dumps(report, indent=1))
+        return
     # the batched modulation launch over the non-excited layers vs one launch per layer
     layers, keep = [], []
     for I, O, R, excited in LAYERS:

@@ -538,7 +538,7 @@ def test_direct_conv_matches_implicit_gemm(cfg):
 
 
 @pytest.mark.parametrize('cfg', [(1, 16, 16, 64, 256, 7), (5, 8, 8, 128, 264, 7), (1, 8, 32, 64, 128, 8), (3, 16, 8, 64, 136, 8),
-                                 (1, 64, 64, 64, 128, 7)])
+                                 (1, 64, 64, 64, 128, 7), (2, 16, 16, 128, 64, 8), (5, 8, 8, 64, 40, 8)])
 def test_halo_staged_conv3_matches_fp32_convolution(cfg):
     """gg_conv3 (activation halo staged once per 64-channel chunk, nine taps read it at a tap-uniform offset, weight tiles by
     LDS-DMA into swizzled rows) against fp32 convolution of the same bf16 operands: whole-image tiles (H*W < 256, ragged
@@ -602,7 +602,37 @@ def test_halo_staged_conv3_applies_the_bank_modulation_on_its_operand_staging(cf
     assert rel_err(got, want) < 1e-5
 
 
-@pytest.mark.parametrize('cfg', [(3, 16, 16, 64, 128, 8, 1), (2, 32, 32, 128, 256, 7, 2), (2, 16, 32, 64, 72, 8, 0)])
+@pytest.mark.parametrize('cfg', [(19, 4, 4, 64, 1, 72, 2), (5, 8, 8, 32, 1, 64, 1), (3, 16, 16, 96, 1, 136, 3), (18, 4, 4, 32, 2, 64, 2),
+                                 (6, 8, 8, 64, 2, 40, 4), (2, 16, 16, 32, 3, 64, 0)])
+def test_low_resolution_conv_matches_fp32_convolution_and_the_modulated_bank(cfg):
+    """gg_lrconv (plan tile 11: 4x4 / 8x8 / 16x16 images, whole images per 256-pixel tile, 32-channel chunks carrying all nine taps,
+    partial image tiles and output-channel tiles, split over the channel chunks or not) == the fp32 convolution; with a stacked
+    bank (CV = N * C, per-(sample, stacked channel) scale on the halo store) == the convolution of the explicitly modulated
+    N-fold activation; the finish applies the adaptive conv's epilogue (demodulation, noise, leaky-relu)."""
+    n, H, W, ci, N, co, sk = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(n, H, W, ci)); w = bf(torch.randn(co, 9 * N * ci) * 0.1)
+    if N == 1:
+        want = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().view(co, 3, 3, ci).permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+        kw = {}
+    else:
+        insc = (torch.rand(n, N * ci) + 0.5)
+        x2 = bf(torch.cat([x.float() * insc[:, None, None, j * ci:(j + 1) * ci] for j in range(N)], dim=-1))
+        want = K.conv2d_nhwc(x2, w, ksize=3, out_dtype=torch.float32, force_tile=1)
+        kw = dict(cv=N * ci, in_scale=insc)
+    K.plan_log = []
+    got = K.conv2d_nhwc(x, w, ksize=3, out_dtype=torch.float32, force_tile=11, force_splitk=sk, **kw)
+    assert K.plan_log[-1][0] == 11 and (sk == 0 or K.plan_log[-1][1] == min(sk, N * ci // 32)), K.plan_log
+    K.plan_log = None
+    assert rel_err(got, want) < 1e-5
+    d = torch.rand(n, co) + 0.5; nz = torch.randn(n * H * W); nw = torch.randn(co)
+    got = K.conv2d_nhwc(x, w, ksize=3, out_scale=d, noise=nz, noise_w=nw, act='lrelu', force_tile=11, force_splitk=sk, **kw)
+    ref = F.leaky_relu(want * d[:, None, None, :] + nz.view(n, H, W, 1) * nw, 0.2)
+    assert rel_err(got, ref) < 4e-3
+
+
+@pytest.mark.parametrize('cfg', [(3, 16, 16, 64, 128, 8, 1), (2, 32, 32, 128, 256, 7, 2), (2, 16, 32, 64, 72, 8, 0), (2, 32, 32, 64, 64, 8, 1),
+                                 (2, 16, 16, 128, 48, 8, 2)])
 def test_halo_staged_conv3_with_per_image_weights(cfg):
     """per-sample weights (the reference's own formulation of the adaptive conv, gp.py:390-409): image i is convolved with w[i];
     row tiles lie inside one image (H * W >= 256)."""
@@ -669,7 +699,7 @@ def test_committed_plan_table_loads_and_is_honoured_by_the_planner():
     from gigagan_pytorch_amd import _C
     L = _C.lib()
     entries = json.loads(_C.PLAN_TABLE.read_text())['entries']
-    assert len(entries) > 50 and all(1 <= e['tile'] <= 10 and e['splitk'] >= 1 for e in entries)
+    assert len(entries) > 50 and all(1 <= e['tile'] <= 12 and e['splitk'] >= 1 for e in entries)
     try:
         L.load_plan_table(entries)
         assert L.plan_entries == len(entries)
@@ -727,27 +757,29 @@ def test_narrow_modconv_layers_take_the_streaming_convolution():
 
 def test_shared_bank_modconv_paths_match_oracle():
     """wide low-resolution no-grad adaptive conv (shared bank, the N kernels stacked along the reduction): from 8x8 up the
-    per-(sample, stacked channel) scale rides on the convolution's operand staging (in_scale, no modulated copy of the activation);
-    4x4 images keep one pointwise pass for both kernels of the bank + the plain gather. Demodulation / noise / activation in the
-    epilogue; both against the oracle."""
+    per-(sample, stacked channel) scale rides on the convolution's operand staging (in_scale, no modulated copy of the activation:
+    gg_conv3 SCALED from 8x8 up, the low-resolution kernel - plan tile 11 - on 4x4 images); odd sizes keep one pointwise pass for
+    both kernels of the bank + the plain gather. Demodulation / noise / activation in the epilogue; all against the oracle."""
     from gigagan_pytorch_amd.modules import AdaptiveConv2DMod
     torch.manual_seed(0)
     conv = AdaptiveConv2DMod(64, 72, 3, num_conv_kernels=2)
-    for res, want_calls in ((8, 0), (4, 1)):
+    for res, want_calls in ((8, 0), (4, 0), (2, 1)):
         x, mod, km = torch.randn(2, 64, res, res), torch.randn(2, 64) * 0.3, torch.randn(2, 2)
         nz, nw = torch.randn(2, 1, res, res), torch.randn(72, 1, 1) * 0.1
         calls, orig = [], K.modulate_bank
         K.desc_log = []
         try:
             K.modulate_bank = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+            K.plan_log = []
             with torch.no_grad():
                 y1 = conv(x, mod, km, noise=nz, noise_weight=nw, act='lrelu')
             assert len(calls) == want_calls, (res, calls)
+            assert res != 4 or K.plan_log[-1][0] == 11, K.plan_log
             from gigagan_pytorch_amd._C import GemmDesc
             d = GemmDesc.from_buffer_copy(K.desc_log[-1])
             assert bool(d.in_scale) == (want_calls == 0) and d.CV == (128 if want_calls == 0 else d.C)
         finally:
-            K.modulate_bank, K.desc_log = orig, None
+            K.modulate_bank, K.desc_log, K.plan_log = orig, None, None
         with torch.no_grad(), ops.use_impl(OracleOps(bf16_operands=True)):
             y0 = conv(x, mod, km, noise=nz, noise_weight=nw, act='lrelu')
         assert rel_err(y1, y0) < 1e-2, res
