@@ -101,6 +101,12 @@ int gg_validate_gemm(const gg_gemm_desc* d) {
         const int oh = (d->H + 2 * d->conv_pad - d->R) / d->conv_stride + 1, ow = (d->W + 2 * d->conv_pad - d->S) / d->conv_stride + 1;
         if ((oh * ow) % 128) return gg_fail(-10, "gg_gemm: b_image_stride needs OH*OW %% 128 == 0 (got %d)", oh * ow);
     }
+    if (d->bank_mix) {      // per-image mix of a stacked bank: only the low-resolution kernel does it (one image per 256-pixel tile)
+        const bool ok = d->a_conv && d->a_layout == GG_ROWK && d->b_layout == GG_ROWK && d->R == 3 && d->S == 3 && d->conv_stride == 1 &&
+                        d->conv_pad == 1 && d->H == 16 && d->W == 16 && !(d->C & 31) && d->CV == 2 * d->C && d->K == 9 * d->CV && d->in_scale &&
+                        d->batch == 1 && !d->d2s && !d->b_image_stride && d->M % 256 == 0 && d->force_tile == 0;
+        if (!ok) return gg_fail(-16, "gg_gemm: bank_mix needs a 3x3 / stride 1 / pad 1 convolution of 16x16 images over two stacked banks with in_scale [img][C]");
+    }
     if (d->ldb % 8) return gg_fail(-10, "gg_gemm: ldb must be a multiple of 8 (got %d)", d->ldb);
     {
         int need = d->b_layout == GG_ROWK ? d->K : d->N;
@@ -274,7 +280,7 @@ static std::string gg_plan_key_of(const gg_gemm_desc* d) {
 }
 
 static bool gg_table_plan(const gg_gemm_desc* d, GemmPlan& pl) {
-    if (g_plan_table.empty() || d->force_tile != 0 || d->force_splitk != 0 || d->b_image_stride) return false;
+    if (g_plan_table.empty() || d->force_tile != 0 || d->force_splitk != 0 || d->b_image_stride || d->bank_mix) return false;
     auto it = g_plan_table.find(gg_plan_key_of(d));
     if (it == g_plan_table.end()) return false;
     const int tile = it->second.tile;
@@ -462,6 +468,7 @@ static bool gg_lrconv_eligible(const gg_gemm_desc* d) {
     if (d->CV != d->C && !d->in_scale) return false;
     if (d->batch != 1 || d->d2s || d->b_image_stride) return false;
     if (d->H != d->W || !(d->W == 4 || d->W == 8 || d->W == 16)) return false;
+    if (d->bank_mix && (d->W != 16 || d->CV != 2 * d->C || !d->in_scale)) return false;      // per-image mix: one image per tile, two banks
     if (d->M % (d->H * d->W)) return false;
     if (gg_a_bytes(d) >= (1ll << 32) || gg_b_bytes(d) >= (1ll << 32)) return false;
     return true;
@@ -471,7 +478,7 @@ static GemmPlan gg_lrconv_plan(const gg_gemm_desc* d, int splitk) {
     GemmPlan pl;
     pl.tile = 11; pl.bm = GG_LR_BM; pl.bn = GG_LR_BN;
     pl.blocks_mn = (long long)((d->M + GG_LR_BM - 1) / GG_LR_BM) * ((d->N + GG_LR_BN - 1) / GG_LR_BN);
-    const int nchunks = d->CV / GG_LR_KC;
+    const int nchunks = (d->bank_mix ? d->C : d->CV) / GG_LR_KC;
     // the scale values of (images of a tile) x (channels of a slice) live in LDS
     const int hw = d->H * d->W, ti = GG_LR_BM / hw;
     int min_sk = 1;
@@ -529,6 +536,7 @@ static bool gg_use_lrconv(const gg_gemm_desc* d) {
 
 GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     GemmPlan pl;
+    if (d->bank_mix) return gg_lrconv_plan(d, d->force_splitk);        // (validated: only the low-resolution kernel mixes banks)
     if ((d->force_tile == 7 || d->force_tile == 8 || d->force_tile == 12) && gg_conv3_eligible(d))
         return gg_conv3_plan(d, d->force_tile, d->force_splitk);
     if (d->force_tile == 10 && gg_wgrad9_eligible(d)) return gg_wgrad9_plan(d, d->force_splitk);
@@ -711,6 +719,7 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     p.act = d->act; p.act_slope = d->act_slope;
     p.partial = (float*)workspace;
     p.b_img_stride = d->b_image_stride;
+    p.bank_mix = d->bank_mix;
     p.a_bytes = gg_a_bytes(d); p.b_bytes = gg_b_bytes(d);
     p.buf_ok = (p.a_bytes + (1ll << 24) < (1ll << 32) && p.b_bytes < (1ll << 32)) ? 31 : 0;
     p.krow_fast = d->a_conv && d->a_layout == GG_KROW && d->conv_stride == 1 && p.OH == d->H && p.OW == d->W && p.w_shift >= 0 &&
@@ -737,7 +746,10 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     else if (pl.tile == 10) GG_LAUNCH(gg_wgrad9_kernel, grid2, dim3(GG2_NT), s, p);
     else if (pl.tile == 11) {
         const bool full = pl.splitk == 1 && (p.bias || p.out_scale || p.noise || p.residual || p.act != GG_ACT_NONE);
-        if (d->W == 4) {
+        if (d->bank_mix) {
+            if (full) GG_LAUNCH((gg_lrconv_kernel<35840, 2048, true, 2>), grid2, dim3(GG_LR_NT), s, p);
+            else GG_LAUNCH((gg_lrconv_kernel<35840, 2048, false, 2>), grid2, dim3(GG_LR_NT), s, p);
+        } else if (d->W == 4) {
             if (full) GG_LAUNCH((gg_lrconv_kernel<57344, 4096, true>), grid2, dim3(GG_LR_NT), s, p);
             else GG_LAUNCH((gg_lrconv_kernel<57344, 4096, false>), grid2, dim3(GG_LR_NT), s, p);
         } else {
@@ -1326,8 +1338,10 @@ extern "C" int gg_sconv_fwd(const void* x, const void* w, int64_t w_bs, void* y,
     p.b = b; p.H = H; p.W = W; p.O = O; p.act = act; p.slope = slope;
     // work item of a wavefront: a 32-pixel-wide strip of `rows` rows (+ one halo row above and below: 2 / rows extra reads);
     // a workgroup = 4 wavefronts inside one image sharing that image's filter bank in LDS
-    int rows = ((long long)b * H * W >= (2 << 20)) ? 16 : 8;
-    if (const char* e = getenv("GG_SCONV_ROWS")) { const int v = atoi(e); if (v >= 4 && v <= 64 && !(v & 3)) rows = v; }   // sweep aid
+    // strip height by measurement at batch 32 (profiles/r03_sconv_rows.log; 8 / 16 / 32 rows): 64 -> 32 @128x128 49.5 / 46.5 / 68.1 us,
+    // 32 -> 32 @128x128 27.3 / 30.9 / 46.4, 32 -> 16 @256x256 58.4 / 56.6 / 51.9, 16 -> 16 @256x256 35.8 / 34.4 / 37.0
+    const bool big = (long long)b * H * W >= (2 << 20);
+    const int rows = C == 64 ? 16 : (C == 32 ? (big ? 32 : 8) : (big ? 16 : 8));
     const int items = (W >> 5) * ((H + rows - 1) / rows);
     int ipw = 1;
     while ((long long)b * ((items + 4 * ipw - 1) / (4 * ipw)) > 2048) ++ipw;

@@ -77,6 +77,7 @@ struct GgGemmParams {
     // HBM once and shared through that XCD's L2. 0: (tiles, 1, batch*splitk) grid.
     int xcd_slices;
     long long b_img_stride;    // conv forward only: > 0: image i's weights start at B + i * b_img_stride (per-sample weights)
+    const float* bank_mix;     // gg_lrconv MIX: [img][CV / C] per-image weights of the stacked banks (null: the banks stay stacked along k)
     // byte extents of the A / B operands as seen from their base pointers (buffer descriptors of the 8-wave kernel's ROWK loaders)
     long long a_bytes, b_bytes;
     int krow_fast;     // weight-gradient conv gather: stride-1 'same' windows, power-of-two image sides, no input scale

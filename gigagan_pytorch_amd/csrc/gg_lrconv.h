@@ -37,7 +37,11 @@ GG_HOST_DEVICE int gg_lr_image_bytes(int H, int W) {
     return (H + 2) * rsb + ((256 - ((2 * rsb) & 255)) & 255);
 }
 
-template <int HB, int SCF, bool FULL_EPI>
+// MIX > 0 (16x16 images: a tile is ONE image): the MIX banks of a stacked bank are combined per image while their weight blocks are
+// parked in LDS, w = sum_n bank_mix[img][n] * W_n (one fma per element in the staging registers), the activation carries the
+// style modulation s[img][i] alone and the reduction runs over the C physical channels - the adaptive conv's algorithmic flops
+// instead of MIX times that (the stacked form multiplies every bank separately).
+template <int HB, int SCF, bool FULL_EPI, int MIX = 0>
 GG_KERNEL GG_LAUNCH_BOUNDS(GG_LR_NT) void gg_lrconv_kernel(GgGemmParams p) {
     constexpr int BM = GG_LR_BM, BN = GG_LR_BN, KC = GG_LR_KC;
     constexpr int TM = 2, TN = 2;                      // four wavefronts stacked along the pixels: 64 pixels x 64 channels each
@@ -59,7 +63,9 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_LR_NT) void gg_lrconv_kernel(GgGemmParams p) {
     const int ks = wg / tiles_mn, tile = wg - ks * tiles_mn;
     const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int nchunks_all = p.CV / KC;
+    constexpr int NB = MIX > 0 ? MIX : 1;                // weight blocks fetched per chunk
+    const int KV = MIX > 0 ? p.C : p.CV;                 // length of the reduction's channel axis
+    const int nchunks_all = KV / KC;
     const int cps = p.splitk > 1 ? p.k_per_split / KC : nchunks_all;
     const int c_lo = ks * cps;
     const int c_hi = c_lo + cps < nchunks_all ? c_lo + cps : nchunks_all;
@@ -95,16 +101,21 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_LR_NT) void gg_lrconv_kernel(GgGemmParams p) {
     for (int i = 0; i < 9; ++i)
         bvoff[i] = n0 + wrow < p.N ? (unsigned)((((long long)wrow) * p.ldb + (long long)i * p.CV + piece * 8) * 2) : 0xFFFFFFFFu;
 
-    u16x8 hreg[4], wreg[9];
+    u16x8 hreg[4], wreg[NB][9];
     auto prefetch = [&](int c) {
         const int cv0 = c * KC;
-        const unsigned sa = (unsigned)((p.CV == p.C ? cv0 : cv0 % p.C) * 2);
+        const unsigned sa = (unsigned)((KV == p.C ? cv0 : cv0 % p.C) * 2);
         const unsigned sb = (unsigned)((((long long)n0) * p.ldb + cv0) * 2);
 #pragma unroll
         for (int i = 0; i < 4; ++i) hreg[i] = gg_buf_load16(bufA, hvoff[i], sa);
 #pragma unroll
-        for (int i = 0; i < 9; ++i) wreg[i] = gg_buf_load16(bufB, bvoff[i], sb);
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int i = 0; i < 9; ++i) wreg[n][i] = gg_buf_load16(bufB, bvoff[i], sb + (unsigned)(n * p.C * 2));
     };
+    float mixv[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) mixv[n] = 1.f;
     auto stash = [&](int c) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -121,7 +132,19 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_LR_NT) void gg_lrconv_kernel(GgGemmParams p) {
             *(u16x8*)(halo + hl[i]) = h;
         }
 #pragma unroll
-        for (int i = 0; i < 9; ++i) *(u16x8*)(wl + i * (BN * 64) + wbase) = wreg[i];
+        for (int i = 0; i < 9; ++i) {
+            u16x8 w = wreg[0][i];
+            if constexpr (MIX > 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = gg_bf2f(w[e]) * mixv[0];
+#pragma unroll
+                    for (int n = 1; n < NB; ++n) f += gg_bf2f(wreg[n][i][e]) * mixv[n];
+                    w[e] = gg_f2bf(f);
+                }
+            }
+            *(u16x8*)(wl + i * (BN * 64) + wbase) = w;
+        }
     };
 
     prefetch(c_lo);
@@ -132,8 +155,12 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_LR_NT) void gg_lrconv_kernel(GgGemmParams p) {
             for (int idx = tid; idx < TI * nsc; idx += GG_LR_NT) {
                 const int il = idx / nsc, j = idx - il * nsc;
                 const int img = img0 + il;
-                scl[idx] = img < n_img ? p.in_scale[(long long)img * p.CV + c_lo * KC + j] : 0.f;
+                scl[idx] = img < n_img ? p.in_scale[(long long)img * KV + c_lo * KC + j] : 0.f;
             }
+        if constexpr (MIX > 0) {        // one image per tile (host): its MIX bank weights, zero for a tile beyond the batch
+#pragma unroll
+            for (int n = 0; n < NB; ++n) mixv[n] = img0 < n_img ? p.bank_mix[(long long)img0 * MIX + n] : 0.f;
+        }
     }
     gg_sync();
 

@@ -119,6 +119,11 @@ class NativeComm:
 
     def destroy(self):
         if self.lib is not None:
+            # captured steps hold this communicator's collectives as graph nodes, and RCCL hangs clean-up work on a graph's
+            # destruction: a trainer that is only unreachable (parameters <-> reducer hooks form cycles) would have its graphs
+            # destroyed by a LATER garbage collection, after the communicator is gone. Collect first, then drain, then destroy.
+            import gc
+            gc.collect()
             torch.cuda.synchronize()
             self.lib.lib.gg_comm_destroy()
             self.lib = None

@@ -205,12 +205,14 @@ def _conv_out(size: int, ksize: int, stride: int, pad: int) -> int:
 def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, *, ksize: int, stride: int = 1, pad: int | None = None,
                 cv: int | None = None, in_scale=None, out_dtype=torch.bfloat16, alpha=1.0, bias=None, bias_scale=1.0,
                 act=None, act_slope=0.2, out_scale=None, noise=None, noise_w=None, residual=None, res_scale=1.0,
-                force_splitk=0, force_tile=0, per_image_weights=False):
+                force_splitk=0, force_tile=0, per_image_weights=False, bank_mix=None):
     """Convolution of an NHWC bf16 activation x (n, H, W, C) with weights w (Cout, ksize*ksize*CV) bf16 laid out
     [co][kh][kw][cv]; window stride `stride`, zero padding `pad` (default: 'same', ksize//2); returns
-    (n, OH, OW, Cout) = act(alpha*conv*out_scale + bias*bias_scale + noise) + residual*res_scale."""
+    (n, OH, OW, Cout) = act(alpha*conv*out_scale + bias*bias_scale + noise) + residual*res_scale. `bank_mix` (n, CV // C) fp32: the
+    banks stacked along cv are mixed per image while they are staged (w_img = sum_j bank_mix[img, j] * W_j) and `in_scale` is
+    (n, C) - 16x16 images, two banks (gg_lrconv MIX)."""
     L = _C.lib()
-    L.require(x, w, in_scale, bias, out_scale, noise, noise_w, residual)
+    L.require(x, w, in_scale, bias, out_scale, noise, noise_w, residual, bank_mix)
     assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_contiguous() and w.is_contiguous()
     n, H, Wd, Cc = x.shape
     cv = cv or Cc
@@ -233,9 +235,13 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, *, ksize: int, stride: int = 1
     d.H, d.W, d.C, d.CV, d.R, d.S = H, Wd, Cc, cv, ksize, ksize
     d.conv_stride, d.conv_pad = stride, pad
     if in_scale is not None:
-        assert in_scale.dtype == torch.float32 and in_scale.shape == (n, cv) and in_scale.is_contiguous()
+        assert in_scale.dtype == torch.float32 and in_scale.shape == (n, Cc if bank_mix is not None else cv) and in_scale.is_contiguous()
         d.in_scale = ptr(in_scale)
         keep.append(in_scale)
+    if bank_mix is not None:
+        assert bank_mix.dtype == torch.float32 and bank_mix.shape == (n, cv // Cc) and bank_mix.is_contiguous() and in_scale is not None
+        d.bank_mix = ptr(bank_mix)
+        keep.append(bank_mix)
     d.C_out, d.ldc, d.c_is_f32 = ptr(out), cout, int(out_dtype == torch.float32)
     d.force_splitk, d.force_tile = force_splitk, force_tile
     if residual is not None:

@@ -1383,7 +1383,13 @@ class HipOps:
                 wk = _table_pack(weights, 'modk')
             if wk is None:
                 wk = wd.permute(1, 3, 4, 0, 2).reshape(O, k * k * N * I).to(ACT_DTYPE).contiguous()
-            if ((W >= 8 and H * W >= 64) or (H == 4 and W == 4)) and I % 64 == 0 and _BANK_IN_SCALE:
+            if H == 16 and W == 16 and N == 2 and I % 32 == 0 and _BANK_IN_SCALE:
+                # a 256-pixel tile is ONE image here: the two kernels of the bank are mixed per image while their tiles are staged
+                # (gg_lrconv MIX: a_0 W_0 + a_1 W_1 in the staging registers) and the reduction runs over the I physical channels -
+                # the reference's per-sample kernel (gp.py:378-386) without writing it, and half the flops of the stacked form
+                y = K.conv2d_nhwc(nhwc(x), wk, ksize=k, cv=N * Ip, in_scale=s.contiguous(), bank_mix=a.contiguous(),
+                                  out_scale=d if demod else None, noise=nz, noise_w=nw, act=act, act_slope=LRELU_SLOPE)
+            elif ((W >= 8 and H * W >= 64) or (H == 4 and W == 4)) and I % 64 == 0 and _BANK_IN_SCALE:
                 # the per-(sample, stacked channel) scale a_n * s_i rides on the convolution's operand staging (gg_conv3 SCALED: applied
                 # once per staged 64-channel halo chunk, shared by the nine taps; 4x4 images: gg_lrconv, plan tile 11): no modulated
                 # copy of the activation is written

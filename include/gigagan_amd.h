@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 6
+#define GG_ABI_VERSION 7
 
 int gg_version(void);
 const char* gg_last_error(void);
@@ -84,6 +84,11 @@ typedef struct gg_gemm_desc {
     int64_t b_image_stride;  /* a_conv forward (GG_ROWK x GG_ROWK) only: > 0 = per-image weight operands, image i reads B + i * b_image_stride
                               * elements (the reference's per-sample weights of AdaptiveConv2DMod, gp.py:388-407); OH*OW must be a
                               * multiple of the row tile, which the planner guarantees (128 or 256 rows) or rejects */
+    const float* bank_mix;   /* optional fp32 [n_img][CV / C]: a kernel bank stacked along the reduction (weights [co][tap][n][ci], CV = n_banks * C)
+                              * is MIXED per image, w_img = sum_n bank_mix[img][n] * W_n, while its tiles are staged (AdaptiveConv2DMod's
+                              * softmax-weighted kernel sum, gp.py:378-386) and the contraction runs over the C physical channels:
+                              * algorithmic flops instead of n_banks times that. in_scale is then fp32 [n_img][C]. 16x16 images,
+                              * 2 banks, 3x3 / stride 1 / pad 1 (gg_lrconv, one image per 256-pixel tile); other shapes are rejected */
 } gg_gemm_desc;
 
 /* Per-device tuning cache (the only persistent native state besides the communicator): measured-best launch

@@ -105,6 +105,11 @@ def main():
                               lambda: K.conv2d_nhwc(K.modulate_bank(x, s, a), wk, ksize=3, **epi), None, res, flops)
             try_variant('old: conv only (planner), pre-modulated input', (lambda x2: (lambda: K.conv2d_nhwc(x2, wk, ksize=3, **epi)))(
                 K.modulate_bank(x, s, a)), ref, res, flops)
+            if R == 16:
+                for sk in (1, 2, 4):
+                    try_variant(f'lowres per-image bank mix sk {sk}',
+                                (lambda k: (lambda: K.conv2d_nhwc(x, wk, ksize=3, cv=N * I, in_scale=s, bank_mix=a, force_splitk=k,
+                                                                 **epi)))(sk), ref, res, flops)
             for sk in (2, 4, 8, 16):
                 try_variant(f'lowres tile 11 sk {sk}',
                             (lambda k: (lambda: K.conv2d_nhwc(x, wk, ksize=3, cv=N * I, in_scale=insc, force_tile=11, force_splitk=k,
@@ -162,7 +167,7 @@ def main():
         for r in res:
             print('      ', r, flush=True)
         del x, w
-    if only:
+    if only and 'modulation' not in only:
         Path(args.json).parent.mkdir(exist_ok=True)
         Path(args.json).write_text(json.dumps(report, indent=1))
         return

@@ -631,6 +631,33 @@ def test_low_resolution_conv_matches_fp32_convolution_and_the_modulated_bank(cfg
     assert rel_err(got, ref) < 4e-3
 
 
+@pytest.mark.parametrize('cfg', [(3, 64, 72, 0), (2, 96, 64, 3), (1, 32, 40, 1)])
+def test_low_resolution_conv_mixes_the_bank_per_image(cfg):
+    """gg_lrconv MIX (16x16 images, two stacked banks): w_img = a[img,0] W_0 + a[img,1] W_1 formed while the weight blocks are staged,
+    the activation scaled by s[img, i], the reduction over the C physical channels == the per-image convolution with the
+    reference's mixed kernel (gp.py:378-386), bf16-rounded where the kernel rounds; split and unsplit, full epilogue in the finish."""
+    n, ci, co, sk = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(n, 16, 16, ci)); w = bf(torch.randn(co, 9, 2, ci) * 0.1)
+    s = torch.rand(n, ci) + 0.5; a = torch.softmax(torch.randn(n, 2), dim=-1)
+    xs = bf(x.float() * s[:, None, None, :]).float()
+    wm = bf(w.float()[None, :, :, 0, :] * a[:, 0, None, None, None] + w.float()[None, :, :, 1, :] * a[:, 1, None, None, None]).float()
+    want = torch.stack([F.conv2d(xs[i:i + 1].permute(0, 3, 1, 2), wm[i].view(co, 3, 3, ci).permute(0, 3, 1, 2), padding=1)[0]
+                        for i in range(n)]).permute(0, 2, 3, 1)
+    K.plan_log = []
+    got = K.conv2d_nhwc(x, w.view(co, -1), ksize=3, cv=2 * ci, in_scale=s, bank_mix=a, out_dtype=torch.float32, force_splitk=sk)
+    assert K.plan_log[-1][0] == 11, K.plan_log
+    K.plan_log = None
+    assert rel_err(got, want) < 1e-5
+    d = torch.rand(n, co) + 0.5; nz = torch.randn(n * 256); nw = torch.randn(co)
+    got = K.conv2d_nhwc(x, w.view(co, -1), ksize=3, cv=2 * ci, in_scale=s, bank_mix=a, out_scale=d, noise=nz, noise_w=nw, act='lrelu',
+                        force_splitk=sk)
+    assert rel_err(got, F.leaky_relu(want * d[:, None, None, :] + nz.view(n, 16, 16, 1) * nw, 0.2)) < 4e-3
+    with pytest.raises(RuntimeError):       # other shapes are refused, not silently run unmixed
+        K.conv2d_nhwc(bf(torch.randn(2, 8, 8, 32)), bf(torch.randn(64, 9 * 64)), ksize=3, cv=64, in_scale=torch.ones(2, 32),
+                      bank_mix=torch.ones(2, 2) * 0.5)
+
+
 @pytest.mark.parametrize('cfg', [(3, 16, 16, 64, 128, 8, 1), (2, 32, 32, 128, 256, 7, 2), (2, 16, 32, 64, 72, 8, 0), (2, 32, 32, 64, 64, 8, 1),
                                  (2, 16, 16, 128, 48, 8, 2)])
 def test_halo_staged_conv3_with_per_image_weights(cfg):

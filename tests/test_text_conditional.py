@@ -250,3 +250,53 @@ def test_text_trainer_needs_clip_for_the_contrastive_loss(tmp_path):
 @pytest.mark.gpu
 def test_hip_text_trainer_steps(tmp_path):
     _text_trainer_steps(tmp_path, 'cuda')
+
+
+class _TextImagesTwoLengths:
+    """a loader whose token encodings change length from batch to batch (the reference accepts any (b, n, d))."""
+    batch_size = 2
+
+    def __init__(self, dev, lengths=(7, 7, 9, 9, 7, 7, 9, 9)):
+        self.dev, self.lengths = dev, lengths
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(0)
+        i = 0
+        while True:
+            n = self.lengths[i % len(self.lengths)]
+            i += 1
+            yield (torch.rand(2, 3, 16, 16, generator=g).to(self.dev),
+                   text_encodings(tokens=n, seed=int(torch.randint(99, (1,), generator=g))).to(self.dev))
+
+
+@pytest.mark.gpu
+def test_hip_graph_replay_follows_the_loader_when_encoding_lengths_change(tmp_path):
+    """a captured step reads the static buffers it was captured with, so the shapes of the staged batches are
+    part of the graph key (gigagan.py `_stage`; the reference draws any (b, n, d) encodings, gp.py:2269 / :2196). A loader that
+    switches between 7 and 9 tokens must capture one graph per staged signature (a 7-token graph replayed on a 9-token batch would
+    train on the previous batch's text), re-use them when a length comes back, and stage what the loader yielded."""
+    from gigagan_pytorch_amd import GigaGAN
+    te = dict(clip_dim_latent=TEXT_CLIP_DIM, **TEXT_ENC)
+    torch.manual_seed(0)
+    gan = GigaGAN(generator=dict(text_encoder=dict(te), **TEXT_G), discriminator=dict(text_encoder=dict(te), **TEXT_D),
+                  apply_gradient_penalty_every=0, generator_contrastive_loss_weight=0., device='cuda', use_hip_graphs=True,
+                  create_ema_generator_at_init=False, model_folder=str(tmp_path / 'm'), results_folder=str(tmp_path / 'r'))
+    # a step draws three loader batches (D: real pairs + the generator's conditioning, G: conditioning): 3 x 7 tokens, 3 x 9, ...
+    loader = _TextImagesTwoLengths('cuda', lengths=(7, 7, 7, 9, 9, 9))
+    it = iter(loader)
+
+    def graph_keys():
+        return {k for k, v in gan._graphs.items() if isinstance(v, tuple) and len(v) == 2 and not torch.is_tensor(v)}
+    counts = []
+    for step in range(4):
+        d, g = gan.train_step(it, 1)
+        vals = [float(v) for v in (*d, *g) if v is not None]
+        assert all(v == v and abs(v) < 1e9 for v in vals), vals
+        assert gan.use_hip_graphs, 'capture was refused'
+        counts.append(len(graph_keys()))
+        want = 7 if step % 2 == 0 else 9
+        assert gan._static_G_src[1].shape[1] == want, (step, gan._static_G_src[1].shape)
+    # steps 0 / 1 capture a D and a G graph each for their token count; steps 2 / 3 replay them
+    assert counts[1] == 2 * counts[0] and counts[2] == counts[1] and counts[3] == counts[1], counts
+    sigs = {k[-1] for k in graph_keys() if k[0] == 'D'}
+    assert len(sigs) == 2, sigs
