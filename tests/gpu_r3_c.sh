@@ -1,5 +1,5 @@
 #!/bin/bash
-# modulation-launch sample split sweep, then the default bench
+# (historical) modulation-launch sample split sweep - the GG_MODW_BC knob it drove was removed after this measurement (profiles/r03_modw_bc_sweep.log) - then the default bench
 mkdir -p gpurun_out
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp LIBC_FATAL_STDERR_=1
