@@ -127,6 +127,7 @@ class Generator(BaseGenerator):
                                               rgb_upsample]))
 
         self.style_to_conv_modulations = Linear(style_network_dim, sum(split_dims))
+        self.style_to_conv_modulations.out_f32 = True      # its column slices feed the fp32 coefficient kernels directly
         self.style_embed_split_dims = split_dims
 
         self.apply(self.init_)

@@ -718,7 +718,8 @@ def modmix_bwd(dy: torch.Tensor, y, Y: torch.Tensor, a: torch.Tensor, d, noise, 
     rc = L.lib.gg_modmix_bwd(ptr(dy), ptr(y), ptr(Y), ptr(a), ptr(d), ptr(noise), ptr(dY), ptr(da), ptr(dd), ptr(dnw),
                              b, H * W, O, Os, N, ch, 1 if act == 'lrelu' else 0, 0.2, L.stream(Y))
     L.check(rc, 'gg_modmix_bwd')
-    return (dY, None if da is None else da.sum(1), None if dd is None else dd.sum(1),
+    fold = (lambda t: t[:, 0]) if ch == 1 else (lambda t: t.sum(1))        # (one chunk: the partials ARE the sums - no launch)
+    return (dY, None if da is None else fold(da), None if dd is None else fold(dd),
             None if dnw is None else dnw.sum((0, 1)))
 
 

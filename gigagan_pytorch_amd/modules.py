@@ -61,7 +61,11 @@ class Conv2d(nn.Conv2d):
 
 
 class Linear(nn.Linear):
+    out_f32 = False     # set on an instance whose consumers read fp32 (the style -> modulation projection)
+
     def forward(self, x):
+        if self.out_f32 and hasattr(ops.impl, 'linear_f32'):
+            return ops.impl.linear_f32(x, self.weight, self.bias)
         return ops.impl.linear(x, self.weight, self.bias)
 
 

@@ -1183,18 +1183,31 @@ class HipOps:
                          (2, 2, 0, 's2d'), float(scale), res)
         return nchw(y)
 
-    def linear(self, x, weight, bias=None, act=None):
-        return matmul_nt(x, weight, None if bias is None else bias.float().contiguous(), act)
-
-    def equal_linear(self, x, weight, bias, lr_mul, act=None):
-        """EqualLinear (gp.py:871-888): act(linear(x, weight * lr_mul, bias * lr_mul)). Parameters of a FlatAdamW-owned model with
-        8-aligned extents run as LinearFn (operand from the pack table, multiplier and activation in the GEMM epilogue)."""
-        if (not second_order and isinstance(weight, torch.nn.Parameter) and getattr(weight, '_gg_pack_table', None) is not None
+    @staticmethod
+    def _table_linear_ok(x, weight, bias, act):
+        """a 2-D weight parameter owned by a FlatAdamW with 8-aligned extents: LinearFn takes its bf16 operand from the pack table."""
+        return (not second_order and isinstance(weight, torch.nn.Parameter) and getattr(weight, '_gg_pack_table', None) is not None
                 and not _DEBUG_NO_TABLE and weight.dim() == 2 and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0
                 and weight.dtype == torch.float32 and (bias is None or bias.dtype == torch.float32)
                 and act in (None, 'lrelu') and x.shape[-1] == weight.shape[1]
                 and not (weight.device.type == 'cuda' and torch.cuda.is_current_stream_capturing()
-                         and '_gg_tpacks' not in weight.__dict__)):
+                         and '_gg_tpacks' not in weight.__dict__))
+
+    def linear(self, x, weight, bias=None, act=None):
+        if self._table_linear_ok(x, weight, bias, act):      # (no per-call weight cast / pad, gradients into the flat views)
+            return LinearFn.apply(x, weight, bias, 1.0, act)
+        return matmul_nt(x, weight, None if bias is None else bias.float().contiguous(), act)
+
+    def linear_f32(self, x, weight, bias=None):
+        """nn.Linear with an fp32 result: the generator's style -> modulation projection (gp.py:1160-1175). Every adaptive conv
+        reads a column slice of it as fp32 rows (the coefficient kernels' input type), so a bf16 result would cost one cast per
+        slice and layer in the forward and one in the backward (~90 launches of a few microseconds per step on config 2)."""
+        return matmul_nt(x, weight, None if bias is None else bias.float().contiguous(), None, out_f32=True)
+
+    def equal_linear(self, x, weight, bias, lr_mul, act=None):
+        """EqualLinear (gp.py:871-888): act(linear(x, weight * lr_mul, bias * lr_mul)). Parameters of a FlatAdamW-owned model with
+        8-aligned extents run as LinearFn (operand from the pack table, multiplier and activation in the GEMM epilogue)."""
+        if self._table_linear_ok(x, weight, bias, act):
             return LinearFn.apply(x, weight, bias, float(lr_mul), act)
         y = self.linear(x, weight * lr_mul, None if bias is None else bias * lr_mul)
         return F.leaky_relu(y, LRELU_SLOPE) if act == 'lrelu' else y

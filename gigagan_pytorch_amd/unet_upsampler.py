@@ -338,6 +338,7 @@ class UnetUpsampler(BaseGenerator):
 
         style_dim = style_network.dim if exists(style_network) else style_network_dim
         self.style_to_conv_modulations = Linear(style_dim, sum(style_embed_split_dims))
+        self.style_to_conv_modulations.out_f32 = True      # its column slices feed the fp32 coefficient kernels directly
         self.style_embed_split_dims = style_embed_split_dims
 
     @property

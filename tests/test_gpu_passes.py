@@ -278,7 +278,7 @@ def test_in_backward_gradient_exchange_is_captured_with_the_step(tmp_path):
     GradReducer issues the sliced all-reduce from inside the backward pass - forked onto the communicator's side stream behind
     an event, joined before the optimizer - and the whole thing is captured into the step's hipGraph (distributed.GradReducer,
     gigagan.py `_run_graphed`). Checks: the captures succeed, slices did go out during the backward, and four steps (plain and
-    gradient-penalty, replayed) leave exactly the parameters of the same run with the exchange issued after the backward."""
+    gradient-penalty, replayed) leave the parameters of the same run with the exchange issued after the backward (to run-to-run noise)."""
     from gigagan_pytorch_amd import GigaGAN, distributed as gdist
     from gigagan_pytorch_amd.data import SyntheticImages
     from gigagan_pytorch_amd.gigagan import cycle
@@ -310,7 +310,11 @@ def test_in_backward_gradient_exchange_is_captured_with_the_step(tmp_path):
             del gan, it, flat
             import gc
             gc.collect()        # the captured graphs (RCCL nodes inside) go before the communicator does
-        assert torch.equal(digests[0], digests[1])
+        # identical up to run-to-run noise: two runs of the SAME configuration differ in one entry by 9e-10 (a bias gradient fed by
+        # fp32 atomics, tests/gpu_overlap_probe.py -> profiles/r03_overlap_probe.log); a slice exchanged before its last gradient
+        # write, or skipped, moves parameters by ~lr = 2e-4 per step
+        diff = (digests[0] - digests[1]).abs()
+        assert float(diff.max()) <= 1e-6 and int((diff > 0).sum()) <= 64, (float(diff.max()), int((diff > 0).sum()))
     finally:
         gdist.shutdown()
 
