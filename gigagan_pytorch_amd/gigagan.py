@@ -487,8 +487,12 @@ class GigaGAN(nn.Module):
                     outs = fn()
                 ops.pack_cache_clear()        # ... and nothing outside may keep tensors of its private pool
                 entry = self._graphs[key] = (graph, outs)
-            except Exception as e:   # noqa: BLE001 - any capture failure means "run eagerly"
-                self.print(f'hipGraph capture of the {key} step failed ({type(e).__name__}: {e}); running eagerly')
+            except RuntimeError as e:   # what HIP / torch raise when a capture is refused; programming errors propagate
+                import warnings
+                msg = (f'hipGraph capture of the {key} step failed ({type(e).__name__}: {e}); running eagerly from here on - '
+                       f'expect roughly half the throughput')
+                warnings.warn(msg, RuntimeWarning, stacklevel=2)
+                self.print(msg)
                 self.use_hip_graphs = False
                 self._graphs.clear()
                 torch.cuda.synchronize(self._device)

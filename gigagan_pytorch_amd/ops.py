@@ -28,6 +28,13 @@ from . import kernels as K
 ACT_DTYPE = torch.bfloat16
 LRELU_SLOPE = 0.2
 second_order = False   # set (by the trainer) while a graph that will be differentiated twice is being built
+shape_fallbacks: dict = {}     # name -> count of calls that took a SHAPE-conditional tensor-algebra form instead of the HIP kernel (ragged
+                               # channel counts, non-dense views ...). The BASELINE-dimension parity tests assert it stays empty: at the
+                               # benchmark's configurations every such op runs on its kernel
+
+
+def _shape_fallback(name):
+    shape_fallbacks[name] = shape_fallbacks.get(name, 0) + 1
 inputs_only = False    # set while a backward pass is run only for gradients w.r.t. activations (the gradient penalty's
                        # d out / d images): custom Functions then skip their parameter gradients, which autograd would
                        # discard anyway but cannot prune inside a Function
@@ -1127,7 +1134,6 @@ class ResampleFn(Function):
 # the op set
 # --------------------------------------------------------------------------------------------------
 _prepared: dict = {}        # id(weights) -> coefficients / per-sample weights computed by HipOps.modconv_prepare for the running forward
-_BANK_IN_SCALE = not os.environ.get('GG_NO_BANK_IN_SCALE')      # A/B switch: modulation on the conv's operand staging vs a separate pass
 
 class HipOps:
     """MI355X implementation: HIP kernels for contractions/resampling, torch glue for pointwise pieces."""
@@ -1229,6 +1235,7 @@ class HipOps:
             x = x.to(ACT_DTYPE)
         flat = _dense_view(x)
         if flat is None or flat.numel() % 8:
+            _shape_fallback('gelu')
             return F.gelu(x)
         y = GeluFn.apply(flat)
         if x.is_contiguous():
@@ -1396,13 +1403,13 @@ class HipOps:
                 wk = _table_pack(weights, 'modk')
             if wk is None:
                 wk = wd.permute(1, 3, 4, 0, 2).reshape(O, k * k * N * I).to(ACT_DTYPE).contiguous()
-            if H == 16 and W == 16 and N == 2 and I % 32 == 0 and _BANK_IN_SCALE:
+            if H == 16 and W == 16 and N == 2 and I % 32 == 0:
                 # a 256-pixel tile is ONE image here: the two kernels of the bank are mixed per image while their tiles are staged
                 # (gg_lrconv MIX: a_0 W_0 + a_1 W_1 in the staging registers) and the reduction runs over the I physical channels -
                 # the reference's per-sample kernel (gp.py:378-386) without writing it, and half the flops of the stacked form
                 y = K.conv2d_nhwc(nhwc(x), wk, ksize=k, cv=N * Ip, in_scale=s.contiguous(), bank_mix=a.contiguous(),
                                   out_scale=d if demod else None, noise=nz, noise_w=nw, act=act, act_slope=LRELU_SLOPE)
-            elif ((W >= 8 and H * W >= 64) or (H == 4 and W == 4)) and I % 64 == 0 and _BANK_IN_SCALE:
+            elif ((W >= 8 and H * W >= 64) or (H == 4 and W == 4)) and I % 64 == 0:
                 # the per-(sample, stacked channel) scale a_n * s_i rides on the convolution's operand staging (gg_conv3 SCALED: applied
                 # once per staged 64-channel halo chunk, shared by the nine taps; 4x4 images: gg_lrconv, plan tile 11): no modulated
                 # copy of the activation is written
@@ -1563,6 +1570,7 @@ class HipOps:
         if act == 'silu' and c % 8 == 0 and not second_order:
             return nchw(RmsNormFn.apply(nhwc(x), gamma.float().reshape(c).contiguous(), False, True))
         if c % 8:
+            _shape_fallback('channel_rmsnorm')
             xf = x.float()
             nrm = xf.norm(dim=1, keepdim=True).clamp(min=1e-12)
             y = (xf / nrm * (c ** 0.5) * gamma.float().view(1, c, 1, 1)).to(ACT_DTYPE)
@@ -1581,6 +1589,8 @@ class HipOps:
         x = to_act(x)
         b, C, H, W = x.shape
         if C % 8 or H % 2 or W % 2 or second_order:       # ragged shapes / twice-differentiated graphs: the tensor-algebra form
+            if not second_order:
+                _shape_fallback('maxpool_highfreq')
             hf = (x.float() - self.blur(x).float()).to(ACT_DTYPE)
             return F.max_pool2d(x, kernel_size=2), hf
         pool, hf = PoolHighFreqFn.apply(nhwc(x))
@@ -1602,6 +1612,8 @@ class HipOps:
         contractions on the batched MFMA GEMM, softmaxes in fp32."""
         b, c, x, y = q.shape
         n, d = x * y, c // heads
+        if not second_order:
+            _shape_fallback('linear_attention')
         qf = q.reshape(b, heads, d, n).float().softmax(dim=2) * scale
         kf = k.reshape(b, heads, d, n).float().softmax(dim=3)
         q2, k2, v2 = (t.reshape(b * heads, d, n).transpose(1, 2).to(ACT_DTYPE).contiguous()      # (BH, n, d)
@@ -1672,6 +1684,8 @@ def demod_coefficients(weights, s, a, eps):
     per-sample weights (gp.py:390-400): a Gram matrix over the kernel bank, contracted with s^2 and a a^T.
     fp32 throughout (these are (b,O)-sized statistics)."""
     N, O, I = weights.shape[:3]
+    if not second_order:
+        _shape_fallback('demod_coefficients')
     wf = weights.float().flatten(3)                                     # (N, O, I, k*k)
     gram = (wf[:, None] * wf[None, :]).sum(-1)                          # (N, N, O, I) — pointwise, no tiny GEMMs
     t = ((s * s) @ gram.reshape(N * N * O, I).t()).view(-1, N, N, O)    # (b, N, N, O): one (b x I)(I x N^2 O) GEMM

@@ -75,7 +75,9 @@ typedef struct gg_gemm_desc {
                            * 10: nine-tap 3x3 weight gradient (reduction-major operands, stride 1, pad 1, C %% 32 == 0, 8 <= W <= 64);
                            * 9: direct 3x3 convolution (C in {16,32,64}, N <= 64, W %% 32 == 0, H %% 8 == 0);
                            * 11: low-resolution 3x3 convolution (stride 1, pad 1, C %% 32 == 0, 4x4 / 8x8 / 16x16 images: the first
-                           *     adaptive convolutions of Generator.forward, gp.py:1184-1245), else heuristic */
+                           *     adaptive convolutions of Generator.forward, gp.py:1184-1245);
+                           * 8 / 12: the halo-staged convolution with 128 / 64 output channels per workgroup (same eligibility as 7),
+                           * else heuristic */
     int32_t conv_stride;  /* >= 1 */
     int32_t conv_pad;     /* >= 0 */
     float bias_scale;     /* multiplies bias (set 1.0f) */
@@ -104,7 +106,7 @@ int gg_gemm_plan_table(const gg_plan_entry* entries, int32_t n);
 
 size_t gg_gemm_workspace_bytes(const gg_gemm_desc* d);
 /* reports the launch plan the library will use for `d`: tile (1: 128x128, 2: 128x64, 3: 128x32, 4: 256x256,
- * 5: 256x128, 6: 128x128 with 8 waves) and the split-K factor; used by bench.py to attribute measured time to kernel instantiations. */
+ * 5: 256x128, 6: 128x128 with 8 waves, 7 - 12: the specialised kernels listed at force_tile) and the split-K factor; used by bench.py to attribute measured time to kernel instantiations. */
 int gg_gemm_plan(const gg_gemm_desc* d, int32_t* tile, int32_t* splitk);
 int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 
