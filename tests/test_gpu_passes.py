@@ -319,15 +319,19 @@ def test_in_backward_gradient_exchange_is_captured_with_the_step(tmp_path):
         gdist.shutdown()
 
 
-@pytest.mark.parametrize('cfg', [(512, 512, 4, 32), (512, 256, 16, 32), (128, 64, 64, 8), (64, 32, 128, 8), (32, 32, 128, 8),
-                                 (32, 16, 256, 4), (16, 16, 256, 4)])
+@pytest.mark.parametrize('cfg', [(512, 512, 4, 32, 11), (512, 512, 8, 32, 8), (512, 256, 16, 32, 11), (256, 256, 16, 32, 11),
+                                 (256, 128, 32, 32, 12), (128, 128, 32, 32, 12), (128, 64, 64, 8, 8), (64, 64, 64, 8, 8),
+                                 (64, 32, 128, 8, 0), (32, 32, 128, 8, 0), (32, 16, 256, 4, 0), (16, 16, 256, 4, 0)])
 def test_no_grad_adaptive_conv_at_config2_layer_shapes(cfg):
-    """the generator's demodulated 3x3 adaptive convs (gp.py:344-409 + noise + leaky-relu) at BASELINE config-2 layer shapes, no-grad
-    path (gg_modw_fwd + gg_sconv_fwd for the narrow layers, gg_modw_fwd + gg_modulate_bank_fwd + the implicit GEMM for the wide
-    ones) against the oracle with bf16-rounded operands: 1e-2 relative L2 (bf16 output rounding + the per-sample weights being
-    rounded to bf16 AFTER modulation / demodulation, as the reference's autocast conv does)."""
+    """the generator's demodulated 3x3 adaptive convs (gp.py:344-409 + noise + leaky-relu) at EVERY BASELINE config-2 layer shape,
+    no-grad path, against the oracle with bf16-rounded operands: 1e-2 relative L2 (bf16 output rounding + the per-sample weights
+    being rounded to bf16 AFTER modulation / demodulation, as the reference's autocast conv does). The last entry of a case is
+    the plan tile its contraction must have run on: 11 = gg_lrconv (4x4: bank modulation on the halo store; 16x16: the bank mixed
+    per image), 8 / 12 = gg_conv3 (8x8: stacked bank with the scale on its operand staging; 32x32 / 64x64: per-image weights on the
+    256x64 / 256x128 tiles), 0 = gg_sconv on per-sample weights (no contraction launch)."""
     from gigagan_pytorch_amd.modules import AdaptiveConv2DMod
-    I, O, R, b = cfg
+    from gigagan_pytorch_amd import kernels as K
+    I, O, R, b, want_tile = cfg
     torch.manual_seed(0)
     conv = AdaptiveConv2DMod(I, O, 3, num_conv_kernels=2)
     x, mod, km = torch.randn(b, I, R, R), torch.randn(b, I) * 0.3, torch.randn(b, 2)
@@ -337,9 +341,14 @@ def test_no_grad_adaptive_conv_at_config2_layer_shapes(cfg):
             y0 = conv(x, mod, km, noise=nz, noise_weight=nw, act='lrelu')
         d = dev()
         conv = conv.to(d)
-        with ops.use_impl(ops.HipOps()):
-            y1 = conv(x.to(d), mod.to(d), km.to(d), noise=nz.to(d), noise_weight=nw.to(d), act='lrelu')
+        K.plan_log = []
+        try:
+            with ops.use_impl(ops.HipOps()):
+                y1 = conv(x.to(d), mod.to(d), km.to(d), noise=nz.to(d), noise_weight=nw.to(d), act='lrelu')
+        finally:
+            plans, K.plan_log = K.plan_log, None
     assert rel_err(y1.float().cpu(), y0) < 1e-2
+    assert ([t for t, _ in plans] == [want_tile]) if want_tile else not plans, plans
 
 
 def test_training_steps_never_read_uninitialised_memory():
