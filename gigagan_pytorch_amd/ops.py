@@ -1335,6 +1335,10 @@ class HipOps:
             metas.append((weights, mod, path, b, excited))
         if not layers:
             return 0
+        # heaviest items first: the per-sample-weight builds (one workgroup per output channel walking every sample) start in the
+        # launch's first wave of workgroups, the short coefficient-only items fill in behind them
+        order = sorted(range(len(layers)), key=lambda i: -(0 if layers[i].get('coef', True) else layers[i]['w'].numel()))
+        layers, metas = [layers[i] for i in order], [metas[i] for i in order]
         outs = K.modw_multi(layers)
         for (weights, mod, path, b, excited), o in zip(metas, outs):
             _prepared[id(weights)] = dict(o, mod_ptr=mod.data_ptr(), path=path, b=b, excited=excited)
