@@ -106,6 +106,20 @@ GG_DEVICE void gg_modw_body(const GgModWParams& p, int o, int chunk, float* wl, 
             if (p.d)
                 for (int c = p.O + tid; c < p.Op; c += 256) p.d[(long long)row * p.Op + c] = 0.f;
         }
+    // cached Gram rows of this channel: fetched into registers FIRST, so that they travel with the bank rows instead of costing a
+    // round trip of their own behind the first barrier (a workgroup of this kernel is a chain of dependent memory round trips)
+    constexpr int GPT = (GG_MW_GMAX + 255) / 256;
+    float greg[GPT];
+    const bool gcached = p.demod && p.gram != nullptr;
+    const int gtot = NP * p.I;
+    if (gcached) {
+#pragma unroll
+        for (int j = 0; j < GPT; ++j) {
+            const int f = tid + 256 * j < gtot ? tid + 256 * j : gtot - 1;
+            const int pair = f / p.I, i = f - pair * p.I;
+            greg[j] = p.gram[((long long)pair * p.O + o) * p.I + i];
+        }
+    }
     // the bank rows of this channel: 16-byte loads, four in flight per thread (I % 4 == 0: rows are 16-byte aligned). Not needed
     // when the Gram rows are cached and no per-sample weights are asked for (workgroup-uniform)
     if (p.wmix || !p.gram) {
@@ -143,13 +157,14 @@ GG_DEVICE void gg_modw_body(const GgModWParams& p, int o, int chunk, float* wl, 
 #pragma unroll
             for (int n = 0; n < N; ++n) p.a[tid * N + n] = av[n];
     }
+    if (gcached) {
+#pragma unroll
+        for (int j = 0; j < GPT; ++j)
+            if (tid + 256 * j < gtot) gram[tid + 256 * j] = greg[j];
+    }
     gg_sync();
     if (p.demod) {
-        if (p.gram) {
-#pragma unroll
-            for (int pair = 0; pair < NP; ++pair)
-                for (int i = tid; i < p.I; i += 256) gram[pair * p.I + i] = p.gram[((long long)pair * p.O + o) * p.I + i];
-        } else {
+        if (!p.gram) {
             int pair = 0;
 #pragma unroll
             for (int n = 0; n < N; ++n)
