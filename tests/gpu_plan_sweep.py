@@ -101,10 +101,14 @@ def main():
     ap.add_argument('--workload', default='uncond')
     ap.add_argument('--min-us', type=float, default=15.0, help='geometries whose planned launch is shorter are left to the cost model')
     ap.add_argument('--gain', type=float, default=0.04)
+    ap.add_argument('--tiles', default='', help='comma-separated candidate tiles (default: 1-10); e.g. 11,12 for the round-3 kernels')
+    ap.add_argument('--keep-table', action='store_true', help='time candidates against the INSTALLED plan table instead of the bare cost model')
     args = ap.parse_args()
+    cand_tiles = tuple(int(t) for t in args.tiles.split(',') if t) or (1, 2, 3, 4, 5, 6, 7, 8, 9, 10)
     dev = torch.device('cuda', 0)
     L = _C.lib()
-    L.load_plan_table([])                       # capture and time against the bare cost model
+    if not args.keep_table:
+        L.load_plan_table([])                   # capture and time against the bare cost model
     batch = 32 if args.workload == 'uncond' else 16
     gan = bench.build_gan(256, dev, use_hip_graphs=False, workload=args.workload)
     if args.workload == 'text':
@@ -168,9 +172,9 @@ def main():
         agrees(f'planner choice {(tile.value, sk.value)}')
         if t_plan >= args.min_us:
             ktiles = (d.K + 31) // 32
-            for ft in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
+            for ft in cand_tiles:
                 seen = set()
-                for fs in (ladder if ft not in (7, 8) else [1, 2, 3, 4, 6, 8, 12, 16]):       # (gg_conv3 splits over 64-channel chunks)
+                for fs in (ladder if ft not in (7, 8, 11, 12) else [1, 2, 3, 4, 6, 8, 12, 16]):       # (gg_conv3 / gg_lrconv split over channel chunks)
                     if fs > ktiles:
                         break
                     d.force_tile, d.force_splitk = ft, fs
