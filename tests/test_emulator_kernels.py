@@ -1201,3 +1201,28 @@ def test_maxpool_highfreq_kernels_vs_torch(shape):
 def test_general_fused_attention_forward_backward_vs_autograd(cfg):
     from helpers import check_general_attention
     check_general_attention(cfg, 'cpu')
+
+
+def test_shape_fallbacks_are_counted_and_only_for_shape_reasons():
+    """ops.shape_fallbacks (what the BASELINE-dimension GPU parity tests assert to stay empty): a ragged channel count sends RMSNorm and
+    GELU-on-a-strided-view to their tensor-algebra forms and is counted; the same ops at kernel-friendly shapes are not; forms taken
+    because a graph is differentiated twice (ops.second_order) are by design and not counted."""
+    torch.manual_seed(0)
+    h = ops.HipOps()
+    ops.shape_fallbacks.clear()
+    with ops.use_impl(h), torch.no_grad():
+        h.channel_rmsnorm(torch.randn(2, 16, 4, 4), torch.ones(16))
+        h.gelu(bf(torch.randn(2, 16, 4, 4)))
+        assert not ops.shape_fallbacks, ops.shape_fallbacks
+        y = h.channel_rmsnorm(torch.randn(2, 12, 4, 4), torch.ones(12))                 # C % 8 != 0
+        assert torch.isfinite(y.float()).all() and ops.shape_fallbacks.get('channel_rmsnorm') == 1
+        h.gelu(bf(torch.randn(2, 16, 4, 6))[..., ::2])                                 # not a dense view
+        assert ops.shape_fallbacks.get('gelu') == 1, ops.shape_fallbacks
+        ops.shape_fallbacks.clear()
+        ops.second_order = True
+        try:
+            h.maxpool_highfreq(torch.randn(2, 8, 4, 4))
+        finally:
+            ops.second_order = False
+        assert not ops.shape_fallbacks, ops.shape_fallbacks
+    ops.shape_fallbacks.clear()
