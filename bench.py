@@ -417,6 +417,13 @@ def main():
             roofline = dict(bound='mfma', kernel=name, achieved=achieved, peak=MFMA_PEAK_TF, unit='TFLOP/s',
                             frac=achieved / MFMA_PEAK_TF, traffic=traffic, traffic_shape=traffic_shape,
                             avg_launch_us=a['ms'] / a['launches'] * 1e3, launches_per_step=a['launches'] / 4,
+                            # everything `achieved` is made of, so that the fraction can be recomputed from this line alone:
+                            # achieved = flops_per_launch / avg_launch_us (algorithmic 2*M*N*K of the kernel's launches in one
+                            # eager 4-step cycle, HIP events on the launch stream); the per-shape table behind it is written to
+                            # gpurun_out/bench_gemm_shapes.json and committed under profiles/ for the closing run
+                            flops_per_launch=a['flops'] / a['launches'], launches_in_cycle=a['launches'],
+                            gemm_kernel_table={k: dict(launches=v['launches'], ms=round(v['ms'], 4), gflop=round(v['flops'] / 1e9, 3))
+                                               for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])},
                             all_gemm_kernels=dict(tflops=tot_fl / tot_ms / 1e9, ms_per_step=tot_ms / 4,
                                                   frac_of_step=tot_ms / 4 / ms_per_step),
                             step=dict(achieved=value / world * GF_PER_IMG / 1e3, peak=MFMA_PEAK_TF,

@@ -6,6 +6,7 @@
 #include "gg_conv3.h"
 #include "gg_lrconv.h"
 #include "gg_wgrad9.h"
+#include "gg_wgrads.h"
 #include "gg_elementwise.h"
 #include "gg_modconv.h"
 #include "gg_attention.h"
@@ -263,6 +264,8 @@ static bool gg_wgrad9_eligible(const gg_gemm_desc* d);
 static GemmPlan gg_wgrad9_plan(const gg_gemm_desc* d, int splitk);
 static bool gg_lrconv_eligible(const gg_gemm_desc* d);
 static GemmPlan gg_lrconv_plan(const gg_gemm_desc* d, int splitk);
+static bool gg_wgrads_eligible(const gg_gemm_desc* d);
+static GemmPlan gg_wgrads_plan(const gg_gemm_desc* d, int splitk);
 
 // ---- tuning cache: measured-best (tile, split-K) per exact geometry (gg_gemm_plan_table) ----------------------------------
 struct GgPlanChoice { int tile, splitk; };
@@ -293,6 +296,11 @@ static bool gg_table_plan(const gg_gemm_desc* d, GemmPlan& pl) {
     if (tile == 7 || tile == 8 || tile == 12) {
         if (!gg_conv3_eligible(d)) return false;
         pl = gg_conv3_plan(d, tile, it->second.splitk);
+        return true;
+    }
+    if (tile == 13) {
+        if (!gg_wgrads_eligible(d)) return false;
+        pl = gg_wgrads_plan(d, it->second.splitk);
         return true;
     }
     if (tile == 10) {
@@ -500,6 +508,68 @@ static GemmPlan gg_lrconv_plan(const gg_gemm_desc* d, int splitk) {
     return pl;
 }
 
+// the streaming weight gradient of the narrow high-resolution layers (gg_wgrads.h, plan tile 13): takes over wherever the planner (table
+// or cost model) would run a 3x3 / stride 1 / pad 1 or 1x1 weight gradient with <= 64 input and output channels over >= 64K pixels
+// on the 4-wave kernel. GG_WGRADS=0 disables that (A/B runs); force_tile 13 selects it wherever eligible.
+static int gg_wgrads_policy() {
+    static int policy = -1;
+    if (policy < 0) {
+        const char* e = getenv("GG_WGRADS");
+        policy = e ? atoi(e) : 1;
+        if (policy < 0) policy = 1;
+    }
+    return policy;
+}
+
+static bool gg_wgrads_shape(const gg_gemm_desc* d, int* spx_out, int* depth_out) {
+    if (!d->a_conv || d->a_layout != GG_KROW || d->b_layout != GG_KROW) return false;
+    const bool k3 = d->R == 3 && d->S == 3 && d->conv_stride == 1 && d->conv_pad == 1;
+    const bool k1 = d->R == 1 && d->S == 1 && d->conv_stride == 1 && d->conv_pad == 0;
+    if (!k3 && !k1) return false;
+    const int taps = k3 ? 9 : 1, C = d->C, N = d->N;
+    if (C != d->CV || d->M != taps * C || (d->ldb & 7) || (d->ldc & 3)) return false;
+    if (!((C == 8 || C == 16 || C == 32 || C == 64) && (N == 8 || N == 16 || N == 32 || N == 64))) return false;
+    if (d->in_scale || d->b_image_stride || d->batch != 1 || d->d2s || !d->c_is_f32) return false;
+    if (d->bias || d->out_scale || d->noise || d->residual || d->act != GG_ACT_NONE) return false;
+    if (!gg_pow2(d->H) || !gg_pow2(d->W) || d->W < 64 || d->W > 256) return false;
+    if (d->K % (d->H * d->W)) return false;
+    if (gg_a_bytes(d) >= (1ll << 32) || gg_b_bytes(d) >= (1ll << 32)) return false;
+    for (int spx : {256, 128}) {
+        if (d->W > spx || d->H * d->W < spx || ((spx * C) & 2047) || ((spx * N) & 2047) || spx * C > 16384 || spx * N > 16384) continue;
+        const int npw = spx * (C + N) / 2048;           // DMA instructions per wave and step
+        for (int depth : {3, 2}) {
+            if (depth * npw > 48) continue;             // vmcnt is a 6-bit counter; gg_wait_vm_le carries literals up to 48
+            if (gg_ws_geom(taps, d->W, C, N, spx, depth).bytes > GG_WS_LDS) continue;
+            if (spx_out) *spx_out = spx;
+            if (depth_out) *depth_out = depth;
+            return true;
+        }
+    }
+    return false;
+}
+
+static bool gg_wgrads_eligible(const gg_gemm_desc* d) { return gg_wgrads_shape(d, nullptr, nullptr); }
+
+static GemmPlan gg_wgrads_plan(const gg_gemm_desc* d, int splitk) {
+    GemmPlan pl;
+    int spx = 256, depth = 2;
+    gg_wgrads_shape(d, &spx, &depth);
+    pl.tile = 13; pl.bm = d->M; pl.bn = d->N; pl.blocks_mn = 1;
+    const int steps = d->K / spx;
+    int sk = splitk > 0 ? splitk : 256;                 // one 152 KB workgroup per CU
+    if (sk > steps) sk = steps;
+    const int per = (steps + sk - 1) / sk;
+    pl.splitk = (steps + per - 1) / per;
+    pl.k_per_split = per * spx;
+    return pl;
+}
+
+static GemmPlan gg_wgrads_substitute(const gg_gemm_desc* d, const GemmPlan& pl) {
+    if (pl.tile < 1 || pl.tile > 3 || d->force_tile != 0 || d->force_splitk != 0 || !gg_wgrads_policy()) return pl;
+    if (d->K < 65536 || !gg_wgrads_eligible(d)) return pl;
+    return gg_wgrads_plan(d, 0);
+}
+
 static GemmPlan gg_wgrad9_substitute(const gg_gemm_desc* d, const GemmPlan& pl) {
     if ((pl.tile != 4 && pl.tile != 5) || d->force_tile != 0 || d->force_splitk != 0 || !gg_wgrad9_policy() || !gg_wgrad9_eligible(d)) return pl;
     return gg_wgrad9_plan(d, 0);
@@ -541,7 +611,8 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
         return gg_conv3_plan(d, d->force_tile, d->force_splitk);
     if (d->force_tile == 10 && gg_wgrad9_eligible(d)) return gg_wgrad9_plan(d, d->force_splitk);
     if (d->force_tile == 11 && gg_lrconv_eligible(d)) return gg_lrconv_plan(d, d->force_splitk);
-    if (gg_table_plan(d, pl)) return gg_wgrad9_substitute(d, gg_conv3_substitute(d, pl, false));
+    if (d->force_tile == 13 && gg_wgrads_eligible(d)) return gg_wgrads_plan(d, d->force_splitk);
+    if (gg_table_plan(d, pl)) return gg_wgrads_substitute(d, gg_wgrad9_substitute(d, gg_conv3_substitute(d, pl, false)));
     if (gg_use_lrconv(d)) return gg_lrconv_plan(d, d->force_splitk);
     if (gg_use_dconv(d)) {
         pl.tile = 9; pl.bm = GG_DC_TH * GG_DC_TW; pl.bn = d->N <= 32 ? 32 : 64;
@@ -594,7 +665,7 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     const int per = (ktiles + pl.splitk - 1) / pl.splitk;
     pl.splitk = (ktiles + per - 1) / per;
     pl.k_per_split = per * tm.bk;
-    return gg_wgrad9_substitute(d, gg_conv3_substitute(d, pl, true));
+    return gg_wgrads_substitute(d, gg_wgrad9_substitute(d, gg_conv3_substitute(d, pl, true)));
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -659,7 +730,7 @@ extern "C" int gg_gemm_plan_table(const gg_plan_entry* entries, int32_t n) {
     g_plan_table.clear();
     for (int i = 0; i < n; ++i) {
         const gg_plan_entry& e = entries[i];
-        if (e.tile < 1 || e.tile > 12 || e.splitk < 1) return gg_fail(-2, "gg_gemm_plan_table: entry %d has tile %d split-K %d", i, e.tile, e.splitk);
+        if (e.tile < 1 || e.tile > 13 || e.splitk < 1) return gg_fail(-2, "gg_gemm_plan_table: entry %d has tile %d split-K %d", i, e.tile, e.splitk);
         g_plan_table[gg_plan_key(&e.M)] = GgPlanChoice{e.tile, e.splitk};
     }
     return 0;
@@ -744,6 +815,11 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
         else { if (wide) gg_launch_dconv<64, 2>(p, s); else gg_launch_dconv<64, 1>(p, s); }
     }
     else if (pl.tile == 10) GG_LAUNCH(gg_wgrad9_kernel, grid2, dim3(GG2_NT), s, p);
+    else if (pl.tile == 13) {
+        gg_wgrads_shape(d, &p.ws_spx, &p.ws_depth);
+        if (d->R == 3) GG_LAUNCH((gg_wgrads_kernel<9>), grid2, dim3(GG_WS_NT), s, p);
+        else GG_LAUNCH((gg_wgrads_kernel<1>), grid2, dim3(GG_WS_NT), s, p);
+    }
     else if (pl.tile == 11) {
         const bool full = pl.splitk == 1 && (p.bias || p.out_scale || p.noise || p.residual || p.act != GG_ACT_NONE);
         if (d->bank_mix) {

@@ -74,6 +74,27 @@ GG_DEVICE void gg_wait_vm() {           // s_waitcnt vmcnt(N): at most N vector-
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// s_waitcnt vmcnt(n) for a WAVE-UNIFORM run-time n (the immediate must be a literal: a scalar jump over the literals a streaming
+// kernel's prefetch depths produce). At most n vector-memory operations of this wave stay outstanding; they retire in order.
+GG_DEVICE void gg_wait_vm_le(int n) {
+#define GG_VMCASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (__builtin_amdgcn_readfirstlane(n)) {
+        GG_VMCASE(1) GG_VMCASE(2) GG_VMCASE(3) GG_VMCASE(4) GG_VMCASE(5) GG_VMCASE(6) GG_VMCASE(7) GG_VMCASE(8) GG_VMCASE(9) GG_VMCASE(10)
+        GG_VMCASE(11) GG_VMCASE(12) GG_VMCASE(13) GG_VMCASE(14) GG_VMCASE(15) GG_VMCASE(16) GG_VMCASE(17) GG_VMCASE(18) GG_VMCASE(19)
+        GG_VMCASE(20) GG_VMCASE(21) GG_VMCASE(22) GG_VMCASE(23) GG_VMCASE(24) GG_VMCASE(25) GG_VMCASE(26) GG_VMCASE(27) GG_VMCASE(28)
+        GG_VMCASE(29) GG_VMCASE(30) GG_VMCASE(31) GG_VMCASE(32) GG_VMCASE(33) GG_VMCASE(34) GG_VMCASE(35) GG_VMCASE(36) GG_VMCASE(37)
+        GG_VMCASE(38) GG_VMCASE(39) GG_VMCASE(40) GG_VMCASE(41) GG_VMCASE(42) GG_VMCASE(43) GG_VMCASE(44) GG_VMCASE(45) GG_VMCASE(46)
+        GG_VMCASE(47) GG_VMCASE(48)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;        // 0, and anything the table does not carry: wait for all
+    }
+#undef GG_VMCASE
+}
+
+// workgroup barrier that leaves vector-memory operations (LDS-DMA prefetches) in flight: __syncthreads() waits for vmcnt(0) first. This
+// wave's LDS reads / writes are retired (lgkmcnt(0)) before it arrives; data another wave's DMA deposited is visible after that wave's
+// own gg_wait_vm_le + this barrier.
+GG_DEVICE void gg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Buffer addressing (SRSRC): a wave-uniform 128-bit descriptor {base, bytes} plus a 32-bit per-lane byte offset and a scalar byte
 // offset. What it buys the convolution gather: no 64-bit per-lane address arithmetic in the k-loop (the per-lane part of an
 // operand address is loop invariant, the per-k-tile part is one scalar), and out-of-range rows / padding taps are zero-filled by
@@ -97,6 +118,31 @@ GG_DEVICE u16x8 gg_buf_load16(GgBuf r, unsigned voff, unsigned soff) {
 GG_DEVICE void gg_buf_load_lds16(GgBuf r, unsigned voff, unsigned soff, void* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (void __attribute__((address_space(3)))*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
 }
+
+// The same transfer issued from inline assembly, for kernels that keep SEVERAL steps of LDS-DMA in flight (gg_wgrads.h): hipcc's
+// waitcnt pass knows that the builtin above writes LDS and, without alias scopes, puts `s_waitcnt vmcnt(0)` in front of EVERY later
+// LDS read of the kernel - the prefetch depth collapses to zero (measured: 3.5 us per 32 KB step). The assembly form is invisible to
+// that pass; ordering is then entirely the kernel's own gg_wait_vm_le + gg_barrier_lds. The descriptor is a plain SGPR quad
+// {base lo, base hi, bytes, flags}; M0 (the LDS base of the wave's 1 KB) is written inside the statement and is not live across it
+// in such kernels (they use no other M0 consumer: check the ISA when adding one).
+typedef u32x4 GgBufS;
+GG_DEVICE GgBufS gg_make_bufs(const void* base, unsigned long long bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    const unsigned nb = (unsigned)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes);
+    GgBufS r = {(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xFFFFu,
+                (unsigned)__builtin_amdgcn_readfirstlane(nb), 0x00020000u};
+    return r;
+}
+GG_DEVICE void gg_bufs_load_lds16(GgBufS r, unsigned voff, unsigned soff, void* lds_wave_base) {
+    // (the low half of a flat LDS address is the LDS byte offset: the shared aperture is 4 GiB aligned. A generic -> local pointer cast
+    // here trips hipcc 7.2's instruction verifier: V_CMP_NE_U32 against src_shared_base)
+    const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)lds_wave_base);
+    const unsigned so = __builtin_amdgcn_readfirstlane(soff);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff), "s"(r), "s"(m), "s"(so) : "memory");
+}
+// a value the program knows to be wave-uniform, moved to a scalar register (loop bounds, LDS bases, branch conditions derived from the
+// wave index would otherwise live in vector registers: divergent-loop code, waterfall loops around scalar operands)
+GG_DEVICE int gg_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 GG_DEVICE float gg_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 GG_DEVICE float gg_shfl(float v, int src) { return __shfl(v, src, 64); }

@@ -15,7 +15,9 @@ them.
 """
 from __future__ import annotations
 
+import atexit
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -58,6 +60,7 @@ class NativeComm:
         self.world = 0
         self.exposed_ms = []        # filled when `timing` is on: how long the compute stream waited per exchange
         self.timing = False
+        self.accepts_host = False   # the RCCL communicator moves device memory only (a CPU test double sets this)
 
     def init(self, device, rank=None, world=None):
         from . import _C
@@ -83,46 +86,71 @@ class NativeComm:
         self.stream = torch.cuda.Stream(device=device)
         return self
 
+    # -- the three stream-side primitives everything below is written in (a test double replaces exactly these) ----------------
+    def fork(self, like: torch.Tensor):
+        """the side stream waits for everything the compute stream has queued so far (an event edge: inside a hipGraph capture
+        it becomes a graph dependency)."""
+        cur = torch.cuda.current_stream(like.device)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.stream.wait_event(ev)
+
+    def allreduce_ptr(self, ptr: int, count: int, dtype_code: int):
+        """in-place sum over the ranks of `count` elements at device address `ptr` (dtype_code 0 = fp32, 1 = bf16), enqueued on
+        the side stream."""
+        self.lib.check(self.lib.lib.gg_comm_allreduce(ptr, count, dtype_code, self.stream.cuda_stream), 'gg_comm_allreduce')
+
+    def allgather_ptr(self, src: int, dst: int, nbytes: int):
+        self.lib.check(self.lib.lib.gg_comm_allgather(src, dst, nbytes, 2, self.stream.cuda_stream), 'gg_comm_allgather')
+
+    def join(self, like: torch.Tensor):
+        """the compute stream waits for the side stream."""
+        torch.cuda.current_stream(like.device).wait_stream(self.stream)
+
+    def _mark(self, like: torch.Tensor):
+        """(timing only) a timed event on the compute stream; None while capturing or when timing is off."""
+        if not self.timing or torch.cuda.is_current_stream_capturing():
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream(like.device))
+        return e
+
+    def _keep(self, *tensors):
+        for t in tensors:
+            t.record_stream(self.stream)
+
     def all_reduce_(self, flat: torch.Tensor, n_slices: int = 4):
         """in-place sum over ranks of a contiguous buffer, issued as `n_slices` large collectives on the side stream after
         everything the compute stream has queued so far; returns a handle whose wait() fences the compute stream."""
-        assert flat.is_cuda and flat.is_contiguous() and flat.dtype in (torch.float32, torch.bfloat16)
-        L = self.lib
-        cur = torch.cuda.current_stream(flat.device)
-        t0 = None
-        if self.timing:
-            t0 = torch.cuda.Event(enable_timing=True)
-            t0.record(cur)
-        self.stream.wait_stream(cur)
+        assert (flat.is_cuda or self.accepts_host) and flat.is_contiguous() and flat.dtype in (torch.float32, torch.bfloat16)
+        t0 = self._mark(flat)
+        self.fork(flat)
         n = flat.numel()
         step = ((n + n_slices - 1) // n_slices + 255) // 256 * 256
         dt = 0 if flat.dtype == torch.float32 else 1
         for s in range(0, n, step):
-            cnt = min(step, n - s)
-            L.check(L.lib.gg_comm_allreduce(flat.data_ptr() + s * flat.element_size(), cnt, dt, self.stream.cuda_stream),
-                    'gg_comm_allreduce')
-        done = torch.cuda.Event()
-        done.record(self.stream)
-        return _Fence(self, done, cur, t0)
+            self.allreduce_ptr(flat.data_ptr() + s * flat.element_size(), min(step, n - s), dt)
+        return _Fence(self, flat, t0)
 
     def all_gather(self, x: torch.Tensor) -> torch.Tensor:
         x = x.contiguous()
         out = torch.empty((self.world * x.shape[0], *x.shape[1:]), dtype=x.dtype, device=x.device)
-        cur = torch.cuda.current_stream(x.device)
-        self.stream.wait_stream(cur)
-        self.lib.check(self.lib.lib.gg_comm_allgather(x.data_ptr(), out.data_ptr(), x.numel() * x.element_size(), 2,
-                                                      self.stream.cuda_stream), 'gg_comm_allgather')
-        cur.wait_stream(self.stream)
-        x.record_stream(self.stream)
-        out.record_stream(self.stream)
+        self.fork(x)
+        self.allgather_ptr(x.data_ptr(), out.data_ptr(), x.numel() * x.element_size())
+        self.join(x)
+        self._keep(x, out)
         return out
 
     def destroy(self):
         if self.lib is not None:
             # captured steps hold this communicator's collectives as graph nodes, and RCCL hangs clean-up work on a graph's
-            # destruction: a trainer that is only unreachable (parameters <-> reducer hooks form cycles) would have its graphs
-            # destroyed by a LATER garbage collection, after the communicator is gone. Collect first, then drain, then destroy.
+            # destruction: a graph destroyed AFTER the communicator aborts the process from a runtime thread. So the communicator
+            # owns the order: (1) collect trainers that are only unreachable (parameter <-> reducer-hook cycles), whose graphs die
+            # with them while the communicator is alive; (2) drop the captured graphs of every trainer that is still alive (they
+            # re-capture on their next step, on whatever transport exists then); (3) drain the device; (4) destroy.
             import gc
+            gc.collect()
+            drop_captured_graphs()
             gc.collect()
             torch.cuda.synchronize()
             self.lib.lib.gg_comm_destroy()
@@ -130,18 +158,41 @@ class NativeComm:
 
 
 class _Fence:
-    def __init__(self, comm, event, stream, t0):
-        self.comm, self.event, self.stream, self.t0 = comm, event, stream, t0
+    def __init__(self, comm, like, t0):
+        self.comm, self.like, self.t0 = comm, like, t0
 
     def wait(self):
-        self.stream.wait_event(self.event)
+        self.comm.join(self.like)
         if self.t0 is not None:
-            t1 = torch.cuda.Event(enable_timing=True)
-            t1.record(self.stream)
-            self.comm.exposed_ms.append((self.t0, t1))
+            self.comm.exposed_ms.append((self.t0, self.comm._mark(self.like)))
+
+
+# ---- captured graphs with RCCL nodes must not outlive the communicator ------------------------------------------------------
+_graph_owners = weakref.WeakSet()
+
+
+def register_graph_owner(owner):
+    """`owner._graphs` (a dict whose values hold torch.cuda.CUDAGraph objects) may contain graphs with this process's RCCL
+    collectives captured as nodes (the in-backward gradient exchange). `NativeComm.destroy()` empties those dicts first."""
+    _graph_owners.add(owner)
+
+
+def drop_captured_graphs():
+    n = 0
+    for o in list(_graph_owners):
+        g = getattr(o, '_graphs', None)
+        if g:
+            n += len(g)
+            g.clear()
+    return n
 
 
 _native: NativeComm | None = None
+
+
+def _use_native(t: torch.Tensor) -> bool:
+    """does the library's own communicator carry collectives on this tensor?"""
+    return _native is not None and (t.is_cuda or _native.accepts_host)
 
 
 def native_comm() -> NativeComm | None:
@@ -209,6 +260,7 @@ def enable_native_comm(device):
               f'({err if err is not None else "a peer failed"}); gradient exchange through torch.distributed', flush=True)
         return None
     _native = comm
+    atexit.register(shutdown)       # before interpreter teardown: graphs first, then the communicator (NativeComm.destroy)
     return _native
 
 
@@ -232,9 +284,9 @@ def all_reduce_flat_grads(flat_grad: torch.Tensor, n_slices: int = 4):
     """sum-reduce a flat gradient buffer across ranks (the mean is folded into the optimizer's grad_scale). On a GPU with the
     native communicator up: gg_comm_allreduce on the side stream; otherwise torch.distributed (gloo on the CPU). Returns
     handles with .wait()."""
-    if not is_distributed() and not (_native is not None and flat_grad.is_cuda):
+    if not is_distributed() and not _use_native(flat_grad):
         return []
-    if _native is not None and flat_grad.is_cuda:
+    if _use_native(flat_grad):
         return [_native.all_reduce_(flat_grad, n_slices)]
     n = flat_grad.numel()
     step = (n + n_slices - 1) // n_slices
@@ -288,15 +340,20 @@ class GradReducer:
         self.next = -1
         self.works = []
         self.launched = 0
+        self.dry = False
         self.in_backward_launches = 0      # statistics of the last armed pass: slices that went out before finish()
 
     @staticmethod
     def active(flat) -> bool:
-        return (is_distributed() and (not flat.is_cuda or _native is not None)) or (_native is not None and flat.is_cuda)
+        return (is_distributed() and (not flat.is_cuda or _native is not None)) or _use_native(flat)
 
-    def arm(self, sig):
-        """start of a step whose ONE backward pass produces all gradients of this model."""
+    def arm(self, sig, dry=False):
+        """start of a step whose ONE backward pass produces all gradients of this model. `dry`: the pass only learns the
+        slice counts of this step kind and enqueues NO collective (the warm-up execution in front of a hipGraph capture: a
+        rank that captures a new graph key must issue exactly as many collectives that step as a peer that only replays
+        one - the captured pass's, at its first replay - or the RCCL sequences of the ranks diverge)."""
         self.sig = sig
+        self.dry = bool(dry)
         self.count = [0] * self.n
         self.learning = sig not in self.expected
         self.next = self.n - 1
@@ -330,14 +387,12 @@ class GradReducer:
     def _launch(self, k):
         lo, hi = self.bounds[k], self.bounds[k + 1]
         g = self.opt.flat_g
+        if self.dry:
+            return
         self.launched += 1
-        if _native is not None and g.is_cuda:
-            cur = torch.cuda.current_stream(g.device)
-            ev = torch.cuda.Event()
-            ev.record(cur)
-            _native.stream.wait_event(ev)
-            _native.lib.check(_native.lib.lib.gg_comm_allreduce(g.data_ptr() + lo * 4, hi - lo, 0, _native.stream.cuda_stream),
-                              'gg_comm_allreduce')
+        if _use_native(g):
+            _native.fork(g)           # behind the write-backs of this slice, which the compute stream has queued by now
+            _native.allreduce_ptr(g.data_ptr() + lo * g.element_size(), hi - lo, 0)
         else:
             self.works.append(dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
@@ -346,23 +401,17 @@ class GradReducer:
         if self.sig is None:
             return
         g = self.opt.flat_g
-        native = _native is not None and g.is_cuda
-        t0 = None
-        if native and _native.timing and not torch.cuda.is_current_stream_capturing():
-            t0 = torch.cuda.Event(enable_timing=True)
-            t0.record(torch.cuda.current_stream(g.device))
+        native = _use_native(g)
+        t0 = _native._mark(g) if native else None
         if self.learning:
             self.expected[self.sig] = list(self.count)
         while self.next >= 0:
             self._launch(self.next)
             self.next -= 1
         if native:
-            cur = torch.cuda.current_stream(g.device)
-            cur.wait_stream(_native.stream)
+            _native.join(g)
             if t0 is not None:
-                t1 = torch.cuda.Event(enable_timing=True)
-                t1.record(cur)
-                _native.exposed_ms.append((t0, t1))
+                _native.exposed_ms.append((t0, _native._mark(g)))
         else:
             for w in self.works:
                 w.wait()
@@ -384,7 +433,7 @@ class _AllGather(Function):
     def forward(ctx, x):
         ws = dist.get_world_size()
         ctx.b = x.shape[0]
-        if _native is not None and x.is_cuda:
+        if _use_native(x):
             return _native.all_gather(x)
         out = torch.empty((ws * x.shape[0], *x.shape[1:]), dtype=x.dtype, device=x.device)
         dist.all_gather_into_tensor(out, x.contiguous())

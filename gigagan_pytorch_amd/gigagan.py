@@ -253,6 +253,8 @@ class GigaGAN(nn.Module):
             use_hip_graphs = self._device.type == 'cuda'
         self.use_hip_graphs = bool(use_hip_graphs) and self._device.type == 'cuda'
         self._graphs: dict = {}
+        self._graph_warmup = False
+        gdist.register_graph_owner(self)      # captured steps may hold RCCL nodes: the communicator drops them before it dies
 
         self.results_folder = Path(results_folder)
         self.model_folder = Path(model_folder)
@@ -474,8 +476,15 @@ class GigaGAN(nn.Module):
             try:
                 side = torch.cuda.Stream(device=self._device)
                 side.wait_stream(torch.cuda.current_stream(self._device))
-                with torch.cuda.stream(side):
-                    fn()                      # warm-up on a side stream (allocator, lazily built tables, workspaces)
+                # warm-up on a side stream (allocator, lazily built tables, workspaces). It is communication-free: the in-backward
+                # gradient exchange only learns its slice counts (`GradReducer.arm(dry=True)`), so a rank that captures a key its
+                # peers already replay (per-rank staged shapes) issues the same collective sequence as they do
+                self._graph_warmup = True
+                try:
+                    with torch.cuda.stream(side):
+                        fn()
+                finally:
+                    self._graph_warmup = False
                 torch.cuda.current_stream(self._device).wait_stream(side)
                 torch.cuda.synchronize(self._device)
                 graph = torch.cuda.CUDAGraph()
@@ -637,7 +646,7 @@ class GigaGAN(nn.Module):
             def fn():
                 self.D_opt.zero_grad()
                 if red is not None:
-                    red.arm(red_sig)
+                    red.arm(red_sig, dry=self._graph_warmup)
                 col = [] if has_matching_awareness else None
                 out = self._d_micro(static_real, None, None, 1, apply_gradient_penalty, calc_multiscale_loss, collect=col)
                 mal = self._matching_aware_pass(col, 1) if has_matching_awareness else torch.zeros((), device=dev)
@@ -777,7 +786,7 @@ class GigaGAN(nn.Module):
                 def fn():
                     self.G_opt.zero_grad()
                     if red is not None:
-                        red.arm(red_sig)
+                        red.arm(red_sig, dry=self._graph_warmup)
                     out = self._g_micro(batch_size, None, 1, calc_multiscale_loss)
                     if red is not None:
                         red.finish()

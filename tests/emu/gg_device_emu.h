@@ -62,6 +62,8 @@ void gg_emu_dma_wait(int keep_newest);
 static inline void gg_sync() { gg_emu_dma_wait(0); gg_emu_syncthreads(); }
 template <int N>
 static inline void gg_wait_vm() { gg_emu_dma_wait(N); }
+static inline void gg_wait_vm_le(int n) { gg_emu_dma_wait(n); }
+static inline void gg_barrier_lds() { gg_emu_syncthreads(); }       // the raw barrier: transfers stay in flight (late model: not landed)
 // buffer addressing stand-in: the hardware range-checks the per-lane offset (not the scalar one) and returns zeros beyond `bytes`
 struct GgBuf { const char* base; unsigned long long bytes; };
 static inline GgBuf gg_make_buf(const void* base, unsigned long long bytes) {
@@ -78,6 +80,10 @@ static inline void gg_buf_load_lds16(GgBuf r, unsigned voff, unsigned soff, void
     const void* src = ((unsigned long long)voff + 16 <= r.bytes) ? (const void*)(r.base + voff + soff) : (const void*)zeros;
     gg_emu_dma_issue(src, (char*)lds_wave_base + 16 * (threadIdx.x & 63u));
 }
+typedef GgBuf GgBufS;
+static inline GgBufS gg_make_bufs(const void* base, unsigned long long bytes) { return gg_make_buf(base, bytes); }
+static inline void gg_bufs_load_lds16(GgBufS r, unsigned voff, unsigned soff, void* lds_wave_base) { gg_buf_load_lds16(r, voff, soff, lds_wave_base); }
+static inline int gg_uniform(int v) { return v; }
 template <typename T>
 static inline const T* gg_late_params(const T& by_value) { return &by_value; }
 static inline f32x16 gg_mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c) {

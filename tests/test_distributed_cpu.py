@@ -91,7 +91,77 @@ def test_data_parallel_equals_large_batch_gradient():
             assert torch.allclose(f, (x + y) / 2, rtol=1e-3, atol=1e-5)
 
 
-def _train_worker(rank, world, port, ret, tmp, overlap=True):
+class GlooBackedNativeComm:
+    """test double for distributed.NativeComm: the SAME class with its three stream-side primitives (fork / allreduce_ptr /
+    allgather_ptr / join) re-implemented on host memory + gloo, so that every line of the native branches of
+    GradReducer._launch / finish, NativeComm.all_reduce_ / all_gather runs at world size 2 without a GPU: slice bounds, byte
+    offsets, element counts and the fork -> collective -> join ordering are what the RCCL entry points would be handed."""
+
+    def __new__(cls, world):
+        from gigagan_pytorch_amd import distributed as gdist
+
+        class _Double(gdist.NativeComm):
+            def __init__(self):
+                super().__init__()
+                self.accepts_host, self.world, self.lib = True, world, None
+                self.log, self.buffers = [], []
+
+            def _view(self, ptr, nbytes):
+                for t in self.buffers:
+                    base = t.data_ptr()
+                    if base <= ptr and ptr + nbytes <= base + t.numel() * t.element_size():
+                        assert (ptr - base) % t.element_size() == 0
+                        lo = (ptr - base) // t.element_size()
+                        return t.view(-1)[lo:lo + nbytes // t.element_size()], t, lo
+                raise AssertionError(f'collective on {nbytes} bytes at {ptr:#x}: not inside any registered buffer')
+
+            def fork(self, like):
+                self.log.append(('fork',))
+
+            def allreduce_ptr(self, ptr, count, dtype_code):
+                assert self.log and self.log[-1][0] in ('fork', 'allreduce'), 'a collective without a fork edge in front of it'
+                v, t, lo = self._view(ptr, count * (4 if dtype_code == 0 else 2))
+                assert v.dtype == (torch.float32 if dtype_code == 0 else torch.bfloat16)
+                dist.all_reduce(v, op=dist.ReduceOp.SUM)
+                self.log.append(('allreduce', id(t), lo, count))
+
+            def allgather_ptr(self, src, dst, nbytes):
+                vs, *_ = self._view(src, nbytes)
+                vd, *_ = self._view(dst, nbytes * self.world)
+                dist.all_gather_into_tensor(vd, vs.contiguous())
+                self.log.append(('allgather', nbytes))
+
+            def join(self, like):
+                self.log.append(('join',))
+
+            def _mark(self, like):
+                return None
+
+            def _keep(self, *tensors):
+                pass
+
+            def all_gather(self, x):
+                x = x.contiguous()
+                self.buffers.append(x)
+                orig_empty = torch.empty
+
+                def grab(*a, **k):
+                    t = orig_empty(*a, **k)
+                    self.buffers.append(t)
+                    return t
+                torch.empty = grab
+                try:
+                    return super().all_gather(x)
+                finally:
+                    torch.empty = orig_empty
+                    del self.buffers[-2:]
+
+            def destroy(self):
+                pass
+        return _Double()
+
+
+def _train_worker(rank, world, port, ret, tmp, overlap=True, native=False):
     if not overlap:
         os.environ['GG_NO_COMM_OVERLAP'] = '1'
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
@@ -106,6 +176,9 @@ def _train_worker(rank, world, port, ret, tmp, overlap=True):
     from helpers import TINY_G, TINY_D
     _C.bind(root / 'tests' / 'emu' / 'libgigagan_amd_emu.so')
     gdist.init_from_env('cpu')
+    fake = None
+    if native:
+        fake = gdist._native = GlooBackedNativeComm(world)
     torch.manual_seed(0)                     # identical initial replicas (and a broadcast on top)
     gan = GigaGAN(generator=dict(TINY_G), discriminator=dict(TINY_D), apply_gradient_penalty_every=2, device='cpu',
                   model_folder=f'{tmp}/m{rank}', results_folder=f'{tmp}/r{rank}')
@@ -113,11 +186,44 @@ def _train_worker(rank, world, port, ret, tmp, overlap=True):
     it = cycle(SyntheticImages(2, 16, seed=rank))
     d0 = gan.D_opt.flat_p.clone()
     in_bwd = []
+    if fake is not None:
+        fake.buffers += [gan.D_opt.flat_g, gan.G_opt.flat_g]
+        assert gdist.comm_backend() == 'gg_comm/rccl' and gan.D_red is not None and gan.G_red is not None
+    native_log = []
     for _ in range(4):                       # steps 2 and 4 carry the gradient penalty; 3 and 4 re-use learned slice counts
         gan.train_step(it, 2)
         if gan.D_red is not None:
             in_bwd.append((gan.D_red.in_backward_launches, gan.G_red.in_backward_launches))
-    assert (gan.D_red is not None) == overlap or not overlap
+        if fake is not None:
+            native_log.append(list(fake.log))
+            fake.log.clear()
+    assert gan.overlap_grad_reduce == overlap
+    if not overlap:                          # GG_NO_COMM_OVERLAP: the reducers exist but are bypassed - one exchange after the backward
+        assert gan.D_red.launched == 0 and gan.G_red.launched == 0 and gan.D_red.sig is None
+    if fake is not None:
+        # every step: each model's flat gradient buffer went through the communicator exactly once, as its reducer's slices, last
+        # slice first, each collective behind a fork edge, and the optimizer launch behind a join
+        for step_log in native_log:
+            for opt, red in ((gan.D_opt, gan.D_red), (gan.G_opt, gan.G_red)):
+                mine = [e for e in step_log if e[0] == 'allreduce' and e[1] == id(opt.flat_g)]
+                assert [(lo, lo + n) for _, _, lo, n in mine] == [(red.bounds[k], red.bounds[k + 1]) for k in reversed(range(red.n))], \
+                    (mine, red.bounds)
+            kinds = [e[0] for e in step_log]
+            assert kinds.count('join') == 2 and kinds[-1] == 'join', kinds
+            for i, k in enumerate(kinds):
+                if k == 'allreduce':
+                    assert kinds[i - 1] == 'fork', kinds
+        # the stand-alone entry points on the same primitives
+        g = torch.full((1000,), float(rank + 1))
+        fake.buffers.append(g)
+        gdist.wait_all(gdist.all_reduce_flat_grads(g, n_slices=3))
+        assert torch.equal(g, torch.full((1000,), 3.0)), g[:4]
+        assert [e[2:] for e in fake.log if e[0] == 'allreduce'] == [(0, 512), (512, 488)], fake.log
+        x = torch.full((2, 3), float(rank + 1), requires_grad=True)
+        out, _ = gdist.all_gather(x)
+        assert out.shape == (4, 3) and torch.equal(out.detach(), torch.tensor([1., 1., 2., 2.])[:, None].expand(4, 3)), out
+        (out * torch.arange(4.)[:, None]).sum().backward()
+        assert torch.equal(x.grad, torch.arange(4.)[rank * 2:(rank + 1) * 2, None].expand(2, 3))
     flat = torch.cat([gan.D_opt.flat_p, gan.G_opt.flat_p])
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
@@ -125,7 +231,7 @@ def _train_worker(rank, world, port, ret, tmp, overlap=True):
     moved = not torch.equal(d0, gan.D_opt.flat_p)
     import hashlib
     ret[rank] = dict(ok=bool(same and moved and torch.isfinite(flat).all()), in_bwd=in_bwd, slices=(gan.D_red.n if gan.D_red else 0),
-                     overlap_on=bool(gan.overlap_grad_reduce),
+                     overlap_on=bool(gan.overlap_grad_reduce), native_steps=len(native_log),
                      digest=hashlib.sha256(flat.numpy().tobytes()).hexdigest())
     dist.barrier()
     dist.destroy_process_group()
@@ -150,3 +256,20 @@ def test_two_rank_training_keeps_replicas_identical(tmp_path):
     ret2 = mgr.dict()
     mp.spawn(_train_worker, args=(world, _free_port(), ret2, str(tmp_path / 'b'), False), nprocs=world, join=True)
     assert ret2[0]['ok'] and not ret2[0]['overlap_on'] and ret2[0]['digest'] == r0['digest'], (dict(ret2), r0)
+
+
+def test_native_comm_branches_run_at_world_2_on_a_gloo_backed_double(tmp_path):
+    """`gg_comm_allreduce` / `gg_comm_allgather` at world > 1 cannot run without GPUs, but everything AROUND
+    them can: with a NativeComm whose stream primitives are backed by gloo, the native branches of GradReducer (in-backward sliced
+    exchange) and of all_reduce_flat_grads / all_gather execute on 2 ranks and must give the same bit-identical replicas - and
+    the same parameters - as the torch.distributed path."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_train_worker, args=(world, _free_port(), ret, str(tmp_path), True, True), nprocs=world, join=True)
+    assert all(ret.get(r) and ret[r]['ok'] for r in range(world)), dict(ret)
+    assert ret[0]['native_steps'] == 4 and ret[0]['digest'] == ret[1]['digest']
+    ref = mgr.dict()
+    mp.spawn(_train_worker, args=(world, _free_port(), ref, str(tmp_path / 'ref')), nprocs=world, join=True)
+    assert ref[0]['digest'] == ret[0]['digest'], 'native-branch exchange and torch.distributed exchange disagree'
+    assert all(d >= ret[0]['slices'] - 1 and g >= 1 for d, g in ret[0]['in_bwd'][2:]), dict(ret[0])

@@ -1226,3 +1226,45 @@ def test_shape_fallbacks_are_counted_and_only_for_shape_reasons():
             ops.second_order = False
         assert not ops.shape_fallbacks, ops.shape_fallbacks
     ops.shape_fallbacks.clear()
+
+
+@pytest.mark.parametrize('cfg', [
+    # n, H, W, ci, co, ksize, splitk      (W x channels decide pixels per step and prefetch depth; splitk 0 = the planner's choice)
+    (1, 64, 64, 32, 32, 3, 0),       # one block, four k-step shares, four image rows per step
+    (2, 64, 64, 8, 32, 3, 3),        # the discriminator stem (3 -> 8 padded channels): 16-byte slots, garbage rows never stored
+    (1, 128, 128, 16, 8, 3, 5),      # to-rgb-like narrow output, two rows per step
+    (1, 64, 64, 64, 64, 3, 2),       # four blocks (one per wave), 128-pixel steps
+    (1, 64, 64, 32, 64, 3, 7),       # two output blocks, two k-step shares
+    (1, 256, 256, 32, 32, 3, 16),    # full-width rows of a 256 x 256 image: one image row per step, the benchmark's layer
+    (2, 64, 64, 16, 32, 1, 0),       # 1x1 (no halo ring)
+    (1, 64, 128, 64, 8, 1, 3),
+])
+def test_streaming_weight_gradient_matches_autograd(cfg):
+    """gg_wgrads (plan tile 13: rows streamed once through LDS rings by LDS-DMA, counted vmcnt waits, raw barriers, transpose-read
+    fragments) against autograd's conv weight gradient on the same bf16 operands. Run under BOTH DMA landing models of the emulator
+    in CI (GG_EMU_DMA=late retires a transfer only at the counted wait that covers it: a mis-counted wait reads stale rows)."""
+    n, H, W, ci, co, ks, sk = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(n, H, W, ci)); dy = bf(torch.randn(n, H, W, co))
+    w = torch.zeros(co, ci, ks, ks, requires_grad=True)
+    F.conv2d(x.float().permute(0, 3, 1, 2), w, padding=ks // 2).backward(dy.float().permute(0, 3, 1, 2))
+    want = w.grad.permute(2, 3, 1, 0).reshape(-1, co)
+    K.plan_log = []
+    got = K.conv2d_wgrad_nhwc(x, dy, ksize=ks, force_tile=13, force_splitk=sk)
+    assert K.plan_log[-1][0] == 13 and (sk == 0 or K.plan_log[-1][1] == sk), K.plan_log
+    K.plan_log = None
+    assert rel_err(got, want) < 1e-5
+
+
+def test_streaming_weight_gradient_takes_over_the_thin_layers_only():
+    """the planner substitutes tile 13 for the 4-wave kernel on >= 64K-pixel launches of eligible geometry; everything else (wide
+    layers, small maps, strided windows, forced tiles) stays where it was."""
+    K.plan_log = []
+    K.conv2d_wgrad_nhwc(bf(torch.randn(16, 64, 64, 32)), bf(torch.randn(16, 64, 64, 32)), ksize=3)         # 64K pixels: streamed
+    K.conv2d_wgrad_nhwc(bf(torch.randn(2, 64, 64, 32)), bf(torch.randn(2, 64, 64, 32)), ksize=3)           # 8K pixels: not worth it
+    K.conv2d_wgrad_nhwc(bf(torch.randn(1, 32, 32, 32)), bf(torch.randn(1, 32, 32, 32)), ksize=3, force_tile=13)   # 32-wide: ineligible
+    K.conv2d_wgrad_nhwc(bf(torch.randn(1, 64, 64, 24)), bf(torch.randn(1, 64, 64, 32)), ksize=3, force_tile=13)   # 24 channels
+    K.conv2d_wgrad_nhwc(bf(torch.randn(16, 64, 64, 32)), bf(torch.randn(16, 64, 64, 32)), ksize=3, force_tile=3)
+    tiles = [t for t, _ in K.plan_log]
+    K.plan_log = None
+    assert tiles[0] == 13 and all(t != 13 for t in tiles[1:]), tiles
