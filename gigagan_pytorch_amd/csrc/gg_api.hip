@@ -509,7 +509,8 @@ static GemmPlan gg_lrconv_plan(const gg_gemm_desc* d, int splitk) {
 }
 
 // the streaming weight gradient of the narrow high-resolution layers (gg_wgrads.h, plan tile 13): takes over wherever the planner (table
-// or cost model) would run a 3x3 / stride 1 / pad 1 or 1x1 weight gradient with <= 64 input and output channels over >= 64K pixels
+// or cost model) would run a 3x3 / stride 1 / pad 1, 1x1, 2x2 / stride 2 or 1x1 / stride 2 weight gradient with <= 64 input and output
+// channels over >= 64K pixels
 // on the 4-wave kernel. GG_WGRADS=0 disables that (A/B runs); force_tile 13 selects it wherever eligible.
 static int gg_wgrads_policy() {
     static int policy = -1;
@@ -521,39 +522,48 @@ static int gg_wgrads_policy() {
     return policy;
 }
 
-static bool gg_wgrads_shape(const gg_gemm_desc* d, int* spx_out, int* depth_out) {
-    if (!d->a_conv || d->a_layout != GG_KROW || d->b_layout != GG_KROW) return false;
-    const bool k3 = d->R == 3 && d->S == 3 && d->conv_stride == 1 && d->conv_pad == 1;
-    const bool k1 = d->R == 1 && d->S == 1 && d->conv_stride == 1 && d->conv_pad == 0;
-    if (!k3 && !k1) return false;
-    const int taps = k3 ? 9 : 1, C = d->C, N = d->N;
-    if (C != d->CV || d->M != taps * C || (d->ldb & 7) || (d->ldc & 3)) return false;
-    if (!((C == 8 || C == 16 || C == 32 || C == 64) && (N == 8 || N == 16 || N == 32 || N == 64))) return false;
+struct GgWsMode { int kh, kw, halo, rpr, cs, cstore, gmul, spx, depth; };
+
+static bool gg_wgrads_shape(const gg_gemm_desc* d, GgWsMode* out) {
+    if (!d->a_conv || d->a_layout != GG_KROW || d->b_layout != GG_KROW || d->R != d->S) return false;
+    GgWsMode m = {0, 0, 0, 1, d->C, d->C, 1, 0, 0};
+    if (d->R == 3 && d->conv_stride == 1 && d->conv_pad == 1) { m.kh = 3; m.kw = 3; m.halo = 1; }
+    else if (d->R == 1 && d->conv_stride == 1 && d->conv_pad == 0) { m.kh = 1; m.kw = 1; }
+    else if (d->R == 2 && d->conv_stride == 2 && d->conv_pad == 0) { m.kh = 2; m.kw = 1; m.rpr = 2; m.cs = m.cstore = 2 * d->C; }   // space-to-depth
+    else if (d->R == 1 && d->conv_stride == 2 && d->conv_pad == 0) { m.kh = 1; m.kw = 1; m.cs = 2 * d->C; m.gmul = 2; }              // even rows, first C of 2C
+    else return false;
+    const int N = d->N, cs = m.cs;
+    if (d->C != d->CV || d->M != d->R * d->S * d->C || (d->ldb & 7) || (d->ldc & 3)) return false;
+    if (!((cs == 8 || cs == 16 || cs == 32 || cs == 64) && (N == 8 || N == 16 || N == 32 || N == 64))) return false;
     if (d->in_scale || d->b_image_stride || d->batch != 1 || d->d2s || !d->c_is_f32) return false;
     if (d->bias || d->out_scale || d->noise || d->residual || d->act != GG_ACT_NONE) return false;
-    if (!gg_pow2(d->H) || !gg_pow2(d->W) || d->W < 64 || d->W > 256) return false;
-    if (d->K % (d->H * d->W)) return false;
+    if (!gg_pow2(d->H) || !gg_pow2(d->W)) return false;
+    const int OW = d->W / d->conv_stride, OH = d->H / d->conv_stride;       // ('same' 3x3, 1x1, or non-overlapping stride-2 windows)
+    if (OW < 64 || OW > 256 || d->K % (OH * OW)) return false;
     if (gg_a_bytes(d) >= (1ll << 32) || gg_b_bytes(d) >= (1ll << 32)) return false;
     for (int spx : {256, 128}) {
-        if (d->W > spx || d->H * d->W < spx || ((spx * C) & 2047) || ((spx * N) & 2047) || spx * C > 16384 || spx * N > 16384) continue;
-        const int npw = spx * (C + N) / 2048;           // DMA instructions per wave and step
+        // a step is whole output rows of one image; every wave issues the same number of 1 KB transfers per step and operand (<= 8)
+        const int xch = cs * m.rpr;              // x channels moved per output pixel
+        if (OW > spx || OH * OW < spx || ((spx * xch) & 2047) || ((spx * N) & 2047) || spx * xch > 16384 || spx * N > 16384) continue;
+        const int npw = spx * (xch + N) / 2048;         // DMA instructions per wave and step
         for (int depth : {3, 2}) {
             if (depth * npw > 48) continue;             // vmcnt is a 6-bit counter; gg_wait_vm_le carries literals up to 48
-            if (gg_ws_geom(taps, d->W, C, N, spx, depth).bytes > GG_WS_LDS) continue;
-            if (spx_out) *spx_out = spx;
-            if (depth_out) *depth_out = depth;
+            if (gg_ws_geom(m.halo, m.rpr, OW, cs, N, spx, depth).bytes > GG_WS_LDS) continue;
+            m.spx = spx; m.depth = depth;
+            if (out) *out = m;
             return true;
         }
     }
     return false;
 }
 
-static bool gg_wgrads_eligible(const gg_gemm_desc* d) { return gg_wgrads_shape(d, nullptr, nullptr); }
+static bool gg_wgrads_eligible(const gg_gemm_desc* d) { return gg_wgrads_shape(d, nullptr); }
 
 static GemmPlan gg_wgrads_plan(const gg_gemm_desc* d, int splitk) {
     GemmPlan pl;
-    int spx = 256, depth = 2;
-    gg_wgrads_shape(d, &spx, &depth);
+    GgWsMode m;
+    gg_wgrads_shape(d, &m);
+    const int spx = m.spx;
     pl.tile = 13; pl.bm = d->M; pl.bn = d->N; pl.blocks_mn = 1;
     const int steps = d->K / spx;
     int sk = splitk > 0 ? splitk : 256;                 // one 152 KB workgroup per CU
@@ -816,9 +826,12 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     }
     else if (pl.tile == 10) GG_LAUNCH(gg_wgrad9_kernel, grid2, dim3(GG2_NT), s, p);
     else if (pl.tile == 13) {
-        gg_wgrads_shape(d, &p.ws_spx, &p.ws_depth);
-        if (d->R == 3) GG_LAUNCH((gg_wgrads_kernel<9>), grid2, dim3(GG_WS_NT), s, p);
-        else GG_LAUNCH((gg_wgrads_kernel<1>), grid2, dim3(GG_WS_NT), s, p);
+        GgWsMode m;
+        gg_wgrads_shape(d, &m);
+        p.ws_spx = m.spx; p.ws_depth = m.depth; p.ws_cs = m.cs; p.ws_cstore = m.cstore; p.ws_gmul = m.gmul;
+        if (m.kh == 3) GG_LAUNCH((gg_wgrads_kernel<3, 3>), grid2, dim3(GG_WS_NT), s, p);
+        else if (m.kh == 2) GG_LAUNCH((gg_wgrads_kernel<2, 1>), grid2, dim3(GG_WS_NT), s, p);
+        else GG_LAUNCH((gg_wgrads_kernel<1, 1>), grid2, dim3(GG_WS_NT), s, p);
     }
     else if (pl.tile == 11) {
         const bool full = pl.splitk == 1 && (p.bias || p.out_scale || p.noise || p.residual || p.act != GG_ACT_NONE);

@@ -82,6 +82,7 @@ struct GgGemmParams {
     long long a_bytes, b_bytes;
     int krow_fast;     // weight-gradient conv gather: stride-1 'same' windows, power-of-two image sides, no input scale
     int ws_spx, ws_depth;   // gg_wgrads_kernel: pixels per step (256 / 128) and prefetch depth in steps
+    int ws_cs, ws_cstore, ws_gmul;   // ... channels per x slot, rows stored per tap, memory rows per ring row
     int buf_ok;        // 31 when both operands' byte extents fit the 32-bit offsets of a buffer descriptor, else 0 (bits: A conv rows,
                        // A dense rows, A reduction-major, B dense rows, B reduction-major)
 };

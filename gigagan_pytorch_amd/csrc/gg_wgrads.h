@@ -1,5 +1,6 @@
-// gg_wgrads.h — STREAMING weight gradient of the narrow high-resolution convolutions (plan tile 13): 3x3 / stride 1 / pad 1 and 1x1,
-// C_in and C_out <= 64 (at most four 32 x 32 blocks), 64..256-wide power-of-two images — the discriminator's stem and first blocks and
+// gg_wgrads.h — STREAMING weight gradient of the narrow high-resolution convolutions (plan tile 13): 3x3 / stride 1 / pad 1, 1x1, and the
+// two stride-2 windows without overlap (2x2 = space-to-depth + 1x1, and the 1x1 / stride 2 residual projection), C_in and C_out <= 64
+// (at most four 32 x 32 blocks), 64..256-wide power-of-two output maps — the discriminator's stem and first blocks and
 // the generator's last blocks (autograd of the F.conv2d call sites gigagan_pytorch.py:402-409, :1608-1621, and of the to/from-rgb 1x1s
 // :1066-1070, :1648):
 //     dW[tap][ci][co] = sum over pixels of x[pixel + tap][ci] * dy[pixel][co]        fp32 [tap * C + ci][co]
@@ -19,6 +20,9 @@
 //   * every wave keeps all taps of ONE (32 ci x 32 co) block in registers (144 accumulators) and takes a share of the step's 16-pixel
 //     k-steps; waves sharing a block are summed through LDS at the end; one fp32 partial [9C][N] per workgroup (<= 256 of them), finished
 //     by gg_splitk_reduce / gg_wgrad_finish like every other split weight gradient.
+// The stride-2 windows are the same kernel over SUPER-PIXELS: an input row of 2 W pixels x C channels is W slots of 2 C channels, so
+// the 2x2 window is two vertically stacked 1-tap reductions over slots (tap = input row parity; [ty][tx * C + c] is exactly the
+// [tap][ci] order of the output) and the 1x1 / stride 2 one reads the even rows and stores only the first C of the 2 C slot channels.
 // Algorithmic bytes: 2 * (C + N) per pixel (+ (W + 2) / W halo columns never fetched: the halo slots are constants).
 #pragma once
 #include "gg_gemm2.h"
@@ -27,45 +31,50 @@
 #define GG_WS_LDS 155648                      // 152 KB: ring budget (one workgroup per CU)
 #define GG_WS_SLACK 128                       // bytes past the last ring row that over-wide fragment reads may touch
 
-// host + device: the ring geometry of a (taps, W, C, N, pixels per step, depth) choice
+// host + device: the ring geometry of a (window, W, slot channels, N, pixels per step, depth) choice. `cs`: channels per x slot (C, or
+// 2 C for the stride-2 windows); `rpr`: x ring rows per output row (2 for the 2x2 window: both input rows of the pair are kept)
 struct GgWsGeom {
-    int sbx, npx, xpp, xp, sby, npy, ypp, yp, rs, nrx, nry, halo;
+    int sbx, npx, xpp, xp, sby, npy, ypp, yp, rs, rsx, nrx, nry, halo;
     long long bytes;
 };
-GG_HOST_DEVICE GgWsGeom gg_ws_geom(int taps, int W, int C, int N, int spx, int depth) {
+GG_HOST_DEVICE GgWsGeom gg_ws_geom(int halo, int rpr, int W, int cs, int N, int spx, int depth) {
     GgWsGeom g;
-    g.halo = taps == 9 ? 1 : 0;
-    g.sbx = (C < 32 ? C : 32) * 2; g.npx = C <= 32 ? 1 : C >> 5;
+    g.halo = halo;
+    g.sbx = (cs < 32 ? cs : 32) * 2; g.npx = cs <= 32 ? 1 : cs >> 5;
     g.sby = (N < 32 ? N : 32) * 2; g.npy = N <= 32 ? 1 : N >> 5;
-    g.xpp = (W + 2 * g.halo) * g.sbx; g.xp = g.npx * g.xpp;
+    g.xpp = (W + 2 * halo) * g.sbx; g.xp = g.npx * g.xpp;
     g.ypp = W * g.sby; g.yp = g.npy * g.ypp;
-    g.rs = spx / W;
-    g.nrx = g.rs * (depth + 1) + 2 * g.halo; g.nry = g.rs * (depth + 1);
-    g.bytes = (long long)(g.nrx + 1) * g.xp + (long long)g.nry * g.yp + GG_WS_SLACK;
+    g.rs = spx / W; g.rsx = g.rs * rpr;
+    g.nrx = g.rsx * (depth + 1) + 2 * halo; g.nry = g.rs * (depth + 1);
+    g.bytes = (long long)(g.nrx + halo) * g.xp + (long long)g.nry * g.yp + GG_WS_SLACK;      // (+ the zero row of the 3x3 window)
     return g;
 }
 
-template <int TAPS>
+// KH x KW: 3 x 3 (stride 1, pad 1), 1 x 1 (stride 1, or stride 2 over super-pixels), 2 x 1 (the 2x2 / stride 2 window over super-pixels).
+// Geometry arrives in the OUTPUT map's terms: p.OW x p.OH pixels per image, p.ws_cs channels per x slot, p.ws_cstore rows stored per tap.
+template <int KH, int KW>
 GG_KERNEL GG_LAUNCH_BOUNDS(GG_WS_NT) void gg_wgrads_kernel(GgGemmParams p) {
-    constexpr int KH = TAPS == 9 ? 3 : 1;
+    constexpr int TAPS = KH * KW, HALO = KW == 3 ? 1 : 0;
+    constexpr int RPR = (KH == 2) ? 2 : 1;            // x ring rows per output row
     GG_SHARED __attribute__((aligned(16))) char smem[GG_WS_LDS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = gg_uniform(tid >> 6);
-    const int W = p.W, H = p.H, C = p.C, N = p.N, ws = p.w_shift;
+    const int W = p.OW, H = p.OH, C = p.ws_cs, N = p.N, ws = p.w_shift;
     const int SPX = p.ws_spx, D = p.ws_depth;
-    const GgWsGeom g = gg_ws_geom(TAPS, W, C, N, SPX, D);
-    const int RS = g.rs, XP = g.xp, YP = g.yp, NRx = g.nrx, NRy = g.nry, HALO = g.halo;
-    const int xring = 0, zrow = NRx * XP, yring = zrow + XP;
+    const int GMUL = p.ws_gmul;                       // memory row of ring row r: r * GMUL (2: the 1x1 / stride 2 window reads even rows)
+    const GgWsGeom g = gg_ws_geom(HALO, RPR, W, C, N, SPX, D);
+    const int RS = g.rs, RSX = g.rsx, XP = g.xp, YP = g.yp, NRx = g.nrx, NRy = g.nry;
+    const int xring = 0, zrow = NRx * XP, yring = zrow + HALO * XP;
 
     // work of this workgroup: steps [s0, s1) of SPX pixels each (a step never straddles an image: H * W >= SPX, powers of two)
-    const int total_steps = p.K / SPX, total_rows = p.K >> ws;
+    const int total_steps = p.K / SPX, total_xrows = (p.K >> ws) * RPR;       // (ring-row units)
     const int spw = p.k_per_split / SPX;
     const int s0 = blockIdx.x * spw;
     int s1 = s0 + spw;
     if (s1 > total_steps) s1 = total_steps;
 
     // constants of the rings: everything that is never DMA'd must read as zero (halo slots, the zero row)
-    for (int v = tid; v < (zrow + XP) / 16; v += GG_WS_NT) *(u16x8*)(smem + v * 16) = gg_zero8();
+    for (int v = tid; v < yring / 16; v += GG_WS_NT) *(u16x8*)(smem + v * 16) = gg_zero8();
 
     GgBufS bufA = gg_make_bufs((const void*)p.A, (unsigned long long)p.a_bytes);
     GgBufS bufB = gg_make_bufs((const void*)p.B, (unsigned long long)p.b_bytes);
@@ -73,7 +82,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_WS_NT) void gg_wgrads_kernel(GgGemmParams p) {
     // DMA plan: a wave instruction moves 64 x 16 bytes = 1 KB of one row-plane. x: SPX * C * 2 / 1024 instructions per step, dy:
     // SPX * N * 2 / 1024, dealt round-robin to the four waves (host: both divisible by 4, so every wave issues the same count)
     const int kbx = (W * g.sbx) >> 10, kby = (W * g.sby) >> 10;            // instructions per row-plane
-    const int nix = RS * g.npx * kbx, niy = RS * g.npy * kby;              // per step, whole workgroup
+    const int nix = RSX * g.npx * kbx, niy = RS * g.npy * kby;             // per step, whole workgroup
     const int npw = (nix + niy) >> 2;                                      // per wave and step
     const int cpsx = g.sbx >> 4, cpsy = g.sby >> 4;                        // 16-byte chunks per slot (1, 2 or 4)
     const int cshx = g.sbx >> 5, cshy = g.sby >> 5;                        // ... and their log2 (16 -> 0, 32 -> 1, 64 -> 2)
@@ -83,7 +92,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_WS_NT) void gg_wgrads_kernel(GgGemmParams p) {
     // per instruction and step it was ~600 scalar / vector instructions in front of every step's multiplication: 1.7 us of 2.7)
     constexpr int MAXI = 8;                   // instructions per wave, step and operand (host: SPX * C <= 16384)
     const int nxw = nix >> 2, nyw = niy >> 2;
-    const int xrowb = W * C * 2, yrowb = W * p.ldb * 2;                     // bytes per image row in memory
+    const int xrowb = W * C * 2 * GMUL, yrowb = W * p.ldb * 2;              // bytes per ring row in memory
     unsigned xvoff[MAXI], yvoff[MAXI];
     int xlds[MAXI], xrr[MAXI], ylds[MAXI], yrr[MAXI];
 #pragma unroll
@@ -109,19 +118,19 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_WS_NT) void gg_wgrads_kernel(GgGemmParams p) {
 
     int xhead = 0, yhead = 0;                 // ring rows the next issued x / dy row lands in
     auto issue_x = [&](int gr, int ring_row, int q) {     // this wave's instruction q of x row gr; rows outside the tensor land as zeros
-        const bool ok = (unsigned)gr < (unsigned)total_rows;
+        const bool ok = (unsigned)gr < (unsigned)total_xrows;
         gg_bufs_load_lds16(bufA, ok ? xvoff[q] : 0xFFFFFFFFu, ok ? (unsigned)gr * (unsigned)xrowb : 0u, smem + ring_row * XP + xlds[q]);
     };
-    auto issue_group = [&](int t) {           // the rows step t adds to the rings: x rows t*RS + HALO .. + RS - 1, dy rows t*RS ..
+    auto issue_group = [&](int t) {           // the rows step t adds to the rings: x rows t*RSX + HALO .. + RSX - 1, dy rows t*RS ..
 #pragma unroll
         for (int q = 0; q < MAXI; ++q) {
             if (q < nxw) {
                 int ring_row = xhead + xrr[q];
                 if (ring_row >= NRx) ring_row -= NRx;
-                issue_x(t * RS + HALO + xrr[q], ring_row, q);
+                issue_x(t * RSX + HALO + xrr[q], ring_row, q);
             }
         }
-        xhead += RS;
+        xhead += RSX;
         if (xhead >= NRx) xhead -= NRx;
 #pragma unroll
         for (int q = 0; q < MAXI; ++q) {
@@ -184,15 +193,15 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_WS_NT) void gg_wgrads_kernel(GgGemmParams p) {
             fb = u16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
 #pragma unroll
             for (int kh = 0; kh < KH; ++kh) {
-                int xr = xtail + ry + kh;
+                int xr = xtail + ry * RPR + kh;
                 if (xr >= NRx) xr -= NRx;
                 const bool in = (unsigned)(y + kh - HALO) < (unsigned)H;
-                const int xo = (in ? xring + xr * XP : zrow) + cx * g.sbx + xlane;
+                const int xo = ((!HALO || in) ? xring + xr * XP : zrow) + cx * g.sbx + xlane;
 #pragma unroll
-                for (int kw = 0; kw < KH; ++kw) {
+                for (int kw = 0; kw < KW; ++kw) {
                     const u16x4 a0 = gg_lds_read_tr16((const bf16_t*)(smem + xo + kw * g.sbx));
                     const u16x4 a1 = gg_lds_read_tr16((const bf16_t*)(smem + xo + (kw + 4) * g.sbx));
-                    fa[kh * KH + kw] = u16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    fa[kh * KW + kw] = u16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                 }
             }
         };
@@ -208,7 +217,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_WS_NT) void gg_wgrads_kernel(GgGemmParams p) {
             if (kk + 2 * kparts < KSTEPS) load(kk + 2 * kparts, fb0, fa0);
             mul(fb1, fa1);
         }
-        xtail += RS;
+        xtail += RSX;
         if (xtail >= NRx) xtail -= NRx;
         ytail += RS;
         if (ytail >= NRy) ytail -= NRy;
@@ -238,10 +247,10 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_WS_NT) void gg_wgrads_kernel(GgGemmParams p) {
 
     // lane owns row ci = cb*32 + (lane & 31) of every tap block; register r holds column nb*32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int ci = cb * 32 + (lane & 31);
-    if (ci >= C) return;
+    if (ci >= p.ws_cstore) return;
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
-        const long long m = (long long)t * C + ci;
+        const long long m = (long long)t * p.ws_cstore + ci;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int n = nb * 32 + 4 * (lane >> 5) + 8 * q;

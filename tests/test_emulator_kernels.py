@@ -1238,19 +1238,25 @@ def test_shape_fallbacks_are_counted_and_only_for_shape_reasons():
     (1, 256, 256, 32, 32, 3, 16),    # full-width rows of a 256 x 256 image: one image row per step, the benchmark's layer
     (2, 64, 64, 16, 32, 1, 0),       # 1x1 (no halo ring)
     (1, 64, 128, 64, 8, 1, 3),
+    (1, 128, 128, 32, 32, 2, 4),     # 2x2 / stride 2 (space-to-depth + 1x1): super-pixel slots of 64 channels, two ring rows per output row
+    (2, 128, 128, 8, 16, 2, 0),
+    (1, 128, 256, 16, 64, -1, 3),    # 1x1 / stride 2 (ksize -1 here): even input rows, the first C of the 2C slot channels stored
+    (2, 128, 128, 8, 32, -1, 0),
 ])
 def test_streaming_weight_gradient_matches_autograd(cfg):
     """gg_wgrads (plan tile 13: rows streamed once through LDS rings by LDS-DMA, counted vmcnt waits, raw barriers, transpose-read
     fragments) against autograd's conv weight gradient on the same bf16 operands. Run under BOTH DMA landing models of the emulator
     in CI (GG_EMU_DMA=late retires a transfer only at the counted wait that covers it: a mis-counted wait reads stale rows)."""
     n, H, W, ci, co, ks, sk = cfg
+    stride, pad = (2, 0) if ks in (2, -1) else (1, ks // 2)
+    ks = abs(ks)
     torch.manual_seed(0)
-    x = bf(torch.randn(n, H, W, ci)); dy = bf(torch.randn(n, H, W, co))
+    x = bf(torch.randn(n, H, W, ci)); dy = bf(torch.randn(n, H // stride, W // stride, co))
     w = torch.zeros(co, ci, ks, ks, requires_grad=True)
-    F.conv2d(x.float().permute(0, 3, 1, 2), w, padding=ks // 2).backward(dy.float().permute(0, 3, 1, 2))
+    F.conv2d(x.float().permute(0, 3, 1, 2), w, stride=stride, padding=pad).backward(dy.float().permute(0, 3, 1, 2))
     want = w.grad.permute(2, 3, 1, 0).reshape(-1, co)
     K.plan_log = []
-    got = K.conv2d_wgrad_nhwc(x, dy, ksize=ks, force_tile=13, force_splitk=sk)
+    got = K.conv2d_wgrad_nhwc(x, dy, ksize=ks, stride=stride, pad=pad, force_tile=13, force_splitk=sk)
     assert K.plan_log[-1][0] == 13 and (sk == 0 or K.plan_log[-1][1] == sk), K.plan_log
     K.plan_log = None
     assert rel_err(got, want) < 1e-5
