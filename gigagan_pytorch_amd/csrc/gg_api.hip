@@ -7,6 +7,7 @@
 #include "gg_lrconv.h"
 #include "gg_wgrad9.h"
 #include "gg_wgrads.h"
+#include "gg_sfwd.h"
 #include "gg_elementwise.h"
 #include "gg_modconv.h"
 #include "gg_attention.h"
@@ -266,6 +267,8 @@ static bool gg_lrconv_eligible(const gg_gemm_desc* d);
 static GemmPlan gg_lrconv_plan(const gg_gemm_desc* d, int splitk);
 static bool gg_wgrads_eligible(const gg_gemm_desc* d);
 static GemmPlan gg_wgrads_plan(const gg_gemm_desc* d, int splitk);
+static bool gg_sfwd_eligible(const gg_gemm_desc* d);
+static GemmPlan gg_sfwd_plan(const gg_gemm_desc* d);
 
 // ---- tuning cache: measured-best (tile, split-K) per exact geometry (gg_gemm_plan_table) ----------------------------------
 struct GgPlanChoice { int tile, splitk; };
@@ -296,6 +299,11 @@ static bool gg_table_plan(const gg_gemm_desc* d, GemmPlan& pl) {
     if (tile == 7 || tile == 8 || tile == 12) {
         if (!gg_conv3_eligible(d)) return false;
         pl = gg_conv3_plan(d, tile, it->second.splitk);
+        return true;
+    }
+    if (tile == 14) {
+        if (!gg_sfwd_eligible(d)) return false;
+        pl = gg_sfwd_plan(d);
         return true;
     }
     if (tile == 13) {
@@ -574,6 +582,70 @@ static GemmPlan gg_wgrads_plan(const gg_gemm_desc* d, int splitk) {
     return pl;
 }
 
+// the streaming forward / data-gradient convolution (gg_sfwd.h, plan tile 14): 3x3 / stride 1 / pad 1, <= 64 channels either side,
+// 64..256-wide images, shared or per-image weights. Takes over from the direct convolution (tile 9) and from the 4-wave kernel
+// (tiles 1-3) on eligible launches of >= 64K pixels. GG_SFWD=0 disables that (A/B runs); force_tile 14 selects it wherever eligible.
+static int gg_sfwd_policy() {
+    static int policy = -1;
+    if (policy < 0) {
+        const char* e = getenv("GG_SFWD");
+        policy = e ? atoi(e) : 1;
+        if (policy < 0) policy = 1;
+    }
+    return policy;
+}
+
+static bool gg_sfwd_shape(const gg_gemm_desc* d, int* spx_out, int* depth_out) {
+    if (!d->a_conv || d->a_layout != GG_ROWK || d->b_layout != GG_ROWK) return false;
+    if (d->R != 3 || d->S != 3 || d->conv_stride != 1 || d->conv_pad != 1) return false;
+    const int C = d->C, N = d->N;
+    if (C != d->CV || d->K != 9 * C || !(C == 8 || C == 16 || C == 32 || C == 64) || N > 64 || (N & 7) || N < 8) return false;
+    if (d->batch != 1 || d->d2s || d->c_is_f32 || d->bank_mix || (d->ldb & 7) || (d->ldc & 7) || (d->residual && d->ldr != d->ldc)) return false;
+    if (d->out_scale || !(d->act == GG_ACT_NONE || d->act == GG_ACT_LRELU)) return false;      // (the epilogue is branch-free: alpha, bias, noise, leaky-relu, residual)
+    if (!gg_pow2(d->H) || !gg_pow2(d->W) || d->W < 64 || d->W > 256 || d->W * C > 8192) return false;
+    if (d->M % (d->H * d->W)) return false;
+    if (gg_a_bytes(d) >= (1ll << 32)) return false;
+    for (int spx : {C == 64 ? 128 : 256}) {             // (the kernel's pixel blocks per wave are tied to this choice)
+        if (d->W > spx || d->H * d->W < spx) continue;
+        const int per_step = spx * C * 2 / 1024;        // 1 KB transfers of the loader wave per step
+        if (per_step < 1) continue;
+        for (int depth : {3, 2}) {
+            if (depth * per_step > 48) continue;
+            if (gg_sf_geom(d->W, C, N, spx, depth).bytes > GG_WS_LDS) continue;
+            if (spx_out) *spx_out = spx;
+            if (depth_out) *depth_out = depth;
+            return true;
+        }
+    }
+    return false;
+}
+
+static bool gg_sfwd_eligible(const gg_gemm_desc* d) { return gg_sfwd_shape(d, nullptr, nullptr); }
+
+static GemmPlan gg_sfwd_plan(const gg_gemm_desc* d) {
+    GemmPlan pl;
+    int spx = 256, depth = 2;
+    gg_sfwd_shape(d, &spx, &depth);
+    pl.tile = 14; pl.bm = spx; pl.bn = d->N; pl.splitk = 1;
+    const int steps = d->M / spx;
+    int wgs = steps < 256 ? steps : 256;                // one 152 KB workgroup per CU, a contiguous run of steps each
+    const int per = (steps + wgs - 1) / wgs;
+    pl.blocks_mn = (steps + per - 1) / per;
+    pl.k_per_split = per * spx;                         // (pixels per workgroup)
+    return pl;
+}
+
+static GemmPlan gg_sfwd_substitute(const gg_gemm_desc* d, const GemmPlan& pl) {
+    if (!((pl.tile >= 1 && pl.tile <= 3) || pl.tile == 9) || d->force_tile != 0 || d->force_splitk != 0 || !gg_sfwd_policy()) return pl;
+    if (pl.splitk != 1 || d->M < 65536 || !gg_sfwd_eligible(d)) return pl;
+    // measured (profiles/r04_sfwd_ab.log): against the 4-wave kernel it wins everywhere (stem 8 -> 32: 285 -> 110 us, 64 -> 64: 239 -> 143 us);
+    // against the direct convolution only when the launch carries a bias / noise / activation / residual epilogue (32 -> 32 @256x256
+    // b=64: 343 -> 159 us; with the plain alpha epilogue gg_dconv runs 3.2-4.3 TB/s and stays)
+    const bool full = d->bias || d->noise || d->residual || d->act != GG_ACT_NONE;
+    if (pl.tile == 9 && !full) return pl;
+    return gg_sfwd_plan(d);
+}
+
 static GemmPlan gg_wgrads_substitute(const gg_gemm_desc* d, const GemmPlan& pl) {
     if (pl.tile < 1 || pl.tile > 3 || d->force_tile != 0 || d->force_splitk != 0 || !gg_wgrads_policy()) return pl;
     if (d->K < 65536 || !gg_wgrads_eligible(d)) return pl;
@@ -622,12 +694,13 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     if (d->force_tile == 10 && gg_wgrad9_eligible(d)) return gg_wgrad9_plan(d, d->force_splitk);
     if (d->force_tile == 11 && gg_lrconv_eligible(d)) return gg_lrconv_plan(d, d->force_splitk);
     if (d->force_tile == 13 && gg_wgrads_eligible(d)) return gg_wgrads_plan(d, d->force_splitk);
-    if (gg_table_plan(d, pl)) return gg_wgrads_substitute(d, gg_wgrad9_substitute(d, gg_conv3_substitute(d, pl, false)));
+    if (d->force_tile == 14 && gg_sfwd_eligible(d)) return gg_sfwd_plan(d);
+    if (gg_table_plan(d, pl)) return gg_sfwd_substitute(d, gg_wgrads_substitute(d, gg_wgrad9_substitute(d, gg_conv3_substitute(d, pl, false))));
     if (gg_use_lrconv(d)) return gg_lrconv_plan(d, d->force_splitk);
     if (gg_use_dconv(d)) {
         pl.tile = 9; pl.bm = GG_DC_TH * GG_DC_TW; pl.bn = d->N <= 32 ? 32 : 64;
         pl.splitk = 1; pl.k_per_split = d->K; pl.blocks_mn = d->M / pl.bm;
-        return pl;
+        return gg_sfwd_substitute(d, pl);
     }
     const bool v2ok = gg_v2_eligible(d) && d->N >= 96 && d->M >= 192;
     const int pol = gg_v2_policy();
@@ -675,7 +748,7 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     const int per = (ktiles + pl.splitk - 1) / pl.splitk;
     pl.splitk = (ktiles + per - 1) / per;
     pl.k_per_split = per * tm.bk;
-    return gg_wgrads_substitute(d, gg_wgrad9_substitute(d, gg_conv3_substitute(d, pl, true)));
+    return gg_sfwd_substitute(d, gg_wgrads_substitute(d, gg_wgrad9_substitute(d, gg_conv3_substitute(d, pl, true))));
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -740,7 +813,7 @@ extern "C" int gg_gemm_plan_table(const gg_plan_entry* entries, int32_t n) {
     g_plan_table.clear();
     for (int i = 0; i < n; ++i) {
         const gg_plan_entry& e = entries[i];
-        if (e.tile < 1 || e.tile > 13 || e.splitk < 1) return gg_fail(-2, "gg_gemm_plan_table: entry %d has tile %d split-K %d", i, e.tile, e.splitk);
+        if (e.tile < 1 || e.tile > 14 || e.splitk < 1) return gg_fail(-2, "gg_gemm_plan_table: entry %d has tile %d split-K %d", i, e.tile, e.splitk);
         g_plan_table[gg_plan_key(&e.M)] = GgPlanChoice{e.tile, e.splitk};
     }
     return 0;
@@ -825,6 +898,20 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
         else { if (wide) gg_launch_dconv<64, 2>(p, s); else gg_launch_dconv<64, 1>(p, s); }
     }
     else if (pl.tile == 10) GG_LAUNCH(gg_wgrad9_kernel, grid2, dim3(GG2_NT), s, p);
+    else if (pl.tile == 14) {
+        gg_sfwd_shape(d, &p.ws_spx, &p.ws_depth);
+        const int ck = d->C <= 16 ? 1 : d->C / 16;
+        const bool nsplit = d->N > 32;
+#define GG_SF(CK)                                                                                          \
+        do {                                                                                               \
+            if (nsplit) GG_LAUNCH((gg_sfwd_kernel<CK, true>), grid2, dim3(GG_SF_NT), s, p);                \
+            else GG_LAUNCH((gg_sfwd_kernel<CK, false>), grid2, dim3(GG_SF_NT), s, p);                      \
+        } while (0)
+        if (ck == 1) GG_SF(1);
+        else if (ck == 2) GG_SF(2);
+        else GG_SF(4);
+#undef GG_SF
+    }
     else if (pl.tile == 13) {
         GgWsMode m;
         gg_wgrads_shape(d, &m);

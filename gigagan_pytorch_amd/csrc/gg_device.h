@@ -140,6 +140,10 @@ GG_DEVICE void gg_bufs_load_lds16(GgBufS r, unsigned voff, unsigned soff, void* 
     const unsigned so = __builtin_amdgcn_readfirstlane(soff);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff), "s"(r), "s"(m), "s"(so) : "memory");
 }
+// hand-over of LDS data between the lanes of ONE wave (a wave-private staging area): the hardware executes a wave's LDS instructions
+// in order, so nothing is emitted - the builtin only pins the compiler's schedule; the emulator, whose lanes are independent fibers,
+// makes it a wave rendezvous
+GG_DEVICE void gg_wave_sync() { __builtin_amdgcn_wave_barrier(); }
 // a value the program knows to be wave-uniform, moved to a scalar register (loop bounds, LDS bases, branch conditions derived from the
 // wave index would otherwise live in vector registers: divergent-loop code, waterfall loops around scalar operands)
 GG_DEVICE int gg_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -84,6 +84,7 @@ typedef GgBuf GgBufS;
 static inline GgBufS gg_make_bufs(const void* base, unsigned long long bytes) { return gg_make_buf(base, bytes); }
 static inline void gg_bufs_load_lds16(GgBufS r, unsigned voff, unsigned soff, void* lds_wave_base) { gg_buf_load_lds16(r, voff, soff, lds_wave_base); }
 static inline int gg_uniform(int v) { return v; }
+static inline void gg_wave_sync() { (void)gg_emu_shfl(0.f, (int)(threadIdx.x & 63u)); }      // a wave collective: every lane arrives before any leaves
 template <typename T>
 static inline const T* gg_late_params(const T& by_value) { return &by_value; }
 static inline f32x16 gg_mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c) {

@@ -36,9 +36,12 @@ def timed(fn, iters=20):
 
 def main():
   for n, H, W, ci, co, ks in SHAPES:
+      stride, pad = (2, 0) if ks in (2, -1) else (1, ks // 2)
+      ks = abs(ks)
+      kw = dict(ksize=ks, stride=stride, pad=pad)
       torch.manual_seed(0)
       x = torch.randn(n, H, W, ci, device=dev).bfloat16()
-      dy = torch.randn(n, H, W, co, device=dev).bfloat16()
+      dy = torch.randn(n, H // stride, W // stride, co, device=dev).bfloat16()
       K.plan_log = []
       old = K.conv2d_wgrad_nhwc(x, dy, **kw)
       new = K.conv2d_wgrad_nhwc(x, dy, force_tile=13, **kw)

@@ -1274,3 +1274,61 @@ def test_streaming_weight_gradient_takes_over_the_thin_layers_only():
     tiles = [t for t, _ in K.plan_log]
     K.plan_log = None
     assert tiles[0] == 13 and all(t != 13 for t in tiles[1:]), tiles
+
+
+@pytest.mark.parametrize('cfg', [
+    # n, H, W, ci, co, per-image weights, epilogue
+    (1, 64, 64, 32, 32, False, 'plain'),        # four image rows per step, every wave 64 pixels x 32 channels
+    (2, 64, 64, 8, 32, False, 'bias_act'),      # the discriminator stem: 16-byte slots, zero weight fragments beyond 8 channels
+    (1, 128, 128, 16, 16, False, 'noise_act'),  # narrow output: 32 staged bytes per pixel
+    (1, 64, 128, 64, 64, False, 'residual'),    # 64 channels in (two planes, 128-pixel steps) and out (channel halves on wave pairs)
+    (1, 64, 64, 32, 64, False, 'bias_act'),
+    (1, 128, 128, 64, 32, False, 'plain'),
+    (1, 256, 256, 32, 16, False, 'noise_act'),  # full-width rows of a 256 x 256 image
+    (3, 64, 64, 32, 32, True, 'noise_act'),     # per-image weights (the adaptive convolution's no-grad form) reloaded at image changes
+    (2, 128, 128, 16, 8, True, 'scale'),        # + per-image input scale folded into the weight fragments
+    (2, 64, 64, 32, 24, False, 'scale'),        # ragged output channel count (24), shared weights with a per-image input scale
+])
+def test_streaming_forward_convolution_matches_conv2d(cfg):
+    """gg_sfwd (plan tile 14: loader wave + LDS-DMA row ring, weights as register-resident MFMA fragments, per-wave output staging)
+    against F.conv2d on the same bf16 operands, every epilogue it carries."""
+    n, H, W, ci, co, per_img, epi = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(n, H, W, ci))
+    w = bf(torch.randn(n if per_img else 1, co, 9 * ci) * 0.1)
+    kw, scale = {}, None
+    if epi == 'scale':
+        scale = torch.rand(n, ci) + 0.5
+        kw['in_scale'] = scale
+    xs = x.float() if scale is None else bf(x.float() * scale[:, None, None, :]).float()    # (the kernel scales the weights instead)
+    want = torch.stack([F.conv2d(xs[i:i + 1].permute(0, 3, 1, 2), w[i if per_img else 0].float().view(co, 3, 3, ci).permute(0, 3, 1, 2),
+                                 padding=1)[0].permute(1, 2, 0) for i in range(n)])
+    if epi == 'bias_act':
+        b = torch.randn(co); kw.update(bias=b, act='lrelu', alpha=0.5, bias_scale=0.5)
+        want = F.leaky_relu(0.5 * (want + b), 0.2)
+    elif epi == 'noise_act':
+        nz = torch.randn(n * H * W); nw = torch.randn(co); kw.update(noise=nz, noise_w=nw, act='lrelu')
+        want = F.leaky_relu(want + nz.view(n, H, W, 1) * nw, 0.2)
+    elif epi == 'residual':
+        r = bf(torch.randn(n, H, W, co)); kw.update(residual=r, res_scale=0.5)
+        want = want + 0.5 * r.float()
+    K.plan_log = []
+    got = K.conv2d_nhwc(x, w if per_img else w[0], ksize=3, per_image_weights=per_img, force_tile=14, **kw)
+    assert K.plan_log[-1][0] == 14, K.plan_log
+    K.plan_log = None
+    assert rel_err(got, want) < (8e-3 if epi == 'scale' else 4e-3)
+
+
+def test_streaming_forward_takes_over_where_it_was_measured_faster():
+    """planner policy for tile 14 (profiles/r04_sfwd_ab.log): every eligible >= 64K-pixel launch the 4-wave kernel would run (the stem,
+    64 -> 64), and the direct convolution's launches only when they carry a bias / activation / noise / residual epilogue."""
+    K.plan_log = []
+    x8, x32 = bf(torch.randn(16, 64, 64, 8)), bf(torch.randn(16, 64, 64, 32))
+    K.conv2d_nhwc(x8, bf(torch.randn(32, 72)), ksize=3)                                        # stem: 4-wave -> streamed
+    K.conv2d_nhwc(x32, bf(torch.randn(32, 288)), ksize=3, bias=torch.randn(32), act='lrelu')   # direct conv with a full epilogue -> streamed
+    K.conv2d_nhwc(x32, bf(torch.randn(32, 288)), ksize=3)                                      # plain: the direct convolution stays
+    K.conv2d_nhwc(x32[:2], bf(torch.randn(32, 288)), ksize=3, bias=torch.randn(32))            # 8K pixels: not worth a persistent launch
+    K.conv2d_nhwc(x32, bf(torch.randn(32, 288)), ksize=3, bias=torch.randn(32), act='gelu')    # no GELU in the branch-free epilogue
+    tiles = [t for t, _ in K.plan_log]
+    K.plan_log = None
+    assert tiles[0] == 14 and tiles[1] == 14 and tiles[2] == 9 and tiles[3] != 14 and tiles[4] != 14, tiles
