@@ -1080,6 +1080,43 @@ extern "C" int gg_colsum_finish(const float* part, float* dst, int32_t P, int32_
     return gg_check_launch();
 }
 
+extern "C" int gg_finish_multi(const gg_finish_item* items, int32_t n, void* stream) {
+    if (n < 0 || (n > 0 && !items)) return gg_fail(-1, "gg_finish_multi: bad arguments");
+    for (int i0 = 0; i0 < n; i0 += GG_FM_MAX) {
+        GgFinishBatch b;
+        memset(&b, 0, sizeof(b));
+        b.n = n - i0 < GG_FM_MAX ? n - i0 : GG_FM_MAX;
+        int wgs = 0;
+        for (int j = 0; j < b.n; ++j) {
+            const gg_finish_item& it = items[i0 + j];
+            if (!it.src || !it.dst) return gg_fail(-1, "gg_finish_multi: item %d: null pointer", i0 + j);
+            GgFinishItem& o = b.item[j];
+            o.src = it.src; o.dst = it.dst; o.kind = it.kind; o.alpha = it.alpha; o.accumulate = it.accumulate;
+            b.first_wg[j] = wgs;
+            if (it.kind == 0) {
+                if (it.O <= 0 || it.I <= 0 || it.T <= 0 || it.C8 < it.I || it.O8 < it.O) return gg_fail(-2, "gg_finish_multi: item %d: bad extents", i0 + j);
+                o.O = it.O; o.I = it.I; o.T = it.T; o.C8 = it.C8; o.O8 = it.O8;
+                wgs += ((it.O + 31) / 32) * ((it.I + GG_WF_IB - 1) / GG_WF_IB);
+            } else if (it.kind == 1) {        // column sums: O = partial rows P, I = row pitch C, T = columns n
+                if (it.O <= 0 || it.I <= 0 || it.T <= 0 || it.T > it.I) return gg_fail(-2, "gg_finish_multi: item %d: bad extents", i0 + j);
+                int groups = (it.O + 15) / 16;
+                if (groups > 32) groups = 32;
+                o.O = it.O; o.I = it.I; o.T = it.T; o.C8 = groups; o.O8 = 0;
+                wgs += ((it.T + 63) / 64) * groups;
+            } else if (it.kind == 2) {        // dst += alpha * src over O elements
+                if (it.O <= 0) return gg_fail(-2, "gg_finish_multi: item %d: bad extents", i0 + j);
+                o.O = it.O;
+                wgs += (it.O + 1023) / 1024;
+            } else return gg_fail(-3, "gg_finish_multi: item %d: unknown kind %d", i0 + j, it.kind);
+        }
+        b.first_wg[b.n] = wgs;
+        GG_LAUNCH(gg_finish_multi_kernel, dim3((unsigned)wgs), dim3(256), (hipStream_t)stream, b);
+        int rc = gg_check_launch();
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 static int gg_modcoef_common(GgModCoefParams& p, const float* w, const float* kmod, int32_t b, int32_t N, int32_t O, int32_t I,
                              int32_t T, int32_t Ip, int32_t Op, float eps) {
     if (!w) return gg_fail(-1, "gg_modcoef: null weights");

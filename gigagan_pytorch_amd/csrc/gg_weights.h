@@ -199,9 +199,9 @@ struct GgWgradFinishParams {
 // element (o = t & 31, i = (t >> 5) & 7): all of a pass's loads are issued before the first use (at most 9 in flight per thread;
 // the first version looped load -> LDS store and every one of its 36 round trips was exposed: ~22 us for ANY layer size), the
 // tile is transposed through LDS, and each output channel's 8 x T run is written (or accumulated) contiguously.
-GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_wgrad_finish_kernel(GgWgradFinishParams p) {
-    GG_SHARED float tile[32][GG_WF_IB * GG_WF_TG + 1];
-    const int o0 = blockIdx.x * 32, i0 = blockIdx.y * GG_WF_IB;
+typedef float GgWfTile[32][GG_WF_IB * GG_WF_TG + 1];
+GG_DEVICE void gg_wgrad_finish_body(const GgWgradFinishParams& p, GgWfTile& tile, int bx, int by) {
+    const int o0 = bx * 32, i0 = by * GG_WF_IB;
     const int t = threadIdx.x;
     const int ol = t & 31, il = (t >> 5) & (GG_WF_IB - 1);
     const bool ok = o0 + ol < p.O && i0 + il < p.I;
@@ -244,19 +244,79 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_wgrad_finish_kernel(GgWgradFinishParams 
     }
 }
 
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_wgrad_finish_kernel(GgWgradFinishParams p) {
+    GG_SHARED GgWfTile tile;
+    gg_wgrad_finish_body(p, tile, blockIdx.x, blockIdx.y);
+}
+
 // dst[c] += alpha * sum_p part[p][c], c < n: the per-workgroup partial column sums of gg_bias_act_bwd (or of any
 // [P][C] fp32 partial buffer) folded, scaled and accumulated into a bias gradient in one launch - replaces the
 // sum / slice / scale / AccumulateGrad chain (4 launches per bias). grid (ceil(n/64), G): workgroup (x, y) folds the
 // partial rows y, y+G, ... (4 waves interleaved) of 64 channels and issues one atomic add per channel; dst holds the
 // running gradient (or zeros).
-GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_colsum_finish_kernel(const float* part, float* dst, int P, int C, int n, float alpha) {
-    GG_SHARED float red[4][64];
+GG_DEVICE void gg_colsum_finish_body(const float* part, float* dst, int P, int C, int n, float alpha, float (&red)[4][64], int bx, int by,
+                                     int groups) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    const int c = bx * 64 + lane;
     float s = 0.f;
     if (c < n)
-        for (int q = blockIdx.y * 4 + wave; q < P; q += 4 * gridDim.y) s += part[(long long)q * C + c];
+        for (int q = by * 4 + wave; q < P; q += 4 * groups) s += part[(long long)q * C + c];
     red[wave][lane] = s;
     gg_sync();
     if (wave == 0 && c < n) gg_atomic_add(dst + c, alpha * ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])));
+}
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_colsum_finish_kernel(const float* part, float* dst, int P, int C, int n, float alpha) {
+    GG_SHARED float red[4][64];
+    gg_colsum_finish_body(part, dst, P, C, n, alpha, red, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+// ---- many finishes in ONE launch -------------------------------------------------------------------------------------------------
+// A backward pass ends every convolution with a weight-gradient finish (and a bias column-sum finish): 221 launches per step of
+// 4-8 us each, every one a handful of dependent round trips on a few KB - 1.5 ms of latency for 0.1 ms of traffic. The host queues
+// them (kernels.FinishQueue) and hands batches of up to GG_FM_MAX items over by value (kernel arguments); a workgroup finds its item
+// in the prefix sums of the items' workgroup counts and runs the single-launch body on it.
+#define GG_FM_MAX 40
+struct GgFinishItem {
+    const float* src;     // kind 0: (T*C8, O8) fp32 weight-gradient GEMM output ; kind 1: (P, C) fp32 partial column sums
+    float* dst;           // kind 0: (O, I, T) fp32 ; kind 1: (n,) fp32, accumulated by atomics
+    int kind, O, I, T, C8, O8, accumulate;      // kind 1: O = P, I = C, T = n, C8 = row groups; kind 2 (dst += alpha * src): O = elements
+    float alpha;
+};
+struct GgFinishBatch {
+    GgFinishItem item[GG_FM_MAX];
+    int first_wg[GG_FM_MAX + 1];      // prefix sums of the items' workgroup counts
+    int n;
+};
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_finish_multi_kernel(GgFinishBatch b) {
+    GG_SHARED GgWfTile tile;
+    const int wg = blockIdx.x;
+    int lo = 0, hi = b.n - 1;                          // last item with first_wg <= wg
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (b.first_wg[mid] <= wg) lo = mid;
+        else hi = mid - 1;
+    }
+    const GgFinishItem& it = b.item[lo];
+    const int local = wg - b.first_wg[lo];
+    if (it.kind == 0) {
+        GgWgradFinishParams p;
+        p.g = it.src; p.dst = it.dst; p.O = it.O; p.I = it.I; p.T = it.T; p.C8 = it.C8; p.O8 = it.O8; p.accumulate = it.accumulate;
+        p.alpha = it.alpha;
+        const int gx = (it.O + 31) / 32;
+        gg_wgrad_finish_body(p, tile, local % gx, local / gx);
+    } else if (it.kind == 2) {                         // dst += alpha * src, 1024 elements per workgroup
+        const long long e0 = (long long)local * 1024 + threadIdx.x * 4;
+        if (e0 + 3 < it.O && !(((unsigned long long)it.src | (unsigned long long)it.dst) & 15)) {
+            const f32x4 a = *(const f32x4*)(it.src + e0);
+            f32x4 d = *(const f32x4*)(it.dst + e0);
+            d[0] += it.alpha * a[0]; d[1] += it.alpha * a[1]; d[2] += it.alpha * a[2]; d[3] += it.alpha * a[3];
+            *(f32x4*)(it.dst + e0) = d;
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (e0 + e < it.O) it.dst[e0 + e] += it.alpha * it.src[e0 + e];
+        }
+    } else {
+        const int gx = (it.T + 63) / 64;
+        gg_colsum_finish_body(it.src, it.dst, it.O, it.I, it.T, it.alpha, *(float (*)[4][64])&tile[0][0], local % gx, local / gx, it.C8);
+    }
 }

@@ -118,11 +118,8 @@ class DiffAugment(nn.Module):
 
 def _backward(loss):
     """loss.backward() with conv weight gradients accumulated directly into the flat gradient buffers (ops.grad_sink)."""
-    ops.grad_sink = True
-    try:
+    with ops.sinking():
         loss.backward()
-    finally:
-        ops.grad_sink = False
 
 
 class GigaGAN(nn.Module):
@@ -622,7 +619,8 @@ class GigaGAN(nn.Module):
 
         graphed = self._graphable(grad_accum_every)
         # one backward pass produces every discriminator gradient of this step -> its all-reduce can ride inside that pass
-        red = self.D_red if (self.overlap_grad_reduce and grad_accum_every == 1 and not has_matching_awareness) else None
+        red = self.D_red if (self.overlap_grad_reduce and grad_accum_every == 1 and not has_matching_awareness
+                             and gdist.GradReducer.active(self.D_opt.flat_g)) else None      # (the transport may have been shut down since)
         red_sig = ('D', bool(apply_gradient_penalty), bool(calc_multiscale_loss))
         staged = None
         if graphed and not self.unconditional:
@@ -739,11 +737,8 @@ class GigaGAN(nn.Module):
                 ms_div = ms_div + generator_hinge_loss(ms)
             ms_detached = ms_div.detach()
             total_loss = total_loss + ms_div * self.multiscale_divergence_loss_weight
-        ops.grad_sink = True
-        try:
+        with ops.sinking():
             (total_loss / grad_accum_every).backward(retain_graph=collect is not None)
-        finally:
-            ops.grad_sink = False
         return divergence.detach(), ms_detached
 
     def _contrastive_adapter(self):
@@ -768,7 +763,8 @@ class GigaGAN(nn.Module):
             p.requires_grad_(False)
         try:
             graphed = self._graphable(grad_accum_every) and not exists(clip)
-            red = self.G_red if (self.overlap_grad_reduce and grad_accum_every == 1 and not exists(clip)) else None
+            red = self.G_red if (self.overlap_grad_reduce and grad_accum_every == 1 and not exists(clip)
+                                 and gdist.GradReducer.active(self.G_opt.flat_g)) else None
             red_sig = ('G', bool(calc_multiscale_loss))
             sig = None
             if graphed and not self.unconditional:

@@ -519,6 +519,75 @@ def colsum_finish(part: torch.Tensor, n: int, alpha: float = 1.0, out: torch.Ten
     return out
 
 
+class FinishItem(C.Structure):       # mirrors gg_finish_item (include/gigagan_amd.h)
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('kind', C.c_int32), ('O', C.c_int32), ('I', C.c_int32), ('T', C.c_int32),
+                ('C8', C.c_int32), ('O8', C.c_int32), ('accumulate', C.c_int32), ('alpha', C.c_float)]
+
+
+class FinishQueue:
+    """weight-gradient / bias-gradient finishes that write into parameters' .grad (the flat gradient buffer) are collected during a
+    backward pass and executed by gg_finish_multi in batches: 221 launches of 4-8 us per step become a handful. `add_*` keeps the
+    source tensors alive until the flush; an item whose destination is already queued flushes first (the batch's items run
+    concurrently); `notify` callbacks (the in-backward gradient exchange's readiness reports) run after the launch that wrote them."""
+    LIMIT = 40                      # GG_FM_MAX: one launch per flush
+
+    def __init__(self):
+        self.items, self.keep, self.notify, self.dsts = [], [], [], set()
+
+    def _add(self, it, dst, keep, notify):
+        if dst.data_ptr() in self.dsts:
+            self.flush()
+        self.items.append(it)
+        self.keep.append(keep)
+        self.dsts.add(dst.data_ptr())
+        if notify is not None:
+            self.notify.append(notify)
+        if len(self.items) >= self.LIMIT:
+            self.flush()
+
+    def add_wgrad(self, g: torch.Tensor, O: int, I: int, T: int, alpha: float, out: torch.Tensor, notify=None):
+        L = _C.lib()
+        L.require(g, out)
+        C8 = g.shape[0] // T
+        assert g.dtype == torch.float32 and g.dim() == 2 and g.is_contiguous() and g.shape[0] == T * C8
+        assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == O * I * T
+        self._add(FinishItem(ptr(g), ptr(out), 0, O, I, T, C8, g.shape[1], 1, float(alpha)), out, (g, out), notify)
+
+    def add_colsum(self, part: torch.Tensor, n: int, alpha: float, out: torch.Tensor, notify=None):
+        L = _C.lib()
+        L.require(part, out)
+        assert part.dtype == torch.float32 and part.dim() == 2 and part.is_contiguous() and n <= part.shape[1]
+        assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == n
+        self._add(FinishItem(ptr(part), ptr(out), 1, part.shape[0], part.shape[1], n, 0, 0, 1, float(alpha)), out, (part, out), notify)
+
+    def add_axpy(self, src: torch.Tensor, alpha: float, out: torch.Tensor, notify=None):
+        """out += alpha * src (fp32, same number of elements: a dense (O, I) linear-layer gradient)."""
+        L = _C.lib()
+        L.require(src, out)
+        assert src.dtype == torch.float32 and src.is_contiguous() and out.dtype == torch.float32 and out.is_contiguous()
+        assert src.numel() == out.numel()
+        self._add(FinishItem(ptr(src), ptr(out), 2, src.numel(), 0, 0, 0, 0, 1, float(alpha)), out, (src, out), notify)
+
+    def clear(self):
+        self.items, self.keep, self.notify, self.dsts = [], [], [], set()
+
+    def flush(self):
+        if not self.items:
+            return
+        L = _C.lib()
+        arr = (FinishItem * len(self.items))(*self.items)
+        like = self.keep[0][0]
+        rc = L.lib.gg_finish_multi(C.cast(arr, C.c_void_p), len(self.items), L.stream(like))
+        notify = self.notify
+        self.items, self.keep, self.notify, self.dsts = [], [], [], set()
+        L.check(rc, 'gg_finish_multi')
+        for fn in notify:
+            fn()
+
+
+finish_queue = FinishQueue()
+
+
 def bias_act_bwd(dy: torch.Tensor, y, want_db: bool, slope: float = 0.2, partials: bool = False):
     """dz = dy * lrelu'(y) (dz is dy itself when y is None) and db = column sums of dz (fp32) in one pass; with
     `partials` the per-workgroup partial sums (P, C) are returned for colsum_finish instead of db."""

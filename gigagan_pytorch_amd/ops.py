@@ -260,6 +260,26 @@ def _grad_sink_of(w):
     return g
 
 
+@contextmanager
+def sinking(on: bool = True):
+    """`with ops.sinking(): loss.backward()` - the trainer's backward passes: weight / bias gradients go straight into the flat
+    gradient buffer (`grad_sink`), their finish passes are queued and the queue is flushed when the pass is over (dropped if it
+    raised)."""
+    global grad_sink
+    prev, grad_sink = grad_sink, bool(on)
+    try:
+        yield
+        K.finish_queue.flush()
+    finally:
+        grad_sink = prev
+        K.finish_queue.clear()
+
+
+def flush_finishes():
+    """run the queued weight- / bias-gradient finishes (end of a backward pass; before anything reads the flat gradient buffer)."""
+    K.finish_queue.flush()
+
+
 def grad_ready(w):
     """a finish kernel has just been enqueued that writes w's gradient into the flat buffer behind autograd's back (no
     AccumulateGrad node runs for it): tell the model's in-backward gradient exchange (distributed.GradReducer), if any."""
@@ -311,10 +331,9 @@ class ConvFn(Function):
         want_db = ctx.has_bias and ctx.needs_input_grad[2] and not inputs_only
         db = None
         bsink = _grad_sink_of(bias) if want_db else None
-        if bsink is not None:       # bias gradient: partial column sums -> one finish launch into the flat .grad
+        if bsink is not None:       # bias gradient: partial column sums -> a queued finish into the flat .grad (K.FinishQueue)
             dz, part = K.bias_act_bwd(dy, y if ctx.act == 'lrelu' else None, True, LRELU_SLOPE, partials=True)
-            K.colsum_finish(part, ctx.n_bias, alpha, out=bsink, accumulate=True)
-            grad_ready(bias)
+            K.finish_queue.add_colsum(part, ctx.n_bias, alpha, bsink, notify=lambda b=bias: grad_ready(b))
         elif ctx.act == 'lrelu' or want_db:
             dz, db = BiasActBwdFn.apply(dy, y if ctx.act == 'lrelu' else None, want_db)
             if want_db:
@@ -342,8 +361,7 @@ class ConvFn(Function):
         if ctx.needs_input_grad[1] and not inputs_only:
             sink = _grad_sink_of(w)
             if sink is not None:
-                WgradFn.compute(x, dz, in_scale, geom, alpha, tuple(w.shape), sink)
-                grad_ready(w)
+                WgradFn.compute(x, dz, in_scale, geom, alpha, tuple(w.shape), sink, notify=lambda w=w: grad_ready(w))
             else:
                 dw = WgradFn.apply(x, dz, in_scale, geom, alpha, tuple(w.shape)).to(w.dtype)
         dres = None
@@ -387,8 +405,7 @@ class DgradFn(Function):
         if ctx.needs_input_grad[1] and not inputs_only:     # dL/dw[co][tap][ci] = alpha * sum_p dz[p][co] * g[p + tap][ci]
             sink = _grad_sink_of(w)
             if sink is not None:
-                WgradFn.compute(g, dz, None, geom, alpha, tuple(w.shape), sink)
-                grad_ready(w)
+                WgradFn.compute(g, dz, None, geom, alpha, tuple(w.shape), sink, notify=lambda w=w: grad_ready(w))
             else:
                 dw = WgradFn.apply(g, dz, None, geom, alpha, tuple(w.shape)).to(w.dtype)
         return ddz, dw, None, None, None, None, (g if ctx.needs_input_grad[6] else None)
@@ -435,9 +452,10 @@ class WgradFn(Function):
         return WgradFn.compute(x, dy, in_scale, geom, alpha, wshape, None)
 
     @staticmethod
-    def compute(x, dy, in_scale, geom, alpha, wshape, sink):
+    def compute(x, dy, in_scale, geom, alpha, wshape, sink, notify=None):
         """the GEMM ([tap][ci][co] fp32, pixels reduced) + the transpose/scale pass into the parameter layout; with
-        `sink` (a parameter's fp32 .grad) the result is accumulated there instead of being returned."""
+        `sink` (a parameter's fp32 .grad) the result is accumulated there instead of being returned - by a QUEUED finish
+        (K.finish_queue: executed in batches, at the latest by `flush_finishes()` at the end of the backward pass)."""
         ksize, stride, pad, wkind = geom
         g = K.conv2d_wgrad_nhwc(x, dy, ksize=ksize, stride=stride, pad=pad, in_scale=in_scale)  # (k*k*C8, O8) fp32
         if wkind == 's2d':              # (O, C, s1, s2) == (O, 4C, 1, 1)
@@ -447,7 +465,7 @@ class WgradFn(Function):
         else:
             O, I = wshape[0], wshape[1]
         if sink is not None:
-            K.wgrad_finish(g, O, I, ksize * ksize, alpha, out=sink, accumulate=True)
+            K.finish_queue.add_wgrad(g, O, I, ksize * ksize, alpha, sink.view(-1), notify=notify)
             return None
         return K.wgrad_finish(g, O, I, ksize * ksize, alpha).view(wshape)
 
@@ -866,8 +884,7 @@ class LinearFn(Function):
             if want_db:
                 bsink = _grad_sink_of(bias)
                 if bsink is not None:
-                    K.colsum_finish(part, O, scale, out=bsink, accumulate=True)
-                    grad_ready(bias)
+                    K.finish_queue.add_colsum(part, O, scale, bsink, notify=lambda b=bias: grad_ready(b))
                 else:
                     db = K.colsum_finish(part, O, scale)
         if ctx.needs_input_grad[0]:     # dx(r, i) = scale * sum_o g(r, o) W(o, i)
@@ -876,8 +893,7 @@ class LinearFn(Function):
             gw = K.gemm(g, xb, trans_a=True, trans_b=False, alpha=scale, out_dtype=torch.float32)[0]
             sink = _grad_sink_of(w)
             if sink is not None:
-                sink.add_(gw)
-                grad_ready(w)
+                K.finish_queue.add_axpy(gw, 1.0, sink.view(-1), notify=lambda w=w: grad_ready(w))
             else:
                 dw = gw
         return dx, dw, db, None, None

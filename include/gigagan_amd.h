@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 7
+#define GG_ABI_VERSION 8
 
 int gg_version(void);
 const char* gg_last_error(void);
@@ -174,6 +174,19 @@ int gg_modcoef_bwd(const float* w, const float* kmod, const float* s, const floa
  * gg_bias_act_bwd (nn.Conv2d bias gradient, gp.py:1608-1621 autograd) into the bias gradient - `dst` is the
  * parameter's .grad (running sum) or a zeroed buffer; fp32 atomics, one per channel and group of 16 partial rows. */
 int gg_colsum_finish(const float* part, float* dst, int32_t P, int32_t C, int32_t n, float alpha, void* stream);
+
+/* many weight-gradient / bias-gradient finishes in ONE launch (a backward pass ends every convolution with one of each: 221
+ * launches of 4-8 us per step). kind 0 = gg_wgrad_finish's work (src (T*C8, O8) fp32 -> dst (O, I, T), accumulate as there);
+ * kind 1 = gg_colsum_finish's (src (P, C) fp32 partial sums with O = P, I = C, T = n columns -> dst (n,), always accumulated);
+ * kind 2 = dst += alpha * src over O fp32 elements (a dense linear-layer weight gradient).
+ * The items are copied into kernel arguments (batches of 40): the array may live in pageable host memory and be reused at once.
+ * Items of one call must not write overlapping destinations. */
+typedef struct gg_finish_item {
+    const float* src; float* dst;
+    int32_t kind, O, I, T, C8, O8, accumulate;
+    float alpha;
+} gg_finish_item;
+int gg_finish_multi(const gg_finish_item* items, int32_t n, void* stream);
 
 /* Row softmax over materialised attention logits (replaces sim*scale, masked_fill, softmax and the dtype casts
  * of gp.py:584-588 / :643-649 with one pass):

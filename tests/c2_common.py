@@ -99,13 +99,13 @@ def latents(batch=BASE_BATCH):
     return torch.randn(BASE_BATCH, 64, generator=torch.Generator().manual_seed(5)).repeat(batch // BASE_BATCH, 1)
 
 
-def make_trainer(G, D, device, tmp):
+def make_trainer(G, D, device, tmp, **kw):
     """our trainer around (copies of) the seeded models; the aux reconstruction loss is weighted 0 (its dropout mask and
     patch choice are the only draws of the step that cannot be replayed across devices), no EMA copy."""
     from gigagan_pytorch_amd import GigaGAN
     return GigaGAN(generator=copy.deepcopy(G), discriminator=copy.deepcopy(D), device=device, use_hip_graphs=False,
                    apply_gradient_penalty_every=4, calc_multiscale_loss_every=1, discr_aux_recon_loss_weight=0.,
-                   create_ema_generator_at_init=False, model_folder=f'{tmp}/m', results_folder=f'{tmp}/r')
+                   create_ema_generator_at_init=False, model_folder=f'{tmp}/m', results_folder=f'{tmp}/r', **kw)
 
 
 def run_step_one(gan, batch):

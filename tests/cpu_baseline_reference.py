@@ -7,7 +7,8 @@ G+D steps incl. optimizer updates, EMA and the per-step `.item()` syncs. Then th
 CPU oracle (`kind: "port"`, what bench.py can time on the GPU box, where /root/reference does not exist): the ratio
 port / reference is what bench.py uses to print `cpu_baseline.reference_equivalent`.
 
-Runs only where /root/reference exists (the build container); writes profiles/r03_cpu_baseline_reference.json.
+Runs only where /root/reference exists (the build container); writes profiles/r04_cpu_baseline_reference_<threads>t.json (one record per
+thread count: bench.py reads them all and reports the ratio with its spread).
 
     python tests/cpu_baseline_reference.py [threads] [first_core]      # pins itself to `threads` cores from `first_core` on
 """
@@ -96,7 +97,8 @@ def main():
                    'img/s over the same 4-step cycle (the port skips the discriminator weight gradients the reference computes and '
                    'discards in the G step and runs D(fake), D(real) as one pass)')
     (ROOT / 'profiles').mkdir(exist_ok=True)
-    (ROOT / 'profiles' / 'r03_cpu_baseline_reference.json').write_text(json.dumps(rec, indent=1))
+    out = os.environ.get('GG_CAL_OUT', f'r04_cpu_baseline_reference_{threads}t.json')
+    (ROOT / 'profiles' / out).write_text(json.dumps(rec, indent=1))
     print(json.dumps(rec, indent=1))
 
 

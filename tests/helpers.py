@@ -80,11 +80,8 @@ def check_flat_optimizer_packs_and_grad_sink(device):
             loss().backward()
             ref = opt.flat_g.clone()
             opt.zero_grad()
-            ops.grad_sink = True
-            try:
+            with ops.sinking():
                 loss().backward()
-            finally:
-                ops.grad_sink = False
             assert opt.flat_g.abs().sum() > 0 and rel_err(opt.flat_g, ref) < 1e-6
             w = net[0].weight
             packed = w._gg_tpacks['fwd'][0]
@@ -115,11 +112,8 @@ def check_style_network_on_linear_fn(device):
         opt.zero_grad()
         z.grad = None
         y = net(z)
-        ops.grad_sink = sink
-        try:
+        with ops.sinking(sink):
             (y.float() * probe).sum().backward()
-        finally:
-            ops.grad_sink = False
         return y.detach().float().cpu(), opt.flat_g.clone().cpu(), z.grad.clone().cpu()
     with ops.use_impl(OracleOps(bf16_operands=True)):
         y_ref, g_ref, dz_ref = run(False)

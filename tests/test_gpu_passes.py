@@ -319,6 +319,41 @@ def test_in_backward_gradient_exchange_is_captured_with_the_step(tmp_path):
         gdist.shutdown()
 
 
+def test_captured_collectives_never_outlive_the_communicator(tmp_path):
+    """a trainer whose captured steps hold RCCL nodes may be dropped - or merely become unreachable
+    (parameters <-> reducer hooks form cycles) - at any time, also AFTER the communicator is gone; RCCL aborts the process from a
+    runtime thread when a graph with its nodes is destroyed behind a destroyed communicator. The communicator therefore owns the
+    order (NativeComm.destroy: collect, drop every live trainer's captured graphs, drain, destroy): here the trainer is still alive and
+    still holds its graphs when the communicator is shut down, is then used again (it re-captures, without collectives), and is
+    finally dropped and collected - none of which may take the process down."""
+    import gc
+    from gigagan_pytorch_amd import GigaGAN, distributed as gdist
+    from gigagan_pytorch_amd.data import SyntheticImages
+    from gigagan_pytorch_amd.gigagan import cycle
+    from helpers import C1_G, C1_D
+    d = dev()
+    comm = gdist.enable_native_comm(d)
+    assert comm is not None
+    torch.manual_seed(0)
+    gan = GigaGAN(generator=dict(C1_G), discriminator=dict(C1_D), apply_gradient_penalty_every=2, device=d,
+                  create_ema_generator_at_init=False, model_folder=str(tmp_path / 'm'), results_folder=str(tmp_path / 'r'))
+    it = cycle(SyntheticImages(2, 64, device=d, seed=3))
+    for _ in range(2):
+        gan.train_step(it, 2)
+    torch.cuda.synchronize()
+    assert gan.use_hip_graphs and len(gan._graphs) >= 2, 'the steps with the exchange inside were not captured'
+    gdist.shutdown()                                     # the trainer is alive and holds graphs with RCCL nodes
+    assert gdist.native_comm() is None and not any(isinstance(v, tuple) and isinstance(v[0], torch.cuda.CUDAGraph)
+                                                   for v in gan._graphs.values()), 'captured graphs survived the communicator'
+    for _ in range(2):                                   # the same trainer keeps working: it captures again, on what exists now
+        gan.train_step(it, 2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(torch.cat([gan.D_opt.flat_p, gan.G_opt.flat_p])).all()
+    del gan, it
+    gc.collect()
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize('cfg', [(512, 512, 4, 32, 11), (512, 512, 8, 32, 8), (512, 256, 16, 32, 11), (256, 256, 16, 32, 11),
                                  (256, 128, 32, 32, 12), (128, 128, 32, 32, 12), (128, 64, 64, 8, 8), (64, 64, 64, 8, 8),
                                  (64, 32, 128, 8, 0), (32, 32, 128, 8, 0), (32, 16, 256, 4, 0), (16, 16, 256, 4, 0)])
