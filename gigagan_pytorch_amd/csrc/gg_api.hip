@@ -123,6 +123,8 @@ int gg_validate_gemm(const gg_gemm_desc* d) {
         if (d->ldr < d->N) return gg_fail(-14, "gg_gemm: ldr %d < N %d", d->ldr, d->N);
         if (d->batch != 1) return gg_fail(-14, "gg_gemm: residual needs batch == 1");
     }
+    if (d->keep_partials && (!d->c_is_f32 || d->bias || d->out_scale || d->noise || d->residual || d->act != GG_ACT_NONE || d->d2s || d->batch != 1))
+        return gg_fail(-17, "gg_gemm: keep_partials needs a plain fp32 [M][N] output (alpha-only epilogue, batch 1)");
     if (d->d2s) {
         if (d->d2s < 1 || d->d2s_taps < 1 || d->d2s_taps > d->d2s || d->d2s_c <= 0 || (d->d2s_c & 3) || d->d2s_oh <= 0 || d->d2s_ow <= 0)
             return gg_fail(-15, "gg_gemm: bad depth-to-space geometry");
@@ -960,7 +962,7 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     else gg_launch_gemm_tile<128, 32, 4, 1>(p, akrow, bkrow, aconv, grid, s);
     rc = gg_check_launch();
     if (rc) return rc;
-    if (pl.splitk > 1) {
+    if (pl.splitk > 1 && !d->keep_partials) {
         long long total = (long long)d->M * d->N * d->batch;
         long long nb = pl.splitk <= 8 ? (total + 255) / 256 : (total + 63) / 64;
         if (nb > 8192) nb = 8192;
@@ -1064,7 +1066,7 @@ extern "C" int gg_wgrad_finish(const float* g, float* dst, int32_t O, int32_t I,
     if (!g || !dst) return gg_fail(-1, "gg_wgrad_finish: null pointer");
     if (O <= 0 || I <= 0 || T <= 0 || C8 < I || O8 < O) return gg_fail(-2, "gg_wgrad_finish: bad extents");
     GgWgradFinishParams p;
-    p.g = g; p.dst = dst; p.O = O; p.I = I; p.T = T; p.C8 = C8; p.O8 = O8; p.accumulate = accumulate; p.alpha = alpha;
+    p.g = g; p.dst = dst; p.O = O; p.I = I; p.T = T; p.C8 = C8; p.O8 = O8; p.accumulate = accumulate; p.alpha = alpha; p.nsplit = 1;
     GG_LAUNCH(gg_wgrad_finish_kernel, dim3((unsigned)((O + 31) / 32), (unsigned)((I + GG_WF_IB - 1) / GG_WF_IB)), dim3(256),
               (hipStream_t)stream, p);
     return gg_check_launch();
@@ -1092,6 +1094,7 @@ extern "C" int gg_finish_multi(const gg_finish_item* items, int32_t n, void* str
             if (!it.src || !it.dst) return gg_fail(-1, "gg_finish_multi: item %d: null pointer", i0 + j);
             GgFinishItem& o = b.item[j];
             o.src = it.src; o.dst = it.dst; o.kind = it.kind; o.alpha = it.alpha; o.accumulate = it.accumulate;
+            o.nsplit = it.nsplit > 1 ? it.nsplit : 1;
             b.first_wg[j] = wgs;
             if (it.kind == 0) {
                 if (it.O <= 0 || it.I <= 0 || it.T <= 0 || it.C8 < it.I || it.O8 < it.O) return gg_fail(-2, "gg_finish_multi: item %d: bad extents", i0 + j);

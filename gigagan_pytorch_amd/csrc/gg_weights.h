@@ -193,6 +193,7 @@ struct GgWgradFinishParams {
     float* dst;           // (O, I, T) fp32
     int O, I, T, C8, O8, accumulate;
     float alpha;
+    int nsplit;           // split-K slices [nsplit][T*C8][O8] behind g, summed while they are read (<= 1: one)
 };
 
 // Workgroup (x, y): output channels 32 x .. + 31, input channels 8 y .. + 7. Thread t reads, for every tap of the pass, the
@@ -213,6 +214,29 @@ GG_DEVICE void gg_wgrad_finish_body(const GgWgradFinishParams& p, GgWfTile& tile
         for (int k = 0; k < GG_WF_TG; ++k) {
             const int tc = k < tg ? t0 + k : t0;
             v[k] = p.g[((long long)tc * p.C8 + ic) * p.O8 + oc];
+        }
+        if (p.nsplit > 1) {           // the split-K reduction folded in: slice s sits s * T * C8 * O8 floats further; fixed order
+            const long long slice = (long long)p.T * p.C8 * p.O8;
+            int s = 1;
+            for (; s + 2 < p.nsplit; s += 3) {            // three slices (27 loads) in flight per thread
+                float a[3][GG_WF_TG];
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int k = 0; k < GG_WF_TG; ++k) {
+                        const int tc = k < tg ? t0 + k : t0;
+                        a[j][k] = p.g[(s + j) * slice + ((long long)tc * p.C8 + ic) * p.O8 + oc];
+                    }
+#pragma unroll
+                for (int k = 0; k < GG_WF_TG; ++k) v[k] += (a[0][k] + a[1][k]) + a[2][k];
+            }
+            for (; s < p.nsplit; ++s) {
+#pragma unroll
+                for (int k = 0; k < GG_WF_TG; ++k) {
+                    const int tc = k < tg ? t0 + k : t0;
+                    v[k] += p.g[s * slice + ((long long)tc * p.C8 + ic) * p.O8 + oc];
+                }
+            }
         }
 #pragma unroll
         for (int k = 0; k < GG_WF_TG; ++k)
@@ -279,6 +303,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_colsum_finish_kernel(const float* part, 
 struct GgFinishItem {
     const float* src;     // kind 0: (T*C8, O8) fp32 weight-gradient GEMM output ; kind 1: (P, C) fp32 partial column sums
     float* dst;           // kind 0: (O, I, T) fp32 ; kind 1: (n,) fp32, accumulated by atomics
+    int nsplit;
     int kind, O, I, T, C8, O8, accumulate;      // kind 1: O = P, I = C, T = n, C8 = row groups; kind 2 (dst += alpha * src): O = elements
     float alpha;
 };
@@ -301,7 +326,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_finish_multi_kernel(GgFinishBatch b) {
     if (it.kind == 0) {
         GgWgradFinishParams p;
         p.g = it.src; p.dst = it.dst; p.O = it.O; p.I = it.I; p.T = it.T; p.C8 = it.C8; p.O8 = it.O8; p.accumulate = it.accumulate;
-        p.alpha = it.alpha;
+        p.alpha = it.alpha; p.nsplit = it.nsplit;
         const int gx = (it.O + 31) / 32;
         gg_wgrad_finish_body(p, tile, local % gx, local / gx);
     } else if (it.kind == 2) {                         // dst += alpha * src, 1024 elements per workgroup

@@ -256,10 +256,15 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, *, ksize: int, stride: int = 1
     return out
 
 
+FOLD_MAX_SLICES = 16      # split-K weight gradients of up to this many slices hand their slices to the queued finish (no reduce launch)
+
+
 def conv2d_wgrad_nhwc(x: torch.Tensor, dy: torch.Tensor, *, ksize: int, stride: int = 1, pad: int | None = None,
-                      cv: int | None = None, in_scale=None, force_splitk=0, force_tile=0):
+                      cv: int | None = None, in_scale=None, force_splitk=0, force_tile=0, keep_slices=False):
     """Weight gradient of conv2d_nhwc: returns fp32 (ksize*ksize*CV, Cout) = sum over output pixels of
-    gather(x)[pixel][(tap, cv)] * dy[pixel][co]."""
+    gather(x)[pixel][(tap, cv)] * dy[pixel][co]. `keep_slices`: returns (tensor, nsplit) instead - when the launch is split over
+    2..FOLD_MAX_SLICES k-slices, the tensor is the slice stack (nsplit, ksize*ksize*CV, Cout) and NO reduction was launched (the
+    caller's finish pass sums them: FinishQueue.add_wgrad(nsplit=)); otherwise the reduced result and 1."""
     L = _C.lib()
     L.require(x, dy, in_scale)
     assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and x.is_contiguous() and dy.is_contiguous()
@@ -269,7 +274,6 @@ def conv2d_wgrad_nhwc(x: torch.Tensor, dy: torch.Tensor, *, ksize: int, stride: 
     OH, OW = _conv_out(H, ksize, stride, pad), _conv_out(Wd, ksize, stride, pad)
     cout = dy.shape[-1]
     assert tuple(dy.shape[:3]) == (n, OH, OW), (dy.shape, (n, OH, OW))
-    out = torch.empty((ksize * ksize * cv, cout), dtype=torch.float32, device=x.device)
     d = GemmDesc()
     d.M, d.N, d.K, d.batch = ksize * ksize * cv, cout, n * OH * OW, 1
     d.A, d.a_layout, d.a_conv = ptr(x), KROW, 1
@@ -279,11 +283,22 @@ def conv2d_wgrad_nhwc(x: torch.Tensor, dy: torch.Tensor, *, ksize: int, stride: 
     if in_scale is not None:
         assert in_scale.dtype == torch.float32 and in_scale.shape == (n, cv) and in_scale.is_contiguous()
         d.in_scale = ptr(in_scale)
-    d.C_out, d.ldc, d.c_is_f32 = ptr(out), cout, 1
+    d.ldc, d.c_is_f32 = cout, 1
     d.alpha = 1.0
     d.bias_scale = 1.0
     d.force_splitk, d.force_tile = force_splitk, force_tile
-    _run_gemm(d, x)
+    nsplit = 1
+    if keep_slices:
+        tile, sk = C.c_int32(0), C.c_int32(0)
+        d.C_out = ptr(x)            # (a placeholder that passes validation: the planner does not look at it)
+        L.check(L.lib.gg_gemm_plan(C.byref(d), C.byref(tile), C.byref(sk)), 'gg_gemm_plan')
+        if 1 < sk.value <= FOLD_MAX_SLICES:
+            nsplit, d.keep_partials = sk.value, 1
+    out = torch.empty((1, 1) if nsplit > 1 else (ksize * ksize * cv, cout), dtype=torch.float32, device=x.device)
+    d.C_out = ptr(out)
+    ws = _run_gemm(d, x)
+    if keep_slices:
+        return (ws[:nsplit * d.M * d.N * 4].view(torch.float32).view(nsplit, d.M, d.N), nsplit) if nsplit > 1 else (out, 1)
     return out
 
 
@@ -521,7 +536,8 @@ def colsum_finish(part: torch.Tensor, n: int, alpha: float = 1.0, out: torch.Ten
 
 class FinishItem(C.Structure):       # mirrors gg_finish_item (include/gigagan_amd.h)
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('kind', C.c_int32), ('O', C.c_int32), ('I', C.c_int32), ('T', C.c_int32),
-                ('C8', C.c_int32), ('O8', C.c_int32), ('accumulate', C.c_int32), ('alpha', C.c_float)]
+                ('C8', C.c_int32), ('O8', C.c_int32), ('accumulate', C.c_int32), ('alpha', C.c_float), ('nsplit', C.c_int32),
+                ('reserved0', C.c_int32)]
 
 
 class FinishQueue:
@@ -545,20 +561,22 @@ class FinishQueue:
         if len(self.items) >= self.LIMIT:
             self.flush()
 
-    def add_wgrad(self, g: torch.Tensor, O: int, I: int, T: int, alpha: float, out: torch.Tensor, notify=None):
+    def add_wgrad(self, g: torch.Tensor, O: int, I: int, T: int, alpha: float, out: torch.Tensor, notify=None, nsplit: int = 1):
+        """g: the weight-gradient GEMM's (T*C8, O8) fp32 output, or with nsplit > 1 its split-K slices (nsplit, T*C8, O8)."""
         L = _C.lib()
         L.require(g, out)
-        C8 = g.shape[0] // T
-        assert g.dtype == torch.float32 and g.dim() == 2 and g.is_contiguous() and g.shape[0] == T * C8
+        rows = g.shape[-2]
+        C8 = rows // T
+        assert g.dtype == torch.float32 and g.is_contiguous() and rows == T * C8 and (g.dim() == 2 if nsplit == 1 else g.shape[0] == nsplit)
         assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == O * I * T
-        self._add(FinishItem(ptr(g), ptr(out), 0, O, I, T, C8, g.shape[1], 1, float(alpha)), out, (g, out), notify)
+        self._add(FinishItem(ptr(g), ptr(out), 0, O, I, T, C8, g.shape[-1], 1, float(alpha), nsplit, 0), out, (g, out), notify)
 
     def add_colsum(self, part: torch.Tensor, n: int, alpha: float, out: torch.Tensor, notify=None):
         L = _C.lib()
         L.require(part, out)
         assert part.dtype == torch.float32 and part.dim() == 2 and part.is_contiguous() and n <= part.shape[1]
         assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == n
-        self._add(FinishItem(ptr(part), ptr(out), 1, part.shape[0], part.shape[1], n, 0, 0, 1, float(alpha)), out, (part, out), notify)
+        self._add(FinishItem(ptr(part), ptr(out), 1, part.shape[0], part.shape[1], n, 0, 0, 1, float(alpha), 1, 0), out, (part, out), notify)
 
     def add_axpy(self, src: torch.Tensor, alpha: float, out: torch.Tensor, notify=None):
         """out += alpha * src (fp32, same number of elements: a dense (O, I) linear-layer gradient)."""
@@ -566,7 +584,7 @@ class FinishQueue:
         L.require(src, out)
         assert src.dtype == torch.float32 and src.is_contiguous() and out.dtype == torch.float32 and out.is_contiguous()
         assert src.numel() == out.numel()
-        self._add(FinishItem(ptr(src), ptr(out), 2, src.numel(), 0, 0, 0, 0, 1, float(alpha)), out, (src, out), notify)
+        self._add(FinishItem(ptr(src), ptr(out), 2, src.numel(), 0, 0, 0, 0, 1, float(alpha), 1, 0), out, (src, out), notify)
 
     def clear(self):
         self.items, self.keep, self.notify, self.dsts = [], [], [], set()

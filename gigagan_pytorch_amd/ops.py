@@ -457,7 +457,9 @@ class WgradFn(Function):
         `sink` (a parameter's fp32 .grad) the result is accumulated there instead of being returned - by a QUEUED finish
         (K.finish_queue: executed in batches, at the latest by `flush_finishes()` at the end of the backward pass)."""
         ksize, stride, pad, wkind = geom
-        g = K.conv2d_wgrad_nhwc(x, dy, ksize=ksize, stride=stride, pad=pad, in_scale=in_scale)  # (k*k*C8, O8) fp32
+        # (k*k*C8, O8) fp32; with a sink and few split-K slices: the slice stack, summed by the queued finish (no reduce launch)
+        g, nsplit = K.conv2d_wgrad_nhwc(x, dy, ksize=ksize, stride=stride, pad=pad, in_scale=in_scale, keep_slices=True) \
+            if sink is not None else (K.conv2d_wgrad_nhwc(x, dy, ksize=ksize, stride=stride, pad=pad, in_scale=in_scale), 1)
         if wkind == 's2d':              # (O, C, s1, s2) == (O, 4C, 1, 1)
             O, I = wshape[0], wshape[1] // 4
         elif len(wshape) == 5:          # kernel bank (N, O, I, k, k) stacked along output channels
@@ -465,7 +467,7 @@ class WgradFn(Function):
         else:
             O, I = wshape[0], wshape[1]
         if sink is not None:
-            K.finish_queue.add_wgrad(g, O, I, ksize * ksize, alpha, sink.view(-1), notify=notify)
+            K.finish_queue.add_wgrad(g, O, I, ksize * ksize, alpha, sink.view(-1), notify=notify, nsplit=nsplit)
             return None
         return K.wgrad_finish(g, O, I, ksize * ksize, alpha).view(wshape)
 

@@ -91,6 +91,9 @@ typedef struct gg_gemm_desc {
                               * softmax-weighted kernel sum, gp.py:378-386) and the contraction runs over the C physical channels:
                               * algorithmic flops instead of n_banks times that. in_scale is then fp32 [n_img][C]. 16x16 images,
                               * 2 banks, 3x3 / stride 1 / pad 1 (gg_lrconv, one image per 256-pixel tile); other shapes are rejected */
+    int32_t keep_partials;   /* split-K launches only (fp32 output, alpha-only epilogue): 1 = leave the slices [splitk][M][N] in the workspace
+                              * and skip the reduction launch - the caller folds it into its own consumer (gg_finish_multi's nsplit) */
+    int32_t reserved0;
 } gg_gemm_desc;
 
 /* Per-device tuning cache (the only persistent native state besides the communicator): measured-best launch
@@ -185,6 +188,8 @@ typedef struct gg_finish_item {
     const float* src; float* dst;
     int32_t kind, O, I, T, C8, O8, accumulate;
     float alpha;
+    int32_t nsplit;      /* kind 0: src holds nsplit split-K slices [nsplit][T*C8][O8] that are summed while they are read (0 / 1: one) */
+    int32_t reserved0;
 } gg_finish_item;
 int gg_finish_multi(const gg_finish_item* items, int32_t n, void* stream);
 

@@ -78,6 +78,37 @@ def main():
                        G=flat(G_, order_G), D=flat(D_, order_D))
             fx['steps'].append(rec)
             print(f'step {step}: {time.time() - t0:.0f} s', rec['d'], rec['g'], flush=True)
+        # the yardstick: the same four steps through OUR trainer on the bf16-operand CPU oracle (what the MFMA kernels compute, with
+        # torch's AdamW arithmetic): how far bf16 contraction operands ALONE move this trajectory away from the fp32 reference. AdamW's
+        # first steps are sign-like, so the rounding noise of near-zero gradient elements flips whole lr-sized updates
+        from gigagan_pytorch_amd import ops
+        from oracle.torch_ops import OracleOps
+        from oracle.cpu_trainer import install_cpu_adamw
+        import itertools
+        ours = c2.make_trainer(G, D, 'cpu', tmp, learning_rate=LR)
+        install_cpu_adamw(ours.G_opt)
+        install_cpu_adamw(ours.D_opt)
+        sub = lambda opt: torch.cat([p.detach().flatten() for p in opt._all])[::c2.GRAD_STRIDE].clone()
+        it2 = itertools.repeat(c2.real_images())
+        fx['oracle_bf16'] = []
+        with ops.use_impl(OracleOps(bf16_operands=True)):
+            for step, want in enumerate(fx['steps'], start=1):
+                t0 = time.time()
+                with c2.randn_replay():
+                    dl = ours.train_discriminator_step(dl_iter=it2, apply_gradient_penalty=want['gp'])
+                with c2.randn_replay():
+                    gl = ours.train_generator_step(batch_size=c2.BASE_BATCH, dl_iter=it2)
+                rec = dict(d=dict(divergence=float(dl.divergence), multiscale=float(dl.multiscale_divergence),
+                                  gradient_penalty=float(dl.gradient_penalty)),
+                           g=dict(divergence=float(gl.divergence), multiscale=float(gl.multiscale_divergence)))
+                for m, opt in (('G', ours.G_opt), ('D', ours.D_opt)):
+                    got = sub(opt)
+                    du, dw = got - fx['p0'][m], want[m] - fx['p0'][m]
+                    rec[m] = dict(update_cosine=float(torch.dot(du, dw) / (du.norm() * dw.norm())),
+                                  max_abs_diff_in_lr=float((got - want[m]).abs().max() / LR),
+                                  rel_l2=float((got - want[m]).norm() / want[m].norm()))
+                fx['oracle_bf16'].append(rec)
+                print(f'oracle_bf16 step {step}: {time.time() - t0:.0f} s', rec, flush=True)
     torch.save(fx, OUT / 'c2_traj.pt')
     print('wrote', OUT / 'c2_traj.pt')
 

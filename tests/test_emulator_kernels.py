@@ -1332,3 +1332,36 @@ def test_streaming_forward_takes_over_where_it_was_measured_faster():
     tiles = [t for t, _ in K.plan_log]
     K.plan_log = None
     assert tiles[0] == 14 and tiles[1] == 14 and tiles[2] == 9 and tiles[3] != 14 and tiles[4] != 14, tiles
+
+
+def test_queued_finishes_match_the_single_launches():
+    """kernels.FinishQueue -> gg_finish_multi: weight-gradient finishes (plain and with split-K slices summed on the way in), bias
+    column sums and dense accumulations, more items than one batch carries (40), a repeated destination (flushes before it is queued
+    again) - against the single-launch kernels / plain tensor algebra. Notifications run after the launch that wrote their item."""
+    torch.manual_seed(0)
+    q = K.FinishQueue()
+    want, dsts, fired = [], [], []
+    for j in range(45):
+        O, I, T = 8 * (1 + j % 5), 8 * (1 + j % 3), (9, 1, 4)[j % 3]
+        nsplit = (1, 3, 5)[j % 3]
+        g = torch.randn(nsplit, T * I, O) if nsplit > 1 else torch.randn(T * I, O)
+        dst = torch.randn(O, I, T)
+        ref = dst + 0.5 * K.wgrad_finish(g.sum(0) if nsplit > 1 else g, O, I, T, 1.0).view(O, I, T)
+        q.add_wgrad(g, O, I, T, 0.5, dst.view(-1), nsplit=nsplit, notify=lambda j=j: fired.append(j))
+        want.append(ref); dsts.append(dst)
+    part, bias = torch.randn(37, 64), torch.randn(50)
+    want.append(bias + 2.0 * part[:, :50].sum(0)); dsts.append(bias)
+    q.add_colsum(part, 50, 2.0, bias)
+    src, acc = torch.randn(1003), torch.randn(1003)
+    want.append(acc - 0.25 * src); dsts.append(acc)
+    q.add_axpy(src, -0.25, acc)
+    assert len(fired) == 40, 'the first full batch was not flushed when the 40th item arrived'
+    again = torch.randn(9 * 8, 8)
+    ref2 = want[0] + K.wgrad_finish(again, 8, 8, 9, 1.0).view(8, 8, 9)
+    q.add_wgrad(again, 8, 8, 9, 1.0, dsts[0].view(-1))          # same destination as item 0 (already written: no flush needed)
+    q.add_wgrad(again, 8, 8, 9, 1.0, dsts[0].view(-1))          # ... and again while it is queued: flushes first
+    q.flush()
+    assert len(fired) == 45 and not q.items
+    for got, ref in zip(dsts[1:], want[1:]):
+        assert rel_err(got, ref) < 1e-6
+    assert rel_err(dsts[0], ref2 + K.wgrad_finish(again, 8, 8, 9, 1.0).view(8, 8, 9)) < 1e-6
