@@ -45,7 +45,8 @@ class GemmDesc(C.Structure):
         ('d2s_ow', C.c_int32),
         ('b_image_stride', C.c_int64),
         ('bank_mix', C.c_void_p),
-        ('keep_partials', C.c_int32), ('reserved0', C.c_int32),
+        ('keep_partials', C.c_int32), ('gelu_mode', C.c_int32),
+        ('gelu_aux', C.c_void_p), ('ld_aux', C.c_int32), ('reserved1', C.c_int32),
     ]
 
 

@@ -123,6 +123,11 @@ int gg_validate_gemm(const gg_gemm_desc* d) {
         if (d->ldr < d->N) return gg_fail(-14, "gg_gemm: ldr %d < N %d", d->ldr, d->N);
         if (d->batch != 1) return gg_fail(-14, "gg_gemm: residual needs batch == 1");
     }
+    if (d->gelu_mode) {
+        if ((d->gelu_mode != 1 && d->gelu_mode != 2) || !d->gelu_aux || (d->ld_aux & 3) || d->ld_aux < d->N || d->c_is_f32 || d->d2s || (d->N & 3) ||
+            (d->ldc & 3) || d->batch != 1 || (d->residual && (d->ldr & 3)))
+            return gg_fail(-18, "gg_gemm: gelu_mode needs a bf16 [M][N] output with N, ldc, ld_aux multiples of 4 and gelu_aux");
+    }
     if (d->keep_partials && (!d->c_is_f32 || d->bias || d->out_scale || d->noise || d->residual || d->act != GG_ACT_NONE || d->d2s || d->batch != 1))
         return gg_fail(-17, "gg_gemm: keep_partials needs a plain fp32 [M][N] output (alpha-only epilogue, batch 1)");
     if (d->d2s) {
@@ -873,6 +878,9 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     p.d2s = d->d2s; p.d2s_t = d->d2s_taps; p.d2s_c = d->d2s_c; p.d2s_oh = d->d2s_oh; p.d2s_ow = d->d2s_ow;
     p.noise = d->noise; p.noise_w = d->noise_w;
     p.act = d->act; p.act_slope = d->act_slope;
+    if (d->gelu_mode && !(pl.tile >= 4 && pl.tile <= 6 && pl.splitk == 1))
+        return gg_fail(-18, "gg_gemm: gelu_mode runs on the 8-wave tiles' staged epilogue only (planned tile %d, split-K %d)", pl.tile, pl.splitk);
+    p.aux = (bf16_t*)d->gelu_aux; p.aux_mode = d->gelu_mode; p.ld_aux = d->ld_aux;
     p.partial = (float*)workspace;
     p.b_img_stride = d->b_image_stride;
     p.bank_mix = d->bank_mix;

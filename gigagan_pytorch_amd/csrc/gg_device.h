@@ -180,6 +180,10 @@ GG_DEVICE float gg_rsqrtf(float x) { return rsqrtf(x); }
 
 // ---- shared scalar helpers (same code on device and in the emulator) ------------------------------
 
+// a * b + c with ONE rounding, spelled out: where several unrolled copies of a reduction must give bit-identical results (the same
+// sample in another batch slot), `a * b + c` leaves the contraction into an fma to the compiler, which may decide differently per copy
+GG_HOST_DEVICE float gg_fmaf(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 GG_HOST_DEVICE float gg_bf2f(bf16_t h) {
     union { unsigned int u; float f; } x;
     x.u = ((unsigned int)h) << 16;

@@ -488,11 +488,11 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_gelu_kernel(GgGeluParams p) {
         if (p.mode == 2) gv = *(const u16x8*)(p.g + v * 8);
         for (int e = 0; e < 8; ++e) {
             const float x = gg_bf2f(xv[e]);
-            const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+            float cdf, pdf;
+            gg_normal_cdf_pdf(x, cdf, pdf);           // (the same arithmetic as the GEMM epilogue's fused form: bit-identical results)
             if (p.mode == 0) {
                 o0[e] = gg_f2bf(x * cdf);
             } else {
-                const float pdf = 0.3989422804014327f * gg_expf(-0.5f * x * x);
                 const float d1 = cdf + x * pdf;
                 if (p.mode == 1) {
                     o0[e] = gg_f2bf(gg_bf2f(dv[e]) * d1);

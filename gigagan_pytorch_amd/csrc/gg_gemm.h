@@ -82,14 +82,36 @@ struct GgGemmParams {
     long long a_bytes, b_bytes;
     int krow_fast;     // weight-gradient conv gather: stride-1 'same' windows, power-of-two image sides, no input scale
     int ws_spx, ws_depth;   // gg_wgrads_kernel: pixels per step (256 / 128) and prefetch depth in steps
+    // gg_gemm2's staged bf16 epilogue, GELU fused around a 1x1 convolution pair (FeedForward, gp.py:726-740): mode 1 = the staged value h
+    // is ALSO stored to aux and the output is gelu(h); mode 2 = aux holds h and the output is staged * gelu'(h)
+    bf16_t* aux; int aux_mode, ld_aux;
     int ws_cs, ws_cstore, ws_gmul;   // ... channels per x slot, rows stored per tap, memory rows per ring row
     int buf_ok;        // 31 when both operands' byte extents fit the 32-bit offsets of a buffer descriptor, else 0 (bits: A conv rows,
                        // A dense rows, A reduction-major, B dense rows, B reduction-major)
 };
 
+// Phi(x) and phi(x) of the standard normal for the exact (erf) GELU of gp.py:731 and its derivatives: Abramowitz-Stegun 7.1.26,
+// |error| < 1.5e-7 in erf - far below the bf16 rounding of everything it feeds - with ONE exponential shared by both (erf's
+// e^{-z^2} at z = x / sqrt 2 IS sqrt(2 pi) phi(x)), one reciprocal and five fmas: cheap enough for a GEMM epilogue (erff + expf cost
+// ~50 instructions per element)
+GG_DEVICE void gg_normal_cdf_pdf(float x, float& cdf, float& pdf) {
+    const float ax = x < 0.f ? -x : x;
+    const float e = gg_expf(-0.5f * x * x);
+    const float t = 1.f / (1.f + 0.3275911f * 0.70710678118654752f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.f - poly * e;
+    cdf = 0.5f * (1.f + (x < 0.f ? -erf_abs : erf_abs));
+    pdf = 0.3989422804014327f * e;
+}
+GG_DEVICE float gg_gelu_f(float x) {
+    float c, d;
+    gg_normal_cdf_pdf(x, c, d);
+    return x * c;
+}
+
 GG_DEVICE float gg_apply_act(float v, int act, float slope) {
     if (act == GG_ACT_LRELU) return v > 0.f ? v : v * slope;
-    if (act == GG_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    if (act == GG_ACT_GELU) return gg_gelu_f(v);
     if (act == GG_ACT_SILU) return v / (1.f + gg_expf(-v));
     return v;
 }

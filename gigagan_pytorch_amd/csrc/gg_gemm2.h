@@ -449,6 +449,18 @@ GG_DEVICE void gg2_stage_writeback(const GgGemmParams& e, int b, const char* sta
         const int m = m_wave + row;
         if (m < e.M && n < e.N) {
             u16x4 o = *(const u16x4*)(stage + row * stage_pitch + qc * 8);
+            if (e.aux_mode == 1) {            // FeedForward up-projection: keep the pre-activation, emit gelu of its bf16 value
+                *(u16x4*)(e.aux + (long long)m * e.ld_aux + n) = o;
+                for (int q = 0; q < 4; ++q) o[q] = gg_f2bf(gg_gelu_f(gg_bf2f(o[q])));
+            } else if (e.aux_mode == 2) {     // data gradient of the down-projection: times gelu'(h) = Phi(h) + h phi(h)
+                const u16x4 h = *(const u16x4*)(e.aux + (long long)m * e.ld_aux + n);
+                for (int q = 0; q < 4; ++q) {
+                    float c, d;
+                    const float x = gg_bf2f(h[q]);
+                    gg_normal_cdf_pdf(x, c, d);
+                    o[q] = gg_f2bf(gg_bf2f(o[q]) * (c + x * d));
+                }
+            }
             if (e.residual) {
                 u16x4 r = *(const u16x4*)(e.residual + (long long)m * e.ldr + n);
                 for (int q = 0; q < 4; ++q) o[q] = gg_f2bf(gg_bf2f(o[q]) + gg_bf2f(r[q]) * e.res_scale);

@@ -209,9 +209,9 @@ GG_DEVICE void gg_modw_body(const GgModWParams& p, int o, int chunk, float* wl, 
 #pragma unroll
                         for (int n = 0; n < N; ++n)
 #pragma unroll
-                            for (int m = n; m < N; ++m, ++pr) q += a_s[bc][n] * a_s[bc][m] * g[pr];
-                        const float sv = mv[u][j] + 1.f;
-                        acc[u] += sv * sv * q;
+                            for (int m = n; m < N; ++m, ++pr) q = gg_fmaf(a_s[bc][n] * a_s[bc][m], g[pr], q);     // (explicit fmas: every
+                        const float sv = mv[u][j] + 1.f;                                                        //  unrolled copy rounds alike)
+                        acc[u] = gg_fmaf(sv * sv, q, acc[u]);
                     }
                 }
             }
@@ -427,8 +427,8 @@ GG_DEVICE void gg_modw_coef_body(const GgModWParams& p, int wg, int nwg) {
                 const float s2 = sv * sv;
                 f32x2 q = {0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < NP; ++k) q += cp[k] * g[k][j];
-                acc += (f32x2){s2, s2} * q;
+                for (int k = 0; k < NP; ++k) q = (f32x2){gg_fmaf(cp[k][0], g[k][j][0], q[0]), gg_fmaf(cp[k][1], g[k][j][1], q[1])};
+                acc = (f32x2){gg_fmaf(s2, q[0], acc[0]), gg_fmaf(s2, q[1], acc[1])};     // (explicit fmas: every unrolled copy rounds alike)
             }
             const float t0 = gg_wave_sum_all(acc[0]), t1 = gg_wave_sum_all(acc[1]);
             if (lane == 0 && bb0 + u < s_hi) {

@@ -209,7 +209,7 @@ def _conv_out(size: int, ksize: int, stride: int, pad: int) -> int:
 def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, *, ksize: int, stride: int = 1, pad: int | None = None,
                 cv: int | None = None, in_scale=None, out_dtype=torch.bfloat16, alpha=1.0, bias=None, bias_scale=1.0,
                 act=None, act_slope=0.2, out_scale=None, noise=None, noise_w=None, residual=None, res_scale=1.0,
-                force_splitk=0, force_tile=0, per_image_weights=False, bank_mix=None):
+                force_splitk=0, force_tile=0, per_image_weights=False, bank_mix=None, gelu_aux=None, gelu_mode=0, plan_only=False):
     """Convolution of an NHWC bf16 activation x (n, H, W, C) with weights w (Cout, ksize*ksize*CV) bf16 laid out
     [co][kh][kw][cv]; window stride `stride`, zero padding `pad` (default: 'same', ksize//2); returns
     (n, OH, OW, Cout) = act(alpha*conv*out_scale + bias*bias_scale + noise) + residual*res_scale. `bank_mix` (n, CV // C) fp32: the
@@ -228,7 +228,7 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, *, ksize: int, stride: int = 1
     else:
         cout, wrow = w.shape[0], w.shape[1]
     assert wrow == ksize * ksize * cv, (w.shape, ksize, cv)
-    out = torch.empty((n, OH, OW, cout), dtype=out_dtype, device=x.device)
+    out = x if plan_only else torch.empty((n, OH, OW, cout), dtype=out_dtype, device=x.device)      # (plan_only: a placeholder pointer)
     keep = [x, w, out]
     d = GemmDesc()
     d.M, d.N, d.K, d.batch = n * OH * OW, cout, ksize * ksize * cv, 1
@@ -248,10 +248,19 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, *, ksize: int, stride: int = 1
         keep.append(bank_mix)
     d.C_out, d.ldc, d.c_is_f32 = ptr(out), cout, int(out_dtype == torch.float32)
     d.force_splitk, d.force_tile = force_splitk, force_tile
-    if residual is not None:
+    if gelu_mode and not plan_only:       # GELU fused around a 1x1 pair (gg_gemm2's staged epilogue): 1 = gelu_aux receives the pre-activation, 2 = holds it
+        assert gelu_aux is not None and gelu_aux.dtype == torch.bfloat16 and gelu_aux.shape == out.shape and gelu_aux.is_contiguous()
+        L.require(gelu_aux)
+        d.gelu_aux, d.gelu_mode, d.ld_aux = ptr(gelu_aux), int(gelu_mode), cout
+        keep.append(gelu_aux)
+    if residual is not None and not plan_only:
         assert residual.shape == out.shape
     _epilogue(d, alpha, bias, out_scale, OH * OW if out_scale is not None else 0, noise, noise_w, act,
               act_slope, keep, bias_scale=bias_scale, residual=residual, res_scale=res_scale)
+    if plan_only:           # (tile, split-K) the launch WOULD take: same descriptor, same planner call as the launch itself
+        tile, sk = C.c_int32(0), C.c_int32(0)
+        L.check(L.lib.gg_gemm_plan(C.byref(d), C.byref(tile), C.byref(sk)), 'gg_gemm_plan')
+        return tile.value, sk.value
     _run_gemm(d, x)
     return out
 

@@ -344,6 +344,11 @@ def _ff_residual(ff, x):
     """ff(x) + x for the channel-first FeedForward (norm, 1x1, gelu, 1x1) with the skip added in the last 1x1's epilogue."""
     norm, conv_in, act, conv_out = ff
     n, x = norm(x, fork=True)
+    fused = getattr(ops.impl, 'ff_tail', None)
+    if fused is not None and conv_in.out_scale == 1.0 and conv_out.out_scale == 1.0 and conv_in.act is None and conv_out.act is None:
+        y = fused(n, conv_in.weight, conv_in.bias, conv_out.weight, conv_out.bias, x)      # GELU on the GEMM epilogues (ops.FFTailFn)
+        if y is not None:
+            return y
     return conv_out(act(conv_in(n)), residual=x)
 
 

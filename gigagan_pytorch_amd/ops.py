@@ -370,6 +370,62 @@ class ConvFn(Function):
         return dx, dw, db, ds, None, None, None, dres, None, None
 
 
+_ff_plan_cache: dict = {}
+_NO_FF_FUSE = bool(os.environ.get('GG_NO_FF_FUSE'))      # A/B switch of the GELU-on-epilogue FeedForward (profiles/r04_ff_fuse_ab.log)
+
+
+class FFTailFn(Function):
+    """conv1x1(gelu(conv1x1(n) + b_in)) + b_out + residual - everything of the channel-first FeedForward behind its norm (gp.py:726-740)
+    as ONE autograd node, with the GELU riding on GEMM epilogues: forward, the up-projection stores its pre-activation h AND gelu(h)
+    (gelu_mode 1: no separate GELU pass over the 4x-wide hidden); backward, the down-projection's data gradient comes out already
+    multiplied by gelu'(h) (gelu_mode 2: no dg tensor, no GELU-backward pass). Parameter gradients go through the grad sink / the
+    queued finishes like ConvFn's. First order only: gradient-penalty graphs keep the separate, twice-differentiable Functions."""
+
+    @staticmethod
+    def forward(ctx, n, w_in, b_in, w_out, b_out, residual):
+        wi, wo = packed_weight(w_in, 'fwd'), packed_weight(w_out, 'fwd')
+        h = torch.empty(n.shape[:3] + (wi.shape[0],), dtype=n.dtype, device=n.device)
+        g = K.conv2d_nhwc(n, wi, ksize=1, bias=b_in, gelu_aux=h, gelu_mode=1)
+        y = K.conv2d_nhwc(g, wo, ksize=1, bias=b_out, residual=residual)
+        ctx.save_for_backward(n, h, g, w_in, b_in, w_out, b_out)
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        n, h, g, w_in, b_in, w_out, b_out = ctx.saved_tensors
+        dy = dy.contiguous()
+        geom = (1, 1, 0, 'oihw')
+
+        def bias_grad(dz, bias, idx):
+            if bias is None or not ctx.needs_input_grad[idx] or inputs_only:
+                return None
+            _, part = K.bias_act_bwd(dz, None, True, LRELU_SLOPE, partials=True)
+            sink = _grad_sink_of(bias)
+            if sink is not None:
+                K.finish_queue.add_colsum(part, bias.shape[0], 1.0, sink, notify=lambda b=bias: grad_ready(b))
+                return None
+            return K.colsum_finish(part, bias.shape[0])
+
+        def weight_grad(x, dz, w, idx):
+            if not ctx.needs_input_grad[idx] or inputs_only:
+                return None
+            sink = _grad_sink_of(w)
+            if sink is not None:
+                WgradFn.compute(x, dz, None, geom, 1.0, tuple(w.shape), sink, notify=lambda w=w: grad_ready(w))
+                return None
+            return WgradFn.compute(x, dz, None, geom, 1.0, tuple(w.shape), None).to(w.dtype)
+
+        db_out = bias_grad(dy, b_out, 4)
+        dw_out = weight_grad(g, dy, w_out, 3)
+        dh = K.conv2d_nhwc(dy, packed_weight(w_out, 'bwd'), ksize=1, gelu_aux=h, gelu_mode=2)      # dgrad * gelu'(h) in one launch
+        db_in = bias_grad(dh, b_in, 2)
+        dw_in = weight_grad(n, dh, w_in, 1)
+        dn = K.conv2d_nhwc(dh, packed_weight(w_in, 'bwd'), ksize=1) if ctx.needs_input_grad[0] else None
+        return dn, dw_in, db_in, dw_out, db_out, (dy if ctx.has_res and ctx.needs_input_grad[5] else None)
+
+
 class DgradFn(Function):
     """data gradient of ConvFn: dx = alpha * conv^T(dz, w). Stride-1 'same' convs run the forward kernel on the
     flipped/transposed weights; the non-overlapping stride-2 windows (1x1 stride 2, space-to-depth) run a dense GEMM
@@ -1195,6 +1251,35 @@ class HipOps:
         if y.shape[-1] != o:
             y = y[..., :o]
         return nchw(y)
+
+    def ff_tail(self, n, w_in, b_in, w_out, b_out, residual):
+        """the FeedForward behind its norm with the GELU on the GEMM epilogues (FFTailFn), or None when this call cannot take that
+        form (twice-differentiated graphs, ragged channel counts, launches the planner would not put on the staged epilogue)."""
+        if second_order or inputs_only or _NO_FF_FUSE:
+            return None
+        hid, dim = w_in.shape[0], w_in.shape[1]
+        if w_in.shape[-1] != 1 or w_out.shape[-1] != 1 or dim % 8 or hid % 8 or w_out.shape[0] != dim or b_in is None:
+            return None
+        nh = nhwc(to_act(n))
+        res = None if residual is None else nhwc(to_act(residual))
+        bi = b_in.float().contiguous()
+        bo = None if b_out is None else b_out.float().contiguous()
+        # both GELU-carrying launches (the up-projection, and the down-projection's data gradient: hid -> dim channels back to hid)
+        # must land on the 8-wave tiles' staged epilogue, unsplit: ask the planner with the launches' own descriptors
+        staged = lambda plan: 4 <= plan[0] <= 6 and plan[1] == 1
+        key = (tuple(nh.shape), hid)
+        ok = _ff_plan_cache.get(key)
+        if ok is None:
+            up = K.conv2d_nhwc(nh, packed_weight(w_in, 'fwd'), ksize=1, bias=bi, plan_only=True)
+            hid_like = nh.new_empty(nh.shape[:3] + (dim,))
+            down = K.conv2d_nhwc(hid_like, packed_weight(w_out, 'bwd'), ksize=1, plan_only=True)
+            ok = _ff_plan_cache[key] = staged(up) and staged(down)
+        if not ok:
+            return None
+        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (n, w_in, b_in, w_out, b_out, residual)):
+            return nchw(FFTailFn.apply(nh, w_in, bi, w_out, bo, res))
+        hgelu = K.conv2d_nhwc(nh, packed_weight(w_in, 'fwd'), ksize=1, bias=bi, act='gelu')      # no-grad: GELU in the epilogue, one output
+        return nchw(K.conv2d_nhwc(hgelu, packed_weight(w_out, 'fwd'), ksize=1, bias=bo, residual=res))
 
     def downsample(self, x, weight, bias=None, residual=None, scale=1.0):
         """scale * (conv1x1(space_to_depth(x), w) + bias) + residual  (gp.py:289-293 and the residual merge

@@ -93,7 +93,11 @@ typedef struct gg_gemm_desc {
                               * 2 banks, 3x3 / stride 1 / pad 1 (gg_lrconv, one image per 256-pixel tile); other shapes are rejected */
     int32_t keep_partials;   /* split-K launches only (fp32 output, alpha-only epilogue): 1 = leave the slices [splitk][M][N] in the workspace
                               * and skip the reduction launch - the caller folds it into its own consumer (gg_finish_multi's nsplit) */
-    int32_t reserved0;
+    int32_t gelu_mode;       /* GELU fused around the 1x1 pair of a FeedForward (gp.py:726-740), bf16 outputs on the 8-wave tiles' staged epilogue
+                              * only (gg_gemm_plan tile 4-6, split-K 1; anything else is rejected): 1 = the result h is ALSO stored to
+                              * gelu_aux and C_out receives gelu(h); 2 = gelu_aux holds h and C_out receives result * gelu'(h) */
+    void* gelu_aux;          /* bf16 [M][ld_aux] */
+    int32_t ld_aux, reserved1;
 } gg_gemm_desc;
 
 /* Per-device tuning cache (the only persistent native state besides the communicator): measured-best launch

@@ -1365,3 +1365,53 @@ def test_queued_finishes_match_the_single_launches():
     for got, ref in zip(dsts[1:], want[1:]):
         assert rel_err(got, ref) < 1e-6
     assert rel_err(dsts[0], ref2 + K.wgrad_finish(again, 8, 8, 9, 1.0).view(8, 8, 9)) < 1e-6
+
+
+def test_feedforward_with_gelu_on_the_gemm_epilogues_matches_the_separate_passes():
+    """ops.FFTailFn (gp.py:726-740 behind the norm): the up-projection's staged epilogue stores h and gelu(h) (gelu_mode 1), the
+    down-projection's data gradient leaves the GEMM already multiplied by gelu'(h) (gelu_mode 2). Output, input gradient and every
+    parameter gradient against the separate conv / gg_gelu / conv Functions (bit-identical forward: the same bf16 rounding points and
+    the same Phi / phi arithmetic) and against fp32 math; no-grad form (GELU as the epilogue activation) included."""
+    from gigagan_pytorch_amd.modules import FeedForward, _ff_residual
+    torch.manual_seed(0)
+    ff = FeedForward(dim=128, mult=4, channel_first=True)
+    for p_ in ff.parameters():
+        if p_.dim() == 1:
+            torch.nn.init.normal_(p_, std=0.3) if p_.shape[0] != 128 or p_ is ff[3].bias else None
+    x = torch.randn(2, 128, 16, 16)
+    probe = torch.randn(2, 128, 16, 16)
+
+    def run(fused, grad=True):
+        xx = x.clone().requires_grad_(grad)
+        for p_ in ff.parameters():
+            p_.grad = None
+        saved, ops.second_order = ops.second_order, not fused           # (second-order graphs keep the separate Functions)
+        K.plan_log = []
+        try:
+            with ops.use_impl(ops.HipOps()), torch.set_grad_enabled(grad):
+                y = _ff_residual(ff, xx)
+                if grad:
+                    (y.float() * probe).sum().backward()
+        finally:
+            ops.second_order = saved
+            plans, K.plan_log = K.plan_log, None
+        return y.detach().float(), (xx.grad.float() if grad else None), [p_.grad.clone() for p_ in ff.parameters()] if grad else None, plans
+
+    y1, dx1, g1, plans1 = run(True)
+    y0, dx0, g0, _ = run(False)
+    assert sum(1 for t, sk in plans1 if 4 <= t <= 6 and sk == 1) >= 2 and len(plans1) == 6, plans1   # both GELU-carrying launches on the staged epilogue; 2 forward + 4 backward contractions, no GELU pass
+    assert torch.equal(y1, y0), float((y1 - y0).abs().max())
+    assert rel_err(dx1, dx0) < 4e-3
+    for a, b in zip(g1, g0):
+        assert rel_err(a, b) < 4e-3, (a.shape, rel_err(a, b))
+    y2, _, _, _ = run(True, grad=False)
+    assert rel_err(y2, y0) < 4e-3
+    with ops.use_impl(OracleOps()):
+        xx = x.clone().requires_grad_()
+        for p_ in ff.parameters():
+            p_.grad = None
+        yr = _ff_residual(ff, xx)
+        (yr * probe).sum().backward()
+    assert rel_err(y1, yr.detach()) < 1e-2 and rel_err(dx1, xx.grad) < 3e-2
+    for a, p_ in zip(g1, ff.parameters()):
+        assert rel_err(a, p_.grad) < 3e-2, (a.shape, rel_err(a, p_.grad))
