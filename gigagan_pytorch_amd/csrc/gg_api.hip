@@ -881,6 +881,11 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     if (d->gelu_mode && !(pl.tile >= 4 && pl.tile <= 6 && pl.splitk == 1))
         return gg_fail(-18, "gg_gemm: gelu_mode runs on the 8-wave tiles' staged epilogue only (planned tile %d, split-K %d)", pl.tile, pl.splitk);
     p.aux = (bf16_t*)d->gelu_aux; p.aux_mode = d->gelu_mode; p.ld_aux = d->ld_aux;
+    {
+        static int narrow = -1;
+        if (narrow < 0) { const char* e = getenv("GG_WB_NARROW"); narrow = e ? atoi(e) : 0; }
+        p.narrow_wb = narrow;
+    }
     p.partial = (float*)workspace;
     p.b_img_stride = d->b_image_stride;
     p.bank_mix = d->bank_mix;

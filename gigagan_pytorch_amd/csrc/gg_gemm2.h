@@ -24,6 +24,7 @@
 //     one M-tile, vertically adjacent pixel rows and — for weight gradients — all output tiles of one pixel slice
 //     share that XCD's L2.
 #pragma once
+#include <type_traits>
 #include "gg_gemm.h"
 
 #define GG2_BK 64
@@ -434,27 +435,37 @@ GG_DEVICE void gg2_epilogue_step(const f32x16 (&acc)[TM][TN], const GgGemmParams
     }
 }
 
-// write-back of a staged WTM x WTN sub-tile: lane -> (row lane / (WTN/4) + it * rows_per_pass, 4 columns)
-template <int WTM, int WTN>
-GG_DEVICE void gg2_stage_writeback(const GgGemmParams& e, int b, const char* stage, int stage_pitch, int m_wave, int n_wave,
-                                   int lane) {
-    constexpr int QPR = WTN / 4;          // quads (8-byte pieces) per row: 16 (WTN 64) or 8 (WTN 32)
-    constexpr int RPP = 64 / QPR;         // rows per pass
-    const int qc = lane % QPR, rr = lane / QPR;
-    const int n = n_wave + qc * 4;
+// write-back of a staged WTM x WTN sub-tile, V = 8 or 4 columns per lane: lane -> (row lane / (WTN/V) + it * rows_per_pass, V columns).
+// V = 8 (N, every row pitch and base 16-byte aligned: the host-visible case of every model layer): 16 bytes per lane and instruction -
+// short-K launches (1x1 convolutions, attention / FeedForward projections) are bound by the ISSUE of this pass's loads and stores, not by
+// bandwidth (MI355X_MICROARCH.md: 8x dwordx4 halves a row-per-lane store tail against 16x dwordx2); the staged tile keeps its pitch
+// (WTN*2 + 8 bytes: conflict-free ds_write_b64), so a lane reads its 16 bytes as two 8-byte halves.
+template <int WTM, int WTN, int V>
+GG_DEVICE void gg2_stage_writeback_v(const GgGemmParams& e, int b, const char* stage, int stage_pitch, int m_wave, int n_wave, int lane) {
+    constexpr int CPR = WTN / V;          // lane slots per row
+    constexpr int RPP = 64 / CPR;         // rows per pass
+    typedef typename std::conditional<V == 8, u16x8, u16x4>::type vec_t;
+    const int qc = lane % CPR, rr = lane / CPR;
+    const int n = n_wave + qc * V;
     bf16_t* cbase = (bf16_t*)e.Cout + (long long)b * e.c_bs;
 #pragma unroll 4
     for (int it = 0; it < WTM / RPP; ++it) {
         const int row = it * RPP + rr;
         const int m = m_wave + row;
         if (m < e.M && n < e.N) {
-            u16x4 o = *(const u16x4*)(stage + row * stage_pitch + qc * 8);
+            vec_t o;
+            if constexpr (V == 8) {
+                const u16x4 lo = *(const u16x4*)(stage + row * stage_pitch + qc * 16), hi = *(const u16x4*)(stage + row * stage_pitch + qc * 16 + 8);
+                o = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            } else {
+                o = *(const u16x4*)(stage + row * stage_pitch + qc * 8);
+            }
             if (e.aux_mode == 1) {            // FeedForward up-projection: keep the pre-activation, emit gelu of its bf16 value
-                *(u16x4*)(e.aux + (long long)m * e.ld_aux + n) = o;
-                for (int q = 0; q < 4; ++q) o[q] = gg_f2bf(gg_gelu_f(gg_bf2f(o[q])));
+                *(vec_t*)(e.aux + (long long)m * e.ld_aux + n) = o;
+                for (int q = 0; q < V; ++q) o[q] = gg_f2bf(gg_gelu_f(gg_bf2f(o[q])));
             } else if (e.aux_mode == 2) {     // data gradient of the down-projection: times gelu'(h) = Phi(h) + h phi(h)
-                const u16x4 h = *(const u16x4*)(e.aux + (long long)m * e.ld_aux + n);
-                for (int q = 0; q < 4; ++q) {
+                const vec_t h = *(const vec_t*)(e.aux + (long long)m * e.ld_aux + n);
+                for (int q = 0; q < V; ++q) {
                     float c, d;
                     const float x = gg_bf2f(h[q]);
                     gg_normal_cdf_pdf(x, c, d);
@@ -462,12 +473,21 @@ GG_DEVICE void gg2_stage_writeback(const GgGemmParams& e, int b, const char* sta
                 }
             }
             if (e.residual) {
-                u16x4 r = *(const u16x4*)(e.residual + (long long)m * e.ldr + n);
-                for (int q = 0; q < 4; ++q) o[q] = gg_f2bf(gg_bf2f(o[q]) + gg_bf2f(r[q]) * e.res_scale);
+                const vec_t r = *(const vec_t*)(e.residual + (long long)m * e.ldr + n);
+                for (int q = 0; q < V; ++q) o[q] = gg_f2bf(gg_bf2f(o[q]) + gg_bf2f(r[q]) * e.res_scale);
             }
-            *(u16x4*)(cbase + (long long)m * e.ldc + n) = o;
+            *(vec_t*)(cbase + (long long)m * e.ldc + n) = o;
         }
     }
+}
+
+template <int WTM, int WTN>
+GG_DEVICE void gg2_stage_writeback(const GgGemmParams& e, int b, const char* stage, int stage_pitch, int m_wave, int n_wave, int lane) {
+    const bool wide = !e.narrow_wb && !(e.N & 7) && !(e.ldc & 7) && !(e.c_bs & 7) && !((unsigned long long)e.Cout & 15) &&
+                      (!e.residual || (!(e.ldr & 7) && !((unsigned long long)e.residual & 15))) &&
+                      (!e.aux_mode || (!(e.ld_aux & 7) && !((unsigned long long)e.aux & 15)));
+    if (wide) gg2_stage_writeback_v<WTM, WTN, 8>(e, b, stage, stage_pitch, m_wave, n_wave, lane);
+    else gg2_stage_writeback_v<WTM, WTN, 4>(e, b, stage, stage_pitch, m_wave, n_wave, lane);
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------------------
