@@ -1371,6 +1371,18 @@ extern "C" int gg_linattn_k_bwd(const void* eks, int32_t ld_eks, const void* dek
     return gg_linattn_k(1, eks, ld_eks, deks, ld_deks, dk, ld_dk, part, stat, b, n, C, stream);
 }
 
+extern "C" int gg_hinge(const void* x, void* dx, const float* gscale, float* loss, int64_t n, int64_t inner, int32_t nb, int32_t split,
+                        int32_t mode, int32_t x_is_f32, void* stream) {
+    if (!x || (!dx && !loss) || (dx && !gscale)) return gg_fail(-1, "gg_hinge: null pointer");
+    if (n <= 0 || inner <= 0 || nb <= 0 || (mode != 0 && mode != 1) || (mode == 1 && (split <= 0 || split >= nb || n % (inner * nb))))
+        return gg_fail(-2, "gg_hinge: bad extents");
+    GgHingeParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.dx = dx; p.gscale = gscale; p.loss = loss; p.n = n; p.inner = inner; p.nb = nb; p.split = split; p.mode = mode; p.x_f32 = x_is_f32;
+    GG_LAUNCH(gg_hinge_kernel, dim3(1), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
 extern "C" int gg_scaled_add(const void* a, const void* b, const void* d, void* y, int64_t n, float c, void* stream) {
     if (!a || !y) return gg_fail(-1, "gg_scaled_add: null pointer");
     if (n <= 0 || (n & 7)) return gg_fail(-2, "gg_scaled_add: n must be a positive multiple of 8");

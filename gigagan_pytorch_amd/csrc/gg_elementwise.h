@@ -764,6 +764,56 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_addcat_bwd_kernel(GgAddCatParams p) {
     }
 }
 
+// ---- hinge losses over a logit tensor in ONE launch (gp.py:157-163: generator_hinge_loss = mean(fake), discriminator_hinge_loss =
+// mean(relu(1 + real) + relu(1 - fake))) and their backward in one more. x is (outer, nb, inner) bf16 or fp32 with the batch on the
+// middle axis; mode 1: rows j < split are the FAKE half, the others the real half (the merged discriminator pass evaluates both as one
+// batch), loss = sum over all elements of relu(1 + sign * x) / (n / 2); mode 0: loss = sum x / n. The tensors are tiny (<= a few 10^5
+// elements) and the reference's formulation is ~16 PyTorch launches per tensor: ONE workgroup, fixed summation order (deterministic).
+// dx == null: forward, loss[0] written. dx != null: dx = gscale[0] * d loss / d x in x's dtype.
+struct GgHingeParams {
+    const void* x;
+    void* dx;
+    const float* gscale;
+    float* loss;
+    long long n, inner;
+    int nb, split, mode, x_f32;
+};
+
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_hinge_kernel(GgHingeParams p) {
+    GG_SHARED float red[256];
+    const int t = threadIdx.x;
+    const float inv = p.mode == 1 ? 2.f / (float)p.n : 1.f / (float)p.n;
+    const float g = p.dx ? p.gscale[0] * inv : 0.f;
+    float acc = 0.f;
+    for (long long i = t; i < p.n; i += 256) {
+        const float x = p.x_f32 ? ((const float*)p.x)[i] : gg_bf2f(((const bf16_t*)p.x)[i]);
+        float f, df;
+        if (p.mode == 1) {
+            const int j = (int)((i / p.inner) % p.nb);
+            const float sgn = j < p.split ? -1.f : 1.f;
+            const float v = 1.f + sgn * x;
+            f = v > 0.f ? v : 0.f;
+            df = v > 0.f ? sgn : 0.f;
+        } else {
+            f = x;
+            df = 1.f;
+        }
+        acc += f;
+        if (p.dx) {
+            if (p.x_f32) ((float*)p.dx)[i] = g * df;
+            else ((bf16_t*)p.dx)[i] = gg_f2bf(g * df);
+        }
+    }
+    if (p.dx) return;
+    red[t] = acc;
+    gg_sync();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) red[t] += red[t + s];
+        gg_sync();
+    }
+    if (t == 0) p.loss[0] = red[0] * inv;
+}
+
 // ---- y = (a + b) * c [+ d] over dense bf16 buffers (b, d optional): the predictor's residual merges (gp.py:1493, :1495) in one
 // pass; with b, d null it is the merge's backward (g * c for both inputs).
 struct GgScaledAddParams {

@@ -568,13 +568,19 @@ class GigaGAN(nn.Module):
             ops.second_order = False
 
         zero = torch.zeros((), device=dev)
-        divergence = discriminator_hinge_loss(real_logits, fake_logits)
+        # the merged pass's logits hold both halves: one launch per tensor (ops.HingeFn) instead of ~16 (casts, 1 +- x, relu, sum, mean)
+        fused_hinge = getattr(ops.impl, 'hinge', None) if merged else None
+
+        def d_hinge(all_, real, fake):
+            out = fused_hinge(all_, b) if fused_hinge is not None else None
+            return out if out is not None else discriminator_hinge_loss(real, fake)
+        divergence = d_hinge(logits_all if merged else None, real_logits, fake_logits)
 
         multiscale_divergence = 0.
         ms_detached = zero
         if self.multiscale_divergence_loss_weight > 0. and len(fake_ms_logits) > 0:
-            for ms_fake, ms_real in zip(fake_ms_logits, real_ms_logits):
-                multiscale_divergence = multiscale_divergence + discriminator_hinge_loss(ms_real, ms_fake)
+            for i, (ms_fake, ms_real) in enumerate(zip(fake_ms_logits, real_ms_logits)):
+                multiscale_divergence = multiscale_divergence + d_hinge(ms_split[i] if merged else None, ms_real, ms_fake)
             ms_detached = multiscale_divergence.detach()
 
         gp_loss = 0.
@@ -728,13 +734,18 @@ class GigaGAN(nn.Module):
 
         logits, ms_logits, _ = self.D(images, rgbs, **maybe_text_kwargs,
                                       return_multiscale_outputs=calc_multiscale_loss, calc_aux_loss=False)
-        divergence = generator_hinge_loss(logits)
+        fused_hinge = getattr(ops.impl, 'hinge', None)
+
+        def g_hinge(t):
+            out = fused_hinge(t) if fused_hinge is not None else None
+            return out if out is not None else generator_hinge_loss(t)
+        divergence = g_hinge(logits)
         total_loss = divergence
         ms_detached = zero
         if self.multiscale_divergence_loss_weight > 0. and len(ms_logits) > 0:
             ms_div = 0.
             for ms in ms_logits:
-                ms_div = ms_div + generator_hinge_loss(ms)
+                ms_div = ms_div + g_hinge(ms)
             ms_detached = ms_div.detach()
             total_loss = total_loss + ms_div * self.multiscale_divergence_loss_weight
         with ops.sinking():

@@ -543,6 +543,25 @@ def colsum_finish(part: torch.Tensor, n: int, alpha: float = 1.0, out: torch.Ten
     return out
 
 
+def hinge(x: torch.Tensor, nb: int, split: int, mode: int, gscale: torch.Tensor | None = None):
+    """gg_hinge: x dense (outer, nb, inner...) bf16 / fp32. gscale None: returns the loss (fp32 scalar tensor); else the gradient
+    gscale * d loss / d x (x's dtype and shape)."""
+    L = _C.lib()
+    L.require(x, gscale)
+    assert x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float32) and x.dim() >= 2 and x.shape[1] == nb
+    inner = x.numel() // (x.shape[0] * nb)
+    if gscale is None:
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        dx = None
+    else:
+        assert gscale.dtype == torch.float32 and gscale.numel() == 1
+        out = dx = torch.empty_like(x)
+    rc = L.lib.gg_hinge(ptr(x), ptr(dx), ptr(gscale), ptr(out) if gscale is None else None, x.numel(), inner, nb, split, mode,
+                        int(x.dtype == torch.float32), L.stream(x))
+    L.check(rc, 'gg_hinge')
+    return out
+
+
 class FinishItem(C.Structure):       # mirrors gg_finish_item (include/gigagan_amd.h)
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('kind', C.c_int32), ('O', C.c_int32), ('I', C.c_int32), ('T', C.c_int32),
                 ('C8', C.c_int32), ('O8', C.c_int32), ('accumulate', C.c_int32), ('alpha', C.c_float), ('nsplit', C.c_int32),

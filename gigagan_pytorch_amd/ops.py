@@ -374,6 +374,25 @@ _ff_plan_cache: dict = {}
 _NO_FF_FUSE = bool(os.environ.get('GG_NO_FF_FUSE'))      # A/B switch of the GELU-on-epilogue FeedForward (profiles/r04_ff_fuse_ab.log)
 
 
+class HingeFn(Function):
+    """the trainer's hinge losses over one logit tensor (gp.py:157-163) in one launch, their backward in one more (kernels.hinge).
+    mode 1: x is (outer, 2b, ...) with the fake half first (the merged discriminator pass); mode 0: mean(x). Piecewise linear: the
+    gradient penalty differentiates the logits themselves, never this loss, so first order is all there is."""
+
+    @staticmethod
+    def forward(ctx, x, nb, split, mode):
+        ctx.cfg = (nb, split, mode)
+        ctx.save_for_backward(x)
+        return K.hinge(x, nb, split, mode)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, = ctx.saved_tensors
+        nb, split, mode = ctx.cfg
+        return K.hinge(x, nb, split, mode, gscale=g.float().reshape(1).contiguous()), None, None, None
+
+
 class FFTailFn(Function):
     """conv1x1(gelu(conv1x1(n) + b_in)) + b_out + residual - everything of the channel-first FeedForward behind its norm (gp.py:726-740)
     as ONE autograd node, with the GELU riding on GEMM epilogues: forward, the up-projection stores its pre-activation h AND gelu(h)
@@ -1251,6 +1270,17 @@ class HipOps:
         if y.shape[-1] != o:
             y = y[..., :o]
         return nchw(y)
+
+    def hinge(self, x, split=None):
+        """discriminator hinge over a merged (outer, 2b, ...) logit tensor whose first `split` batch rows are the fake half, or
+        (split None) the generator's hinge mean(x); None when the tensor is not in a form the kernel takes."""
+        if x.dtype not in (torch.bfloat16, torch.float32) or x.dim() < 2 or not x.is_contiguous() or x.numel() == 0:
+            return None
+        if split is None:
+            return HingeFn.apply(x, x.shape[1], 0, 0)
+        if x.shape[1] != 2 * split:
+            return None
+        return HingeFn.apply(x, x.shape[1], split, 1)
 
     def ff_tail(self, n, w_in, b_in, w_out, b_out, residual):
         """the FeedForward behind its norm with the GELU on the GEMM epilogues (FFTailFn), or None when this call cannot take that

@@ -300,6 +300,14 @@ int gg_linattn_k_fwd(const void* k, int32_t ld_k, void* eks, int32_t ld_eks, flo
 int gg_linattn_k_bwd(const void* eks, int32_t ld_eks, const void* deks, int32_t ld_deks, void* dk, int32_t ld_dk, float* part,
                      float* stat, int32_t b, int32_t n, int32_t C, void* stream);
 
+/* Hinge losses of the trainer over one logit tensor (reference gp.py:157-163) and their backward, one launch each (the reference's
+ * formulation is ~16 PyTorch launches per tensor, ~95 per step). x: (outer, nb, inner) bf16 or fp32, the batch on the middle axis.
+ * mode 0: loss = mean(x) (generator_hinge_loss). mode 1: rows j < split are the fake half, the rest the real half of a merged
+ * discriminator batch: loss = mean over a half of relu(1 + real) + relu(1 - fake) (discriminator_hinge_loss). dx == NULL: forward
+ * (loss[0] fp32 written); dx != NULL: dx (x's dtype) = gscale[0] * d loss / d x. One workgroup, deterministic summation order. */
+int gg_hinge(const void* x, void* dx, const float* gscale, float* loss, int64_t n, int64_t inner, int32_t nb, int32_t split,
+             int32_t mode, int32_t x_is_f32, void* stream);
+
 /* y = (a + b) * c + d over n bf16 elements (b, d may be null): the predictor blocks' residual merge `(x + inner) * 2^-0.5`
  * (reference gp.py:1493), the last one together with the `+ residual` of gp.py:1495, as one pass; with b and d null its backward. */
 int gg_scaled_add(const void* a, const void* b, const void* d, void* y, int64_t n, float c, void* stream);

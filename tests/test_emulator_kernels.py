@@ -1415,3 +1415,31 @@ def test_feedforward_with_gelu_on_the_gemm_epilogues_matches_the_separate_passes
     assert rel_err(y1, yr.detach()) < 1e-2 and rel_err(dx1, xx.grad) < 3e-2
     for a, p_ in zip(g1, ff.parameters()):
         assert rel_err(a, p_.grad) < 3e-2, (a.shape, rel_err(a, p_.grad))
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_fused_hinge_losses_match_the_reference_formulation(dtype):
+    """ops.HingeFn (gg_hinge: one launch per logit tensor, one more for its backward) against gp.py:157-163 on the halves of a merged
+    discriminator batch (fake rows first) and on the generator's mean, values and gradients."""
+    from gigagan_pytorch_amd.gigagan import discriminator_hinge_loss, generator_hinge_loss
+    torch.manual_seed(0)
+    b = 6
+    for shape in ((1, 2 * b), (3, 2 * b, 4, 4), (2, 2 * b, 5)):
+        x = (torch.randn(shape) * 1.5).to(dtype)
+        xr = x.clone().float().requires_grad_()
+        want = discriminator_hinge_loss(xr[:, b:], xr[:, :b]) * 0.7
+        want.backward()
+        xh = x.clone().requires_grad_()
+        got = ops.HipOps().hinge(xh, b) * 0.7
+        got.backward()
+        assert abs(float(got) - float(want)) <= 1e-5 * max(1., abs(float(want))), (shape, float(got), float(want))
+        assert rel_err(xh.grad.float(), xr.grad) < (4e-3 if dtype == torch.bfloat16 else 1e-6)
+        xr = x.clone().float().requires_grad_()
+        want = generator_hinge_loss(xr)
+        want.backward()
+        xh = x.clone().requires_grad_()
+        got = ops.HipOps().hinge(xh)
+        got.backward()
+        assert abs(float(got) - float(want)) <= 1e-5 * max(1., abs(float(want)))
+        assert rel_err(xh.grad.float(), xr.grad) < (4e-3 if dtype == torch.bfloat16 else 1e-6)
+    assert ops.HipOps().hinge(torch.randn(4, 12).t(), 2) is None          # a non-dense view: the caller keeps the tensor-algebra form
