@@ -173,6 +173,11 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_SF_NT) void gg_sfwd_kernel(GgGemmParams p) {
 #pragma unroll
             for (int kc = 0; kc < CK; ++kc)                                // channels kc*16 + 8*hi ..: plane kc >> 1, chunk 2 * (kc & 1) + hi
                 fo[b][kw][kc] = (X + 1) * sb + (kc >> 1) * g.xpp + (((2 * (kc & 1) + hi) ^ key) << 4);
+            // 8-channel inputs: the upper half of the 16-channel k-step does not exist. Those lanes read the row's left halo slot
+            // (constant zeros) - NOT the neighbouring slot: its bytes times the zero weight fragment are zero only while they are
+            // finite, and past the zero row they are whatever the previous kernel left in LDS (NaN under hipGraph replay: found
+            // as a non-finite generator loss in the text-conditional bench, profiles/r04_text_nan.log)
+            if (C < 16 && hi) fo[b][kw][0] = 0;
         }
     }
     const int SPITCH = NB2 + 16;                          // staging pitch per pixel (bank spread)

@@ -1274,8 +1274,10 @@ class HipOps:
     def hinge(self, x, split=None):
         """discriminator hinge over a merged (outer, 2b, ...) logit tensor whose first `split` batch rows are the fake half, or
         (split None) the generator's hinge mean(x); None when the tensor is not in a form the kernel takes."""
-        if x.dtype not in (torch.bfloat16, torch.float32) or x.dim() < 2 or not x.is_contiguous() or x.numel() == 0:
+        if x.dtype not in (torch.bfloat16, torch.float32) or x.dim() < 2 or x.numel() == 0:
             return None
+        if not x.is_contiguous():       # (a channels_last map viewed as (s, 2b, c, h, w): one dense copy of a tiny tensor, still 2 launches for ~16)
+            x = x.contiguous()
         if split is None:
             return HingeFn.apply(x, x.shape[1], 0, 0)
         if x.shape[1] != 2 * split:

@@ -66,6 +66,9 @@ def materialise(d, dev):
         d.noise_w = buf(d.N, f32)
     if d.residual:
         d.residual = buf(d.M * d.ldr, bf)
+    d.keep_partials = 0              # (round 4: the step's weight gradients leave their split-K slices to the queued finish; here every plan reduces)
+    if d.gelu_mode:                  # (round 4: GELU fused around a 1x1 pair: a pre-activation buffer of the output's shape)
+        d.gelu_aux = buf(d.M * d.ld_aux, bf)
     return keep
 
 

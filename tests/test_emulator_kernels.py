@@ -1442,4 +1442,5 @@ def test_fused_hinge_losses_match_the_reference_formulation(dtype):
         got.backward()
         assert abs(float(got) - float(want)) <= 1e-5 * max(1., abs(float(want)))
         assert rel_err(xh.grad.float(), xr.grad) < (4e-3 if dtype == torch.bfloat16 else 1e-6)
-    assert ops.HipOps().hinge(torch.randn(4, 12).t(), 2) is None          # a non-dense view: the caller keeps the tensor-algebra form
+    xt = torch.randn(12, 4, requires_grad=True)                            # a non-dense view is copied once (still 2 launches for ~16)
+    assert abs(float(ops.HipOps().hinge(xt.t(), 6)) - float(discriminator_hinge_loss(xt.t()[:, 6:], xt.t()[:, :6]))) < 1e-5
