@@ -216,9 +216,7 @@ def modconv_forward_roofline(gan, batch, dev):
                 run_all()
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                run_all()
+            g, _, _ = K.capture_graph(run_all)
         for _ in range(3):
             g.replay()
         g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -376,8 +374,9 @@ def main():
         comm.timing = False
         mine.update(exposed_comm_ms_per_step=sum(a.elapsed_time(b) for a, b in comm.exposed_ms) / steps,
                     exposed_comm_measured='timed region (eager launches)')
-    finite = bool(torch.isfinite(gan.G_opt.flat_p).all() and torch.isfinite(gan.D_opt.flat_p).all()
-                  and torch.isfinite(gan.G_opt.flat_g).all() and torch.isfinite(gan.D_opt.flat_g).all())
+    nonfinite = {k: int((~torch.isfinite(v)).sum()) for k, v in (('g_params', gan.G_opt.flat_p), ('d_params', gan.D_opt.flat_p),
+                                                                 ('g_grads', gan.G_opt.flat_g), ('d_grads', gan.D_opt.flat_g))}
+    finite = not any(nonfinite.values())
     loss_vals = [float(v) for v in (*d_losses, *g_losses) if v is not None]
     finite = finite and all(v == v and abs(v) != float('inf') for v in loss_vals)
 
@@ -471,12 +470,12 @@ def main():
             vs_baseline=None, dtype='bf16',
             data='synthetic' if args.data == 'resident' else 'synthetic (fp32 host batches: DataLoader + pinned prefetch to the device)',
             config=dict(workload=f'{what} bf16 bs={args.batch}/GPU, GP every 4th step', global_batch=args.batch * world,
-                        parallelism=f'dp{world}', hip_graphs=bool(gan._graphable(1)), comm=gdist.comm_backend(),
+                        parallelism=f'dp{world}', hip_graphs=bool(gan._graphable(1)), graph_memset_nodes_repaired=sum(gan._graph_memsets.values()), comm=gdist.comm_backend(),
                         comm_world=(comm.world if comm is not None else (world if world > 1 else 0)),
                         comm_overlap=('in-backward slices: D %d, G %d' % (gan.D_red.n, gan.G_red.n)
                                       if (gan.D_red is not None and gan.overlap_grad_reduce) else 'none')),
             roofline=roofline, cpu_baseline=cpu,
-            finite=finite, state_restored_every_cycle=snap is not None, per_rank=per_rank,
+            finite=finite, nonfinite=nonfinite, state_restored_every_cycle=snap is not None, per_rank=per_rank,
             last_losses=dict(d=float(d_losses.divergence), g=float(g_losses.divergence),
                              gp=float(d_losses.gradient_penalty), msd=float(d_losses.multiscale_divergence)))
         print(json.dumps(line), flush=True)

@@ -24,6 +24,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <unordered_map>
+#include <vector>
 #include <string>
 
 static thread_local char g_err[512] = "";
@@ -51,6 +52,88 @@ extern "C" int gg_is_emulator(void) {
 #if defined(GG_HOST_EMULATION)
     return 1;
 #else
+    return 0;
+#endif
+}
+
+// ---- hipGraph repair ---------------------------------------------------------------------------------
+// This ROCm runtime (HIP 7.0.51831, the one PyTorch 2.10+rocm7.0 carries) re-executes a captured hipMemsetAsync with a corrupted VALUE
+// from the second replay on (tests/gpu_graph_memset_probe.py: the cleared bytes read 16 / 57 / 64 / 128 instead of 0). PyTorch clears
+// the semaphores of its split reductions with exactly such a memset (ATen/native/cuda/Reduce.cuh:1301), so a captured `t.sum(0)` over
+// >= 1024 columns returns garbage on every replay but the first. The captured graph is repaired before it is instantiated: behind every
+// memset node goes a kernel node that writes the intended value, and every node that depended on the memset now also depends on it.
+#if !defined(GG_HOST_EMULATION)
+struct GgGraphFillParams { void* dst; unsigned value; unsigned elem; unsigned long long width, height, pitch; };
+
+__global__ void gg_graph_fill_kernel(GgGraphFillParams p) {
+    const unsigned long long n = p.width * p.height;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long r = i / p.width, c = i - r * p.width;
+        char* row = (char*)p.dst + r * p.pitch;
+        if (p.elem == 1) ((unsigned char*)row)[c] = (unsigned char)p.value;
+        else if (p.elem == 2) ((unsigned short*)row)[c] = (unsigned short)p.value;
+        else ((unsigned*)row)[c] = p.value;
+    }
+}
+#endif
+
+extern "C" int gg_graph_patch_memsets(void* hip_graph, int32_t* n_patched) {
+    if (n_patched) *n_patched = 0;
+#if defined(GG_HOST_EMULATION)
+    (void)hip_graph;
+    return 0;
+#else
+    if (!hip_graph) return gg_fail(-1, "gg_graph_patch_memsets: null graph");
+    hipGraph_t g = (hipGraph_t)hip_graph;
+    size_t n = 0;
+    hipError_t e = hipGraphGetNodes(g, nullptr, &n);
+    if (e != hipSuccess) return gg_fail(-2, "gg_graph_patch_memsets: hipGraphGetNodes: %s", hipGetErrorString(e));
+    if (!n) return 0;
+    std::vector<hipGraphNode_t> nodes(n);
+    e = hipGraphGetNodes(g, nodes.data(), &n);
+    if (e != hipSuccess) return gg_fail(-2, "gg_graph_patch_memsets: hipGraphGetNodes: %s", hipGetErrorString(e));
+    int patched = 0;
+    for (size_t i = 0; i < n; ++i) {
+        hipGraphNodeType ty;
+        e = hipGraphNodeGetType(nodes[i], &ty);
+        if (e != hipSuccess) return gg_fail(-2, "gg_graph_patch_memsets: hipGraphNodeGetType: %s", hipGetErrorString(e));
+        if (ty != hipGraphNodeTypeMemset) continue;
+        hipMemsetParams mp;
+        e = hipGraphMemsetNodeGetParams(nodes[i], &mp);
+        if (e != hipSuccess) return gg_fail(-2, "gg_graph_patch_memsets: hipGraphMemsetNodeGetParams: %s", hipGetErrorString(e));
+        if (mp.elementSize != 1 && mp.elementSize != 2 && mp.elementSize != 4)
+            return gg_fail(-3, "gg_graph_patch_memsets: memset node with element size %u", mp.elementSize);
+        size_t nd = 0;
+        e = hipGraphNodeGetDependentNodes(nodes[i], nullptr, &nd);
+        if (e != hipSuccess) return gg_fail(-2, "gg_graph_patch_memsets: hipGraphNodeGetDependentNodes: %s", hipGetErrorString(e));
+        std::vector<hipGraphNode_t> after(nd);
+        if (nd) {
+            e = hipGraphNodeGetDependentNodes(nodes[i], after.data(), &nd);
+            if (e != hipSuccess) return gg_fail(-2, "gg_graph_patch_memsets: hipGraphNodeGetDependentNodes: %s", hipGetErrorString(e));
+        }
+        GgGraphFillParams fp;
+        fp.dst = mp.dst; fp.value = mp.value; fp.elem = mp.elementSize;
+        fp.width = mp.width; fp.height = mp.height ? mp.height : 1; fp.pitch = mp.pitch;
+        const unsigned long long total = fp.width * fp.height;
+        if (!total) continue;
+        void* args[] = {&fp};
+        hipKernelNodeParams kp;
+        memset(&kp, 0, sizeof(kp));
+        kp.func = (void*)gg_graph_fill_kernel;
+        kp.blockDim = dim3(256);
+        unsigned long long blocks = (total + 255) / 256;
+        kp.gridDim = dim3((unsigned)(blocks > 1024 ? 1024 : blocks));
+        kp.kernelParams = args;
+        hipGraphNode_t fill;
+        e = hipGraphAddKernelNode(&fill, g, &nodes[i], 1, &kp);
+        if (e != hipSuccess) return gg_fail(-2, "gg_graph_patch_memsets: hipGraphAddKernelNode: %s", hipGetErrorString(e));
+        for (size_t j = 0; j < nd; ++j) {
+            e = hipGraphAddDependencies(g, &fill, &after[j], 1);
+            if (e != hipSuccess) return gg_fail(-2, "gg_graph_patch_memsets: hipGraphAddDependencies: %s", hipGetErrorString(e));
+        }
+        ++patched;
+    }
+    if (n_patched) *n_patched = patched;
     return 0;
 #endif
 }
@@ -1371,15 +1454,20 @@ extern "C" int gg_linattn_k_bwd(const void* eks, int32_t ld_eks, const void* dek
     return gg_linattn_k(1, eks, ld_eks, deks, ld_deks, dk, ld_dk, part, stat, b, n, C, stream);
 }
 
-extern "C" int gg_hinge(const void* x, void* dx, const float* gscale, float* loss, int64_t n, int64_t inner, int32_t nb, int32_t split,
-                        int32_t mode, int32_t x_is_f32, void* stream) {
+extern "C" int gg_hinge(const void* x, void* dx, const float* gscale, float* loss, void* scratch, int64_t n, int64_t inner, int32_t nb,
+                        int32_t split, int32_t mode, int32_t x_is_f32, void* stream) {
     if (!x || (!dx && !loss) || (dx && !gscale)) return gg_fail(-1, "gg_hinge: null pointer");
-    if (n <= 0 || inner <= 0 || nb <= 0 || (mode != 0 && mode != 1) || (mode == 1 && (split <= 0 || split >= nb || n % (inner * nb))))
+    if (n <= 0 || n >= (1ll << 31) || inner <= 0 || nb <= 0 || (mode != 0 && mode != 1) ||
+        (mode == 1 && (split <= 0 || split >= nb || n % (inner * nb))))
         return gg_fail(-2, "gg_hinge: bad extents");
     GgHingeParams p;
     memset(&p, 0, sizeof(p));
     p.x = x; p.dx = dx; p.gscale = gscale; p.loss = loss; p.n = n; p.inner = inner; p.nb = nb; p.split = split; p.mode = mode; p.x_f32 = x_is_f32;
-    GG_LAUNCH(gg_hinge_kernel, dim3(1), dim3(256), (hipStream_t)stream, p);
+    p.scratch = (unsigned*)scratch;
+    long long blocks = (n + 2047) / 2048;                  // >= 8 elements per lane
+    if (blocks > GG_HINGE_MAXB) blocks = GG_HINGE_MAXB;
+    if (!dx && !scratch) blocks = 1;                       // forward without scratch: one workgroup
+    GG_LAUNCH(gg_hinge_kernel, dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, p);
     return gg_check_launch();
 }
 

@@ -171,6 +171,15 @@ GG_DEVICE float gg_wave_sum_all(float v) {
            (__builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48)));
 }
 GG_DEVICE void gg_atomic_add(float* p, float v) { atomicAdd(p, v); }
+// "last workgroup to arrive" ticket: release this workgroup's global writes, take a ticket; the taker of the last ticket sees every
+// other workgroup's writes (acquire) and puts the counter back to zero when it is done
+GG_DEVICE unsigned gg_ticket_take(unsigned* p) {
+    __threadfence();
+    const unsigned v = atomicAdd(p, 1u);
+    __threadfence();
+    return v;
+}
+GG_DEVICE void gg_ticket_reset(unsigned* p) { atomicExch(p, 0u); }
 GG_DEVICE float gg_expf(float x) { return __expf(x); }
 GG_DEVICE float gg_exp2f(float x) { return __builtin_amdgcn_exp2f(x); }     // bare v_exp_f32 (no range fix-ups: x <= 128 here)
 GG_DEVICE bool gg_wave_any(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0; }    // wave-uniform result

@@ -768,29 +768,34 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_addcat_bwd_kernel(GgAddCatParams p) {
 // mean(relu(1 + real) + relu(1 - fake))) and their backward in one more. x is (outer, nb, inner) bf16 or fp32 with the batch on the
 // middle axis; mode 1: rows j < split are the FAKE half, the others the real half (the merged discriminator pass evaluates both as one
 // batch), loss = sum over all elements of relu(1 + sign * x) / (n / 2); mode 0: loss = sum x / n. The tensors are tiny (<= a few 10^5
-// elements) and the reference's formulation is ~16 PyTorch launches per tensor: ONE workgroup, fixed summation order (deterministic).
+// elements) and the reference's formulation is ~16 PyTorch launches per tensor: up to 64 workgroups, fixed summation order (deterministic).
 // dx == null: forward, loss[0] written. dx != null: dx = gscale[0] * d loss / d x in x's dtype.
 struct GgHingeParams {
     const void* x;
     void* dx;
     const float* gscale;
     float* loss;
+    unsigned* scratch;      // forward with more than one workgroup: [0] ticket (zero between launches), [1 + b] partial of workgroup b
     long long n, inner;
     int nb, split, mode, x_f32;
 };
 
+#define GG_HINGE_MAXB 64
+
 GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_hinge_kernel(GgHingeParams p) {
     GG_SHARED float red[256];
+    GG_SHARED int last;
     const int t = threadIdx.x;
     const float inv = p.mode == 1 ? 2.f / (float)p.n : 1.f / (float)p.n;
     const float g = p.dx ? p.gscale[0] * inv : 0.f;
+    const unsigned n = (unsigned)p.n, inner = (unsigned)p.inner, nb = (unsigned)p.nb;
     float acc = 0.f;
-    for (long long i = t; i < p.n; i += 256) {
+    for (unsigned i = blockIdx.x * 256u + t; i < n; i += gridDim.x * 256u) {
         const float x = p.x_f32 ? ((const float*)p.x)[i] : gg_bf2f(((const bf16_t*)p.x)[i]);
         float f, df;
         if (p.mode == 1) {
-            const int j = (int)((i / p.inner) % p.nb);
-            const float sgn = j < p.split ? -1.f : 1.f;
+            const unsigned j = (i / inner) % nb;
+            const float sgn = j < (unsigned)p.split ? -1.f : 1.f;
             const float v = 1.f + sgn * x;
             f = v > 0.f ? v : 0.f;
             df = v > 0.f ? sgn : 0.f;
@@ -811,7 +816,23 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_hinge_kernel(GgHingeParams p) {
         if (t < s) red[t] += red[t + s];
         gg_sync();
     }
-    if (t == 0) p.loss[0] = red[0] * inv;
+    if (gridDim.x == 1) {
+        if (t == 0) p.loss[0] = red[0] * inv;
+        return;
+    }
+    // several workgroups: partials in a fixed slot each, the last workgroup to arrive adds them in slot order (deterministic) and
+    // leaves the ticket at zero for the next launch on this stream
+    if (t == 0) {
+        ((volatile float*)p.scratch)[1 + blockIdx.x] = red[0];
+        last = gg_ticket_take(p.scratch) == gridDim.x - 1;
+    }
+    gg_sync();
+    if (last && t == 0) {
+        float sum = 0.f;
+        for (unsigned b = 0; b < gridDim.x; ++b) sum += ((volatile float*)p.scratch)[1 + b];
+        p.loss[0] = sum * inv;
+        gg_ticket_reset(p.scratch);
+    }
 }
 
 // ---- y = (a + b) * c [+ d] over dense bf16 buffers (b, d optional): the predictor's residual merges (gp.py:1493, :1495) in one

@@ -15,6 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import distributed as gdist
+from . import kernels as K
 from . import ops
 from .discriminator import Discriminator
 from .ema import EMA
@@ -250,6 +251,7 @@ class GigaGAN(nn.Module):
             use_hip_graphs = self._device.type == 'cuda'
         self.use_hip_graphs = bool(use_hip_graphs) and self._device.type == 'cuda'
         self._graphs: dict = {}
+        self._graph_memsets: dict = {}      # graph key -> memset nodes repaired at capture (K.capture_graph)
         self._graph_warmup = False
         gdist.register_graph_owner(self)      # captured steps may hold RCCL nodes: the communicator drops them before it dies
 
@@ -484,13 +486,13 @@ class GigaGAN(nn.Module):
                     self._graph_warmup = False
                 torch.cuda.current_stream(self._device).wait_stream(side)
                 torch.cuda.synchronize(self._device)
-                graph = torch.cuda.CUDAGraph()
                 ops.pack_cache_clear()        # the graph must contain its own weight packing launches ...
                 # with a process group alive, its watchdog thread polls events concurrently: only this thread's (and the
                 # autograd thread's stream-ordered) calls must be capture-safe, so do not police other threads
                 mode = 'thread_local' if gdist.is_distributed() else 'global'
-                with torch.cuda.graph(graph, capture_error_mode=mode):
-                    outs = fn()
+                # (capture_graph also repairs the captured memset nodes: this HIP runtime replays them with a corrupted value,
+                # which turns PyTorch's split reductions - the folds of per-workgroup gradient partials - into garbage)
+                graph, outs, self._graph_memsets[key] = K.capture_graph(fn, capture_error_mode=mode)
                 ops.pack_cache_clear()        # ... and nothing outside may keep tensors of its private pool
                 entry = self._graphs[key] = (graph, outs)
             except RuntimeError as e:   # what HIP / torch raise when a capture is refused; programming errors propagate

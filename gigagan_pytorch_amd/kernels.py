@@ -52,7 +52,7 @@ class LaunchProfiler:
     active - contraction, coefficient, modulation, mixing, resampling ... - so that an op's time is the time of everything it
     launches. Implemented as a proxy in front of the ctypes library object; eager execution only."""
     _NOT_LAUNCHES = ('gg_gemm_plan', 'gg_gemm_workspace_bytes', 'gg_last_error', 'gg_version', 'gg_is_emulator',
-                     'gg_bias_act_bwd_partials', 'gg_rmsnorm_blocks', 'gg_gemm_plan_table', 'gg_comm_')
+                     'gg_bias_act_bwd_partials', 'gg_rmsnorm_blocks', 'gg_gemm_plan_table', 'gg_comm_', 'gg_graph_')
 
     def __init__(self):
         self.records = []       # (entry point, start event, end event)
@@ -543,6 +543,23 @@ def colsum_finish(part: torch.Tensor, n: int, alpha: float = 1.0, out: torch.Ten
     return out
 
 
+def capture_graph(fn, capture_error_mode: str = 'global'):
+    """capture `fn()` into a hipGraph, repair it (gg_graph_patch_memsets: this HIP runtime replays captured memset nodes with a
+    corrupted value, which breaks every PyTorch split reduction inside the graph from the second replay on), instantiate it.
+    Returns (graph, fn's outputs, number of memset nodes repaired). The caller has warmed `fn` up on a side stream."""
+    L = _C.lib()
+    graph = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(graph, capture_error_mode=capture_error_mode):
+        outs = fn()
+    n = C.c_int32(0)
+    L.check(L.lib.gg_graph_patch_memsets(C.c_void_p(graph.raw_cuda_graph()), C.byref(n)), 'gg_graph_patch_memsets')
+    graph.instantiate()
+    return graph, outs, int(n.value)
+
+
+_hinge_scratch: dict = {}
+
+
 def hinge(x: torch.Tensor, nb: int, split: int, mode: int, gscale: torch.Tensor | None = None):
     """gg_hinge: x dense (outer, nb, inner...) bf16 / fp32. gscale None: returns the loss (fp32 scalar tensor); else the gradient
     gscale * d loss / d x (x's dtype and shape)."""
@@ -556,8 +573,13 @@ def hinge(x: torch.Tensor, nb: int, split: int, mode: int, gscale: torch.Tensor 
     else:
         assert gscale.dtype == torch.float32 and gscale.numel() == 1
         out = dx = torch.empty_like(x)
-    rc = L.lib.gg_hinge(ptr(x), ptr(dx), ptr(gscale), ptr(out) if gscale is None else None, x.numel(), inner, nb, split, mode,
-                        int(x.dtype == torch.float32), L.stream(x))
+    scratch = None
+    if gscale is None:
+        scratch = _hinge_scratch.get(x.device)
+        if scratch is None:         # ticket + 64 partials; the kernel leaves the ticket at zero (launches on one stream are ordered)
+            scratch = _hinge_scratch[x.device] = torch.zeros(65, dtype=torch.float32, device=x.device)
+    rc = L.lib.gg_hinge(ptr(x), ptr(dx), ptr(gscale), ptr(out) if gscale is None else None, ptr(scratch), x.numel(), inner, nb, split,
+                        mode, int(x.dtype == torch.float32), L.stream(x))
     L.check(rc, 'gg_hinge')
     return out
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 8
+#define GG_ABI_VERSION 9
 
 int gg_version(void);
 const char* gg_last_error(void);
@@ -304,9 +304,11 @@ int gg_linattn_k_bwd(const void* eks, int32_t ld_eks, const void* deks, int32_t 
  * formulation is ~16 PyTorch launches per tensor, ~95 per step). x: (outer, nb, inner) bf16 or fp32, the batch on the middle axis.
  * mode 0: loss = mean(x) (generator_hinge_loss). mode 1: rows j < split are the fake half, the rest the real half of a merged
  * discriminator batch: loss = mean over a half of relu(1 + real) + relu(1 - fake) (discriminator_hinge_loss). dx == NULL: forward
- * (loss[0] fp32 written); dx != NULL: dx (x's dtype) = gscale[0] * d loss / d x. One workgroup, deterministic summation order. */
-int gg_hinge(const void* x, void* dx, const float* gscale, float* loss, int64_t n, int64_t inner, int32_t nb, int32_t split,
-             int32_t mode, int32_t x_is_f32, void* stream);
+ * (loss[0] fp32 written); dx != NULL: dx (x's dtype) = gscale[0] * d loss / d x. Up to 64 workgroups; the forward's partial sums are added in
+ * a fixed order by the last workgroup to arrive (deterministic). scratch: 65 x 4 bytes, zero before the first use, owned by one stream at a
+ * time (the kernel leaves its ticket at zero); NULL = a one-workgroup forward. */
+int gg_hinge(const void* x, void* dx, const float* gscale, float* loss, void* scratch, int64_t n, int64_t inner, int32_t nb,
+             int32_t split, int32_t mode, int32_t x_is_f32, void* stream);
 
 /* y = (a + b) * c + d over n bf16 elements (b, d may be null): the predictor blocks' residual merge `(x + inner) * 2^-0.5`
  * (reference gp.py:1493), the last one together with the `+ residual` of gp.py:1495, as one pass; with b and d null its backward. */
@@ -398,6 +400,14 @@ int gg_sconv_fwd(const void* x, const void* w, int64_t w_bs, void* y, const floa
                  int32_t b, int32_t H, int32_t W, int32_t C, int32_t O, int32_t act, float slope, void* stream);
 int gg_modulate_bank_fwd(const void* x, const float* s, const float* a, void* out, int32_t b, int32_t P, int32_t Cin, int32_t Cout,
                          void* stream);
+
+/* ---- hipGraph repair. The training step is replayed as a captured hipGraph (the reference has no counterpart: it launches eagerly,
+ * gp.py:2227-2580). The HIP runtime PyTorch 2.10+rocm7.0 carries (7.0.51831) re-executes a captured hipMemsetAsync with a corrupted
+ * value from the second replay on; PyTorch's split reductions clear their semaphores with one (ATen/native/cuda/Reduce.cuh:1301), so a
+ * captured column sum over >= 1024 columns is garbage on every replay but the first (tests/gpu_graph_memset_probe.py,
+ * tests/gpu_graph_sum_probe.py). gg_graph_patch_memsets walks a captured, not yet instantiated hipGraph_t and puts a kernel node that
+ * writes the intended value behind every memset node (dependents of the memset also depend on it). *n_patched = memset nodes found. */
+int gg_graph_patch_memsets(void* hip_graph, int32_t* n_patched);
 
 /* ---- data-parallel exchange: RCCL over xGMI (replaces accelerate / DDP's gradient all-reduce, gp.py:1898-1908, :1987, and the
  * reference's all_gather, distributed.py:20-68). One communicator per process (one process per GPU). RCCL is bound at run time

@@ -104,6 +104,8 @@ static inline float gg_wave_sum_all(float v) {     // wave collective; the devic
     return (gg_emu_shfl(v, 0) + gg_emu_shfl(v, 16)) + (gg_emu_shfl(v, 32) + gg_emu_shfl(v, 48));
 }
 static inline void gg_atomic_add(float* p, float v) { *p += v; }
+static inline unsigned gg_ticket_take(unsigned* p) { return (*p)++; }      // workgroups run one after another on the host
+static inline void gg_ticket_reset(unsigned* p) { *p = 0; }
 
 static inline float gg_expf(float x) { return expf(x); }
 static inline float gg_exp2f(float x) { return exp2f(x); }

@@ -1,11 +1,13 @@
 #!/bin/bash
-# which round-4 switch (if any) makes the text-conditional bench's last generator loss NaN? (its losses are ~1e5 .. 1e11 by step 4)
+# text-conditional bench (config 4; its losses are ~1e5 .. 1e12 within a few steps on random data): which buffers go non-finite, and with which switch?
 cd "$(dirname "$0")/.."
-run() { env "$@" timeout 300 python bench.py --workload text --steps 8 --no-cpu-baseline --no-profile-cycle 2>&1 | grep '^{' | python -c "
+run() { env "$@" timeout 300 python bench.py --workload text --no-cpu-baseline --no-profile-cycle $EXTRA 2>&1 | grep '^{' | python -c "
 import sys, json
-d = json.loads(sys.stdin.read()); print('$*', round(d['value'], 1), 'finite', d['finite'], d['last_losses'])"; }
+d = json.loads(sys.stdin.read()); print('$* $EXTRA', round(d['value'], 1), 'finite', d['finite'], d['nonfinite'], d['last_losses'])"; }
+EXTRA="--steps 8" run A=0
+EXTRA="--steps 8" run GG_SFWD=0
 run A=0
-run GG_NO_FF_FUSE=1
 run GG_SFWD=0
-run GG_WGRADS=0
+EXTRA="--no-graphs" run A=0
+EXTRA="--no-graphs" run GG_SFWD=0
 run GG_NO_FF_FUSE=1 GG_SFWD=0 GG_WGRADS=0 GG_WB_NARROW=1

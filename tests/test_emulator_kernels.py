@@ -1424,7 +1424,7 @@ def test_fused_hinge_losses_match_the_reference_formulation(dtype):
     from gigagan_pytorch_amd.gigagan import discriminator_hinge_loss, generator_hinge_loss
     torch.manual_seed(0)
     b = 6
-    for shape in ((1, 2 * b), (3, 2 * b, 4, 4), (2, 2 * b, 5)):
+    for shape in ((1, 2 * b), (3, 2 * b, 4, 4), (2, 2 * b, 5), (2, 2 * b, 37, 41), (1, 2 * b, 128, 128)):   # (the last two: 18 / 64 workgroups)
         x = (torch.randn(shape) * 1.5).to(dtype)
         xr = x.clone().float().requires_grad_()
         want = discriminator_hinge_loss(xr[:, b:], xr[:, :b]) * 0.7
