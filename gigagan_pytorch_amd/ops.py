@@ -704,22 +704,21 @@ class FlashAttnFn(Function):
             k = q
         o, lse = K.attn_fwd(q, k, v, k0b, v0b, heads, alpha, beta)
         ctx.cfg = (heads, alpha, beta)
-        ctx.save_for_backward(q, k, v, k0, v0, o, lse)
+        ctx.save_for_backward(q, k, v, k0, v0, o, lse, k0b, v0b)      # (the bf16 null key / value: two launches fewer per backward)
         return o
 
     @staticmethod
     def backward(ctx, d_o):
-        q, k, v, k0, v0, o, lse = ctx.saved_tensors
+        q, k, v, k0, v0, o, lse, k0b, v0b = ctx.saved_tensors
         heads, alpha, beta = ctx.cfg
         if torch.is_grad_enabled():       # this backward is being differentiated: keep it on the autograd tape
             dq, dk, dv, dk0, dv0 = FlashAttnBwdFn.apply(q, k, v, k0, v0, o, lse, d_o.contiguous(), heads, alpha, beta)
             if ctx.tied:
                 dq, dk = dq + dk, None
         else:
-            k0b, v0b = k0.to(ACT_DTYPE).contiguous(), v0.to(ACT_DTYPE).contiguous()
             dq, dk, dv, dk0q, dv0, dbias0 = K.attn_bwd(q, k, v, k0b, v0b, o, lse, d_o.contiguous(), heads, alpha, beta,
                                                        tied=ctx.tied)
-            dk0 = dk0q + (2.0 * beta) * dbias0[:, None] * k0b.float()
+            dk0 = torch.addcmul(dk0q, dbias0[:, None], k0b.float(), value=2.0 * beta)
             if ctx.tied:
                 dk = None
         return dq, dk, dv, dk0.to(k0.dtype), dv0.to(v0.dtype), None, None, None
