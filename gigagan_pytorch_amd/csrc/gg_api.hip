@@ -1827,6 +1827,22 @@ static int gg_rms_launch(int mode, const void* x, const void* g, const void* v, 
     p.act = act;
     if (act < 0 || act > 1 || (act && mode == 2)) return gg_fail(-3, "gg_rmsnorm: activation must be none (0) or silu (1), first order only");
     hipStream_t s = (hipStream_t)stream;
+    // C = 8 * LPR <= 512: LPR lanes per row, several rows per wavefront (same summation order, 2-4x the bandwidth)
+    const char* rows_env = getenv("GG_RMS_ROWS");             // (read per call: the tests compare both kernels in one process)
+    const int rows_kernel = rows_env ? atoi(rows_env) : 1;
+    if (rows_kernel && mode <= 1 && (C == 32 || C == 64 || C == 128 || C == 256 || C == 512)) {
+#define GG_RMS_ROWS_LAUNCH(M, A, L) GG_LAUNCH((gg_rmsnorm_rows_kernel<M, A, L>), dim3((unsigned)blocks), dim3(256), s, p)
+#define GG_RMS_ROWS_C(M, A) \
+        do { if (C == 32) GG_RMS_ROWS_LAUNCH(M, A, 4); else if (C == 64) GG_RMS_ROWS_LAUNCH(M, A, 8); else if (C == 128) GG_RMS_ROWS_LAUNCH(M, A, 16); \
+             else if (C == 256) GG_RMS_ROWS_LAUNCH(M, A, 32); else GG_RMS_ROWS_LAUNCH(M, A, 64); } while (0)
+        if (mode == 0 && act) GG_RMS_ROWS_C(0, true);
+        else if (mode == 0) GG_RMS_ROWS_C(0, false);
+        else if (act) GG_RMS_ROWS_C(1, true);
+        else GG_RMS_ROWS_C(1, false);
+#undef GG_RMS_ROWS_C
+#undef GG_RMS_ROWS_LAUNCH
+        return gg_check_launch();
+    }
     if (mode == 0 && act) GG_LAUNCH((gg_rmsnorm_kernel<0, true>), dim3((unsigned)blocks), dim3(256), s, p);
     else if (mode == 1 && act) GG_LAUNCH((gg_rmsnorm_kernel<1, true>), dim3((unsigned)blocks), dim3(256), s, p);
     else if (mode == 0) GG_LAUNCH(gg_rmsnorm_kernel<0>, dim3((unsigned)blocks), dim3(256), s, p);

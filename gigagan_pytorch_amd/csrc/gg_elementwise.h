@@ -642,6 +642,115 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_rmsnorm_kernel(GgRmsParams p) {
     }
 }
 
+// ---- the same fwd / bwd passes for C = 8 * LPR <= 512 channels: LPR lanes per pixel row, 64 / LPR rows per wavefront and pass --------
+// The kernel above gives a whole wavefront to one row: at C = 256 half of its lanes idle, at C = 64 seven in eight, and every row pays
+// full 64-lane butterflies - 1.1-2.2 TB/s on the trainer's shapes (tests/gpu_rmsnorm_probe.py). Here a row belongs to a group of LPR
+// lanes (one 16-byte vector each), a wavefront walks 64 / LPR rows per pass and keeps TWO passes in flight (all loads of both before the
+// arithmetic). The group butterflies run over LPR lanes only; they add the same values in the same order as the first log2(LPR) steps of
+// the 64-lane butterfly (whose remaining steps add zeros there): y / dx differ from the kernel above only where the compiler contracts an
+// fma in one and not the other (1 bf16 ulp on ~1e-5 of the elements). The gain gradient's
+// per-lane partial sums are folded over the row groups of a wavefront by the remaining butterfly steps, over the four wavefronts in LDS.
+template <int LPR>
+GG_DEVICE float gg_group_sum(float v) {
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) v += gg_shfl_xor(v, o);
+    return v;
+}
+
+template <int MODE, bool ACT, int LPR>   // MODE 0 fwd, 1 bwd
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_rmsnorm_rows_kernel(GgRmsParams p) {
+    GG_SHARED float red[4][512];
+    constexpr int G = 64 / LPR;                    // rows per wavefront and pass
+    constexpr int U = 2;                           // passes in flight
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, c = (lane % LPR) * 8;
+    const float s = sqrtf((float)p.C);
+    float gam[8], dgam[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gam[e] = p.gamma[c + e]; dgam[e] = 0.f; }
+    const long long npass = (p.rows + G - 1) / G;
+    const long long nwaves = (long long)gridDim.x * 4;
+    for (long long q0 = (long long)blockIdx.x * 4 + wave; q0 < npass; q0 += nwaves * U) {
+        u16x8 xv[U], gv[U], cv[U];
+        bool live[U];
+        long long off[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long r = (q0 + u * nwaves) * G + sub;
+            live[u] = (q0 + u * nwaves) < npass && r < p.rows;
+            off[u] = r * p.C + c;
+            const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            xv[u] = z; gv[u] = z; cv[u] = z;
+            if (live[u]) {
+                xv[u] = *(const u16x8*)(p.x + off[u]);
+                if (MODE == 1) {
+                    gv[u] = *(const u16x8*)(p.g + off[u]);
+                    if (p.v) cv[u] = *(const u16x8*)(p.v + off[u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float xf[8], hf[8], gf[8];
+            float ss = 0.f, uh = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xf[e] = gg_bf2f(xv[u][e]);
+                ss += xf[e] * xf[e];
+                if (MODE == 1) {
+                    gf[e] = gg_bf2f(gv[u][e]);
+                    hf[e] = gf[e] * gam[e];
+                    uh += xf[e] * hf[e];
+                }
+            }
+            ss = gg_group_sum<LPR>(ss);
+            const float nrm = sqrtf(ss);
+            const bool clamped = nrm < p.eps;
+            const float n = clamped ? p.eps : nrm;
+            const float rn = s / n;
+            if (MODE == 1 && ACT) {
+                uh = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float z = xf[e] * rn * gam[e];
+                    const float sg = 1.f / (1.f + gg_expf(-z));
+                    gf[e] *= sg * (1.f + z * (1.f - sg));
+                    hf[e] = gf[e] * gam[e];
+                    uh += xf[e] * hf[e];
+                }
+            }
+            if (MODE == 1) uh = gg_group_sum<LPR>(uh) / n;
+            if (clamped) uh = 0.f;
+            u16x8 o0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (MODE == 0) {
+                    float z = xf[e] * rn * gam[e];
+                    if (ACT) z = z / (1.f + gg_expf(-z));
+                    o0[e] = gg_f2bf(z);
+                } else {
+                    const float uu = xf[e] / n;
+                    o0[e] = gg_f2bf(rn * (hf[e] - uu * uh) + gg_bf2f(cv[u][e]));
+                    dgam[e] += rn * xf[e] * gf[e];          // (dead rows carry x = 0)
+                }
+            }
+            if (live[u]) *(u16x8*)(p.out0 + off[u]) = o0;
+        }
+    }
+    if (MODE == 1 && p.dgamma_part) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = dgam[e];
+#pragma unroll
+            for (int o = LPR; o < 64; o <<= 1) v += gg_shfl_xor(v, o);
+            if (sub == 0) red[wave][c + e] = v;
+        }
+        gg_sync();
+        for (int cc = threadIdx.x; cc < p.C; cc += 256)
+            p.dgamma_part[(long long)blockIdx.x * p.C + cc] = red[0][cc] + red[1][cc] + red[2][cc] + red[3][cc];
+    }
+}
+
 // ---- SqueezeExcite's pool (gp.py:300: mean over the pixels) and its backward -------------------------------------
 // forward: x [b][P][C] bf16 -> part [b][chunks][C] fp32 partial sums (grid (chunks, b); deterministic: no atomics), then
 // out [b][C] = scale * sum over chunks. backward: y[b][p][c] = g[b][p][c] + gs[b][c] (g optional: the gradient that reached

@@ -1143,8 +1143,9 @@ def rmsnorm_fwd(x: torch.Tensor, gamma: torch.Tensor, silu: bool = False) -> tor
     return y
 
 
-def rmsnorm_bwd(x, g, gamma, want_dgamma: bool, carry=None, silu: bool = False):
-    """(dx [+ carry], dgamma or None); `carry` (x's shape, bf16) is the skip branch's gradient, added inside the pass."""
+def rmsnorm_bwd(x, g, gamma, want_dgamma: bool, carry=None, silu: bool = False, partials: bool = False):
+    """(dx [+ carry], dgamma or None); `carry` (x's shape, bf16) is the skip branch's gradient, added inside the pass. `partials`: the
+    per-workgroup partial sums (P, C) are returned instead of dgamma (for FinishQueue.add_colsum)."""
     L = _C.lib()
     L.require(x, g, gamma, carry)
     assert g.dtype == torch.bfloat16 and g.is_contiguous() and g.shape == x.shape
@@ -1155,6 +1156,8 @@ def rmsnorm_bwd(x, g, gamma, want_dgamma: bool, carry=None, silu: bool = False):
     part = torch.empty((L.lib.gg_rmsnorm_blocks(rows), Cc), dtype=torch.float32, device=x.device) if want_dgamma else None
     rc = L.lib.gg_rmsnorm_bwd(ptr(x), ptr(g), ptr(gamma), ptr(carry), ptr(dx), ptr(part), rows, Cc, RMS_EPS, int(silu), L.stream(x))
     L.check(rc, 'gg_rmsnorm_bwd')
+    if partials:
+        return dx, part
     return dx, (part.sum(0) if part is not None else None)
 
 

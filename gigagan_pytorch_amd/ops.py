@@ -641,10 +641,13 @@ class RmsNormFn(Function):
     `silu=True`: y = silu(norm(x)) in the same pass (the unet Block, unet.py:268-269); first-order backward only."""
 
     @staticmethod
-    def forward(ctx, x, gamma, fork=False, silu=False):
+    def forward(ctx, x, gamma, fork=False, silu=False, gamma_param=None):
+        """gamma: (C,) fp32; gamma_param: the nn.Parameter it is a view of, if any - under `ops.sinking()` its gradient then goes
+        through the finish queue straight into the flat gradient buffer (no partial-sum fold, no AccumulateGrad launch)."""
         ctx.save_for_backward(x, gamma)
         ctx.set_materialize_grads(False)
         ctx.silu = silu
+        ctx.gamma_param = gamma_param
         y = K.rmsnorm_fwd(x, gamma, silu)
         return (y, x.view_as(x)) if fork else y
 
@@ -653,14 +656,19 @@ class RmsNormFn(Function):
         x, gamma = ctx.saved_tensors
         want_dgamma = ctx.needs_input_grad[1] and not inputs_only
         if g is None:
-            return g_alias, None, None, None
+            return g_alias, None, None, None, None
         carry = None if g_alias is None else g_alias.contiguous()
-        if ctx.silu:
-            assert not torch.is_grad_enabled(), 'RmsNormFn(silu=True) is first-order only'
-            dx, dgamma = K.rmsnorm_bwd(x, g.contiguous(), gamma, want_dgamma, carry, silu=True)
+        if ctx.silu or not torch.is_grad_enabled():
+            assert not (ctx.silu and torch.is_grad_enabled()), 'RmsNormFn(silu=True) is first-order only'
+            gp = ctx.gamma_param
+            sink = _grad_sink_of(gp) if (want_dgamma and gp is not None) else None
+            dx, dgamma = K.rmsnorm_bwd(x, g.contiguous(), gamma, want_dgamma, carry, silu=ctx.silu, partials=sink is not None)
+            if sink is not None:
+                K.finish_queue.add_colsum(dgamma, gamma.numel(), 1.0, sink, notify=lambda q=gp: grad_ready(q))
+                dgamma = None
         else:
             dx, dgamma = RmsNormBwdFn.apply(x, g.contiguous(), gamma, want_dgamma, carry)
-        return dx, (dgamma if want_dgamma else None), None, None
+        return dx, (dgamma if want_dgamma else None), None, None, None
 
 
 class RmsNormBwdFn(Function):
@@ -1694,6 +1702,11 @@ class HipOps:
         return self_attention_unfused(self, q, k, v, null_kv, heads, scale, l2)
 
     # -- norms / resampling ------------------------------------------------------------------------
+    @staticmethod
+    def _sinkable(p):
+        """the parameter itself when its gradient may be written behind autograd's back under `ops.sinking()` (fp32, dense), else None"""
+        return p if (isinstance(p, torch.nn.Parameter) and p.dtype == torch.float32 and p.is_contiguous()) else None
+
     def channel_rmsnorm(self, x, gamma, act=None, fork=False):
         """F.normalize(x, dim=1) * sqrt(C) * gamma (gp.py:224-232, unet.py:224-234), fp32 statistics, one fused pass
         over NHWC; `act='silu'` is the unet Block's activation (unet.py:268-269). `fork=True` returns (y, x'): x' goes to the
@@ -1703,17 +1716,17 @@ class HipOps:
         if fork:
             if c % 8 or act is not None:
                 return self.channel_rmsnorm(x, gamma, act), x
-            y, xa = RmsNormFn.apply(nhwc(x), gamma.float().reshape(c).contiguous(), True)
+            y, xa = RmsNormFn.apply(nhwc(x), gamma.float().reshape(c).contiguous(), True, False, self._sinkable(gamma))
             return nchw(y), nchw(xa)
         if act == 'silu' and c % 8 == 0 and not second_order:
-            return nchw(RmsNormFn.apply(nhwc(x), gamma.float().reshape(c).contiguous(), False, True))
+            return nchw(RmsNormFn.apply(nhwc(x), gamma.float().reshape(c).contiguous(), False, True, self._sinkable(gamma)))
         if c % 8:
             _shape_fallback('channel_rmsnorm')
             xf = x.float()
             nrm = xf.norm(dim=1, keepdim=True).clamp(min=1e-12)
             y = (xf / nrm * (c ** 0.5) * gamma.float().view(1, c, 1, 1)).to(ACT_DTYPE)
         else:
-            y = nchw(RmsNormFn.apply(nhwc(x), gamma.float().reshape(c).contiguous()))
+            y = nchw(RmsNormFn.apply(nhwc(x), gamma.float().reshape(c).contiguous(), False, False, self._sinkable(gamma)))
         if act == 'silu':
             y = F.silu(y)
         else:

@@ -501,6 +501,34 @@ def test_flat_optimizer_packs_and_grad_sink_match_autograd():
     check_flat_optimizer_packs_and_grad_sink('cpu')
 
 
+@pytest.mark.parametrize('C,act', [(32, None), (24, None), (64, 'silu')])
+def test_rmsnorm_gain_gradient_through_the_finish_queue_matches_autograd(C, act):
+    """under `ops.sinking()` ChannelRMSNorm's gain gradient is a queued column-sum finish into the parameter's .grad (no partial-sum fold,
+    no AccumulateGrad launch); without it autograd delivers it - same numbers, also when the gain is used twice, and .grad keeps
+    what was in it (accumulation)."""
+    torch.manual_seed(0)
+    H_ = ops.HipOps()
+    x = bf(torch.randn(2, C, 5, 6)).float()
+    w = torch.randn(2, C, 5, 6)
+    gamma0 = torch.rand(C, 1, 1) + 0.5
+    res = {}
+    for tag in ('autograd', 'sink'):
+        gamma = torch.nn.Parameter(gamma0.clone())
+        gamma.grad = torch.full_like(gamma, 0.25)
+        xi = x.clone().requires_grad_()
+        with ops.use_impl(H_):
+            y = H_.channel_rmsnorm(xi, gamma, act=act).float()
+            y2 = H_.channel_rmsnorm(xi * 0.5, gamma, act=act).float()
+            loss = (y * w).sum() + (y2 * w).sum() * 0.3
+            if tag == 'sink':
+                with ops.sinking():
+                    loss.backward()
+            else:
+                loss.backward()
+        res[tag] = (gamma.grad.clone(), xi.grad.clone())
+    assert rel_err(res['sink'][0], res['autograd'][0]) < 1e-5 and rel_err(res['sink'][1], res['autograd'][1]) < 1e-6
+
+
 def test_many_way_splitk_reduce_and_xcd_slice_mapping():
     """split counts above 8 take the wave-per-64-outputs reduce, and few-tile split-K launches of the 4-wave kernel use
     the slice-major (XCD-aware) 1-D grid: same numbers as the unsplit launch."""
@@ -1188,6 +1216,44 @@ def test_rmsnorm_with_fused_silu_matches_oracle():
     ya, ga = run(H_); yb, gb = run(O_)
     assert rel_err(ya, yb) < 6e-3
     assert rel_err(ga[0], gb[0]) < 2e-2 and rel_err(ga[1], gb[1]) < 2e-2
+
+
+@pytest.mark.parametrize('C', [32, 64, 128, 256, 512])
+@pytest.mark.parametrize('silu', [False, True])
+def test_rmsnorm_rows_kernel_matches_the_wave_per_row_kernel(C, silu, monkeypatch):
+    """gg_rmsnorm_rows_kernel (C = 8 * LPR <= 512: LPR lanes per pixel row, 64 / LPR rows per wavefront, two passes in flight) against
+    gg_rmsnorm_kernel (a wavefront per row; GG_RMS_ROWS=0) on ragged row counts, with and without the carry: same summation order
+    (the group butterflies are the leading steps of the 64-lane ones), so y and dx agree except where the compiler contracts an fma
+    in one kernel and not the other (<= 1 bf16 ulp, or 1e-4 absolute where the terms cancel, on <= 0.1 % of the elements); the gain gradient to fp32 summation order; and both
+    against the fp32 formulas (gp.py:224-232)."""
+    torch.manual_seed(C + silu)
+    for rows in (1, 37, 64 * 4 * 2 + 5, 1201):
+        x = bf(torch.randn(rows, C) * 1.7)
+        x[rows // 2] = x[rows // 2] * 1e-9            # a row below eps (the clamped branch)
+        g = bf(torch.randn(rows, C))
+        carry = bf(torch.randn(rows, C))
+        gamma = torch.rand(C) + 0.5
+        res = {}
+        for tag, env in (('rows', '1'), ('wave', '0')):
+            monkeypatch.setenv('GG_RMS_ROWS', env)
+            y = K.rmsnorm_fwd(x, gamma, silu)
+            dx, dgam = K.rmsnorm_bwd(x, g, gamma, True, None, silu=silu)
+            dxc, _ = K.rmsnorm_bwd(x, g, gamma, False, carry, silu=silu)
+            res[tag] = (y, dx, dxc, dgam)
+        for a, b in zip(res['rows'][:3], res['wave'][:3]):
+            d = (a.float() - b.float()).abs()
+            assert float((d > 0).float().mean()) <= 1e-3 and bool((d <= 2. ** -7 * b.float().abs() + 1e-4).all()), (C, silu, rows)
+        assert rel_err(res['rows'][3], res['wave'][3]) < 1e-5
+        xf = x.float().requires_grad_()
+        gm = gamma.clone().requires_grad_()
+        n = xf.norm(dim=-1, keepdim=True).clamp(min=K.RMS_EPS)
+        yr = xf / n * C ** 0.5 * gm
+        if silu:
+            yr = torch.nn.functional.silu(yr)
+        gx, gg = torch.autograd.grad((yr * g.float()).sum(), [xf, gm])
+        assert rel_err(res['rows'][0].float(), yr.detach()) < 6e-3
+        assert rel_err(res['rows'][1].float(), gx) < 1e-2 and rel_err(res['rows'][3], gg) < 1e-2
+        assert rel_err(res['rows'][2].float(), gx + carry.float()) < 1e-2
 
 
 @pytest.mark.parametrize('shape', [(2, 8, 8, 16), (1, 6, 4, 8), (2, 2, 2, 24)])
