@@ -1259,6 +1259,64 @@ extern "C" int gg_modcoef_bwd(const float* w, const float* kmod, const float* s,
     return gg_check_launch();
 }
 
+// ---- the coefficients through the bank's Gram rows (gg_modcoef.h, second half) --------------------------------------------------------
+static int gg_modgram_common(GgModGramParams& p, const float* w, const float* gram, const float* kmod, int32_t b, int32_t N, int32_t O,
+                             int32_t I, int32_t T, int32_t Ip, int32_t Op, float eps) {
+    if (!gram) return gg_fail(-1, "gg_modcoef_gram: null Gram rows");
+    if (b <= 0 || N <= 0 || O <= 0 || I <= 0 || T <= 0 || Ip < I || Op < O) return gg_fail(-2, "gg_modcoef_gram: bad extents");
+    if (N > GG_MC_NMAX || I > GG_MC_IMAX || O > GG_MC_IMAX || b > GG_MG_BMAX)
+        return gg_fail(-3, "gg_modcoef_gram: supports N <= %d kernels, I, O <= %d channels, b <= %d samples", GG_MC_NMAX, GG_MC_IMAX, GG_MG_BMAX);
+    if (N > 1 && !kmod) return gg_fail(-1, "gg_modcoef_gram: kernel_mod is required for N > 1");
+    memset(&p, 0, sizeof(p));
+    p.w = w; p.gram = (float*)gram; p.kmod = kmod; p.b = b; p.N = N; p.P = N * (N + 1) / 2; p.O = O; p.I = I; p.T = T; p.Ip = Ip; p.Op = Op;
+    p.eps = eps;
+    return 0;
+}
+
+extern "C" int gg_modgram(const float* w, float* gram, int32_t N, int32_t O, int32_t I, int32_t T, void* stream) {
+    if (!w) return gg_fail(-1, "gg_modgram: null weights");
+    GgModGramParams p;
+    int rc = gg_modgram_common(p, w, gram, (const float*)w, 1, N, O, I, T, I, O, 0.f);
+    if (rc) return rc;
+    GG_LAUNCH(gg_modgram_kernel, dim3((unsigned)O), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+extern "C" int gg_modcoef_gram_fwd(const float* gram, const float* mod, const float* kmod, float* s, float* a, float* d, float* tsum,
+                                   int32_t b, int32_t N, int32_t O, int32_t I, int32_t Ip, int32_t Op, float eps, void* stream) {
+    GgModGramParams p;
+    int rc = gg_modgram_common(p, nullptr, gram, kmod, b, N, O, I, 1, Ip, Op, eps);
+    if (rc) return rc;
+    if (!mod || !s || !a || !d || !tsum) return gg_fail(-1, "gg_modcoef_gram_fwd: null pointer");
+    p.mod = mod; p.s = s; p.a = a; p.d = d; p.tsum = tsum;
+#define GG_MG_BY_N(KERNEL, GRID) \
+    do { if (N == 1) GG_LAUNCH((KERNEL<1>), GRID, dim3(256), (hipStream_t)stream, p); else if (N == 2) GG_LAUNCH((KERNEL<2>), GRID, dim3(256), (hipStream_t)stream, p); \
+         else if (N == 3) GG_LAUNCH((KERNEL<3>), GRID, dim3(256), (hipStream_t)stream, p); else GG_LAUNCH((KERNEL<4>), GRID, dim3(256), (hipStream_t)stream, p); } while (0)
+    GG_MG_BY_N(gg_modcoef_gram_fwd_kernel, dim3((unsigned)O));
+    return gg_check_launch();
+}
+
+extern "C" int gg_modcoef_gram_bwd(const float* w, const float* gram, const float* kmod, const float* s, const float* d,
+                                   const float* tsum, const float* gs, const float* ga, const float* gd, float* gmod, float* gkmod,
+                                   float* da_slots, float* gw, int32_t b, int32_t N, int32_t O, int32_t I, int32_t T, int32_t Ip,
+                                   int32_t Op, float eps, void* stream) {
+    GgModGramParams p;
+    int rc = gg_modgram_common(p, w, gram, kmod, b, N, O, I, T, Ip, Op, eps);
+    if (rc) return rc;
+    if (!s || !d || !tsum || !gd || !gmod) return gg_fail(-1, "gg_modcoef_gram_bwd: null pointer");
+    if (N > 1 && (!gkmod || !da_slots)) return gg_fail(-1, "gg_modcoef_gram_bwd: gkmod and da_slots are required for N > 1");
+    if (gw && !w) return gg_fail(-1, "gg_modcoef_gram_bwd: the weights are required with gw");
+    p.s = (float*)s; p.d = (float*)d; p.tsum = (float*)tsum; p.gs = gs; p.ga = ga; p.gd = gd; p.gmod = gmod; p.gkmod = gkmod;
+    p.da_slots = da_slots; p.gw = gw;
+    if (gw || N > 1) {
+        GG_MG_BY_N(gg_modcoef_gram_bwd_o_kernel, dim3((unsigned)O));
+        rc = gg_check_launch();
+        if (rc) return rc;
+    }
+    GG_MG_BY_N(gg_modcoef_gram_bwd_i_kernel, dim3((unsigned)((I + 63) / 64), (unsigned)b));
+    return gg_check_launch();
+}
+
 static int gg_softmax_common(GgSoftmaxParams& p, int64_t rows, int32_t rows_per_batch, int32_t n_valid, int32_t ld,
                              float alpha) {
     if (rows <= 0 || rows_per_batch <= 0 || n_valid <= 0 || ld < n_valid) return gg_fail(-2, "gg_softmax: bad extents");

@@ -223,3 +223,266 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modcoef_bwd_s_kernel(GgModCoefParams p) 
         }
     }
 }
+
+// ===== the same coefficients through the bank's Gram rows ===========================================================================
+// The kernels above walk (b, o, i, t): 75 M (sample, weight) pairs on a 512 x 512 x 9 bank at batch 32, ~17 VALU operations each -
+// 30 M wavefront instructions per backward launch, 200-290 us, VALU-bound (profiles/r04_pmc_modcoef.log), 2 ms per training step.
+// With H[n,m,o,i] = sum_t W_n W_m (the tap sum does not depend on the sample):
+//     sumsq[b,o] = sum_i s^2[b,i] sum_{n<=m} a_n a_m G[(n,m),o,i],        G = H on the diagonal, 2 H off it           (t is gone)
+//                = sum_p A[b,p] T[b,p,o],   A_p = a_n a_m,   T[b,p,o] = sum_i s^2[b,i] G[p,o,i]
+// and, with g[b,o] = dL/d sumsq as above,
+//     ga[b,k]    += sum_o g[b,o] sum_p T[b,p,o] dA_p/da_k                                                    (slots per o, added by K_i)
+//     gs[b,i]     = gs_ext + 2 s[b,i] sum_p A[b,p] R[b,p,i],   R[b,p,i] = sum_o g[b,o] G[p,o,i]
+//     gW[n,o,i,t] += sum_m W[m,o,i,t] Q[(n,m),o,i],            Q[p,o,i] = sum_b 2 g[b,o] A[b,p] s^2[b,i]
+// T, R and Q are three thin contractions of 2 * b * O * I * P flops each (0.05 GF at the shape above) and the weights are touched once,
+// in the element-wise gW update. P = N (N + 1) / 2 pairs, ordered n <= m row-major (the order of gg_pack_weights' 'gram' kind).
+#define GG_MG_PMAX 10          // N = 4
+#define GG_MG_BMAX 64          // samples per launch (the per-sample tables of a workgroup live in LDS / registers)
+
+struct GgModGramParams {
+    const float* w;        // (N, O, I, T)
+    float* gram;           // (P, O, I): written by gg_modgram_kernel, read by the others
+    const float* mod;      // (b, I)
+    const float* kmod;     // (b, N) or null
+    float* s;              // (b, Ip)
+    float* a;              // (b, N)
+    float* d;              // (b, Op)
+    float* tsum;           // (b, P, O): T, kept for the backward
+    const float* gs;       // (b, Ip) or null
+    const float* ga;       // (b, N) or null
+    const float* gd;       // (b, Op)
+    float* gmod;           // (b, I)
+    float* gkmod;          // (b, N) or null
+    float* da_slots;       // (O, b, N) scratch: ga through d, one slot per output channel (K_o -> K_i workgroup 0)
+    float* gw;             // (N, O, I, T) accumulated in place, or null
+    int b, N, P, O, I, T, Ip, Op;
+    float eps;
+};
+
+template <int NN>
+GG_DEVICE void gg_mg_softmax(const GgModGramParams& p, int row, float (&a)[NN]) {
+    if (p.kmod && NN > 1) {
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int n = 0; n < NN; ++n) { a[n] = p.kmod[row * NN + n]; mx = a[n] > mx ? a[n] : mx; }
+        float sum = 0.f;
+#pragma unroll
+        for (int n = 0; n < NN; ++n) { a[n] = gg_expf(a[n] - mx); sum += a[n]; }
+#pragma unroll
+        for (int n = 0; n < NN; ++n) a[n] /= sum;
+    } else {
+#pragma unroll
+        for (int n = 0; n < NN; ++n) a[n] = n == 0 ? 1.f : 0.f;
+    }
+}
+
+// G[p][o][i]: workgroup per output channel, threads along the input channels
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modgram_kernel(GgModGramParams p) {
+    const int o = blockIdx.x;
+    for (int i = threadIdx.x; i < p.I; i += 256) {
+        float acc[GG_MG_PMAX];
+        for (int q = 0; q < GG_MG_PMAX; ++q) acc[q] = 0.f;
+        for (int t = 0; t < p.T; ++t) {
+            float wv[GG_MC_NMAX];
+            for (int n = 0; n < GG_MC_NMAX; ++n) wv[n] = n < p.N ? p.w[(((long long)n * p.O + o) * p.I + i) * p.T + t] : 0.f;
+            int q = 0;
+            for (int n = 0; n < p.N; ++n)
+                for (int m = n; m < p.N; ++m, ++q) acc[q] += wv[n] * wv[m];
+        }
+        int q = 0;
+        for (int n = 0; n < p.N; ++n)
+            for (int m = n; m < p.N; ++m, ++q) p.gram[((long long)q * p.O + o) * p.I + i] = (n == m ? 1.f : 2.f) * acc[q];
+    }
+}
+
+// forward: workgroup per output channel; its Gram rows sit in LDS, a wavefront per sample (lanes along the input channels)
+template <int NN>       // kernels of the bank (compile-time: the pair tables stay in registers)
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modcoef_gram_fwd_kernel(GgModGramParams p) {
+    constexpr int PP = NN * (NN + 1) / 2;
+    GG_SHARED float g_s[GG_MG_PMAX * GG_MC_IMAX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int o = blockIdx.x;
+    for (int row = blockIdx.x; row < p.b; row += gridDim.x) {       // rows of s / a and the zero padding of d: the workgroups in turn
+        for (int i = tid; i < p.Ip; i += 256) p.s[(long long)row * p.Ip + i] = i < p.I ? p.mod[(long long)row * p.I + i] + 1.f : 0.f;
+        for (int c = p.O + tid; c < p.Op; c += 256) p.d[(long long)row * p.Op + c] = 0.f;
+        if (tid == 0) {
+            float av[NN];
+            gg_mg_softmax<NN>(p, row, av);
+            _Pragma("unroll") for (int n = 0; n < NN; ++n) p.a[row * NN + n] = av[n];
+        }
+    }
+    for (int idx = tid; idx < PP * p.I; idx += 256) {
+        const int q = idx / p.I, i = idx - q * p.I;
+        g_s[idx] = p.gram[((long long)q * p.O + o) * p.I + i];
+    }
+    gg_sync();
+    for (int row = wave; row < p.b; row += 4) {
+        float acc[PP];
+        _Pragma("unroll") for (int q = 0; q < PP; ++q) acc[q] = 0.f;
+        for (int i = lane; i < p.I; i += 64) {
+            const float sv = p.mod[(long long)row * p.I + i] + 1.f;
+            const float s2 = sv * sv;
+            _Pragma("unroll") for (int q = 0; q < PP; ++q) acc[q] += s2 * g_s[q * p.I + i];
+        }
+        float av[NN];
+        gg_mg_softmax<NN>(p, row, av);
+        float sumsq = 0.f;
+        int q = 0;
+        _Pragma("unroll") for (int n = 0; n < NN; ++n)
+            _Pragma("unroll") for (int m = n; m < NN; ++m, ++q) {
+                const float tv = gg_mc_wave_sum(acc[q]);
+                sumsq += av[n] * av[m] * tv;
+                if (lane == 0) p.tsum[((long long)row * PP + q) * p.O + o] = tv;
+            }
+        if (lane == 0) p.d[(long long)row * p.Op + o] = gg_rsqrtf(sumsq > p.eps ? sumsq : p.eps);
+    }
+}
+
+// backward K_o: workgroup per output channel: the ga slots of this channel, Q[p,o,:] and the weights' gradient
+template <int NN>
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modcoef_gram_bwd_o_kernel(GgModGramParams p) {
+    constexpr int PP = NN * (NN + 1) / 2;
+    GG_SHARED float a_s[GG_MG_BMAX][GG_MC_NMAX];
+    GG_SHARED float g2a_s[GG_MG_BMAX][GG_MG_PMAX];      // 2 g[b,o] A[b,p]
+    GG_SHARED float g_s[GG_MG_BMAX];
+    const int tid = threadIdx.x;
+    const int o = blockIdx.x;
+    if (tid < p.b) {
+        float av[NN];
+        gg_mg_softmax<NN>(p, tid, av);
+        const float dv = p.d[(long long)tid * p.Op + o];
+        const float gv = dv < gg_rsqrtf(p.eps) ? -0.5f * p.gd[(long long)tid * p.Op + o] * dv * dv * dv : 0.f;
+        g_s[tid] = gv;
+        _Pragma("unroll") for (int n = 0; n < NN; ++n) a_s[tid][n] = av[n];
+        int q = 0;
+        _Pragma("unroll") for (int n = 0; n < NN; ++n)
+            _Pragma("unroll") for (int m = n; m < NN; ++m, ++q) g2a_s[tid][q] = 2.f * gv * av[n] * av[m];
+    }
+    gg_sync();
+    if (NN > 1)
+        for (int idx = tid; idx < p.b * NN; idx += 256) {
+            const int row = idx / NN, k = idx - row * NN;
+            float acc = 0.f;
+            int q = 0;
+            _Pragma("unroll") for (int n = 0; n < NN; ++n)
+                _Pragma("unroll") for (int m = n; m < NN; ++m, ++q) {
+                    const float tv = p.tsum[((long long)row * PP + q) * p.O + o];
+                    const float c = (n == k ? a_s[row][m] : 0.f) + (m == k ? a_s[row][n] : 0.f);      // dA_p / da_k
+                    acc += tv * c;
+                }
+            p.da_slots[((long long)o * p.b + row) * NN + k] = g_s[row] * acc;
+        }
+    if (!p.gw) return;
+    for (int i = tid; i < p.I; i += 256) {
+        float qv[PP];
+        _Pragma("unroll") for (int q = 0; q < PP; ++q) qv[q] = 0.f;
+        for (int row = 0; row < p.b; ++row) {
+            const float sv = p.s[(long long)row * p.Ip + i];
+            const float s2 = sv * sv;
+            _Pragma("unroll") for (int q = 0; q < PP; ++q) qv[q] += g2a_s[row][q] * s2;
+        }
+        // nine taps per pass: every load of the pass (weights and the old gradient) is issued before the first store (gw may alias w as
+        // far as the compiler knows; one tap at a time every tap paid two dependent round trips)
+        for (int t0 = 0; t0 < p.T; t0 += 9) {
+            float wv[9][NN], old[9][NN];
+#pragma unroll
+            for (int tt = 0; tt < 9; ++tt)
+#pragma unroll
+                for (int n = 0; n < NN; ++n) {
+                    const bool on = n < NN && t0 + tt < p.T;
+                    const long long off = (((long long)n * p.O + o) * p.I + i) * p.T + t0 + tt;
+                    wv[tt][n] = on ? p.w[off] : 0.f;
+                    old[tt][n] = on ? p.gw[off] : 0.f;
+                }
+#pragma unroll
+            for (int tt = 0; tt < 9; ++tt) {
+                if (t0 + tt >= p.T) break;
+                _Pragma("unroll") for (int n = 0; n < NN; ++n) {
+                    float acc = old[tt][n];
+                    _Pragma("unroll") for (int m = 0; m < NN; ++m) {
+                        const int lo = n < m ? n : m, hi = n < m ? m : n;
+                        acc += wv[tt][m] * qv[lo * NN - lo * (lo - 1) / 2 + (hi - lo)];
+                    }
+                    p.gw[(((long long)n * p.O + o) * p.I + i) * p.T + t0 + tt] = acc;
+                }
+            }
+        }
+    }
+}
+
+// backward K_i: workgroup per (64 input channels, sample): lane = input channel, the four wavefronts split the output channels; R and
+// gs of that sample. The workgroups of the first channel block also add the sample's ga slots up and finish its kernel-selection softmax
+// backward. (A first version - 16 channels x all samples per workgroup, I / 16 workgroups, one dependent Gram load per output channel -
+// took 250 us at O = I = 512: 32 workgroups on 256 CUs and 512 serial round trips each.)
+template <int NN>
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modcoef_gram_bwd_i_kernel(GgModGramParams p) {
+    constexpr int PP = NN * (NN + 1) / 2;
+    GG_SHARED float g_s[GG_MC_IMAX];
+    GG_SHARED float red[4][GG_MG_PMAX][64];
+    GG_SHARED float dsum[4][GG_MC_NMAX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.y;
+    const int i = blockIdx.x * 64 + lane;
+    const float lim = gg_rsqrtf(p.eps);
+    for (int oo = tid; oo < p.O; oo += 256) {
+        const float dv = p.d[(long long)row * p.Op + oo];
+        g_s[oo] = dv < lim ? -0.5f * p.gd[(long long)row * p.Op + oo] * dv * dv * dv : 0.f;
+    }
+    gg_sync();
+    float r[PP];
+    _Pragma("unroll") for (int q = 0; q < PP; ++q) r[q] = 0.f;
+    const int oq = (p.O + 3) / 4;
+    const int o_begin = wave * oq, o_end = (o_begin + oq < p.O) ? o_begin + oq : p.O;
+    if (i < p.I) {
+        const float* gcol = p.gram + i;
+        int oo = o_begin;
+        for (; oo + 8 <= o_end; oo += 8) {             // eight output channels per pass: their Gram loads first
+            float gq[8][PP];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                _Pragma("unroll") for (int q = 0; q < PP; ++q) gq[u][q] = gcol[((long long)q * p.O + oo + u) * p.I];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float gv = g_s[oo + u];
+                _Pragma("unroll") for (int q = 0; q < PP; ++q) r[q] += gv * gq[u][q];
+            }
+        }
+        for (; oo < o_end; ++oo) {
+            const float gv = g_s[oo];
+            _Pragma("unroll") for (int q = 0; q < PP; ++q) r[q] += gv * gcol[((long long)q * p.O + oo) * p.I];
+        }
+    }
+    _Pragma("unroll") for (int q = 0; q < PP; ++q) red[wave][q][lane] = r[q];
+    gg_sync();
+    float av[NN];
+    gg_mg_softmax<NN>(p, row, av);
+    if (wave == 0 && i < p.I) {
+        float tot = 0.f;
+        int q = 0;
+        _Pragma("unroll") for (int n = 0; n < NN; ++n)
+            _Pragma("unroll") for (int m = n; m < NN; ++m, ++q)
+                tot += av[n] * av[m] * ((red[0][q][lane] + red[1][q][lane]) + (red[2][q][lane] + red[3][q][lane]));
+        const float sv = p.s[(long long)row * p.Ip + i];
+        p.gmod[(long long)row * p.I + i] = (p.gs ? p.gs[(long long)row * p.Ip + i] : 0.f) + 2.f * sv * tot;
+    }
+    if (blockIdx.x == 0 && p.gkmod) {
+        // ga through d for this sample: the per-output-channel slots, added in a fixed order
+        float part[NN];
+        _Pragma("unroll") for (int n = 0; n < NN; ++n) part[n] = 0.f;
+        for (int oo = tid; oo < p.O; oo += 256)
+            _Pragma("unroll") for (int n = 0; n < NN; ++n) part[n] += p.da_slots[((long long)oo * p.b + row) * NN + n];
+        _Pragma("unroll") for (int n = 0; n < NN; ++n) {
+            const float v = gg_mc_wave_sum(part[n]);
+            if (lane == 0) dsum[wave][n] = v;
+        }
+        gg_sync();
+        if (tid == 0) {
+            float gt[NN], dot = 0.f;
+            _Pragma("unroll") for (int n = 0; n < NN; ++n) {
+                gt[n] = (p.ga ? p.ga[row * NN + n] : 0.f) + ((dsum[0][n] + dsum[1][n]) + (dsum[2][n] + dsum[3][n]));
+                dot += av[n] * gt[n];
+            }
+            _Pragma("unroll") for (int n = 0; n < NN; ++n) p.gkmod[row * NN + n] = av[n] * (gt[n] - dot);
+        }
+    }
+}

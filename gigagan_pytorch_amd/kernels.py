@@ -682,8 +682,9 @@ def bias_act_bwd(dy: torch.Tensor, y, want_db: bool, slope: float = 0.2, partial
 # --------------------------------------------------------------------------------------------------
 
 def _chunks(P: int, C: int) -> int:
-    """workgroups per image for the per-image reductions: ~4096 16-byte vectors each, at most 64."""
-    return max(1, min(64, (P * (C // 8) + 4095) // 4096))
+    """workgroups per image for the per-image reductions: ~1024 16-byte vectors each (four per thread: the low-resolution layers were
+    latency-bound on 1-2 workgroups per image), at most 64."""
+    return max(1, min(64, (P * (C // 8) + 1023) // 1024))
 
 
 def modulate(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
@@ -1303,6 +1304,57 @@ def modcoef_fwd(w: torch.Tensor, mod: torch.Tensor, kmod, demod: bool, eps: floa
                               L.stream(w))
     L.check(rc, 'gg_modcoef_fwd')
     return s, a, d
+
+
+MODGRAM_MAX_B = 64
+
+
+def modgram(w: torch.Tensor) -> torch.Tensor:
+    """w (N, O, I, k, k) fp32 -> the bank's Gram rows (P, O, I) fp32, P = N (N + 1) / 2 pairs n <= m (factor 2 off the diagonal)."""
+    L = _C.lib()
+    L.require(w)
+    assert w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 5
+    N, O, I = w.shape[:3]
+    gram = torch.empty((N * (N + 1) // 2, O, I), dtype=torch.float32, device=w.device)
+    L.check(L.lib.gg_modgram(ptr(w), ptr(gram), N, O, I, w.shape[3] * w.shape[4], L.stream(w)), 'gg_modgram')
+    return gram
+
+
+def modcoef_gram_fwd(gram: torch.Tensor, N: int, mod: torch.Tensor, kmod, eps: float, Ip: int, Op: int):
+    """gram (P, O, I), mod (b, I), kmod (b, N) or None -> s (b, Ip), a (b, N), d (b, Op), tsum (b, P, O) (kept for the backward)."""
+    L = _C.lib()
+    L.require(gram, mod, kmod)
+    P, O, I = gram.shape
+    b = mod.shape[0]
+    assert P == N * (N + 1) // 2 and mod.dtype == torch.float32 and mod.is_contiguous() and mod.shape == (b, I) and b <= MODGRAM_MAX_B
+    assert kmod is None or (kmod.shape == (b, N) and kmod.dtype == torch.float32 and kmod.is_contiguous())
+    s = torch.empty((b, Ip), dtype=torch.float32, device=gram.device)
+    a = torch.empty((b, N), dtype=torch.float32, device=gram.device)
+    d = torch.empty((b, Op), dtype=torch.float32, device=gram.device)
+    tsum = torch.empty((b, P, O), dtype=torch.float32, device=gram.device)
+    rc = L.lib.gg_modcoef_gram_fwd(ptr(gram), ptr(mod), ptr(kmod), ptr(s), ptr(a), ptr(d), ptr(tsum), b, N, O, I, Ip, Op, float(eps),
+                                   L.stream(gram))
+    L.check(rc, 'gg_modcoef_gram_fwd')
+    return s, a, d, tsum
+
+
+def modcoef_gram_bwd(w, gram, kmod, s, d, tsum, gs, ga, gd, gw, eps: float):
+    """-> (gmod (b, I), gkmod (b, N) or None); adds the demodulation path's weight gradient into gw (w-shaped) if given."""
+    L = _C.lib()
+    L.require(w, gram, kmod, s, d, tsum, gs, ga, gd, gw)
+    N, O, I = w.shape[:3]
+    T = w.shape[3] * w.shape[4]
+    b, Ip = s.shape
+    Op = d.shape[1]
+    for t in (gs, ga, gd, gw):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    gmod = torch.empty((b, I), dtype=torch.float32, device=w.device)
+    gkmod = torch.empty((b, N), dtype=torch.float32, device=w.device) if N > 1 else None
+    slots = torch.empty((O, b, N), dtype=torch.float32, device=w.device) if N > 1 else None
+    rc = L.lib.gg_modcoef_gram_bwd(ptr(w), ptr(gram), ptr(kmod), ptr(s), ptr(d), ptr(tsum), ptr(gs), ptr(ga), ptr(gd), ptr(gmod),
+                                   ptr(gkmod), ptr(slots), ptr(gw), b, N, O, I, T, Ip, Op, float(eps), L.stream(w))
+    L.check(rc, 'gg_modcoef_gram_bwd')
+    return gmod, gkmod
 
 
 def modcoef_bwd(w, kmod, s, d, gs, ga, gd, gw, eps: float):

@@ -371,6 +371,7 @@ class ConvFn(Function):
 
 
 _ff_plan_cache: dict = {}
+_NO_MODGRAM = bool(os.environ.get('GG_NO_MODGRAM'))      # A/B switch: the adaptive conv's coefficients over (b, o, i, t) instead of through the Gram rows
 _NO_FF_FUSE = bool(os.environ.get('GG_NO_FF_FUSE'))      # A/B switch of the GELU-on-epilogue FeedForward (profiles/r04_ff_fuse_ab.log)
 
 
@@ -584,15 +585,21 @@ class ModCoefFn(Function):
     @staticmethod
     def forward(ctx, mod, kmod, weights, eps, Ip, Op):
         ctx.set_materialize_grads(False)
-        s, a, d = K.modcoef_fwd(weights.detach(), mod, kmod, True, eps, Ip, Op)
         ctx.eps = eps
-        ctx.save_for_backward(kmod, weights, s, d)
+        ctx.gram = not _NO_MODGRAM and mod.shape[0] <= K.MODGRAM_MAX_B
+        if ctx.gram:       # through the bank's Gram rows: 17x fewer operations (gg_modcoef.h, second half)
+            gram = K.modgram(weights.detach())
+            s, a, d, tsum = K.modcoef_gram_fwd(gram, weights.shape[0], mod, kmod, eps, Ip, Op)
+            ctx.save_for_backward(kmod, weights, s, d, gram, tsum)
+        else:
+            s, a, d = K.modcoef_fwd(weights.detach(), mod, kmod, True, eps, Ip, Op)
+            ctx.save_for_backward(kmod, weights, s, d)
         return s, a, d
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gs, ga, gd):
-        kmod, weights, s, d = ctx.saved_tensors
+        kmod, weights, s, d = ctx.saved_tensors[:4]
 
         def f32(t):
             return None if t is None else t.float().contiguous()
@@ -608,7 +615,11 @@ class ModCoefFn(Function):
                 a = kmod.softmax(dim=-1)
                 gk = a * (ga - (a * ga).sum(-1, keepdim=True))
             return gmod, gk, None, None, None, None
-        gmod, gk = K.modcoef_bwd(weights.detach(), kmod, s, d, gs, ga, gd, gw, ctx.eps)
+        if ctx.gram:
+            gram, tsum = ctx.saved_tensors[4:]
+            gmod, gk = K.modcoef_gram_bwd(weights.detach(), gram, kmod, s, d, tsum, gs, ga, gd, gw, ctx.eps)
+        else:
+            gmod, gk = K.modcoef_bwd(weights.detach(), kmod, s, d, gs, ga, gd, gw, ctx.eps)
         if sink is not None:
             grad_ready(weights)
         return gmod, gk, (gw if (gw is not None and sink is None) else None), None, None, None

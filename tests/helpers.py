@@ -159,9 +159,9 @@ def check_modcoef(cfg, device):
     g1 = torch.autograd.grad(loss1, [t for t in (mod, kmod, w) if t is not None])
     for x, y in zip(g1, g0):
         assert rel_err(x, y) < 2e-5, (x.shape, rel_err(x, y))
-    # forward-only entry (no-grad generator pass)
+    # forward-only entry (no-grad generator pass): the direct (b, o, i, t) kernel; ModCoefFn goes through the bank's Gram rows
     s2, a2, d2 = K.modcoef_fwd(w.detach(), mod.detach(), None if kmod is None else kmod.detach(), True, 1e-8, r8(I), r8(O))
-    assert torch.equal(s2, s1) and torch.equal(d2, d1)
+    assert torch.equal(s2, s1) and rel_err(d2, d1) < 1e-5
 
 
 # UnetUpsampler (BASELINE config 5 at toy size): two no-downsample stages (8 -> 32), linear attention in the first stage,

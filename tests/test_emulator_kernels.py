@@ -529,6 +529,61 @@ def test_rmsnorm_gain_gradient_through_the_finish_queue_matches_autograd(C, act)
     assert rel_err(res['sink'][0], res['autograd'][0]) < 1e-5 and rel_err(res['sink'][1], res['autograd'][1]) < 1e-6
 
 
+@pytest.mark.parametrize('cfg', [(5, 2, 24, 40, 9), (3, 1, 16, 8, 9), (17, 3, 72, 33, 4), (32, 4, 40, 24, 1), (2, 2, 130, 70, 9)])
+def test_modcoef_through_gram_rows_matches_the_direct_kernels(cfg):
+    """gg_modgram + gg_modcoef_gram_fwd / _bwd (the coefficients through the bank's Gram rows: the tap sum leaves the per-sample work)
+    against gg_modcoef_fwd / _bwd (walks (b, o, i, t)) and against autograd of the reference formulas (gp.py:378-400): s, a, d; gmod,
+    gkernel_mod and the weights' gradient accumulated onto what gw held; with and without the external gs / ga; a clamped row."""
+    b, N, O, I, T = cfg
+    k = int(T ** 0.5)
+    torch.manual_seed(b * 7 + N)
+    w = torch.randn(N, O, I, k, k) * 0.2
+    mod = torch.randn(b, I) * 0.4
+    mod[0] = -1.0                                    # s = 0 for sample 0: sumsq = 0 -> the eps clamp is active there
+    km = torch.randn(b, N) if N > 1 else None
+    Ip, Op = (I + 7) // 8 * 8, (O + 7) // 8 * 8
+    eps = 1e-8
+    s0, a0, d0 = K.modcoef_fwd(w, mod, km, True, eps, Ip, Op)
+    gram = K.modgram(w)
+    s1, a1, d1, tsum = K.modcoef_gram_fwd(gram, N, mod, km, eps, Ip, Op)
+    H = torch.einsum('noit,moit->nmoi', w.view(N, O, I, T), w.view(N, O, I, T))
+    q = 0
+    for n in range(N):
+        for m in range(n, N):
+            assert rel_err(gram[q], H[n, m] * (1. if n == m else 2.)) < 1e-5
+            q += 1
+    assert torch.equal(s1, s0) and rel_err(a1, a0) < 1e-6
+    assert rel_err(d1[1:], d0[1:]) < 1e-5 and bool((d1[0, :O] == d0[0, :O]).all()) and float(d1[:, O:].abs().max() if Op > O else 0.) == 0.
+    for with_ext in (True, False):
+        gs = torch.randn(b, Ip) if with_ext else None
+        ga = torch.randn(b, N) if (with_ext and N > 1) else None
+        gd = torch.randn(b, Op)
+        gw0 = torch.randn_like(w) * 0.1
+        gw1 = gw0.clone()
+        gm0, gk0 = K.modcoef_bwd(w, km, s0, d0, gs, ga, gd, gw0, eps)
+        gm1, gk1 = K.modcoef_gram_bwd(w, gram, km, s1, d1, tsum, gs, ga, gd, gw1, eps)
+        assert rel_err(gm1, gm0) < 2e-5 and rel_err(gw1, gw0) < 2e-5
+        if N > 1:
+            assert rel_err(gk1, gk0) < 2e-5
+        gm2, _ = K.modcoef_gram_bwd(w, gram, km, s1, d1, tsum, gs, ga, gd, None, eps)       # no weight gradient wanted
+        assert rel_err(gm2, gm0) < 2e-5
+    # autograd of the reference formulas
+    wr, modr = w.clone().requires_grad_(), mod.clone().requires_grad_()
+    kmr = km.clone().requires_grad_() if N > 1 else None
+    a = kmr.softmax(-1) if N > 1 else torch.ones(b, 1)
+    sr = modr + 1.
+    mix = torch.einsum('bn,noikl->boikl', a, wr) * sr[:, None, :, None, None]
+    dr = mix.pow(2).sum((2, 3, 4)).clamp(min=eps).rsqrt()
+    gd = torch.randn(b, O)
+    grads = torch.autograd.grad((dr * gd).sum(), [modr, wr] + ([kmr] if N > 1 else []))
+    gdp = torch.zeros(b, Op); gdp[:, :O] = gd
+    gwz = torch.zeros_like(w)
+    gm, gk = K.modcoef_gram_bwd(w, gram, km, s1, d1, tsum, None, None, gdp, gwz, eps)
+    assert rel_err(gm[1:], grads[0][1:]) < 1e-4 and rel_err(gwz, grads[1]) < 1e-4
+    if N > 1:
+        assert rel_err(gk, grads[2]) < 1e-4
+
+
 def test_many_way_splitk_reduce_and_xcd_slice_mapping():
     """split counts above 8 take the wave-per-64-outputs reduce, and few-tile split-K launches of the 4-wave kernel use
     the slice-major (XCD-aware) 1-D grid: same numbers as the unsplit launch."""
