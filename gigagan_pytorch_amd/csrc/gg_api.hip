@@ -1888,13 +1888,14 @@ static int gg_rms_launch(int mode, const void* x, const void* g, const void* v, 
     // C = 8 * LPR <= 512: LPR lanes per row, several rows per wavefront (same summation order, 2-4x the bandwidth)
     const char* rows_env = getenv("GG_RMS_ROWS");             // (read per call: the tests compare both kernels in one process)
     const int rows_kernel = rows_env ? atoi(rows_env) : 1;
-    if (rows_kernel && mode <= 1 && (C == 32 || C == 64 || C == 128 || C == 256 || C == 512)) {
+    if (rows_kernel && mode <= 2 && (C == 32 || C == 64 || C == 128 || C == 256 || C == 512)) {
 #define GG_RMS_ROWS_LAUNCH(M, A, L) GG_LAUNCH((gg_rmsnorm_rows_kernel<M, A, L>), dim3((unsigned)blocks), dim3(256), s, p)
 #define GG_RMS_ROWS_C(M, A) \
         do { if (C == 32) GG_RMS_ROWS_LAUNCH(M, A, 4); else if (C == 64) GG_RMS_ROWS_LAUNCH(M, A, 8); else if (C == 128) GG_RMS_ROWS_LAUNCH(M, A, 16); \
              else if (C == 256) GG_RMS_ROWS_LAUNCH(M, A, 32); else GG_RMS_ROWS_LAUNCH(M, A, 64); } while (0)
         if (mode == 0 && act) GG_RMS_ROWS_C(0, true);
         else if (mode == 0) GG_RMS_ROWS_C(0, false);
+        else if (mode == 2) GG_RMS_ROWS_C(2, false);
         else if (act) GG_RMS_ROWS_C(1, true);
         else GG_RMS_ROWS_C(1, false);
 #undef GG_RMS_ROWS_C

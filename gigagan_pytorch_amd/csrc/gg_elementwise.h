@@ -657,7 +657,7 @@ GG_DEVICE float gg_group_sum(float v) {
     return v;
 }
 
-template <int MODE, bool ACT, int LPR>   // MODE 0 fwd, 1 bwd
+template <int MODE, bool ACT, int LPR>   // MODE 0 fwd, 1 bwd, 2 bwd2 (ACT: first order only)
 GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_rmsnorm_rows_kernel(GgRmsParams p) {
     GG_SHARED float red[4][512];
     constexpr int G = 64 / LPR;                    // rows per wavefront and pass
@@ -683,24 +683,29 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_rmsnorm_rows_kernel(GgRmsParams p) {
             xv[u] = z; gv[u] = z; cv[u] = z;
             if (live[u]) {
                 xv[u] = *(const u16x8*)(p.x + off[u]);
-                if (MODE == 1) {
+                if (MODE >= 1) {
                     gv[u] = *(const u16x8*)(p.g + off[u]);
-                    if (p.v) cv[u] = *(const u16x8*)(p.v + off[u]);
+                    if (MODE == 2 || p.v) cv[u] = *(const u16x8*)(p.v + off[u]);     // bwd: the carry; bwd2: the incoming v
                 }
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            float xf[8], hf[8], gf[8];
-            float ss = 0.f, uh = 0.f;
+            float xf[8], hf[8], gf[8], vf[8];
+            float ss = 0.f, uh = 0.f, uv = 0.f, vh = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 xf[e] = gg_bf2f(xv[u][e]);
                 ss += xf[e] * xf[e];
-                if (MODE == 1) {
+                if (MODE >= 1) {
                     gf[e] = gg_bf2f(gv[u][e]);
                     hf[e] = gf[e] * gam[e];
                     uh += xf[e] * hf[e];
+                }
+                if (MODE == 2) {
+                    vf[e] = gg_bf2f(cv[u][e]);
+                    uv += xf[e] * vf[e];
+                    vh += vf[e] * hf[e];
                 }
             }
             ss = gg_group_sum<LPR>(ss);
@@ -719,25 +724,37 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_rmsnorm_rows_kernel(GgRmsParams p) {
                     uh += xf[e] * hf[e];
                 }
             }
-            if (MODE == 1) uh = gg_group_sum<LPR>(uh) / n;
-            if (clamped) uh = 0.f;
-            u16x8 o0;
+            if (MODE >= 1) uh = gg_group_sum<LPR>(uh) / n;
+            if (MODE == 2) { uv = gg_group_sum<LPR>(uv) / n; vh = gg_group_sum<LPR>(vh); }
+            if (clamped) { uh = 0.f; uv = 0.f; }
+            u16x8 o0, o1;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (MODE == 0) {
                     float z = xf[e] * rn * gam[e];
                     if (ACT) z = z / (1.f + gg_expf(-z));
                     o0[e] = gg_f2bf(z);
-                } else {
+                } else if (MODE == 1) {
                     const float uu = xf[e] / n;
                     o0[e] = gg_f2bf(rn * (hf[e] - uu * uh) + gg_bf2f(cv[u][e]));
                     dgam[e] += rn * xf[e] * gf[e];          // (dead rows carry x = 0)
+                } else {
+                    const float uu = xf[e] / n;
+                    const float pv = vf[e] - uu * uv;       // (P v)_c
+                    const float ph = hf[e] - uu * uh;       // (P h)_c
+                    o1[e] = gg_f2bf(gam[e] * rn * pv);
+                    dgam[e] += gf[e] * rn * pv;
+                    const float gx = clamped ? 0.f : -(rn / n) * (uu * (vh - uv * uh) + uh * pv + uv * ph);
+                    o0[e] = gg_f2bf(gx);
                 }
             }
-            if (live[u]) *(u16x8*)(p.out0 + off[u]) = o0;
+            if (live[u]) {
+                *(u16x8*)(p.out0 + off[u]) = o0;
+                if (MODE == 2) *(u16x8*)(p.out1 + off[u]) = o1;
+            }
         }
     }
-    if (MODE == 1 && p.dgamma_part) {
+    if (MODE >= 1 && p.dgamma_part) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float v = dgam[e];

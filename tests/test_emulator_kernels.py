@@ -1295,10 +1295,17 @@ def test_rmsnorm_rows_kernel_matches_the_wave_per_row_kernel(C, silu, monkeypatc
             dx, dgam = K.rmsnorm_bwd(x, g, gamma, True, None, silu=silu)
             dxc, _ = K.rmsnorm_bwd(x, g, gamma, False, carry, silu=silu)
             res[tag] = (y, dx, dxc, dgam)
+            if not silu:          # the second-order pass (gradient penalty): v = carry as the gradient w.r.t. dx
+                gx2, gg2, dg2 = K.rmsnorm_bwd2(x, g, carry, gamma, True)
+                res[tag + '2'] = (gx2, gg2, dg2)
         for a, b in zip(res['rows'][:3], res['wave'][:3]):
             d = (a.float() - b.float()).abs()
             assert float((d > 0).float().mean()) <= 1e-3 and bool((d <= 2. ** -7 * b.float().abs() + 1e-4).all()), (C, silu, rows)
         assert rel_err(res['rows'][3], res['wave'][3]) < 1e-5
+        if not silu:
+            for a, b in zip(res['rows2'][:2], res['wave2'][:2]):
+                assert rel_err(a.float(), b.float()) < 2e-3 and float(((a.float() - b.float()).abs() > 0).float().mean()) <= 2e-2, (C, rows)
+            assert rel_err(res['rows2'][2], res['wave2'][2]) < 1e-5
         xf = x.float().requires_grad_()
         gm = gamma.clone().requires_grad_()
         n = xf.norm(dim=-1, keepdim=True).clamp(min=K.RMS_EPS)
