@@ -1111,7 +1111,13 @@ extern "C" int gg_resample_nhwc_bf16(const void* in, void* out, int32_t n, int32
     long long total = (long long)n * oh * ow * ((c + 7) / 8);
     const dim3 grid(gg_grid_for(total));
     hipStream_t s = (hipStream_t)stream;
-    if ((c % 8) == 0 && ty == tx && (ty == 1 || ty == 2 || ty == 3 || ty == 6)) {
+    const char* blk_env = getenv("GG_RESAMPLE_2X2");
+    if ((c % 8) == 0 && ty == tx && (ty == 2 || ty == 3) && oh >= ih && ow >= iw && !(oh & 1) && !(ow & 1) && (!blk_env || atoi(blk_env))) {
+        // up-sampling / same-size filters: 2 x 2 output pixels per thread from one shared window
+        const dim3 grid4(gg_grid_for(total / 4));
+        if (ty == 2) GG_LAUNCH((gg_resample_taps2x2_kernel<2, 2>), grid4, dim3(256), s, p);
+        else GG_LAUNCH((gg_resample_taps2x2_kernel<3, 3>), grid4, dim3(256), s, p);
+    } else if ((c % 8) == 0 && ty == tx && (ty == 1 || ty == 2 || ty == 3 || ty == 6)) {
         if (ty == 1) GG_LAUNCH((gg_resample_taps_kernel<1, 1>), grid, dim3(256), s, p);
         else if (ty == 2) GG_LAUNCH((gg_resample_taps_kernel<2, 2>), grid, dim3(256), s, p);
         else if (ty == 3) GG_LAUNCH((gg_resample_taps_kernel<3, 3>), grid, dim3(256), s, p);

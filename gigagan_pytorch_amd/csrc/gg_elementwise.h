@@ -118,6 +118,104 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_resample_taps_kernel(GgResampleParams p)
     }
 }
 
+// Up-sampling / same-size filters (neighbouring outputs start their windows 0 or 1 input pixels apart): a thread produces a 2 x 2 block of
+// output pixels from ONE (TY + 1) x (TX + 1) window - 16 loads for four outputs at 3 x 3 taps where the kernel above issues 36. That kernel
+// is bound by the vector-memory pipe, not by HBM (ten 16-byte operations per 16 bytes stored: 1.4-2.1 TB/s of in + out on the generator's
+// feature up-sampling, tests/gpu_bw_census.py). A block whose windows are further apart (never with the trainer's tables) falls back to
+// direct loads, so the kernel is correct for any table.
+template <int TY, int TX>
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_resample_taps2x2_kernel(GgResampleParams p) {
+    const int cg = p.C / 8;
+    const int BH = p.OH / 2, BW = p.OW / 2;
+    const long long total = (long long)p.n * BH * BW * cg;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int g = (int)(idx % cg);
+        const long long blk = idx / cg;
+        const int bx = (int)(blk % BW);
+        const long long t = blk / BW;
+        const int by = (int)(t % BH);
+        const int img = (int)(t / BH);
+        const int oy0 = 2 * by, ox0 = 2 * bx;
+        const int ya = p.iy0[oy0], xa = p.ix0[ox0];
+        const int dy = p.iy0[oy0 + 1] - ya, dx = p.ix0[ox0 + 1] - xa;
+        const bf16_t* base = p.in + (long long)img * p.IH * p.IW * p.C + g * 8;
+        float acc[2][2][8];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[j][i][e] = 0.f;
+        if (dy < 0 || dy > 1 || dx < 0 || dx > 1) {          // windows too far apart for one shared window: four direct evaluations
+            for (int j = 0; j < 2; ++j)
+                for (int i = 0; i < 2; ++i) {
+                    const int y0 = p.iy0[oy0 + j], x0 = p.ix0[ox0 + i];
+                    for (int a = 0; a < TY; ++a) {
+                        const int iy = y0 + a;
+                        if (iy < 0 || iy >= p.IH) continue;
+                        for (int b = 0; b < TX; ++b) {
+                            const int ix = x0 + b;
+                            if (ix < 0 || ix >= p.IW) continue;
+                            const float w = p.wy[(oy0 + j) * TY + a] * p.wx[(ox0 + i) * TX + b];
+                            const u16x8 v = *(const u16x8*)(base + ((long long)iy * p.IW + ix) * p.C);
+                            for (int e = 0; e < 8; ++e) acc[j][i][e] += w * gg_bf2f(v[e]);
+                        }
+                    }
+                }
+        } else {
+            float wyj[2][TY + 1], wxj[2][TX + 1];
+            int cy[TY + 1], cx[TX + 1];
+#pragma unroll
+            for (int r = 0; r <= TY; ++r) {
+                const int iy = ya + r;
+                const bool in = iy >= 0 && iy < p.IH;
+                cy[r] = iy < 0 ? 0 : (iy >= p.IH ? p.IH - 1 : iy);
+                wyj[0][r] = (in && r < TY) ? p.wy[oy0 * TY + r] : 0.f;
+                const int r1 = r - dy;
+                wyj[1][r] = (in && r1 >= 0 && r1 < TY) ? p.wy[(oy0 + 1) * TY + r1] : 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c <= TX; ++c) {
+                const int ix = xa + c;
+                const bool in = ix >= 0 && ix < p.IW;
+                cx[c] = ix < 0 ? 0 : (ix >= p.IW ? p.IW - 1 : ix);
+                wxj[0][c] = (in && c < TX) ? p.wx[ox0 * TX + c] : 0.f;
+                const int c1 = c - dx;
+                wxj[1][c] = (in && c1 >= 0 && c1 < TX) ? p.wx[(ox0 + 1) * TX + c1] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r <= TY; ++r) {
+                u16x8 v[TX + 1];
+#pragma unroll
+                for (int c = 0; c <= TX; ++c) v[c] = *(const u16x8*)(base + ((long long)cy[r] * p.IW + cx[c]) * p.C);
+#pragma unroll
+                for (int c = 0; c <= TX; ++c) {
+                    float f[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = gg_bf2f(v[c][e]);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const float w = wyj[j][r] * wxj[i][c];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc[j][i][e] += w * f[e];
+                        }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                u16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = gg_f2bf(acc[j][i][e]);
+                *(u16x8*)(p.out + (((long long)img * p.OH + oy0 + j) * p.OW + ox0 + i) * p.C + g * 8) = o;
+            }
+    }
+}
+
 // ---- fused multi-tensor AdamW -------------------------------------------------------------------------
 // One launch updates a whole model (reference: torch.optim.AdamW built by optimizer.py:10-34, stepped at
 // gp.py:2477 / :2596). Parameters, gradients and both moments live in flat fp32 buffers; every parameter

@@ -156,6 +156,45 @@ def test_resample_matches_reference_semantics():
     assert rel_err(ops.HipOps().resize_nearest(x, 16), F.interpolate(bf(x).float(), (16, 16))) == 0.
 
 
+@pytest.mark.parametrize('kind', ['upblur', 'blur', 'bilinear_up', 'bilinear_down', 'upblur_T', 'custom_far'])
+def test_resample_two_by_two_blocks_match_the_dense_operator(kind, monkeypatch):
+    """gg_resample_taps2x2_kernel (a 2 x 2 block of output pixels per thread from one shared window; taken for 2 / 3-tap up-sampling and
+    same-size filters with C % 8 == 0 and even output extents) and the per-pixel kernels (GG_RESAMPLE_2X2=0) against the dense separable
+    operator out = My x Mx^T, incl. non-square maps, a table whose neighbouring windows are further apart than one pixel (the kernel's
+    per-block fallback) and operators the blocked kernel does not take (down-sampling, 6-tap adjoints)."""
+    torch.manual_seed(0)
+    H, W, C, n = 6, 10, 16, 2
+    if kind == 'upblur':
+        spec = K.ResampleSpec.upsample_blur(H, W)
+    elif kind == 'blur':
+        spec = K.ResampleSpec.blur(H, W)
+    elif kind == 'bilinear_up':
+        spec = K.ResampleSpec.bilinear(H, W, 2 * H, 2 * W)
+    elif kind == 'bilinear_down':
+        spec = K.ResampleSpec.bilinear(H, W, H // 2, W // 2)
+    elif kind == 'upblur_T':
+        spec = K.ResampleSpec.upsample_blur(H // 2, W // 2).transposed()
+    else:       # 3-tap rows whose windows jump by two input pixels between neighbouring outputs, on a map that does not shrink
+        my = torch.zeros(H, H); mx = torch.zeros(W, W)
+        for o in range(H):
+            for a in range(3):
+                my[o, (2 * o) % (H - 2) + a] = 0.2 + 0.1 * a
+        for o in range(W):
+            for a in range(3):
+                mx[o, (3 * o) % (W - 2) + a] = 0.3 - 0.05 * a
+        spec = K.ResampleSpec(my, mx, ('custom_far', H, W))
+        assert spec.ty == 3 and spec.tx == 3
+    x = bf(torch.randn(n, spec.ih, spec.iw, C))
+    want = torch.einsum('oh,nhwc->nowc', spec.my.float(), x.float())
+    want = torch.einsum('pw,nowc->nopc', spec.mx.float(), want)
+    outs = {}
+    for env in ('1', '0'):
+        monkeypatch.setenv('GG_RESAMPLE_2X2', env)
+        outs[env] = K.resample_nhwc(x, spec)
+        assert rel_err(outs[env].float(), want) < 4e-3, (kind, env)
+    assert rel_err(outs['1'].float(), outs['0'].float()) < 3e-3
+
+
 def test_fused_adamw_and_ema_match_torch():
     from gigagan_pytorch_amd.optimizer import FlatAdamW
     torch.manual_seed(0)
