@@ -184,6 +184,7 @@ GG_DEVICE float gg_expf(float x) { return __expf(x); }
 GG_DEVICE float gg_exp2f(float x) { return __builtin_amdgcn_exp2f(x); }     // bare v_exp_f32 (no range fix-ups: x <= 128 here)
 GG_DEVICE bool gg_wave_any(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0; }    // wave-uniform result
 GG_DEVICE float gg_rsqrtf(float x) { return rsqrtf(x); }
+GG_DEVICE float gg_rcpf(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32 (1 ulp): `1.f / x` compiles to a ~10-instruction IEEE division
 
 #endif  // GG_HOST_EMULATION
 

@@ -115,3 +115,4 @@ static inline bool gg_wave_any(bool pred) {     // wave collective: every fiber 
     return f > 0.f;
 }
 static inline float gg_rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float gg_rcpf(float x) { return 1.0f / x; }

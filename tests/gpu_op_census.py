@@ -21,6 +21,7 @@ B = 32 if workload == 'uncond' else 16
 gan = bench.build_gan(256, dev, use_hip_graphs=False, workload=workload)
 it = iter(bench.SyntheticTextImages(B, 256, dev)) if workload == 'text' else cycle(SyntheticImages(B, 256, device=dev))
 gp = 'gp' in sys.argv[1:]
+STRIDES = 'strides' in sys.argv[1:]
 for _ in range(2):
     gan.train_discriminator_step(dl_iter=it, apply_gradient_penalty=False)
     gan.train_generator_step(batch_size=B, dl_iter=it)
@@ -47,6 +48,8 @@ class M(TorchDispatchMode):
                 loc += ' @' + nd.name()
             dt = str(ts[0].dtype).replace('torch.', '') if ts else ''
             shp = tuple(ts[0].shape) if (ts and nbytes > (32 << 20)) else ()
+            if STRIDES and nbytes > (16 << 20) and ('add' in name or 'copy' in name or 'clone' in name or 'contiguous' in name):
+                shp = (tuple(ts[0].shape), tuple(tuple(t.stride()) for t in ts[:2]), tuple(o.stride() for o in outs[:1]))
             key = (name.replace('aten.', ''), loc, dt, shp)
             cnt[key] += 1
             byt[key] += nbytes
