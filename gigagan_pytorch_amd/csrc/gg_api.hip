@@ -1184,6 +1184,30 @@ extern "C" int gg_colsum_finish(const float* part, float* dst, int32_t P, int32_
     return gg_check_launch();
 }
 
+extern "C" int gg_reduce_multi(const gg_reduce_item* items, int32_t n, void* stream) {
+    if (!items || n <= 0) return gg_fail(-1, "gg_reduce_multi: no items");
+    for (int base = 0; base < n; base += GG_FM_MAX) {
+        GgReduceBatch b;
+        memset(&b, 0, sizeof(b));
+        b.n = n - base < GG_FM_MAX ? n - base : GG_FM_MAX;
+        long long wgs = 0;
+        for (int i = 0; i < b.n; ++i) {
+            const gg_reduce_item& it = items[base + i];
+            if (!it.src || it.n <= 0 || it.nsplit < 2) return gg_fail(-2, "gg_reduce_multi: item %d: need a slice stack of >= 2 slices", base + i);
+            if (((uintptr_t)it.src) & 3) return gg_fail(-3, "gg_reduce_multi: item %d: unaligned", base + i);
+            b.item[i].src = it.src; b.item[i].n = it.n; b.item[i].nsplit = it.nsplit;
+            b.first_wg[i] = (int)wgs;
+            wgs += (it.n + 63) / 64;
+            if (wgs > 0x7fffffffll) return gg_fail(-2, "gg_reduce_multi: too many outputs in one batch");
+        }
+        b.first_wg[b.n] = (int)wgs;
+        GG_LAUNCH(gg_reduce_multi_kernel, dim3((unsigned)wgs), dim3(256), (hipStream_t)stream, b);
+        int rc = gg_check_launch();
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 extern "C" int gg_finish_multi(const gg_finish_item* items, int32_t n, void* stream) {
     if (n < 0 || (n > 0 && !items)) return gg_fail(-1, "gg_finish_multi: bad arguments");
     for (int i0 = 0; i0 < n; i0 += GG_FM_MAX) {

@@ -345,3 +345,53 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_finish_multi_kernel(GgFinishBatch b) {
         gg_colsum_finish_body(it.src, it.dst, it.O, it.I, it.T, it.alpha, *(float (*)[4][64])&tile[0][0], local % gx, local / gx, it.C8);
     }
 }
+
+// ---- many split-K slice reductions in ONE launch ----------------------------------------------------------------------------------------
+// Weight gradients split over more than 16 k-slices (thin layers: a few thousand outputs, 32..512 slices) ended in one
+// gg_splitk_reduce launch each (~70 per step) before their finish was queued. The slice stacks are kept instead (kernels.FinishQueue) and
+// a flush first folds all of them here - slice 0 += slices 1.. in place, fixed order: a workgroup per 64 consecutive outputs (256-byte rows
+// of the stack), its four wavefronts interleaved over the slices and combined through LDS, as in gg_splitk_reduce_kernel - then runs the
+// finishes on slice 0.
+struct GgReduceItem {
+    float* src;              // (nsplit, n) fp32 slice stack; the sum is left in slice 0
+    long long n;             // elements per slice
+    int nsplit;
+    int reserved;
+};
+struct GgReduceBatch {
+    GgReduceItem item[GG_FM_MAX];
+    int first_wg[GG_FM_MAX + 1];
+    int n;
+};
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_reduce_multi_kernel(GgReduceBatch b) {
+    GG_SHARED float part[3][64];
+    const int wg = blockIdx.x;
+    int lo = 0, hi = b.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (b.first_wg[mid] <= wg) lo = mid;
+        else hi = mid - 1;
+    }
+    const GgReduceItem& it = b.item[lo];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long idx = (long long)(wg - b.first_wg[lo]) * 64 + lane;
+    const bool valid = idx < it.n;
+    float s = 0.f;
+    if (valid) {
+        const float* src = it.src + idx;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int ks = wave;
+        for (; ks + 12 < it.nsplit; ks += 16) {
+            s0 += src[(long long)ks * it.n];
+            s1 += src[(long long)(ks + 4) * it.n];
+            s2 += src[(long long)(ks + 8) * it.n];
+            s3 += src[(long long)(ks + 12) * it.n];
+        }
+        for (; ks < it.nsplit; ks += 4) s0 += src[(long long)ks * it.n];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    if (wave) part[wave - 1][lane] = s;
+    gg_sync();
+    if (wave == 0 && valid) it.src[idx] = s + part[0][lane] + part[1][lane] + part[2][lane];
+}
+

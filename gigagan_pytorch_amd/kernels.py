@@ -272,8 +272,8 @@ def conv2d_wgrad_nhwc(x: torch.Tensor, dy: torch.Tensor, *, ksize: int, stride: 
                       cv: int | None = None, in_scale=None, force_splitk=0, force_tile=0, keep_slices=False):
     """Weight gradient of conv2d_nhwc: returns fp32 (ksize*ksize*CV, Cout) = sum over output pixels of
     gather(x)[pixel][(tap, cv)] * dy[pixel][co]. `keep_slices`: returns (tensor, nsplit) instead - when the launch is split over
-    2..FOLD_MAX_SLICES k-slices, the tensor is the slice stack (nsplit, ksize*ksize*CV, Cout) and NO reduction was launched (the
-    caller's finish pass sums them: FinishQueue.add_wgrad(nsplit=)); otherwise the reduced result and 1."""
+    k-slices, the tensor is the slice stack (nsplit, ksize*ksize*CV, Cout) and NO reduction was launched (the caller's finish pass
+    sums them: FinishQueue.add_wgrad(nsplit=)); otherwise the result and 1."""
     L = _C.lib()
     L.require(x, dy, in_scale)
     assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and x.is_contiguous() and dy.is_contiguous()
@@ -301,7 +301,7 @@ def conv2d_wgrad_nhwc(x: torch.Tensor, dy: torch.Tensor, *, ksize: int, stride: 
         tile, sk = C.c_int32(0), C.c_int32(0)
         d.C_out = ptr(x)            # (a placeholder that passes validation: the planner does not look at it)
         L.check(L.lib.gg_gemm_plan(C.byref(d), C.byref(tile), C.byref(sk)), 'gg_gemm_plan')
-        if 1 < sk.value <= FOLD_MAX_SLICES:
+        if sk.value > 1:       # (more than FOLD_MAX_SLICES slices: the queue folds the stack with its batched reduce before the finish)
             nsplit, d.keep_partials = sk.value, 1
     out = torch.empty((1, 1) if nsplit > 1 else (ksize * ksize * cv, cout), dtype=torch.float32, device=x.device)
     d.C_out = ptr(out)
@@ -584,6 +584,10 @@ def hinge(x: torch.Tensor, nb: int, split: int, mode: int, gscale: torch.Tensor 
     return out
 
 
+class ReduceItem(C.Structure):       # mirrors gg_reduce_item (include/gigagan_amd.h)
+    _fields_ = [('src', C.c_void_p), ('n', C.c_int64), ('nsplit', C.c_int32), ('reserved', C.c_int32)]
+
+
 class FinishItem(C.Structure):       # mirrors gg_finish_item (include/gigagan_amd.h)
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('kind', C.c_int32), ('O', C.c_int32), ('I', C.c_int32), ('T', C.c_int32),
                 ('C8', C.c_int32), ('O8', C.c_int32), ('accumulate', C.c_int32), ('alpha', C.c_float), ('nsplit', C.c_int32),
@@ -598,7 +602,7 @@ class FinishQueue:
     LIMIT = 40                      # GG_FM_MAX: one launch per flush
 
     def __init__(self):
-        self.items, self.keep, self.notify, self.dsts = [], [], [], set()
+        self.items, self.keep, self.notify, self.dsts, self.reduces = [], [], [], set(), []
 
     def _add(self, it, dst, keep, notify):
         if dst.data_ptr() in self.dsts:
@@ -619,6 +623,9 @@ class FinishQueue:
         C8 = rows // T
         assert g.dtype == torch.float32 and g.is_contiguous() and rows == T * C8 and (g.dim() == 2 if nsplit == 1 else g.shape[0] == nsplit)
         assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == O * I * T
+        if nsplit > FOLD_MAX_SLICES:      # a deep stack: folded into its slice 0 by the flush's batched reduce, the finish reads that
+            self.reduces.append(ReduceItem(ptr(g), g[0].numel(), nsplit, 0))
+            nsplit = 1
         self._add(FinishItem(ptr(g), ptr(out), 0, O, I, T, C8, g.shape[-1], 1, float(alpha), nsplit, 0), out, (g, out), notify)
 
     def add_colsum(self, part: torch.Tensor, n: int, alpha: float, out: torch.Tensor, notify=None):
@@ -637,18 +644,23 @@ class FinishQueue:
         self._add(FinishItem(ptr(src), ptr(out), 2, src.numel(), 0, 0, 0, 0, 1, float(alpha), 1, 0), out, (src, out), notify)
 
     def clear(self):
-        self.items, self.keep, self.notify, self.dsts = [], [], [], set()
+        self.items, self.keep, self.notify, self.dsts, self.reduces = [], [], [], set(), []
 
     def flush(self):
         if not self.items:
             return
         L = _C.lib()
-        arr = (FinishItem * len(self.items))(*self.items)
         like = self.keep[0][0]
-        rc = L.lib.gg_finish_multi(C.cast(arr, C.c_void_p), len(self.items), L.stream(like))
+        rc = 0
+        if self.reduces:
+            red = (ReduceItem * len(self.reduces))(*self.reduces)
+            rc = L.lib.gg_reduce_multi(C.cast(red, C.c_void_p), len(self.reduces), L.stream(like))
+        arr = (FinishItem * len(self.items))(*self.items)
+        rc2 = L.lib.gg_finish_multi(C.cast(arr, C.c_void_p), len(self.items), L.stream(like)) if rc == 0 else 0
         notify = self.notify
-        self.items, self.keep, self.notify, self.dsts = [], [], [], set()
-        L.check(rc, 'gg_finish_multi')
+        self.items, self.keep, self.notify, self.dsts, self.reduces = [], [], [], set(), []
+        L.check(rc, 'gg_reduce_multi')
+        L.check(rc2, 'gg_finish_multi')
         for fn in notify:
             fn()
 

@@ -209,6 +209,17 @@ typedef struct gg_finish_item {
 } gg_finish_item;
 int gg_finish_multi(const gg_finish_item* items, int32_t n, void* stream);
 
+/* Many split-K slice stacks folded by ONE launch: for each item, slice 0 += slices 1 .. nsplit-1 in place (fixed order). What a flush of
+ * the host's finish queue runs first for weight gradients that were split over more than 16 k-slices (one gg_gemm_bf16 split-K reduce
+ * launch each before: ~70 per step); their finishes then read slice 0. src: (nsplit, n) fp32. */
+typedef struct {
+    float* src;
+    int64_t n;
+    int32_t nsplit;
+    int32_t reserved;
+} gg_reduce_item;
+int gg_reduce_multi(const gg_reduce_item* items, int32_t n, void* stream);
+
 /* Row softmax over materialised attention logits (replaces sim*scale, masked_fill, softmax and the dtype casts
  * of gp.py:584-588 / :643-649 with one pass):
  *   S[r][j] = softmax_j(alpha * x[r][j] + bias[r / rows_per_batch][j]) for j < n_valid, 0 for n_valid <= j < ld.

@@ -1502,7 +1502,8 @@ def test_streaming_forward_takes_over_where_it_was_measured_faster():
 
 
 def test_queued_finishes_match_the_single_launches():
-    """kernels.FinishQueue -> gg_finish_multi: weight-gradient finishes (plain and with split-K slices summed on the way in), bias
+    """kernels.FinishQueue -> gg_reduce_multi + gg_finish_multi: weight-gradient finishes (plain, with up to 16 split-K slices summed on
+    the way in, and deep slice stacks folded by the batched reduce that a flush runs first), bias
     column sums and dense accumulations, more items than one batch carries (40), a repeated destination (flushes before it is queued
     again) - against the single-launch kernels / plain tensor algebra. Notifications run after the launch that wrote their item."""
     torch.manual_seed(0)
@@ -1510,7 +1511,7 @@ def test_queued_finishes_match_the_single_launches():
     want, dsts, fired = [], [], []
     for j in range(45):
         O, I, T = 8 * (1 + j % 5), 8 * (1 + j % 3), (9, 1, 4)[j % 3]
-        nsplit = (1, 3, 5)[j % 3]
+        nsplit = (1, 3, 5)[j % 3] if j % 7 else (17, 40, 131)[j % 3]         # (> 16 slices: folded by the flush's batched reduce first)
         g = torch.randn(nsplit, T * I, O) if nsplit > 1 else torch.randn(T * I, O)
         dst = torch.randn(O, I, T)
         ref = dst + 0.5 * K.wgrad_finish(g.sum(0) if nsplit > 1 else g, O, I, T, 1.0).view(O, I, T)
