@@ -166,15 +166,34 @@ class Generator(BaseGenerator):
                 noise = torch.randn((batch_size, self.style_network_dim), device=self.device)
             styles = self.style_network(noise, global_text_tokens)
 
-        conv_mods = self.style_to_conv_modulations(styles).split(self.style_embed_split_dims, dim=-1)
+        mods = self.style_to_conv_modulations(styles)
         batch = styles.shape[0]
         device = styles.device
+        if torch.is_grad_enabled() and mods.requires_grad and mods.is_contiguous():
+            # the differentiable pass hands every layer a dense (b, I) block (the coefficient kernels take dense rows): ONE gather into
+            # layer-major order instead of ~30 per-layer `.contiguous()` copies of column slices; its backward is one index_add
+            conv_mods = self._layer_major(mods, batch)
+        else:
+            conv_mods = mods.split(self.style_embed_split_dims, dim=-1)
         prepared = self._announce_adaptive_convs(conv_mods, batch)
         try:
             return self._synthesise(iter(conv_mods), batch, device, fine_text_tokens, text_mask, return_all_rgbs)
         finally:
             if prepared:
                 ops.impl.modconv_release()
+
+    def _layer_major(self, mods, batch):
+        dims = tuple(self.style_embed_split_dims)
+        key = (batch, mods.device)
+        cache = self.__dict__.setdefault('_layer_major_idx', {})
+        idx = cache.get(key)
+        if idx is None:
+            total = sum(dims)
+            cols = torch.arange(total).split(dims)
+            rows = torch.arange(batch)[:, None] * total
+            idx = cache[key] = torch.cat([(rows + c[None, :]).reshape(-1) for c in cols]).to(mods.device)
+        flat = mods.reshape(-1).index_select(0, idx)
+        return tuple(c.view(batch, d) for c, d in zip(flat.split([batch * d for d in dims]), dims))
 
     def _announce_adaptive_convs(self, conv_mods, batch):
         """no-grad forward on an op set that batches the style-dependent work (ops.HipOps.modconv_prepare): hand over every demodulated

@@ -371,6 +371,20 @@ class ConvFn(Function):
 
 
 _ff_plan_cache: dict = {}
+_ones_cache: dict = {}
+
+
+def _ones_col(b, device):
+    """a shared read-only (b, 1) fp32 column of ones (the kernel-selection weights of a one-kernel bank: one fill launch per call before)"""
+    key = (b, device)
+    t = _ones_cache.get(key)
+    if t is None:
+        t = torch.ones((b, 1), device=device, dtype=torch.float32)
+        if not (device.type == 'cuda' and torch.cuda.is_current_stream_capturing()):      # (a graph's private pool is not ours to keep)
+            _ones_cache[key] = t
+    return t
+
+
 _NO_MODGRAM = bool(os.environ.get('GG_NO_MODGRAM'))      # A/B switch: the adaptive conv's coefficients over (b, o, i, t) instead of through the Gram rows
 _NO_FF_FUSE = bool(os.environ.get('GG_NO_FF_FUSE'))      # A/B switch of the GELU-on-epilogue FeedForward (profiles/r04_ff_fuse_ab.log)
 
@@ -717,7 +731,13 @@ class FlashAttnFn(Function):
     def forward(ctx, q, k, v, k0, v0, heads, alpha, beta):
         """k None: the keys ARE the queries (tied projections of the L2 attention, gp.py:566-569); the backward then stores
         dq + dk in one buffer instead of handing autograd two tensors to add."""
-        k0b, v0b = k0.to(ACT_DTYPE).contiguous(), v0.to(ACT_DTYPE).contiguous()
+        if (k0.is_contiguous() and v0.is_contiguous() and k0.dtype == v0.dtype and k0.shape == v0.shape
+                and v0.data_ptr() == k0.data_ptr() + k0.numel() * k0.element_size()):
+            # the two halves of one (2, heads, 64) null_kv parameter (gp.py:541): one cast launch for both
+            kvb = torch.as_strided(k0, (2, *k0.shape), (k0.numel(), *k0.stride())).to(ACT_DTYPE)
+            k0b, v0b = kvb[0], kvb[1]
+        else:
+            k0b, v0b = k0.to(ACT_DTYPE).contiguous(), v0.to(ACT_DTYPE).contiguous()
         ctx.tied = k is None
         if k is None:
             k = q
@@ -1597,7 +1617,7 @@ class HipOps:
             if N > 1:
                 a = kernel_mod.float().softmax(dim=-1)                  # (b, N)
             else:
-                a = torch.ones((b, 1), device=x.device, dtype=torch.float32)
+                a = _ones_col(b, x.device)
             d = None
             if demod:
                 d = demod_coefficients(weights, s, a, eps)              # (b, O) fp32
