@@ -623,6 +623,25 @@ def test_modcoef_through_gram_rows_matches_the_direct_kernels(cfg):
         assert rel_err(gk, grads[2]) < 1e-4
 
 
+def test_generator_layer_major_modulations_equal_the_column_slices():
+    """Generator._layer_major (the differentiable pass: one gather hands every layer a dense (b, I) block of the style -> modulation
+    projection) against the plain `.split()` column slices: same blocks, and the same gradient back at the projection's output."""
+    from gigagan_pytorch_amd.generator import Generator
+    torch.manual_seed(0)
+    G = Generator(image_size=32, dim_capacity=8, dim_max=32, dim_latent=32, style_network=dict(dim=32, depth=2),
+                  unconditional=True, num_skip_layers_excite=2, self_attn_resolutions=())
+    dims = tuple(G.style_embed_split_dims)
+    mods = torch.randn(3, sum(dims), requires_grad=True)
+    blocks = G._layer_major(mods, 3)
+    want = mods.split(dims, dim=-1)
+    assert len(blocks) == len(want) and all(b.is_contiguous() and torch.equal(b, w) for b, w in zip(blocks, want))
+    probe = [torch.randn_like(w) for w in want]
+    ga, = torch.autograd.grad(sum((b * p).sum() for b, p in zip(blocks, probe)), mods)
+    gb, = torch.autograd.grad(sum((w * p).sum() for w, p in zip(want, probe)), mods)
+    assert torch.equal(ga, gb)
+    assert G._layer_major(mods, 3)[0].data_ptr() != blocks[0].data_ptr() and len(G._layer_major_idx) == 1      # (index table cached per batch)
+
+
 def test_many_way_splitk_reduce_and_xcd_slice_mapping():
     """split counts above 8 take the wave-per-64-outputs reduce, and few-tile split-K launches of the 4-wave kernel use
     the slice-major (XCD-aware) 1-D grid: same numbers as the unsplit launch."""
