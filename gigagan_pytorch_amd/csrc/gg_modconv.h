@@ -107,9 +107,9 @@ struct GgModMixParams {
     bf16_t* y;             // fwd out / bwd: the forward output (activation mask), optional in bwd
     const bf16_t* dy;      // bwd in   [b][P][O]
     bf16_t* dY;            // bwd out  [b][P][N*Os]
-    float* da_part;        // bwd out  [b][chunks][N]   (only when N > 1)
-    float* dd_part;        // bwd out  [b][chunks][O]   (only when d != null)
-    float* dnw_part;       // bwd out  [b][chunks][O]   (only when noise != null)
+    float* da_part;        // bwd out  [chunks][b][N]   (only when N > 1)   chunk-major: a slice stack for gg_reduce_multi
+    float* dd_part;        // bwd out  [chunks][b][O]   (only when d != null)
+    float* dnw_part;       // bwd out  [chunks][b][O]   (only when noise != null)
     int b, P, O, Os, N, chunks;
     int act;               // 0 none, 1 leaky relu
     float slope;
@@ -210,7 +210,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modmix_bwd_kernel(GgModMixParams p) {
             if (rl == 0) {
                 for (int k = 1; k < row_lanes; ++k)
                     for (int e = 0; e < 8; ++e) dd[e] += red[k * lanes_per_row + cgl][e];
-                float* dst = p.dd_part + ((long long)img * p.chunks + chunk) * p.O + cg * 8;
+                float* dst = p.dd_part + ((long long)chunk * p.b + img) * p.O + cg * 8;
                 for (int e = 0; e < 8; ++e) dst[e] = dd[e];
             }
             gg_sync();
@@ -221,7 +221,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modmix_bwd_kernel(GgModMixParams p) {
             if (rl == 0) {
                 for (int k = 1; k < row_lanes; ++k)
                     for (int e = 0; e < 8; ++e) dnw[e] += red[k * lanes_per_row + cgl][e];
-                float* dst = p.dnw_part + ((long long)img * p.chunks + chunk) * p.O + cg * 8;
+                float* dst = p.dnw_part + ((long long)chunk * p.b + img) * p.O + cg * 8;
                 for (int e = 0; e < 8; ++e) dst[e] = dnw[e];
             }
             gg_sync();
@@ -233,7 +233,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modmix_bwd_kernel(GgModMixParams p) {
         if (t < GG_MIX_MAXN) {
             float s = 0.f;
             for (int k = 0; k < 256; ++k) s += red_a[k][t];
-            if (t < p.N) p.da_part[((long long)img * p.chunks + chunk) * p.N + t] = s;
+            if (t < p.N) p.da_part[((long long)chunk * p.b + img) * p.N + t] = s;
         }
     }
 }

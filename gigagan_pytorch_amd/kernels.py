@@ -588,6 +588,18 @@ class ReduceItem(C.Structure):       # mirrors gg_reduce_item (include/gigagan_a
     _fields_ = [('src', C.c_void_p), ('n', C.c_int64), ('nsplit', C.c_int32), ('reserved', C.c_int32)]
 
 
+def reduce_multi(stacks):
+    """stacks: [(tensor, n, nsplit)]: fp32 slice stacks (nsplit, n) folded IN PLACE into their slice 0 by one gg_reduce_multi launch."""
+    if not stacks:
+        return
+    L = _C.lib()
+    L.require(*[t for t, _, _ in stacks])
+    for t, n, ns in stacks:
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n * ns and ns >= 2
+    arr = (ReduceItem * len(stacks))(*[ReduceItem(ptr(t), n, ns, 0) for t, n, ns in stacks])
+    L.check(L.lib.gg_reduce_multi(C.cast(arr, C.c_void_p), len(stacks), L.stream(stacks[0][0])), 'gg_reduce_multi')
+
+
 class FinishItem(C.Structure):       # mirrors gg_finish_item (include/gigagan_amd.h)
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('kind', C.c_int32), ('O', C.c_int32), ('I', C.c_int32), ('T', C.c_int32),
                 ('C8', C.c_int32), ('O8', C.c_int32), ('accumulate', C.c_int32), ('alpha', C.c_float), ('nsplit', C.c_int32),
@@ -866,15 +878,19 @@ def modmix_bwd(dy: torch.Tensor, y, Y: torch.Tensor, a: torch.Tensor, d, noise, 
     ch = _chunks(H * W, O)
     dev = Y.device
     dY = torch.empty_like(Y) if Os == O else torch.zeros_like(Y)
-    da = torch.empty((b, ch, N), dtype=torch.float32, device=dev) if N > 1 else None
-    dd = torch.empty((b, ch, O), dtype=torch.float32, device=dev) if d is not None else None
-    dnw = torch.empty((b, ch, O), dtype=torch.float32, device=dev) if noise is not None else None
+    da = torch.empty((ch, b, N), dtype=torch.float32, device=dev) if N > 1 else None
+    dd = torch.empty((ch, b, O), dtype=torch.float32, device=dev) if d is not None else None
+    dnw = torch.empty((ch * b, O), dtype=torch.float32, device=dev) if noise is not None else None
     rc = L.lib.gg_modmix_bwd(ptr(dy), ptr(y), ptr(Y), ptr(a), ptr(d), ptr(noise), ptr(dY), ptr(da), ptr(dd), ptr(dnw),
                              b, H * W, O, Os, N, ch, 1 if act == 'lrelu' else 0, 0.2, L.stream(Y))
     L.check(rc, 'gg_modmix_bwd')
-    fold = (lambda t: t[:, 0]) if ch == 1 else (lambda t: t.sum(1))        # (one chunk: the partials ARE the sums - no launch)
-    return (dY, None if da is None else fold(da), None if dd is None else fold(dd),
-            None if dnw is None else dnw.sum((0, 1)))
+    # the partials are chunk-major slice stacks: ONE gg_reduce_multi launch folds all of them into their first slice (three torch
+    # reductions per layer before); dnw is a stack of ch * b slices of O values
+    stacks = [(t, t[0].numel(), t.shape[0]) for t in (da, dd) if t is not None and ch > 1]
+    if dnw is not None and ch * b > 1:
+        stacks.append((dnw, O, ch * b))
+    reduce_multi(stacks)
+    return (dY, None if da is None else da[0], None if dd is None else dd[0], None if dnw is None else dnw[0])
 
 
 # --------------------------------------------------------------------------------------------------

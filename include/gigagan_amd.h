@@ -267,8 +267,8 @@ int gg_modulate_bwd(const void* g, const void* x, const float* s, void* dx, floa
 int gg_modmix_fwd(const void* Y, const float* a, const float* d, const float* noise, const float* noise_w, void* y, int32_t b,
                   int32_t P, int32_t O, int32_t Os, int32_t N, int32_t act, float slope, void* stream);
 /* gradient of gg_modmix_fwd: dz = dy * act'(y); dY[b][p][n*Os + o] = a[b,n] * d[b,o] * dz; partial sums
- * da_part[b][chunk][n] = sum dz * d * Y_n, dd_part[b][chunk][o] = sum_p dz * sum_n a_n Y_n (iff d), dnw_part[b][chunk][o] =
- * sum_p dz * noise (iff noise). */
+ * da_part[chunk][b][n] = sum dz * d * Y_n, dd_part[chunk][b][o] = sum_p dz * sum_n a_n Y_n (iff d), dnw_part[chunk][b][o] =
+ * sum_p dz * noise (iff noise): chunk-major, i.e. slice stacks that gg_reduce_multi folds in one launch. */
 int gg_modmix_bwd(const void* dy, const void* y, const void* Y, const float* a, const float* d, const float* noise, void* dY,
                   float* da_part, float* dd_part, float* dnw_part, int32_t b, int32_t P, int32_t O, int32_t Os, int32_t N,
                   int32_t chunks, int32_t act, float slope, void* stream);

@@ -642,6 +642,43 @@ def test_generator_layer_major_modulations_equal_the_column_slices():
     assert G._layer_major(mods, 3)[0].data_ptr() != blocks[0].data_ptr() and len(G._layer_major_idx) == 1      # (index table cached per batch)
 
 
+@pytest.mark.parametrize('cfg', [(3, 40, 40, 32, 2, True, True), (2, 12, 9, 16, 1, False, True), (1, 64, 64, 64, 3, True, False)])
+def test_modmix_backward_partials_folded_by_one_launch(cfg):
+    """K.modmix_bwd (gg_modmix_bwd's chunk-major partial stacks folded by ONE gg_reduce_multi launch) against autograd of
+    y = act(d * sum_n a_n Y_n + noise_w * noise) (gp.py:344-409 in the batched form), several chunks per image included."""
+    b, H, W, O, N, demod, with_noise = cfg
+    torch.manual_seed(0)
+    Y = bf(torch.randn(b, H, W, N * O))
+    a = torch.softmax(torch.randn(b, N), -1)
+    d = torch.rand(b, O) + 0.5 if demod else None
+    noise = torch.randn(b, H * W) if with_noise else None
+    nw = torch.randn(O) * 0.3 if with_noise else None
+    dy = bf(torch.randn(b, H, W, O))
+    assert K._chunks(H * W, O) > 1 or H * W * O < 9000
+    Yr, ar = Y.float().requires_grad_(), a.clone().requires_grad_()
+    dr = d.clone().requires_grad_() if demod else None
+    nwr = nw.clone().requires_grad_() if with_noise else None
+    z = torch.einsum('bn,bhwno->bhwo', ar, Yr.view(b, H, W, N, O))
+    if demod:
+        z = z * dr[:, None, None, :]
+    if with_noise:
+        z = z + noise.view(b, H, W, 1) * nwr
+    yr = torch.nn.functional.leaky_relu(z, 0.2)
+    grads = torch.autograd.grad((yr * dy.float()).sum(), [Yr, ar] + ([dr] if demod else []) + ([nwr] if with_noise else []))
+    y = K.modmix_fwd(Y, a, d, noise, nw, O, N, 'lrelu')
+    dY, da, dd, dnw = K.modmix_bwd(dy, y, Y, a, d, noise, O, N, 'lrelu')
+    mask = (yr.detach().abs() > 1e-2).all()         # (the sign of y decides the leaky-relu branch: bf16 y and fp32 y agree away from 0)
+    assert rel_err(dY.float(), grads[0]) < 2e-2
+    if N > 1:
+        assert rel_err(da, grads[1]) < 2e-2
+    k = 2
+    if demod:
+        assert rel_err(dd, grads[k]) < 2e-2
+        k += 1
+    if with_noise:
+        assert rel_err(dnw, grads[k]) < 2e-2
+
+
 def test_many_way_splitk_reduce_and_xcd_slice_mapping():
     """split counts above 8 take the wave-per-64-outputs reduce, and few-tile split-K launches of the 4-wave kernel use
     the slice-major (XCD-aware) 1-D grid: same numbers as the unsplit launch."""
