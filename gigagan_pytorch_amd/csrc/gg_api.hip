@@ -1117,6 +1117,13 @@ extern "C" int gg_resample_nhwc_bf16(const void* in, void* out, int32_t n, int32
         const dim3 grid4(gg_grid_for(total / 4));
         if (ty == 2) GG_LAUNCH((gg_resample_taps2x2_kernel<2, 2>), grid4, dim3(256), s, p);
         else GG_LAUNCH((gg_resample_taps2x2_kernel<3, 3>), grid4, dim3(256), s, p);
+    } else if (c == 3 && ty == tx && (ty == 1 || ty == 2 || ty == 3 || ty == 6) && (!blk_env || atoi(blk_env))) {
+        // the rgb maps: a thread per output pixel, all taps loaded unconditionally
+        const dim3 grid1(gg_grid_for((long long)n * oh * ow));
+        if (ty == 1) GG_LAUNCH((gg_resample_taps_small_kernel<1, 1, 3>), grid1, dim3(256), s, p);
+        else if (ty == 2) GG_LAUNCH((gg_resample_taps_small_kernel<2, 2, 3>), grid1, dim3(256), s, p);
+        else if (ty == 3) GG_LAUNCH((gg_resample_taps_small_kernel<3, 3, 3>), grid1, dim3(256), s, p);
+        else GG_LAUNCH((gg_resample_taps_small_kernel<6, 6, 3>), grid1, dim3(256), s, p);
     } else if ((c % 8) == 0 && ty == tx && (ty == 1 || ty == 2 || ty == 3 || ty == 6)) {
         if (ty == 1) GG_LAUNCH((gg_resample_taps_kernel<1, 1>), grid, dim3(256), s, p);
         else if (ty == 2) GG_LAUNCH((gg_resample_taps_kernel<2, 2>), grid, dim3(256), s, p);

@@ -118,6 +118,53 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_resample_taps_kernel(GgResampleParams p)
     }
 }
 
+// The same for the rgb maps (C = 3: 6-byte pixels, no 16-byte vectors): one thread per output pixel, every tap loaded unconditionally from
+// clamped coordinates (three 2-byte loads) and weighted by zero outside the image - the generic kernel branches around each scalar load
+// and waits for it (29 us per 256 x 256 x 32 rgb map: 0.5 TB/s).
+template <int TY, int TX, int CC>
+GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_resample_taps_small_kernel(GgResampleParams p) {
+    const long long total = (long long)p.n * p.OH * p.OW;
+    for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (long long)gridDim.x * 256) {
+        const int ox = (int)(pix % p.OW);
+        const long long t = pix / p.OW;
+        const int oy = (int)(t % p.OH);
+        const int img = (int)(t / p.OH);
+        const int y0 = p.iy0[oy], x0 = p.ix0[ox];
+        float wxv[TX];
+        int cx[TX];
+#pragma unroll
+        for (int b = 0; b < TX; ++b) {
+            const int ix = x0 + b;
+            wxv[b] = (ix >= 0 && ix < p.IW) ? p.wx[ox * TX + b] : 0.f;
+            cx[b] = ix < 0 ? 0 : (ix >= p.IW ? p.IW - 1 : ix);
+        }
+        float acc[CC];
+#pragma unroll
+        for (int e = 0; e < CC; ++e) acc[e] = 0.f;
+        const bf16_t* base = p.in + (long long)img * p.IH * p.IW * CC;
+#pragma unroll
+        for (int a = 0; a < TY; ++a) {
+            const int iy = y0 + a;
+            const float wya = (iy >= 0 && iy < p.IH) ? p.wy[oy * TY + a] : 0.f;
+            const int cy = iy < 0 ? 0 : (iy >= p.IH ? p.IH - 1 : iy);
+            bf16_t v[TX][CC];
+#pragma unroll
+            for (int b = 0; b < TX; ++b)
+#pragma unroll
+                for (int e = 0; e < CC; ++e) v[b][e] = base[((long long)cy * p.IW + cx[b]) * CC + e];
+#pragma unroll
+            for (int b = 0; b < TX; ++b) {
+                const float w = wya * wxv[b];
+#pragma unroll
+                for (int e = 0; e < CC; ++e) acc[e] += w * gg_bf2f(v[b][e]);
+            }
+        }
+        bf16_t* dst = p.out + pix * CC;
+#pragma unroll
+        for (int e = 0; e < CC; ++e) dst[e] = gg_f2bf(acc[e]);
+    }
+}
+
 // Up-sampling / same-size filters (neighbouring outputs start their windows 0 or 1 input pixels apart): a thread produces a 2 x 2 block of
 // output pixels from ONE (TY + 1) x (TX + 1) window - 16 loads for four outputs at 3 x 3 taps where the kernel above issues 36. That kernel
 // is bound by the vector-memory pipe, not by HBM (ten 16-byte operations per 16 bytes stored: 1.4-2.1 TB/s of in + out on the generator's

@@ -184,15 +184,16 @@ def test_resample_two_by_two_blocks_match_the_dense_operator(kind, monkeypatch):
                 mx[o, (3 * o) % (W - 2) + a] = 0.3 - 0.05 * a
         spec = K.ResampleSpec(my, mx, ('custom_far', H, W))
         assert spec.ty == 3 and spec.tx == 3
-    x = bf(torch.randn(n, spec.ih, spec.iw, C))
-    want = torch.einsum('oh,nhwc->nowc', spec.my.float(), x.float())
-    want = torch.einsum('pw,nowc->nopc', spec.mx.float(), want)
-    outs = {}
-    for env in ('1', '0'):
-        monkeypatch.setenv('GG_RESAMPLE_2X2', env)
-        outs[env] = K.resample_nhwc(x, spec)
-        assert rel_err(outs[env].float(), want) < 4e-3, (kind, env)
-    assert rel_err(outs['1'].float(), outs['0'].float()) < 3e-3
+    for Cc in (C, 3):            # (3: the rgb maps take gg_resample_taps_small_kernel - every tap loaded unconditionally)
+        x = bf(torch.randn(n, spec.ih, spec.iw, Cc))
+        want = torch.einsum('oh,nhwc->nowc', spec.my.float(), x.float())
+        want = torch.einsum('pw,nowc->nopc', spec.mx.float(), want)
+        outs = {}
+        for env in ('1', '0'):
+            monkeypatch.setenv('GG_RESAMPLE_2X2', env)
+            outs[env] = K.resample_nhwc(x, spec)
+            assert rel_err(outs[env].float(), want) < 4e-3, (kind, env, Cc)
+        assert rel_err(outs['1'].float(), outs['0'].float()) < 3e-3
 
 
 def test_fused_adamw_and_ema_match_torch():
