@@ -186,20 +186,29 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modmix_bwd_kernel(GgModMixParams p) {
                 }
                 float tmix[8];
                 for (int e = 0; e < 8; ++e) tmix[e] = 0.f;
-                for (int n = 0; n < p.N; ++n) {
-                    const long long yoff = row * ((long long)p.N * p.Os) + (long long)n * p.Os + cg * 8;
-                    u16x8 v = *(const u16x8*)(p.Y + yoff);
-                    u16x8 o;
+                // all kernels' Y vectors first, the dY stores last (a store between two loads serialises them: dY may alias Y as far as
+                // the compiler knows)
+                const long long ybase = row * ((long long)p.N * p.Os) + cg * 8;
+                u16x8 yv4[GG_MIX_MAXN], o4[GG_MIX_MAXN];
+#pragma unroll
+                for (int n = 0; n < GG_MIX_MAXN; ++n) {
+                    const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                    yv4[n] = n < p.N ? *(const u16x8*)(p.Y + ybase + (long long)n * p.Os) : z;
+                }
+#pragma unroll
+                for (int n = 0; n < GG_MIX_MAXN; ++n) {
                     float dan = 0.f;
                     for (int e = 0; e < 8; ++e) {
-                        const float yv = gg_bf2f(v[e]);
+                        const float yv = gg_bf2f(yv4[n][e]);
                         tmix[e] += an[n] * yv;
                         dan += dz[e] * dv[e] * yv;
-                        o[e] = gg_f2bf(an[n] * dv[e] * dz[e]);
+                        o4[n][e] = gg_f2bf(an[n] * dv[e] * dz[e]);
                     }
                     da[n] += dan;
-                    *(u16x8*)(p.dY + yoff) = o;
                 }
+#pragma unroll
+                for (int n = 0; n < GG_MIX_MAXN; ++n)
+                    if (n < p.N) *(u16x8*)(p.dY + ybase + (long long)n * p.Os) = o4[n];
                 for (int e = 0; e < 8; ++e) dd[e] += dz[e] * tmix[e];
             }
         }

@@ -880,17 +880,15 @@ def modmix_bwd(dy: torch.Tensor, y, Y: torch.Tensor, a: torch.Tensor, d, noise, 
     dY = torch.empty_like(Y) if Os == O else torch.zeros_like(Y)
     da = torch.empty((ch, b, N), dtype=torch.float32, device=dev) if N > 1 else None
     dd = torch.empty((ch, b, O), dtype=torch.float32, device=dev) if d is not None else None
-    dnw = torch.empty((ch * b, O), dtype=torch.float32, device=dev) if noise is not None else None
+    dnw = torch.empty((ch, b, O), dtype=torch.float32, device=dev) if noise is not None else None
     rc = L.lib.gg_modmix_bwd(ptr(dy), ptr(y), ptr(Y), ptr(a), ptr(d), ptr(noise), ptr(dY), ptr(da), ptr(dd), ptr(dnw),
                              b, H * W, O, Os, N, ch, 1 if act == 'lrelu' else 0, 0.2, L.stream(Y))
     L.check(rc, 'gg_modmix_bwd')
-    # the partials are chunk-major slice stacks: ONE gg_reduce_multi launch folds all of them into their first slice (three torch
-    # reductions per layer before); dnw is a stack of ch * b slices of O values
-    stacks = [(t, t[0].numel(), t.shape[0]) for t in (da, dd) if t is not None and ch > 1]
-    if dnw is not None and ch * b > 1:
-        stacks.append((dnw, O, ch * b))
-    reduce_multi(stacks)
-    return (dY, None if da is None else da[0], None if dd is None else dd[0], None if dnw is None else dnw[0])
+    # the partials are chunk-major slice stacks: ONE gg_reduce_multi launch folds the chunks of all three into their first slices (three
+    # torch reductions per layer before); the noise weights' gradient is then summed over the images (a (b, O) table: a stack of b * ch
+    # slices of O values would give the fold one workgroup)
+    reduce_multi([(t, t[0].numel(), ch) for t in (da, dd, dnw) if t is not None and ch > 1])
+    return (dY, None if da is None else da[0], None if dd is None else dd[0], None if dnw is None else dnw[0].sum(0))
 
 
 # --------------------------------------------------------------------------------------------------
