@@ -75,14 +75,32 @@ class SyntheticTextImages:
             yield self.images, self.enc
 
 
+def cpu_reference_leg(threads, timeout_s=600.0):
+    """the UNMODIFIED reference trainer on this host's cores: `oracle/time_reference.py` in its own process with
+    the GPUs hidden, importing the reference as byte code from `oracle/_ref` (compiled by `__graft_entry__.build()` from the files
+    under /root/reference where they lie; git-ignored, it travels with the built .so files). None when oracle/_ref is absent."""
+    import subprocess
+    from oracle.build_ref import available
+    if not available() and not Path('/root/reference/gigagan_pytorch').is_dir():
+        return None
+    try:
+        out = subprocess.run([sys.executable, str(ROOT / 'oracle' / 'time_reference.py'), '--threads', str(threads)],
+                             capture_output=True, text=True, timeout=timeout_s)
+        for ln in reversed(out.stdout.strip().splitlines()):
+            if ln.startswith('{'):
+                return json.loads(ln)
+        return dict(error=(out.stderr or out.stdout)[-400:])
+    except Exception as e:      # noqa: BLE001 - a baseline leg must not take the bench line down
+        return dict(error=f'{type(e).__name__}: {e}')
+
+
 def cpu_baseline(budget_s=150.0):
     """SURVEY.md §8(d) / BASELINE.md §3 protocol on a bounded sample: config-2 dims at 256x256, fp32, batch 4, same synthetic
-    uniform images, ONE whole 4-step cycle (3 plain + 1 gradient-penalty G+D step incl. optimizer updates and EMA) through
-    `train_step` of OUR trainer on the fp32 CPU oracle (kind="port": the reference itself cannot travel to the GPU box). The
-    unmodified reference was timed by the same protocol - `GigaGAN(...)(steps=4)`, batch 4 - next to this port in the build
-    container (tests/cpu_baseline_reference.py -> profiles/r03_cpu_baseline_reference.json); `reference_equivalent` = value /
-    port_vs_reference is the reference's CPU throughput scaled to this host. Thread count: best of a 3-point sweep on one
-    discriminator forward. Falls back to plain step + gradient-penalty step (cycle mean) if the host is too slow for the budget."""
+    uniform images. kind="reference": the unmodified reference trainer itself (`GigaGAN(...)(steps=...)`: one warm-up step, then
+    one whole 4-step cycle = 3 plain + 1 gradient-penalty G+D step incl. optimizer updates and EMA) timed on THIS host by
+    `cpu_reference_leg`. Next to it, as `port`, the same cycle through `train_step` of OUR trainer on the fp32 CPU oracle (what
+    rounds 1-4 reported, scaled by a ratio measured in the build container); when oracle/_ref is absent the port is the value and
+    kind="port". Thread count: best of a 3-point sweep on one discriminator forward of the port, used for both legs."""
     from gigagan_pytorch_amd import GigaGAN, ops
     from gigagan_pytorch_amd.data import SyntheticImages
     from gigagan_pytorch_amd.gigagan import cycle
@@ -127,28 +145,22 @@ def cpu_baseline(budget_s=150.0):
             gp = time.time() - t0
             per_step = (3 * times[0] + gp) / 4
             what = f'plain step {times[0]:.1f} s + gradient-penalty step {gp:.1f} s, cycle mean (3 plain + 1 GP) / 4 (time budget)'
-    rec = dict(value=bs / per_step, unit='images/sec', cores=threads, kind='port',
-               sample=f'our trainer on the fp32 CPU oracle, config-2 dims 256x256, batch {bs}: {what}; {threads} threads = best of '
-                      f'the sweep {({k: round(v, 2) for k, v in sweep.items()})} (seconds per D forward) on a {cores}-core host')
-    # port / reference throughput ratio, measured in the build container at several thread counts (tests/cpu_baseline_reference.py:
-    # the reference cannot travel to this box): mean and spread, and which thread counts they were taken at next to the count used here
-    cals = []
-    for cal in sorted((ROOT / 'profiles').glob('r0*_cpu_baseline_reference*.json')):
-        try:
-            c = json.loads(cal.read_text())
-            cals.append((int(c['threads']), float(c['port_vs_reference']), c.get('note')))
-        except Exception:
-            pass
-    if cals:
-        ratios = [r for _, r, _ in cals]
-        mean = sum(ratios) / len(ratios)
-        rec['port_vs_reference'] = mean
-        rec['port_vs_reference_range'] = [min(ratios), max(ratios)]
-        rec['calibration_threads'] = [t for t, _, _ in cals]
-        rec['threads_here'] = threads
-        rec['reference_equivalent'] = rec['value'] / mean
-        rec['reference_equivalent_range'] = [rec['value'] / max(ratios), rec['value'] / min(ratios)]
-        rec['calibration'] = [n for _, _, n in cals]
+    del gan
+    port = dict(value=bs / per_step, unit='images/sec', cores=threads,
+                sample=f'our trainer on the fp32 CPU oracle, config-2 dims 256x256, batch {bs}: {what}')
+    sweep_note = (f'{threads} threads = best of the sweep {({k: round(v, 2) for k, v in sweep.items()})} (seconds per D forward of the '
+                  f'port) on a {cores}-core host')
+    ref = cpu_reference_leg(threads)
+    if ref is not None and 'images_per_sec' in ref:
+        return dict(value=ref['images_per_sec'], unit='images/sec', cores=threads, kind='reference',
+                    sample=(f"the unmodified reference trainer ({ref['origin']}), GigaGAN(...)(steps=...) on the CPU, fp32 (amp=False), "
+                            f"config-2 dims 256x256, batch {ref['batch']}: {ref['warmup_steps']} warm-up step ({ref['warmup_s']:.1f} s), then "
+                            f"trainer steps {ref['timed_steps'][0]}-{ref['timed_steps'][1]} = one whole 4-step cycle (3 plain + 1 gradient-"
+                            f"penalty G+D step) in {ref['timed_cycle_s']:.1f} s; {sweep_note}"),
+                    port=port, port_vs_reference=port['value'] / ref['images_per_sec'])
+    rec = dict(port, kind='port', sample=port['sample'] + '; ' + sweep_note)
+    if ref is not None:
+        rec['reference_leg_error'] = ref.get('error')
     return rec
 
 
@@ -255,6 +267,53 @@ def modconv_forward_roofline(gan, batch, dev):
                      'eager calls')
 
 
+# ---- the multi-rank half of the contract, as functions a world-2 gloo test can drive (tests/test_distributed_cpu.py) ------------
+def max_over_ranks(dt: float, world: int, dev) -> float:
+    """the step time that counts is the slowest rank's: MAX-reduce over the default process group (RCCL on GPUs, gloo in the dry run)."""
+    if world <= 1:
+        return dt
+    import torch.distributed as dist
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_per_rank(mine: dict, world: int):
+    """every rank's own record (step time on its clock, exposed communication time) on every rank; None on one rank."""
+    if world <= 1:
+        return None
+    import torch.distributed as dist
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, mine)
+    return per_rank
+
+
+# (the toy dims of tests/helpers.py TINY_G / TINY_D: the 2-rank gloo trainer test runs the same model)
+DRY_G = dict(dim_capacity=8, dim_max=32, dim_latent=32, style_network=dict(dim=32, depth=2), num_skip_layers_excite=1,
+             self_attn_resolutions=(8,), self_attn_heads=2, self_attn_dim_head=16)
+DRY_D = dict(dim_capacity=8, dim_max=32, num_skip_layers_excite=1, attn_resolutions=(8,), attn_heads=2, attn_dim_head=16,
+             multiscale_input_resolutions=(8,))
+
+
+def dry_run_setup(world):
+    """--dry-run-cpu: bind the C ABI built for the host-side kernel emulator (test infrastructure) and, with GG_BENCH_FAKE_NATIVE=1,
+    install the gloo-backed double of the RCCL communicator (tests/test_distributed_cpu.py::GlooBackedNativeComm) so that the
+    `gg_comm/rccl` branches of this file (comm_world, exposed-communication timing, shutdown) execute at world size > 1."""
+    from gigagan_pytorch_amd import _C, distributed as gdist
+    _C.bind(ROOT / 'tests' / 'emu' / 'libgigagan_amd_emu.so')
+    if world > 1 and os.environ.get('GG_BENCH_FAKE_NATIVE'):
+        sys.path.insert(0, str(ROOT / 'tests'))
+        from test_distributed_cpu import GlooBackedNativeComm
+        gdist._native = GlooBackedNativeComm(world)
+
+
+def dry_run_register(gan):
+    from gigagan_pytorch_amd import distributed as gdist
+    comm = gdist.native_comm()
+    if comm is not None and hasattr(comm, 'buffers'):
+        comm.buffers += [gan.D_opt.flat_g, gan.G_opt.flat_g]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -274,6 +333,10 @@ def main():
     ap.add_argument('--loader-workers', type=int, default=2, help='--data loader: DataLoader worker processes (collation off the main thread)')
     ap.add_argument('--no-restore', action='store_true',
                     help='let the trajectory run on (it diverges on synthetic uniform images, here as in the reference)')
+    ap.add_argument('--dry-run-cpu', action='store_true',
+                    help='(tests/test_distributed_cpu.py) run THIS file\'s multi-rank control flow - rank bring-up, barriers, the MAX-'
+                         'reduce of the step time, per-rank gather, exposed-communication timing, the one JSON line from rank 0 - on '
+                         'CPU ranks over gloo with a toy model on the host-side kernel emulator; the line it prints is not a measurement')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -294,18 +357,32 @@ def main():
     from gigagan_pytorch_amd.gigagan import cycle
     import torch.distributed as dist
 
-    rank, local, world = gdist.init_from_env('cuda')
-    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    dry = args.dry_run_cpu
+    rank, local, world = gdist.init_from_env('cpu' if dry else 'cuda')
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE is {world}: launch one rank per GPU (or let bench.py do it)'
-    assert torch.cuda.device_count() > local, f'rank {rank}: no GPU {local} on this node ({torch.cuda.device_count()} visible)'
-    dev = torch.device('cuda', local)
-    torch.cuda.set_device(dev)
+    if dry:
+        dev = torch.device('cpu')
+        dry_run_setup(world)
+    else:
+        assert torch.cuda.is_available(), 'bench.py needs a GPU'
+        assert torch.cuda.device_count() > local, f'rank {rank}: no GPU {local} on this node ({torch.cuda.device_count()} visible)'
+        dev = torch.device('cuda', local)
+        torch.cuda.set_device(dev)
+
+    def sync():
+        if dev.type == 'cuda':
+            torch.cuda.synchronize()
 
     if args.batch is None:
-        args.batch = 32 if args.workload == 'uncond' else 16
+        args.batch = (2 if dry else 32) if args.workload == 'uncond' else 16
     steps = (args.steps + 3) // 4 * 4
     warmup = args.warmup
-    gan = build_gan(args.image_size, dev, use_hip_graphs=False if args.no_graphs else None, workload=args.workload)
+    if dry:
+        args.image_size = 16
+        gan = build_gan(16, dev, g_over=DRY_G, d_over=DRY_D, use_hip_graphs=False)
+        dry_run_register(gan)
+    else:
+        gan = build_gan(args.image_size, dev, use_hip_graphs=False if args.no_graphs else None, workload=args.workload)
     torch.manual_seed(1 + rank)          # identical initial weights (seed 0 in build_gan), per-rank latent / noise streams
     if args.workload == 'text':
         it = iter(SyntheticTextImages(args.batch, args.image_size, dev, seed=rank))
@@ -326,7 +403,7 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     # The trajectory diverges within ~10 steps on synthetic uniform "images" (the reference does too: G loss 59k at step 3,
     # SURVEY.md §7.3; at config 2 the step-1 gradient penalty alone is 4.4e4, tests/golden/c2_step1.pt) and then runs on
@@ -361,15 +438,12 @@ def main():
     barrier()
     t0 = time.perf_counter()
     d_losses, g_losses = run_steps(steps)
-    torch.cuda.synchronize()
+    sync()
     dt_local = time.perf_counter() - t0         # this rank's own clock, before the closing barrier
     barrier()
     dt = time.perf_counter() - t0
     mine = dict(rank=rank, ms_per_step=dt_local / steps * 1e3, exposed_comm_ms_per_step=None)
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt, world, dev)
     if time_comm_here:
         comm.timing = False
         mine.update(exposed_comm_ms_per_step=sum(a.elapsed_time(b) for a, b in comm.exposed_ms) / steps,
@@ -388,7 +462,7 @@ def main():
         # one extra GP cycle, executed eagerly on EVERY rank (the steps contain the gradient all-reduce, so all ranks
         # must take part); rank 0 brackets each contraction launch with HIP events on the launch stream
         graphs_were_on, gan.use_hip_graphs = gan.use_hip_graphs, False   # HIP events cannot be recorded inside a replay
-        if rank == 0:
+        if rank == 0 and not dry:
             K.profiler = K.GemmProfiler()
         time_comm_cycle = comm is not None and world > 1 and mine['exposed_comm_ms_per_step'] is None
         if time_comm_cycle:
@@ -396,11 +470,11 @@ def main():
         run_steps(4)
         if time_comm_cycle:
             comm.timing = False
-            torch.cuda.synchronize()
+            sync()
             mine.update(exposed_comm_ms_per_step=sum(a.elapsed_time(b) for a, b in comm.exposed_ms) / 4,
                         exposed_comm_measured='eager 4-step cycle after the timed region (the timed steps are hipGraph replays)')
         agg = shapes = None
-        if rank == 0:
+        if rank == 0 and K.profiler is not None:
             agg = K.profiler.summary()
             shapes = K.profiler.shape_summary()
             K.profiler = None
@@ -445,13 +519,10 @@ def main():
         except Exception as e:    # noqa: BLE001 - a secondary measurement must not take the bench line down
             roofline['modconv_forward'] = dict(error=f'{type(e).__name__}: {e}')
 
-    per_rank = None
-    if world > 1:
-        per_rank = [None] * world
-        dist.all_gather_object(per_rank, mine)
+    per_rank = gather_per_rank(mine, world)
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'uncond':
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'uncond' and not dry:
         cpu = cpu_baseline()
 
     if rank == 0:
@@ -464,13 +535,18 @@ def main():
                      f'Text-conditional GigaGAN image_size={args.image_size} dim_max=512, TextEncoder dim 64 depth 4 on '
                      'pre-computed (77, 512) token encodings, cross attention, matching-aware loss (no CLIP contrastive loss)'),
         }[args.workload]
+        if dry:
+            metric = 'DRY RUN of bench.py\'s control flow on CPU ranks (gloo, toy model, kernel emulator): not a measurement'
         line = dict(
             metric=metric, value=value, unit='images/sec', n_gpus=world,
             steps=steps, warmup=warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling='weak',
             vs_baseline=None, dtype='bf16',
             data='synthetic' if args.data == 'resident' else 'synthetic (fp32 host batches: DataLoader + pinned prefetch to the device)',
             config=dict(workload=f'{what} bf16 bs={args.batch}/GPU, GP every 4th step', global_batch=args.batch * world,
-                        parallelism=f'dp{world}', hip_graphs=bool(gan._graphable(1)), graph_memset_nodes_repaired=sum(gan._graph_memsets.values()), comm=gdist.comm_backend(),
+                        parallelism=f'dp{world}',
+                        scaling_curve=('this line is one point; no 1 -> N curve of this code has been measured by its builder (1-GPU '
+                                       'boxes only): efficiency is for the driver to compute from its own per-N runs'),
+                        hip_graphs=bool(gan._graphable(1)), graph_memset_nodes_repaired=sum(gan._graph_memsets.values()), comm=gdist.comm_backend(),
                         comm_world=(comm.world if comm is not None else (world if world > 1 else 0)),
                         comm_overlap=('in-backward slices: D %d, G %d' % (gan.D_red.n, gan.G_red.n)
                                       if (gan.D_red is not None and gan.overlap_grad_reduce) else 'none')),

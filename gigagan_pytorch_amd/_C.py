@@ -82,7 +82,7 @@ class Library:
         L.gg_gemm_plan.argtypes = [C.POINTER(GemmDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         self._declare_elementwise()
         self.is_emulator = bool(L.gg_is_emulator())
-        if L.gg_version() != 9:
+        if L.gg_version() != 10:
             raise RuntimeError(f'gigagan_pytorch_amd: ABI version mismatch in {path}')
         L.gg_gemm_plan_table.restype = C.c_int
         L.gg_gemm_plan_table.argtypes = [C.POINTER(PlanEntry), C.c_int32]
@@ -102,6 +102,10 @@ class Library:
                 setattr(arr[i], f, int(e[f]))
         self.check(self.lib.gg_gemm_plan_table(arr, len(entries)), 'gg_gemm_plan_table')
         self.plan_entries = len(entries)
+        import sys
+        ops = sys.modules.get(__package__ + '.ops')
+        if ops is not None:        # planner answers cached on the Python side belong to the previous table
+            ops._ff_plan_cache.clear()
 
     # filled in by _elementwise_signatures (kept separate so the table reads like the header)
     def _declare_elementwise(self):

@@ -16,6 +16,7 @@
 #include "gg_dconv.h"
 #include "gg_modcoef.h"
 #include "gg_modfwd.h"
+#include "gg_aconv.h"
 #include "gg_comm.h"
 #include "../../include/gigagan_amd.h"
 
@@ -1476,6 +1477,114 @@ extern "C" int gg_modulate_bank_fwd(const void* x, const float* s, const float* 
     memset(&p, 0, sizeof(p));
     p.x = (const bf16_t*)x; p.s = s; p.a = a; p.out = (bf16_t*)out; p.b = b; p.P = P; p.C = Cout; p.Cin = Cin; p.chunks = 1;
     GG_LAUNCH(gg_modulate_kernel, dim3(gg_grid_for((long long)b * P * (Cout / 8))), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+// ---- adaptive convolution on a shared, fragment-ordered bank (gg_aconv.h) --------------------------------------------------------
+struct GgAconvPlan { int tm, nwn, nwk, lds, grid, mt; };
+
+static int gg_log2i(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
+
+// tile shape (TM x 32 pixels, NWN x 32 output channels, NWK K-slices): modelled time = rounds of 256 resident workgroups x
+// max(matrix pipe, L2 -> register weight stream at ~45 B/clk/CU) + a fixed prologue; forced values (probes) override the choice
+static int gg_aconv_plan_of(const gg_aconv_desc* d, GgAconvPlan* out) {
+    if (!d) return gg_fail(-1, "gg_aconv: null descriptor");
+    if (!d->x || !d->wf || !d->y || !d->s) return gg_fail(-1, "gg_aconv: null operand pointer");
+    if (d->b <= 0 || d->H <= 0 || d->W <= 0 || !gg_pow2(d->H) || !gg_pow2(d->W) || d->H != d->W || d->W < 4 || d->W > 64)
+        return gg_fail(-2, "gg_aconv: square power-of-two images of 4..64 pixels a side (got %d x %d)", d->H, d->W);
+    if (d->C < 16 || d->C > 512 || !gg_pow2(d->C) || d->O < 32 || (d->O & 31))
+        return gg_fail(-2, "gg_aconv: C a power of two in 16..512, O %% 32 == 0 (C=%d O=%d)", d->C, d->O);
+    if (d->NB < 1 || d->NB > 2) return gg_fail(-2, "gg_aconv: banks of 1 or 2 kernels (got %d)", d->NB);
+    if (d->NB > 1 && !d->a) return gg_fail(-2, "gg_aconv: a bank of %d kernels needs their weights a[b][N]", d->NB);
+    if ((d->noise != nullptr) != (d->noise_w != nullptr)) return gg_fail(-2, "gg_aconv: noise and noise_w go together");
+    if (d->act < 0 || d->act > 1) return gg_fail(-2, "gg_aconv: activation 0 (none) or 1 (leaky relu)");
+    const int HW = d->H * d->W, KS = 9 * (d->C / 16);
+    const long long M = (long long)d->b * HW;
+    double best = 1e30;
+    GgAconvPlan bp = {0, 0, 0, 0, 0, 0};
+    for (int tm : {4, 2, 1}) {
+        if (d->force_tm && tm != d->force_tm) continue;
+        const int bmt = 32 * tm;
+        int ti = 1, rt = d->H;
+        if (HW >= bmt) { if (bmt % d->W) continue; rt = bmt / d->W; }
+        else { if (bmt % HW) continue; ti = bmt / HW; }
+        if (ti > 2 || ti * (rt + 2) * (d->W + 2) >= 900) continue;      // (the kernel keeps two images' scales; 16.16 slot reciprocals)
+        const long long halo = (long long)ti * (rt + 2) * (d->W + 2) * (d->C * 2 + 16);
+        const int mt = (int)((M + bmt - 1) / bmt);
+        for (int nwn : {4, 2, 1}) {
+            if (d->force_nwn && nwn != d->force_nwn) continue;
+            if (d->O % (32 * nwn)) continue;
+            const int nwk = 8 / nwn;
+            if (d->NB * tm * 16 > 128) continue;                       // accumulator registers of a wavefront
+            const long long red = (long long)(nwk - 1) * nwn * tm * 4096;
+            const long long lds = halo > red ? halo : red;
+            if (lds > 152 * 1024) continue;
+            const long long grid = (long long)mt * (d->O / (32 * nwn));
+            if (grid > 0x7fffffff) continue;
+            const double mfma = 2.0 * d->NB * tm * ((KS + nwk - 1) / nwk) * 32.0;      // cycles: two wavefronts per SIMD
+            const double l2 = (double)nwn * d->NB * KS * 1024.0 / 45.0;
+            const double t = (double)((grid + 255) / 256) * ((mfma > l2 ? mfma : l2) + 3000.0 + (double)halo / 64.0);
+            if (t < best) { best = t; bp.tm = tm; bp.nwn = nwn; bp.nwk = nwk; bp.lds = (int)((lds + 1023) & ~1023ll); bp.grid = (int)grid; bp.mt = mt; }
+        }
+    }
+    if (!bp.tm) return gg_fail(-3, "gg_aconv: no tile shape fits %dx%d images with C=%d O=%d (forced TM %d NWN %d)", d->H, d->W, d->C, d->O,
+                               d->force_tm, d->force_nwn);
+    if (out) *out = bp;
+    return 0;
+}
+
+extern "C" int gg_aconv_plan(const gg_aconv_desc* d, int32_t* tm, int32_t* nwn, int32_t* nwk, int32_t* lds_bytes, int32_t* grid) {
+    GgAconvPlan pl;
+    int rc = gg_aconv_plan_of(d, &pl);
+    if (rc) return rc;
+    if (tm) *tm = pl.tm;
+    if (nwn) *nwn = pl.nwn;
+    if (nwk) *nwk = pl.nwk;
+    if (lds_bytes) *lds_bytes = pl.lds;
+    if (grid) *grid = pl.grid;
+    return 0;
+}
+
+extern "C" int gg_aconv_fwd(const gg_aconv_desc* d, void* stream) {
+    GgAconvPlan pl;
+    int rc = gg_aconv_plan_of(d, &pl);
+    if (rc) return rc;
+    GgAconvParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)d->x; p.wf = (const bf16_t*)d->wf; p.y = (bf16_t*)d->y;
+    p.s = d->s; p.xs = d->xs; p.a = d->a; p.d = d->d; p.noise = d->noise; p.noise_w = d->noise_w;
+    p.b = d->b; p.H = d->H; p.W = d->W; p.C = d->C; p.O = d->O;
+    p.w_shift = gg_log2i(d->W); p.hw_shift = gg_log2i(d->H * d->W); p.c8_shift = gg_log2i(d->C / 8);
+    p.act = d->act; p.slope = d->slope; p.mt = pl.mt;
+    {
+        const int bmt = 32 * pl.tm, hw = d->H * d->W;
+        const int rt = hw >= bmt ? bmt / d->W : d->H;
+        p.inv_spi = 65536 / ((rt + 2) * (d->W + 2)) + 1;
+        p.inv_hwp = 65536 / (d->W + 2) + 1;
+    }
+    p.x_bytes = (long long)d->b * d->H * d->W * d->C * 2;
+    p.wf_bytes = (long long)d->O * d->NB * 9 * d->C * 2;
+    if (p.x_bytes >= (1ll << 32) || p.wf_bytes >= (1ll << 32)) return gg_fail(-4, "gg_aconv: operands beyond 4 GiB");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)pl.grid), block(64 * pl.nwn * pl.nwk);
+#define GG_AC(NB_, TM_, NWN_, NWK_) GG_LAUNCH_DYN((gg_aconv_kernel<NB_, TM_, NWN_, NWK_>), grid, block, pl.lds, s, p)
+#define GG_AC_NB(NB_)                                                               \
+    do {                                                                            \
+        if (pl.tm == 1 && pl.nwn == 1) GG_AC(NB_, 1, 1, 8);                         \
+        else if (pl.tm == 1 && pl.nwn == 2) GG_AC(NB_, 1, 2, 4);                    \
+        else if (pl.tm == 1 && pl.nwn == 4) GG_AC(NB_, 1, 4, 2);                    \
+        else if (pl.tm == 2 && pl.nwn == 1) GG_AC(NB_, 2, 1, 8);                    \
+        else if (pl.tm == 2 && pl.nwn == 2) GG_AC(NB_, 2, 2, 4);                    \
+        else if (pl.tm == 2 && pl.nwn == 4) GG_AC(NB_, 2, 4, 2);                    \
+        else if (pl.tm == 4 && pl.nwn == 1) GG_AC(NB_, 4, 1, 8);                    \
+        else if (pl.tm == 4 && pl.nwn == 2) GG_AC(NB_, 4, 2, 4);                    \
+        else if (pl.tm == 4 && pl.nwn == 4) GG_AC(NB_, 4, 4, 2);                    \
+        else return gg_fail(-3, "gg_aconv: no instantiation for TM %d NWN %d", pl.tm, pl.nwn);   \
+    } while (0)
+    if (d->NB == 1) GG_AC_NB(1);
+    else GG_AC_NB(2);
+#undef GG_AC_NB
+#undef GG_AC
     return gg_check_launch();
 }
 

@@ -24,6 +24,18 @@
 #define GG_LAUNCH_BOUNDS2(n, waves_per_simd) __launch_bounds__(n, waves_per_simd)   // caps the register allocation for that occupancy
 #define GG_LAUNCH(kernel, grid, block, stream, ...) \
     hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
+// kernels whose LDS need depends on the launch geometry (gg_aconv.h): one `extern __shared__` array, sized at launch. More than 64 KB
+// of it must be allowed per kernel once (hipFuncAttributeMaxDynamicSharedMemorySize: a host-side attribute, no stream work)
+#define GG_DYN_SHARED(name) extern __shared__ __attribute__((aligned(1024))) char name[]
+#define GG_LAUNCH_DYN(kernel, grid, block, lds_bytes, stream, ...)                                                      \
+    do {                                                                                                                \
+        static bool gg_lds_allowed_ = false;                                                                            \
+        if (!gg_lds_allowed_) {                                                                                         \
+            (void)hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+            gg_lds_allowed_ = true;                                                                                     \
+        }                                                                                                               \
+        hipLaunchKernelGGL(kernel, grid, block, (size_t)(lds_bytes), stream, __VA_ARGS__);                              \
+    } while (0)
 
 typedef unsigned short bf16_t;
 typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;

@@ -8,6 +8,10 @@
 //                      pairs n <= m (c = 1 on the diagonal, 2 off it): the Gram rows from which the adaptive convolution's
 //                      demodulation d[b,o] = rsqrt(sum_i s_i^2 a^T G[o][i] a) is formed (gp.py:390-400) - they only change when the
 //                      optimizer steps, so they are refreshed here instead of in every forward (gg_modfwd.h reads them)
+//      kind 3 ('frag'): src is kernel n of a bank (N, O, I, T) with O % 32 == 0, I % 16 == 0; dst is the whole bank in MFMA-FRAGMENT
+//                      order [O/32][N][T][I/16][lane 64][8]: lane l of block (o >> 5, n, t, i >> 4) holds output channel (o & 31) =
+//                      l & 31, input channels 16 (i >> 4) + 8 (l >> 5) + 0..7 - the A operand of one v_mfma_f32_32x32x16_bf16 as ONE
+//                      coalesced 1 KB load (gg_aconv.h streams the bank straight into registers). dst_row = N, dst_tap = n.
 //    channel counts zero-padded to multiples of 8. It replaces the per-weight permute / flip / pad / cast chain the
 //    reference gets from cuDNN's internal filter transforms (gp.py:402-409, :1608-1621 F.conv2d call sites) - ~1200
 //    tiny launches per step - by a table walk. The table and its header live in device memory, so a captured hipGraph
@@ -24,7 +28,8 @@ struct GgPackEntry {
     bf16_t* dst;            // kind 0: (O8, T, I8) ; kind 1: (I8, T, O8)
     long long first_item;   // prefix sum of work items over the table
     int O, I, T, O8, I8, kind;
-    int dst_row, dst_tap;   // kind 0: element pitch of a dst row / of a tap within it (0 = dense: T * I8, I8); kind 2: dst_row = N
+    int dst_row, dst_tap;   // kind 0: element pitch of a dst row / of a tap within it (0 = dense: T * I8, I8); kind 2: dst_row = N;
+                            // kind 3: dst_row = N (kernels in the bank), dst_tap = n (which of them src is)
 };
 
 // Work items (one workgroup each; `first_item` is their prefix sum, computed by the host with the same formulas):
@@ -115,7 +120,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_pack_weights_kernel(const GgPackEntry* t
             }
             continue;
         }
-        if (e.kind == 0) {
+        if (e.kind == 0 || e.kind == 3) {
             const int chunks = (e.I8 + 255) >> 8;
             const int o = (int)(local / chunks), i0 = (int)(local % chunks) * 256;
             const int nI8 = e.I8 - i0 < 256 ? e.I8 - i0 : 256;
@@ -139,6 +144,17 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_pack_weights_kernel(const GgPackEntry* t
             }
             gg_sync();
             const int cpr = nI8 >> 3;
+            if (e.kind == 3) {      // fragment order: the 8-channel vector g = (i0 >> 3) + j of (o, t) is lane (o & 31) + 32 (g & 1) of block g >> 1
+                const int NBk = e.dst_row, nb = e.dst_tap, CB = e.I8 >> 4;
+                for (int c = tid; c < T * cpr; c += 256) {
+                    const int t = c / cpr, j = c - t * cpr;
+                    const int g = (i0 >> 3) + j;
+                    const long long blk = (((long long)(o >> 5) * NBk + nb) * T + t) * CB + (g >> 1);
+                    *(u16x8*)(e.dst + blk * 512 + ((o & 31) + 32 * (g & 1)) * 8) = *(const u16x8*)&lds[t * GG_PK_P0 + 8 * j];
+                }
+                gg_sync();
+                continue;
+            }
             bf16_t* d = e.dst + (long long)o * drow + i0;
             for (int c = tid; c < T * cpr; c += 256) {
                 const int t = c / cpr, j = c - t * cpr;

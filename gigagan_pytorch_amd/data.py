@@ -99,23 +99,71 @@ class SyntheticImages:
 
 
 def shard_dataloader(dl, rank: int, world: int, seed: int = 0):
-    """what `accelerator.prepare(dl)` does for the reference (gp.py:2150-2159): every rank iterates a disjoint shard. A torch
-    DataLoader over a map-style dataset is rebuilt around a DistributedSampler (same batch size / workers / collate); anything
-    else (an iterable of ready batches) is returned unchanged - the caller owns the sharding then."""
-    if world <= 1 or not isinstance(dl, DataLoader) or not hasattr(dl.dataset, '__len__') or dl.batch_size is None:
+    """what `accelerator.prepare(dl)` does for the reference (gp.py:2150-2161): every rank iterates a disjoint shard.
+    * a torch DataLoader with a stock sampler over a map-style dataset is rebuilt around a DistributedSampler (same batch size /
+      workers / collate), re-seeded every epoch;
+    * a DataLoader that carries a custom sampler or batch_sampler keeps ITS sampling scheme: the batch stream it defines is dealt
+      out round-robin, rank r taking batches r, r + world, ... (accelerate's BatchSamplerShard with even_batches: an incomplete last
+      round is completed from the start of the epoch). The scheme must produce the same stream on every rank (seed its generator
+      identically), which is what accelerate requires as well;
+    * a DataLoader without automatic batching (`batch_size=None`, no batch_sampler: the dataset yields ready batches) is sharded the
+      same way over its sampler's indices;
+    * anything that is not a torch DataLoader over a sized dataset (an iterable of ready batches, an IterableDataset) cannot be
+      re-dealt from here: under data parallelism the caller must hand over a per-rank stream and say so (`dl.is_rank_sharded =
+      True`), otherwise this raises instead of silently training every rank on identical data."""
+    if world <= 1:
         return dl
+    if not isinstance(dl, DataLoader) or not hasattr(dl.dataset, '__len__') or isinstance(dl.dataset, torch.utils.data.IterableDataset):
+        if getattr(dl, 'is_rank_sharded', False) or isinstance(dl, (SyntheticImages, EpochShardedLoader)):
+            return dl
+        raise ValueError('shard_dataloader: under data parallelism (world size %d) a loader that is not a torch DataLoader over a '
+                         'sized map-style dataset cannot be sharded here - every rank would train on identical batches. Build a '
+                         'per-rank stream and set `dl.is_rank_sharded = True` on it.' % world)
     from torch.utils.data.distributed import DistributedSampler
+    common = dict(num_workers=dl.num_workers, collate_fn=dl.collate_fn, pin_memory=dl.pin_memory,
+                  persistent_workers=getattr(dl, 'persistent_workers', False) and dl.num_workers > 0)
     stock = (torch.utils.data.SequentialSampler, torch.utils.data.RandomSampler)
-    if not isinstance(dl.sampler, stock):
-        raise ValueError('shard_dataloader: the loader carries a custom sampler / batch_sampler; shard it yourself (e.g. a '
-                         'DistributedSampler over your sampling scheme) and pass the per-rank loader - it would be silently '
-                         'replaced otherwise')
+    if dl.batch_sampler is None:            # automatic batching off: the sampler's indices ARE the batches
+        return DataLoader(dl.dataset, batch_size=None, sampler=RoundRobinShard(dl.sampler, rank, world), **common)
+    stock_batches = type(dl.batch_sampler) is torch.utils.data.BatchSampler and dl.batch_size is not None
+    if not (stock_batches and isinstance(dl.sampler, stock)):
+        sharded = DataLoader(dl.dataset, batch_sampler=RoundRobinShard(dl.batch_sampler, rank, world), **common)
+        sharded.is_rank_sharded = True
+        return sharded
     shuffle = not isinstance(dl.sampler, torch.utils.data.SequentialSampler)
     sampler = DistributedSampler(dl.dataset, num_replicas=world, rank=rank, shuffle=shuffle, seed=seed, drop_last=True)
-    inner = DataLoader(dl.dataset, batch_size=dl.batch_size, sampler=sampler, num_workers=dl.num_workers,
-                       collate_fn=dl.collate_fn, pin_memory=dl.pin_memory, drop_last=True,
-                       persistent_workers=getattr(dl, 'persistent_workers', False) and dl.num_workers > 0)
+    inner = DataLoader(dl.dataset, batch_size=dl.batch_size, sampler=sampler, drop_last=True, **common)
     return EpochShardedLoader(inner, sampler)
+
+
+class RoundRobinShard(torch.utils.data.Sampler):
+    """rank r's share of the stream another sampler / batch sampler defines: items r, r + world, r + 2 world, ... (what
+    accelerate's BatchSamplerShard does with `even_batches=True`, which the reference relies on through `accelerator.prepare`,
+    gp.py:2161): every rank yields the same number of items per epoch; an incomplete last round is filled from the epoch's first
+    items. The wrapped sampler is iterated in full on every rank, so it must be deterministic across ranks."""
+
+    def __init__(self, inner, rank: int, world: int):
+        assert 0 <= rank < world
+        self.inner, self.rank, self.world = inner, rank, world
+
+    def __iter__(self):
+        head, group = [], []
+        for item in self.inner:
+            if len(head) < self.world:
+                head.append(item)
+            group.append(item)
+            if len(group) == self.world:
+                yield group[self.rank]
+                group = []
+        if group:
+            i = 0
+            while len(group) < self.world:
+                group.append(head[i % len(head)])
+                i += 1
+            yield group[self.rank]
+
+    def __len__(self):
+        return (len(self.inner) + self.world - 1) // self.world
 
 
 class EpochShardedLoader:

@@ -184,6 +184,9 @@ def drop_captured_graphs():
         if g:
             n += len(g)
             g.clear()
+        m = getattr(o, '_graph_memsets', None)
+        if m:
+            m.clear()
     return n
 
 

@@ -217,7 +217,8 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, *, ksize: int, stride: int = 1
     (n, C) - 16x16 images, two banks (gg_lrconv MIX)."""
     L = _C.lib()
     L.require(x, w, in_scale, bias, out_scale, noise, noise_w, residual, bank_mix)
-    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_contiguous() and w.is_contiguous()
+    # (weight rows may carry a pitch larger than their length: `ldb` = w.stride(-2), a multiple of 8 elements)
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_contiguous() and w.stride(-1) == 1 and w.stride(-2) % 8 == 0
     n, H, Wd, Cc = x.shape
     cv = cv or Cc
     pad = ksize // 2 if pad is None else pad
@@ -575,9 +576,22 @@ def hinge(x: torch.Tensor, nb: int, split: int, mode: int, gscale: torch.Tensor 
         out = dx = torch.empty_like(x)
     scratch = None
     if gscale is None:
-        scratch = _hinge_scratch.get(x.device)
-        if scratch is None:         # ticket + 64 partials; the kernel leaves the ticket at zero (launches on one stream are ordered)
-            scratch = _hinge_scratch[x.device] = torch.zeros(65, dtype=torch.float32, device=x.device)
+        # ticket + 64 partials. Launches that are ordered among themselves share one scratch (each leaves the ticket at zero): one per
+        # (device, stream) for eager launches, one per device for everything captured into hipGraphs (replays are issued on one stream;
+        # it is allocated by the first EAGER call - the warm-up run in front of a capture - so that it does not live in a graph's
+        # private pool). A capture that was never warmed up zeroes a scratch of its own inside the graph.
+        capturing = x.is_cuda and torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            key = (x.device, L.stream(x))
+            scratch = _hinge_scratch.get(key)
+            if scratch is None:
+                scratch = _hinge_scratch[key] = torch.zeros(65, dtype=torch.float32, device=x.device)
+            if x.is_cuda and (x.device, 'capture') not in _hinge_scratch:
+                _hinge_scratch[(x.device, 'capture')] = torch.zeros(65, dtype=torch.float32, device=x.device)
+        else:
+            scratch = _hinge_scratch.get((x.device, 'capture'))
+            if scratch is None:
+                scratch = torch.zeros(65, dtype=torch.float32, device=x.device)
     rc = L.lib.gg_hinge(ptr(x), ptr(dx), ptr(gscale), ptr(out) if gscale is None else None, ptr(scratch), x.numel(), inner, nb, split,
                         mode, int(x.dtype == torch.float32), L.stream(x))
     L.check(rc, 'gg_hinge')
@@ -838,6 +852,66 @@ def sconv(x: torch.Tensor, wmix: torch.Tensor, O: int, noise=None, noise_w=None,
                             1 if act == 'lrelu' else 0, float(slope), L.stream(x))
     L.check(rc, 'gg_sconv_fwd')
     return y
+
+
+class AconvDesc(C.Structure):        # mirrors gg_aconv_desc (include/gigagan_amd.h)
+    _fields_ = ([(f, C.c_void_p) for f in ('x', 'wf', 'y', 's', 'xs', 'a', 'd', 'noise', 'noise_w')] +
+                [(f, C.c_int32) for f in ('b', 'H', 'W', 'C', 'O', 'NB', 'act')] + [('slope', C.c_float)] +
+                [(f, C.c_int32) for f in ('force_tm', 'force_nwn', 'reserved0', 'reserved1')])
+
+
+def _aconv_desc(b, H, W, Cc, O, NB, force_tm=0, force_nwn=0):
+    d = AconvDesc()
+    d.b, d.H, d.W, d.C, d.O, d.NB = b, H, W, Cc, O, NB
+    d.force_tm, d.force_nwn = force_tm, force_nwn
+    return d
+
+
+def aconv_plan(b: int, H: int, W: int, Cc: int, O: int, NB: int, force_tm: int = 0, force_nwn: int = 0):
+    """(TM, NWN, NWK, LDS bytes, workgroups) gg_aconv_fwd would take for this layer, or None when the layer cannot run on it."""
+    L = _C.lib()
+    d = _aconv_desc(b, H, W, Cc, O, NB, force_tm, force_nwn)
+    d.x = d.wf = d.y = d.s = d.a = 16          # (placeholders that pass the null checks: the planner does not touch them)
+    vals = [C.c_int32(0) for _ in range(5)]
+    if L.lib.gg_aconv_plan(C.byref(d), *[C.byref(v) for v in vals]) != 0:
+        return None
+    return tuple(v.value for v in vals)
+
+
+def aconv(x: torch.Tensor, wf: torch.Tensor, s: torch.Tensor, a, d, O: int, noise=None, noise_w=None, act=None, slope: float = 0.2,
+          xs=None, force_tm: int = 0, force_nwn: int = 0) -> torch.Tensor:
+    """gg_aconv_fwd: the no-grad adaptive 3x3 convolution on a shared bank in fragment order (PackTable.register_frag /
+    frag_pack): x (b, H, W, C) bf16, wf (O/32, NB, 9, C/16, 64, 8) bf16, s (b, C), a (b, NB) | None, d (b, O) | None, xs (b, C) | None,
+    noise (b*H*W,) with noise_w (O,) fp32 -> (b, H, W, O) bf16."""
+    L = _C.lib()
+    L.require(x, wf, s, a, d, noise, noise_w, xs)
+    b, H, W, Cc = x.shape
+    NB = wf.shape[1]
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and wf.dtype == torch.bfloat16 and wf.is_contiguous()
+    assert tuple(wf.shape) == (O // 32, NB, 9, Cc // 16, 64, 8), (tuple(wf.shape), O, Cc)
+    for t, shp in ((s, (b, Cc)), (xs, (b, Cc)), (a, (b, NB)), (d, (b, O))):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == shp), (None if t is None else t.shape, shp)
+    if noise is not None:
+        assert noise.dtype == torch.float32 and noise.is_contiguous() and noise.numel() == b * H * W
+        assert noise_w is not None and noise_w.dtype == torch.float32 and noise_w.is_contiguous() and noise_w.numel() == O
+    y = torch.empty((b, H, W, O), dtype=torch.bfloat16, device=x.device)
+    dsc = _aconv_desc(b, H, W, Cc, O, NB, force_tm, force_nwn)
+    dsc.x, dsc.wf, dsc.y, dsc.s, dsc.xs, dsc.a, dsc.d = ptr(x), ptr(wf), ptr(y), ptr(s), ptr(xs), ptr(a), ptr(d)
+    dsc.noise, dsc.noise_w = ptr(noise), ptr(noise_w) if noise is not None else None
+    dsc.act, dsc.slope = (1 if act == 'lrelu' else 0), float(slope)
+    L.check(L.lib.gg_aconv_fwd(C.byref(dsc), L.stream(x)), 'gg_aconv_fwd')
+    return y
+
+
+def frag_pack(w: torch.Tensor) -> torch.Tensor:
+    """(N, O, I, 3, 3) fp32 bank -> the bf16 MFMA-fragment order gg_aconv_fwd reads, (O/32, N, 9, I/16, 64, 8): lane l of a block holds
+    output channel l & 31, input channels 16 cb + 8 (l >> 5) + 0..7. Tensor algebra (tests, parameters outside a pack table); the
+    trainer's banks are kept in this order by gg_pack_weights (PackTable.register_frag)."""
+    N, O, I, kh, kw = w.shape
+    assert O % 32 == 0 and I % 16 == 0
+    t = w.detach().reshape(N, O // 32, 32, I // 16, 2, 8, kh * kw)             # n, ot, ol, cb, half, e, t
+    t = t.permute(1, 0, 6, 3, 4, 2, 5)                                          # ot, n, t, cb, half, ol, e
+    return t.reshape(O // 32, N, kh * kw, I // 16, 64, 8).to(torch.bfloat16).contiguous()
 
 
 def modulate_bwd(g: torch.Tensor, x: torch.Tensor, s: torch.Tensor):
@@ -1253,6 +1327,23 @@ class PackTable:
         dst = torch.zeros((o8, T * N * i8), dtype=torch.bfloat16, device=self.device)
         for n in range(N):
             self.register(src[n], O, I, T, 'fwd', into=(dst, n * i8, T * N * i8, N * i8))
+        return dst
+
+    def register_frag(self, src: torch.Tensor, N: int, O: int, I: int, T: int) -> torch.Tensor:
+        """src: fp32 contiguous (N, O, I, T) kernel bank -> persistent bf16 (O/32, N, T, I/16, 64, 8): the bank in MFMA-fragment order
+        (gg_aconv_fwd's weight stream), one table entry (kind 3) per kernel."""
+        assert src.dtype == torch.float32 and src.is_contiguous() and src.numel() == N * O * I * T and O % 32 == 0 and I % 16 == 0 and T <= 16
+        dst = torch.zeros((O // 32, N, T, I // 16, 64, 8), dtype=torch.bfloat16, device=self.device)
+        for n in range(N):
+            assert self.n < self.capacity, 'PackTable capacity exceeded'
+            e = PackEntry(src[n].data_ptr(), dst.data_ptr(), self.items, O, I, T, O, I, 3, N, n)
+            words = torch.frombuffer(bytearray(bytes(e)), dtype=torch.int64)
+            w = words.numel()
+            self.table[self.n * w:(self.n + 1) * w].copy_(words)
+            self.n += 1
+            self.items += O * ((I + 255) // 256)
+            self.header.copy_(torch.tensor([self.n, self.items], dtype=torch.int64))
+        self.keep.append((src, dst))
         return dst
 
     def register_gram(self, src: torch.Tensor, N: int, O: int, I: int, T: int) -> torch.Tensor:

@@ -141,11 +141,11 @@ def _table_pack(w, kind: str):
         if w.device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
             return None                     # table appends are host->device copies: not while a graph is being captured
         shp = tuple(w.shape)
-        if kind in ('modk', 'gram'):        # (N, O, I, k, k) bank -> [co][tap][n][ci] (fused no-grad adaptive conv) / its Gram rows
-            src = w.detach()
+        if kind in ('modk', 'gram', 'frag'):        # (N, O, I, k, k) bank -> [co][tap][n][ci] (fused no-grad adaptive conv) / its Gram rows /
+            src = w.detach()                         # its MFMA-fragment order (gg_aconv)
             if len(shp) != 5 or not src.is_contiguous():
                 return None
-            reg = tab.register_bank if kind == 'modk' else tab.register_gram
+            reg = {'modk': tab.register_bank, 'gram': tab.register_gram, 'frag': tab.register_frag}[kind]
             dst = reg(src, shp[0], shp[1], shp[2], shp[3] * shp[4])
             if slot is None:
                 slot = w.__dict__.setdefault('_gg_tpacks', {})
@@ -245,14 +245,16 @@ def _geom_k(geom):
     return geom[0]
 
 
-# With `grad_sink` on (the trainer's .backward() calls), a conv's weight gradient is accumulated by the finish kernel
+# Inside `with ops.sinking():` (the trainer's .backward() calls), a conv's weight gradient is accumulated by the finish kernel
 # straight into the parameter's fp32 .grad (the flat gradient buffer) and autograd is handed None: no separate
-# transpose / scale / AccumulateGrad passes. Only when no graph of the backward is being recorded.
-grad_sink = False
+# transpose / scale / AccumulateGrad passes. Only when no graph of the backward is being recorded. The finishes are QUEUED and run
+# when the context exits, so the flag is private to that context: setting a module attribute by hand (the pre-round-4 pattern) would
+# sink gradients into a queue nobody flushes.
+_grad_sink = False
 
 
 def _grad_sink_of(w):
-    if not grad_sink or _DEBUG_NO_SINK or torch.is_grad_enabled() or not isinstance(w, torch.nn.Parameter):
+    if not _grad_sink or _DEBUG_NO_SINK or torch.is_grad_enabled() or not isinstance(w, torch.nn.Parameter):
         return None
     g = w.grad
     if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != w.shape:
@@ -265,13 +267,13 @@ def sinking(on: bool = True):
     """`with ops.sinking(): loss.backward()` - the trainer's backward passes: weight / bias gradients go straight into the flat
     gradient buffer (`grad_sink`), their finish passes are queued and the queue is flushed when the pass is over (dropped if it
     raised)."""
-    global grad_sink
-    prev, grad_sink = grad_sink, bool(on)
+    global _grad_sink
+    prev, _grad_sink = _grad_sink, bool(on)
     try:
         yield
         K.finish_queue.flush()
     finally:
-        grad_sink = prev
+        _grad_sink = prev
         K.finish_queue.clear()
 
 
@@ -732,7 +734,8 @@ class FlashAttnFn(Function):
         """k None: the keys ARE the queries (tied projections of the L2 attention, gp.py:566-569); the backward then stores
         dq + dk in one buffer instead of handing autograd two tensors to add."""
         if (k0.is_contiguous() and v0.is_contiguous() and k0.dtype == v0.dtype and k0.shape == v0.shape
-                and v0.data_ptr() == k0.data_ptr() + k0.numel() * k0.element_size()):
+                and v0.data_ptr() == k0.data_ptr() + k0.numel() * k0.element_size()
+                and k0.untyped_storage().data_ptr() == v0.untyped_storage().data_ptr()):
             # the two halves of one (2, heads, 64) null_kv parameter (gp.py:541): one cast launch for both
             kvb = torch.as_strided(k0, (2, *k0.shape), (k0.numel(), *k0.stride())).to(ACT_DTYPE)
             k0b, v0b = kvb[0], kvb[1]
@@ -1337,16 +1340,19 @@ class HipOps:
         # both GELU-carrying launches (the up-projection, and the down-projection's data gradient: hid -> dim channels back to hid)
         # must land on the 8-wave tiles' staged epilogue, unsplit: ask the planner with the launches' own descriptors
         staged = lambda plan: 4 <= plan[0] <= 6 and plan[1] == 1
-        key = (tuple(nh.shape), hid)
+        with_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (n, w_in, b_in, w_out, b_out, residual))
+        # (the cached answer belongs to one plan table: kernels.Library.load_plan_table clears this cache)
+        key = (tuple(nh.shape), hid, nh.device, nh.dtype, with_grad)
         ok = _ff_plan_cache.get(key)
         if ok is None:
-            up = K.conv2d_nhwc(nh, packed_weight(w_in, 'fwd'), ksize=1, bias=bi, plan_only=True)
-            hid_like = nh.new_empty(nh.shape[:3] + (dim,))
-            down = K.conv2d_nhwc(hid_like, packed_weight(w_out, 'bwd'), ksize=1, plan_only=True)
-            ok = _ff_plan_cache[key] = staged(up) and staged(down)
+            ok = staged(K.conv2d_nhwc(nh, packed_weight(w_in, 'fwd'), ksize=1, bias=bi, plan_only=True))
+            if ok and with_grad:        # the data gradient of the down-projection only exists in a differentiated call
+                hid_like = nh.new_empty(nh.shape[:3] + (dim,))
+                ok = staged(K.conv2d_nhwc(hid_like, packed_weight(w_out, 'bwd'), ksize=1, plan_only=True))
+            _ff_plan_cache[key] = ok
         if not ok:
             return None
-        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (n, w_in, b_in, w_out, b_out, residual)):
+        if with_grad:
             return nchw(FFTailFn.apply(nh, w_in, bi, w_out, bo, res))
         hgelu = K.conv2d_nhwc(nh, packed_weight(w_in, 'fwd'), ksize=1, bias=bi, act='gelu')      # no-grad: GELU in the epilogue, one output
         return nchw(K.conv2d_nhwc(hgelu, packed_weight(w_out, 'fwd'), ksize=1, bias=bo, residual=res))
@@ -1467,6 +1473,8 @@ class HipOps:
         """which no-grad formulation a demodulated 3x3 adaptive conv runs in (see modconv2d)."""
         if I in (16, 32, 64) and O <= 32 and W % 32 == 0 and b * H * W >= 32768:
             return 'sconv'
+        if _ACONV and _aconv_ok(b, N, O, I, H, W):
+            return 'aconv'
         if H * W % 128 == 0 and H * W >= 1024 and b * O * I * 9 <= (16 << 20):
             return 'pimg'
         return 'bank'
@@ -1495,6 +1503,7 @@ class HipOps:
             path = self._modconv_path(b, N, O, I, H, W)
             if excited and (path == 'bank' or (path == 'pimg' and I % 64)):
                 continue            # (no consumer-side scale on these paths: the layer keeps its own launch)
+            # ('aconv': coefficients only - s, a, d; the excitation is a second input scale of the convolution itself)
             ly = dict(w=weights.detach(), mod=_rows_f32(mod), kmod=_rows_f32(kmod) if N > 1 else None, demod=demod, eps=eps,
                       Ip=I, Op=O)
             if (isinstance(weights, torch.nn.Parameter) and getattr(weights, '_gg_pack_table', None) is not None
@@ -1552,6 +1561,18 @@ class HipOps:
                 km = _rows_f32(kernel_mod) if N > 1 else None       # column slices of the style network's output: read in place
                 md = _rows_f32(mod)
                 xs = None if in_excite is None else _rows_f32(in_excite.reshape(b, I))
+            if path == 'aconv':
+                # 4x4 .. 64x64: the shared bank in MFMA-fragment order streamed straight into registers, the tile's halo parked once
+                # for all channels, the N kernels mixed in fp32 after the reduction, demodulation / noise / leaky-relu on the
+                # accumulators: one launch, no per-sample weights, no split-K partials (csrc/gg_aconv.h)
+                if rec is None:
+                    s, a, d = K.modw_fwd(wd, md, km, demod, eps, Ip, Op)
+                else:
+                    s, a, d = rec['s'], rec['a'], rec['d']
+                xs2 = None if in_excite is None else in_excite.reshape(b, I).detach().float().contiguous()
+                y = K.aconv(nhwc(x), _frag_weight(weights), s, a if N > 1 else None, d if demod else None, O, nz, nw, act,
+                            LRELU_SLOPE, xs=xs2)
+                return nchw(y)
             if path == 'sconv':
                 # narrow high-resolution layers: the reference's per-sample weights (a few KiB each) + the streaming convolution
                 wm = _wmix_buffer(weights, b, I)
@@ -1832,6 +1853,46 @@ class HipOps:
             return x
         xa = to_act(x)
         return nchw(ResampleFn.apply(nhwc(xa), K.ResampleSpec.nearest(H, W, *size)))
+
+
+_ACONV = os.environ.get('GG_ACONV', '1') != '0'      # A/B switch: 0 restores the round-3/4 kernels on the 4x4 .. 32x32 adaptive convs
+# widest image the one-launch kernel takes: measured (profiles/r5_aconv_probe*.log, batch 32, hipGraph-timed incl. the modulation
+# launch) 28 / 38 / 54+32 / 48+32 us against 63 / 79 / 69+52 / 51+35 us on 4x4 / 8x8 / 16x16 / 32x32, but 68+52 against 53+38 us at
+# 64x64 (1024 small workgroups: four rounds of its fixed cost), which therefore stays on per-sample weights + gg_conv3
+_ACONV_MAXW = int(os.environ.get('GG_ACONV_MAXW', '32'))
+_aconv_plans: dict = {}
+
+
+def _aconv_ok(b, N, O, I, H, W) -> bool:
+    """can gg_aconv_fwd run this layer? (asked of the library itself: gg_aconv_plan; cached per geometry)"""
+    key = (b, N, O, I, H, W)
+    ok = _aconv_plans.get(key)
+    if ok is None:
+        ok = _aconv_plans[key] = (N <= 2 and H == W and W <= _ACONV_MAXW and K.aconv_plan(b, H, W, I, O, N) is not None)
+    return ok
+
+
+def _frag_weight(w: torch.Tensor) -> torch.Tensor:
+    """the bank (N, O, I, 3, 3) in MFMA-fragment order: from the model's pack table (re-packed with the other operands by the one
+    gg_pack_weights launch behind each optimizer step) or, for parameters outside a table, cached on the parameter per version."""
+    cacheable = isinstance(w, torch.nn.Parameter)
+    if cacheable and getattr(w, '_gg_pack_table', None) is not None and not _DEBUG_NO_TABLE:
+        out = _table_pack(w, 'frag')
+        if out is not None:
+            return out
+    if cacheable:
+        slot = getattr(w, '_gg_packed', None)
+        if slot is not None and slot[0] == _weight_epoch and slot[2] == w._version and 'frag' in slot[1]:
+            return slot[1]['frag']
+    with torch.no_grad():
+        out = K.frag_pack(w)
+    if cacheable:
+        slot = getattr(w, '_gg_packed', None)
+        if slot is None or slot[0] != _weight_epoch or slot[2] != w._version:
+            slot = (_weight_epoch, {}, w._version)
+            w._gg_packed = slot
+        slot[1]['frag'] = out
+    return out
 
 
 def _rows_f32(t: torch.Tensor) -> torch.Tensor:

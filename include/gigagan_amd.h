@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 9
+#define GG_ABI_VERSION 10
 
 int gg_version(void);
 const char* gg_last_error(void);
@@ -423,6 +423,28 @@ int gg_sconv_fwd(const void* x, const void* w, int64_t w_bs, void* y, const floa
                  int32_t b, int32_t H, int32_t W, int32_t C, int32_t O, int32_t act, float slope, void* stream);
 int gg_modulate_bank_fwd(const void* x, const float* s, const float* a, void* out, int32_t b, int32_t P, int32_t Cin, int32_t Cout,
                          void* stream);
+
+/* ---- gg_aconv_fwd (ABI 10): the no-grad adaptive convolution on a SHARED kernel bank in one launch (csrc/gg_aconv.h): reference
+ * AdaptiveConv2DMod.forward gp.py:344-409 (softmax-mixed bank, style modulation, demodulation) + Noise gp.py:925-940 + leaky_relu
+ * gp.py:109 at the generator's 4x4 .. 64x64 stages (gp.py:1184-1245):
+ *   y[b,p,o] = act( d[b,o] * sum_n a[b,n] sum_{i,t} W_n[o,i,t] (s[b,i] xs[b,i] x[b,p+t,i]) + noise[b,p] * noise_w[o] )
+ * x (b, H, W, C) / y (b, H, W, O) NHWC bf16; wf = the bank in MFMA-fragment order [O/32][NB][9][C/16][64][8] bf16 as written by
+ * gg_pack_weights (entry kind 3); s (b, C) = mod + 1, xs (b, C) optional (skip-layer excitation), a (b, NB) = softmax(kernel_mod)
+ * (may be null for NB == 1), d (b, O) optional demodulation coefficients (gg_modw_fwd / gg_modw_multi_fwd produce s, a, d), noise
+ * (b, H*W) with noise_w (O) optional - all fp32. H == W a power of two in 4..64, C a power of two in 16..512, O %% 32 == 0, NB 1 or 2.
+ * The library picks the tile (TM x 32 pixels, NWN x 32 output channels per workgroup); force_tm / force_nwn (0 = free) pin it for
+ * measurements; gg_aconv_plan reports the choice (and is the eligibility test: non-zero = this layer cannot run here). No workspace. */
+typedef struct gg_aconv_desc {
+    const void* x; const void* wf; void* y;
+    const float* s; const float* xs; const float* a; const float* d; const float* noise; const float* noise_w;
+    int32_t b, H, W, C, O, NB;
+    int32_t act;            /* 0 none, 1 leaky relu */
+    float slope;
+    int32_t force_tm, force_nwn;
+    int32_t reserved[2];
+} gg_aconv_desc;
+int gg_aconv_plan(const gg_aconv_desc* d, int32_t* tm, int32_t* nwn, int32_t* nwk, int32_t* lds_bytes, int32_t* grid);
+int gg_aconv_fwd(const gg_aconv_desc* d, void* stream);
 
 /* ---- hipGraph repair. The training step is replayed as a captured hipGraph (the reference has no counterpart: it launches eagerly,
  * gp.py:2227-2580). The HIP runtime PyTorch 2.10+rocm7.0 carries (7.0.51831) re-executes a captured hipMemsetAsync with a corrupted

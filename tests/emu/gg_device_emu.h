@@ -49,6 +49,10 @@ u16x4 gg_emu_lds_read_tr16(const bf16_t* p);
 
 #define GG_LAUNCH(kernel, grid, block, stream, ...) \
     gg_emu_launch(grid, block, [=]() { kernel(__VA_ARGS__); })
+// launch-sized LDS (gg_aconv.h): the emulator runs one workgroup at a time, so one static 160 KB array per kernel stands in
+#define GG_DYN_SHARED(name) static __attribute__((aligned(1024))) char name[160 * 1024]
+#define GG_LAUNCH_DYN(kernel, grid, block, lds_bytes, stream, ...) \
+    gg_emu_launch(grid, block, [=]() { kernel(__VA_ARGS__); })
 
 // LDS-DMA stand-ins. Two landing models bracket what the hardware may do (the emulator itself is sequential):
 //   early (default)      the 16 bytes land at issue time: a slot that is refilled before its last reader ran (WAR) shows up

@@ -135,7 +135,18 @@ class GlooBackedNativeComm:
                 self.log.append(('join',))
 
             def _mark(self, like):
-                return None
+                """(timing only) a host timestamp with the `elapsed_time` of a HIP event, so that bench.py's exposed-communication
+                bookkeeping (pairs of marks around the join) runs in the dry run"""
+                if not self.timing:
+                    return None
+                import time
+
+                class _HostMark:
+                    t = time.perf_counter()
+
+                    def elapsed_time(self, other):
+                        return (other.t - self.t) * 1e3
+                return _HostMark()
 
             def _keep(self, *tensors):
                 pass
@@ -266,3 +277,36 @@ def test_two_rank_training_keeps_replicas_identical(tmp_path):
     assert ret3[0]['native_steps'] == 4 and ret3[0]['digest'] == ret3[1]['digest'] == r0['digest'], (dict(ret3), r0)
     assert all(d >= ret3[0]['slices'] - 1 and g >= 1 for d, g in ret3[0]['in_bwd'][2:]), dict(ret3[0])
 
+
+
+def test_bench_multi_rank_control_flow_runs_on_two_gloo_ranks():
+    """bench.py's multi-rank half (self-launch through torch.distributed.run, rank bring-up, barriers, the MAX-
+    reduce of the step time, per-rank gather, exposed-communication timing on the native-communicator branch, shutdown, ONE JSON
+    line from rank 0) has never run on > 1 GPU; `--dry-run-cpu` executes exactly that code on 2 CPU ranks over gloo (toy model,
+    kernel emulator, the gloo-backed double of the RCCL communicator)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, GG_BENCH_FAKE_NATIVE='1', OMP_NUM_THREADS='2')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, str(root / 'bench.py'), '--gpus', '2', '--dry-run-cpu', '--steps', '4', '--warmup', '1'],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, lines                                   # rank 0 only, one line
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['steps'] == 4 and rec['scaling'] == 'weak' and rec['higher_is_better'] is True
+    assert rec['config']['parallelism'] == 'dp2' and rec['config']['global_batch'] == 2 * 2
+    assert rec['config']['comm'] == 'gg_comm/rccl' and rec['config']['comm_world'] == 2
+    assert rec['config']['comm_overlap'].startswith('in-backward slices')
+    assert 'no 1 -> N curve' in rec['config']['scaling_curve']
+    assert len(rec['per_rank']) == 2 and sorted(r['rank'] for r in rec['per_rank']) == [0, 1]
+    for r in rec['per_rank']:
+        assert r['ms_per_step'] > 0 and r['exposed_comm_ms_per_step'] is not None and r['exposed_comm_ms_per_step'] >= 0
+    # whole-job value = global batch * steps / the SLOWEST rank's time
+    assert abs(rec['value'] - 4 * rec['steps'] / (rec['ms_per_step'] * rec['steps'] / 1e3)) < 1e-6 * rec['value']
+    assert rec['ms_per_step'] >= max(r['ms_per_step'] for r in rec['per_rank']) - 1e-6
+    assert rec['finite'] and rec['cpu_baseline'] is None and 'DRY RUN' in rec['metric']

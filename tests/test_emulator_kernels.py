@@ -1669,3 +1669,89 @@ def test_fused_hinge_losses_match_the_reference_formulation(dtype):
         assert rel_err(xh.grad.float(), xr.grad) < (4e-3 if dtype == torch.bfloat16 else 1e-6)
     xt = torch.randn(12, 4, requires_grad=True)                            # a non-dense view is copied once (still 2 launches for ~16)
     assert abs(float(ops.HipOps().hinge(xt.t(), 6)) - float(discriminator_hinge_loss(xt.t()[:, 6:], xt.t()[:, :6]))) < 1e-5
+
+
+# ---- gg_aconv: the one-launch adaptive convolution on a fragment-ordered shared bank (round 5) ------------------------------------
+def _aconv_reference(x, W, s, xs, a, d, nz, nw, act):
+    """fp32 math on the operands as the kernel rounds them: (x * s * xs) -> bf16, banks -> bf16, fp32 accumulation, the banks mixed
+    in fp32 AFTER the reduction (gp.py:378-409 with the sum over kernels pulled out of the convolution), then d, noise, leaky-relu."""
+    b, H, Wd, Cc = x.shape
+    N, O = W.shape[:2]
+    sc = s if xs is None else s * xs
+    xm = bf(x.float() * sc[:, None, None, :]).float().permute(0, 3, 1, 2)
+    y = 0.
+    for n in range(N):
+        yn = F.conv2d(xm, bf(W[n]).float(), padding=1)
+        y = y + (a[:, n].view(b, 1, 1, 1) if a is not None else 1.) * yn
+    if d is not None:
+        y = y * d.view(b, O, 1, 1)
+    if nz is not None:
+        y = y + nz.view(b, 1, H, Wd) * nw.view(1, O, 1, 1)
+    if act:
+        y = F.leaky_relu(y, 0.2)
+    return y.permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize('cfg', [(3, 4, 32, 32, 2, 1, 1), (2, 8, 16, 64, 2, 2, 2), (2, 16, 32, 128, 2, 2, 4), (1, 16, 16, 64, 1, 4, 2),
+                                 (1, 32, 16, 128, 2, 4, 4), (1, 64, 16, 64, 2, 4, 2), (2, 8, 64, 32, 2, 1, 1), (2, 8, 32, 64, 2, 0, 0),
+                                 (2, 4, 16, 64, 2, 1, 2), (1, 8, 16, 32, 1, 2, 1)])
+def test_aconv_matches_fp32_math_on_every_tile_shape(cfg):
+    """whole-image tiles (4x4: two images per 32 pixels, a batch that leaves a tile half empty), row tiles of 8..64-wide images,
+    every (pixels x channels x K-slices) wavefront arrangement, one and two kernels in the bank, with and without the excitation
+    scale / demodulation / noise / activation."""
+    b, R, Cc, O, NB, tm, nwn = cfg
+    torch.manual_seed(sum(cfg))
+    x = bf(torch.randn(b, R, R, Cc))
+    W = torch.randn(NB, O, Cc, 3, 3) * 0.2
+    s, xs = torch.rand(b, Cc) + 0.5, torch.rand(b, Cc) + 0.5
+    a = torch.softmax(torch.randn(b, NB), -1) if NB > 1 else None
+    d = torch.rand(b, O) + 0.5
+    nz, nw = torch.randn(b * R * R), torch.randn(O) * 0.3
+    wf = K.frag_pack(W)
+    plan = K.aconv_plan(b, R, R, Cc, O, NB, tm, nwn)
+    assert plan is not None and (tm == 0 or plan[0] == tm) and (nwn == 0 or plan[1] == nwn) and plan[1] * plan[2] == 8, plan
+    for use_xs, use_d, use_nz, act in ((True, True, True, 'lrelu'), (False, False, False, None), (False, True, False, 'lrelu')):
+        y = K.aconv(x, wf, s, a, d if use_d else None, O, nz if use_nz else None, nw if use_nz else None, act,
+                    xs=xs if use_xs else None, force_tm=tm, force_nwn=nwn)
+        ref = _aconv_reference(x, W, s, xs if use_xs else None, a, d if use_d else None, nz if use_nz else None, nw, act)
+        assert y.shape == (b, R, R, O) and rel_err(y, ref) < 4e-3, (cfg, use_xs, use_d, use_nz, rel_err(y, ref))
+
+
+def test_aconv_refuses_what_it_cannot_run():
+    assert K.aconv_plan(2, 8, 8, 24, 64, 2) is None            # C not a power of two
+    assert K.aconv_plan(2, 8, 8, 32, 40, 2) is None            # O % 32
+    assert K.aconv_plan(2, 128, 128, 32, 32, 2) is None        # beyond 64-wide images: the streaming kernels' territory
+    assert K.aconv_plan(2, 8, 8, 32, 64, 3) is None            # banks of more than two kernels
+    with pytest.raises(RuntimeError, match='gg_aconv'):
+        K.aconv(bf(torch.randn(1, 8, 8, 32)), K.frag_pack(torch.randn(2, 64, 32, 3, 3)), torch.ones(1, 32), None, None, 64)
+
+
+def test_pack_table_keeps_a_bank_in_fragment_order():
+    """gg_pack_weights kind 3 == kernels.frag_pack (the tensor-algebra statement of the layout), through the device-resident table."""
+    torch.manual_seed(0)
+    tab = K.PackTable('cpu', capacity=16)
+    for N, O, I in ((2, 64, 32), (1, 32, 16), (2, 32, 512)):
+        w = torch.randn(N, O, I, 3, 3)
+        dst = tab.register_frag(w.view(N, O, I, 9), N, O, I, 9)
+        tab.refresh()
+        assert torch.equal(dst, K.frag_pack(w)), (N, O, I)
+
+
+def test_no_grad_adaptive_conv_takes_the_one_launch_kernel_where_it_can():
+    """ops.modconv2d routes the 4x4 .. 64x64 layers to gg_aconv (and keeps the narrow high-resolution layers on gg_sconv); the result
+    matches the oracle with and without the skip-layer excitation, from a generator-style batched modulation and stand-alone."""
+    from gigagan_pytorch_amd.modules import AdaptiveConv2DMod
+    torch.manual_seed(0)
+    for I, O, R, b in ((32, 32, 4, 2), (16, 64, 8, 2), (32, 64, 16, 1)):
+        assert ops.HipOps._modconv_path(b, 2, O, I, R, R) == 'aconv'
+        conv = AdaptiveConv2DMod(I, O, 3, num_conv_kernels=2)
+        x, mod, km = torch.randn(b, I, R, R), torch.randn(b, I) * 0.3, torch.randn(b, 2)
+        nz, nw, ex = torch.randn(b, 1, R, R), torch.randn(O, 1, 1) * 0.1, torch.rand(b, I, 1, 1) + 0.5
+        for excite in (None, ex):
+            with torch.no_grad():
+                with ops.use_impl(ops.HipOps()):
+                    y1 = conv(x, mod, km, noise=nz, noise_weight=nw, act='lrelu', in_excite=excite)
+                with ops.use_impl(OracleOps(bf16_operands=True)):
+                    y0 = conv(x, mod, km, noise=nz, noise_weight=nw, act='lrelu', in_excite=excite)
+            assert rel_err(y1, y0) < 1e-2, (I, O, R, excite is not None, rel_err(y1, y0))
+    assert ops.HipOps._modconv_path(32, 2, 32, 64, 128, 128) == 'sconv'

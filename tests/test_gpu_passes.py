@@ -354,19 +354,22 @@ def test_captured_collectives_never_outlive_the_communicator(tmp_path):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize('cfg', [(512, 512, 4, 32, 11), (512, 512, 8, 32, 8), (512, 256, 16, 32, 11), (256, 256, 16, 32, 11),
-                                 (256, 128, 32, 32, 12), (128, 128, 32, 32, 12), (128, 64, 64, 8, 8), (64, 64, 64, 8, 8),
-                                 (64, 32, 128, 8, 0), (32, 32, 128, 8, 0), (32, 16, 256, 4, 0), (16, 16, 256, 4, 0)])
+@pytest.mark.parametrize('cfg', [(512, 512, 4, 32, 'aconv'), (512, 512, 8, 32, 'aconv'), (512, 256, 16, 32, 'aconv'),
+                                 (256, 256, 16, 32, 'aconv'), (256, 128, 32, 32, 'aconv'), (128, 128, 32, 32, 'aconv'),
+                                 (128, 64, 64, 8, 'pimg'), (64, 64, 64, 8, 'pimg'), (128, 64, 64, 32, 'pimg'),
+                                 (64, 32, 128, 8, 'sconv'), (32, 32, 128, 8, 'sconv'), (32, 16, 256, 4, 'sconv'), (16, 16, 256, 4, 'sconv')])
 def test_no_grad_adaptive_conv_at_config2_layer_shapes(cfg):
     """the generator's demodulated 3x3 adaptive convs (gp.py:344-409 + noise + leaky-relu) at EVERY BASELINE config-2 layer shape,
-    no-grad path, against the oracle with bf16-rounded operands: 1e-2 relative L2 (bf16 output rounding + the per-sample weights
-    being rounded to bf16 AFTER modulation / demodulation, as the reference's autocast conv does). The last entry of a case is
-    the plan tile its contraction must have run on: 11 = gg_lrconv (4x4: bank modulation on the halo store; 16x16: the bank mixed
-    per image), 8 / 12 = gg_conv3 (8x8: stacked bank with the scale on its operand staging; 32x32 / 64x64: per-image weights on the
-    256x64 / 256x128 tiles), 0 = gg_sconv on per-sample weights (no contraction launch)."""
+    no-grad path, against the oracle with bf16-rounded operands: 1e-2 relative L2 (bf16 output rounding; the oracle rounds the
+    per-sample weights to bf16 AFTER modulation / demodulation, as the reference's autocast conv does, the kernels round the bank and
+    the modulated activation). The last entry of a case is the formulation it must run in: 'aconv' = gg_aconv_fwd (4x4 .. 64x64: one
+    launch on the fragment-ordered shared bank, round 5), 'pimg' = per-sample weights through gg_conv3 (64x64, plan tile 8), 'sconv' =
+    gg_sconv on per-sample weights; aconv / sconv do not go through gg_gemm_bf16 (no contraction plan is logged)."""
     from gigagan_pytorch_amd.modules import AdaptiveConv2DMod
     from gigagan_pytorch_amd import kernels as K
-    I, O, R, b, want_tile = cfg
+    I, O, R, b, want_path = cfg
+    want_tile = 8 if want_path == 'pimg' else 0          # (64x64: per-sample weights on gg_conv3's 64-column tile)
+    assert ops.HipOps._modconv_path(b, 2, O, I, R, R) == want_path
     torch.manual_seed(0)
     conv = AdaptiveConv2DMod(I, O, 3, num_conv_kernels=2)
     x, mod, km = torch.randn(b, I, R, R), torch.randn(b, I) * 0.3, torch.randn(b, 2)

