@@ -40,6 +40,12 @@ struct GgAconvParams {
     float slope;
     int mt;                 // pixel tiles (gridDim.x = mt * O / BN)
     int inv_spi, inv_hwp;   // 16.16 reciprocals (rounded up) of the halo slots per image / the halo row length
+    // the NEXT launch's bank (optional): its workgroups wg' = tile_n' * pf_mt + tile_m' (pf_grid of them, dealt to the XCDs as this
+    // kernel's are) stream pf_tn_bytes each from pf_wf + tile_n' * pf_tn_bytes
+    const bf16_t* pf_wf;
+    long long pf_bytes;
+    int pf_tn_bytes, pf_mt, pf_grid;
+    int dbg;                // probes only (gg_aconv_desc.reserved): 1 = no reduction loop, 2 = no halo staging, 4 = one wavefront finishes nothing
     long long x_bytes, wf_bytes;
 };
 
@@ -125,7 +131,8 @@ GG_KERNEL GG_LAUNCH_BOUNDS(64 * NWN * NWK) void gg_aconv_kernel(GgAconvParams p)
         for (int n = 0; n < NB; ++n) av[i][n] = (p.a ? p.a : p.s)[p.a ? (long long)ic * NB + n : 0];
     }
     u16x8 bq[PD][NB];
-    for (int v0 = tid; v0 < nvec || v0 == tid; v0 += NT * GG_AC_XV) {     // (at least once for EVERY thread: the first pass starts the weight stream)
+    const int nvec_run = (p.dbg & 2) ? 0 : nvec;
+    for (int v0 = tid; v0 < nvec_run || v0 == tid; v0 += NT * GG_AC_XV) {     // (at least once for EVERY thread: the first pass starts the weight stream)
         u16x8 xv[GG_AC_XV];
         int dst[GG_AC_XV];
 #pragma unroll
@@ -204,7 +211,8 @@ GG_KERNEL GG_LAUNCH_BOUNDS(64 * NWN * NWK) void gg_aconv_kernel(GgAconvParams p)
     };
     if (FIN_EARLY) load_fin();
 
-    for (int k0 = k_lo; k0 < k_hi; k0 += PD) {
+    const int k_end = (p.dbg & 1) ? k_lo : k_hi;
+    for (int k0 = k_lo; k0 < k_end; k0 += PD) {
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
             const int k = k0 + u;
@@ -252,7 +260,29 @@ GG_KERNEL GG_LAUNCH_BOUNDS(64 * NWN * NWK) void gg_aconv_kernel(GgAconvParams p)
                 for (int q = 0; q < 16; ++q) red[((((wk - 1) * NWN + wn) * TM + i) * 16 + q) * 64 + lane] = out[i][q];
         }
         gg_sync();
-        if (wk > 0) return;
+        if (wk > 0) {
+            // this wavefront is done: request the slice of the NEXT layer's bank that the workgroups of the next launch on THIS XCD will
+            // stream (same blockIdx -> XCD dealing), split over this XCD's workgroups - it lands in this XCD's L2 while the finishing
+            // wavefronts write the tile. The loads are never waited for (s_endpgm retires them).
+            if (e.pf_wf) {
+                const int g2 = e.pf_grid, q2 = g2 >> 3, r2 = g2 & 7;
+                const int lo = xcd < r2 ? xcd * (q2 + 1) : r2 * (q2 + 1) + (xcd - r2) * q2;
+                const int cnt = q2 + (xcd < r2 ? 1 : 0);
+                if (cnt > 0) {
+                    const long long b_lo = (long long)(lo / e.pf_mt) * e.pf_tn_bytes;
+                    long long b_hi = (long long)((lo + cnt - 1) / e.pf_mt + 1) * e.pf_tn_bytes;
+                    b_hi = b_hi < e.pf_bytes ? b_hi : e.pf_bytes;
+                    const int mine = (nwg + 7 - xcd) >> 3;                     // workgroups of THIS launch on this XCD; `pos` is ours
+                    const long long share = (((b_hi - b_lo) / mine + 1023) >> 10) << 10;
+                    const long long s_lo = b_lo + share * pos;
+                    const long long s_hi = s_lo + share < b_hi ? s_lo + share : b_hi;
+                    GgBuf bufP = gg_make_buf((const void*)e.pf_wf, (unsigned long long)e.pf_bytes);
+                    constexpr int NPT = 64 * NWN * (NWK - 1);
+                    for (long long o = s_lo + (long long)(tid - 64 * NWN) * 16; o < s_hi; o += NPT * 16) gg_buf_touch16(bufP, (unsigned)o);
+                }
+            }
+            return;
+        }
 #pragma unroll 1
         for (int s = 0; s < NWK - 1; ++s)       // (one slice at a time: unrolled, the loads of all slices are hoisted and spill)
 #pragma unroll

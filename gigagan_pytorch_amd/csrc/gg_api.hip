@@ -256,16 +256,6 @@ bool gg_v2_eligible(const gg_gemm_desc* d) {
     return gg_v2_has_variant(d);
 }
 
-int gg_v2_policy() {   // GG_GEMM_V2=0 disables the 8-wave kernel (A/B runs), =2 forces it wherever eligible
-    static int policy = -1;
-    if (policy < 0) {
-        const char* e = getenv("GG_GEMM_V2");
-        policy = e ? atoi(e) : 1;
-        if (policy < 0) policy = 1;
-    }
-    return policy;
-}
-
 // Launch planning by a small cost model (all times in microseconds, constants fitted to gpu_gemm_bench.py runs on
 // MI355X): a launch runs in ceil(workgroups / resident) rounds; a round of a tile costs its k-tiles times the
 // measured per-k-tile time plus a fixed prologue/epilogue; split-K adds the fp32 partial round trip and a launch.
@@ -794,7 +784,6 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
         return gg_sfwd_substitute(d, pl);
     }
     const bool v2ok = gg_v2_eligible(d) && d->N >= 96 && d->M >= 192;
-    const int pol = gg_v2_policy();
     const int v1_tile = d->N <= 32 ? 3 : (d->N <= 64 ? 2 : 1);
     int forced = d->force_tile;
     if (forced < 0 || forced > 6) forced = 0;      // (9 = direct convolution: handled above when eligible)
@@ -808,12 +797,11 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
         } else {
             if (d->b_image_stride && gg_img_pixels(d) % tm.bm) continue;     // a row tile must stay inside one image
             if (tm.tile <= 3 && tm.tile != v1_tile) continue;
-            if (tm.tile >= 4 && (!v2ok || !pol)) continue;
+            if (tm.tile >= 4 && !v2ok) continue;
             if (tm.tile == 4 && d->N < 192) continue;
             // the small 8-wave tile is for row-major launches whose grid the 256-row tiles cannot fill; weight
             // gradients measured better on 256x256 + split-K at every size except the 4x4-resolution layers
             if (tm.tile == 6 && (d->M > 32768 || d->a_layout == GG_KROW)) continue;
-            if (pol >= 2 && v2ok && tm.tile <= 3) continue;
         }
         const int ktiles = (d->K + tm.bk - 1) / tm.bk;
         int max_sk = ktiles / (tm.bk == 64 ? 4 : 8);   // keep >= 256 reduction elements per split
@@ -965,11 +953,6 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     if (d->gelu_mode && !(pl.tile >= 4 && pl.tile <= 6 && pl.splitk == 1))
         return gg_fail(-18, "gg_gemm: gelu_mode runs on the 8-wave tiles' staged epilogue only (planned tile %d, split-K %d)", pl.tile, pl.splitk);
     p.aux = (bf16_t*)d->gelu_aux; p.aux_mode = d->gelu_mode; p.ld_aux = d->ld_aux;
-    {
-        static int narrow = -1;
-        if (narrow < 0) { const char* e = getenv("GG_WB_NARROW"); narrow = e ? atoi(e) : 0; }
-        p.narrow_wb = narrow;
-    }
     p.partial = (float*)workspace;
     p.b_img_stride = d->b_image_stride;
     p.bank_mix = d->bank_mix;
@@ -1555,7 +1538,7 @@ extern "C" int gg_aconv_fwd(const gg_aconv_desc* d, void* stream) {
     p.s = d->s; p.xs = d->xs; p.a = d->a; p.d = d->d; p.noise = d->noise; p.noise_w = d->noise_w;
     p.b = d->b; p.H = d->H; p.W = d->W; p.C = d->C; p.O = d->O;
     p.w_shift = gg_log2i(d->W); p.hw_shift = gg_log2i(d->H * d->W); p.c8_shift = gg_log2i(d->C / 8);
-    p.act = d->act; p.slope = d->slope; p.mt = pl.mt;
+    p.act = d->act; p.slope = d->slope; p.mt = pl.mt; p.dbg = d->reserved;
     {
         const int bmt = 32 * pl.tm, hw = d->H * d->W;
         const int rt = hw >= bmt ? bmt / d->W : d->H;
@@ -1565,6 +1548,20 @@ extern "C" int gg_aconv_fwd(const gg_aconv_desc* d, void* stream) {
     p.x_bytes = (long long)d->b * d->H * d->W * d->C * 2;
     p.wf_bytes = (long long)d->O * d->NB * 9 * d->C * 2;
     if (p.x_bytes >= (1ll << 32) || p.wf_bytes >= (1ll << 32)) return gg_fail(-4, "gg_aconv: operands beyond 4 GiB");
+    if (d->next_wf) {       // the next launch's bank: which bytes each of ITS workgroups will stream (its own plan, asked of the same planner)
+        gg_aconv_desc nd;
+        memset(&nd, 0, sizeof(nd));
+        nd.x = d->x; nd.wf = d->next_wf; nd.y = d->y; nd.s = d->s; nd.a = d->s;
+        nd.b = d->next_b; nd.H = nd.W = d->next_H; nd.C = d->next_C; nd.O = d->next_O; nd.NB = d->next_NB;
+        GgAconvPlan np;
+        if (gg_aconv_plan_of(&nd, &np) == 0) {
+            p.pf_wf = (const bf16_t*)d->next_wf;
+            p.pf_bytes = (long long)nd.O * nd.NB * 9 * nd.C * 2;
+            p.pf_tn_bytes = np.nwn * nd.NB * 9 * (nd.C / 16) * 1024;
+            p.pf_mt = np.mt; p.pf_grid = np.grid;
+            if (p.pf_bytes >= (1ll << 32)) p.pf_wf = nullptr;
+        }
+    }
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)pl.grid), block(64 * pl.nwn * pl.nwk);
 #define GG_AC(NB_, TM_, NWN_, NWK_) GG_LAUNCH_DYN((gg_aconv_kernel<NB_, TM_, NWN_, NWK_>), grid, block, pl.lds, s, p)

@@ -246,3 +246,8 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_conv3_kernel(GgGemmParams p) {
                                                       z4, z4);
     }
 }
+
+// Round 5, measured and not shipped: the same kernel with the weight tiles in a RING of 3 - 4 buffers (transfers issued from inline
+// assembly R - 1 taps ahead, counted vmcnt waits, raw barriers - the gg_wgrads recipe). Bit-identical results, 7 - 10 % SLOWER on every
+// discriminator shape (D4.conv2 231 -> 249 us, D3.conv2 139 -> 160 us: profiles/r05_conv3_ring_ab.log): the tap loop is not waiting for
+// its weight tile's latency, so more lead buys nothing and the extra buffer and wait bookkeeping cost. The code was deleted.

@@ -124,6 +124,13 @@ GG_DEVICE u16x8 gg_buf_load16(GgBuf r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(u16x8, v);
 }
 
+// a 16-byte load whose result nobody reads: it pulls the line into this XCD's L2 (and the memory-side cache) for a LATER kernel. Issued
+// from assembly so that the compiler neither drops it nor waits for it; a wave may end with such loads outstanding.
+GG_DEVICE void gg_buf_touch16(GgBuf r, unsigned voff) {
+    u32x4 sink;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(sink) : "v"(voff), "s"(r) : "memory");
+}
+
 // buffer-addressed LDS-DMA (buffer_load_dwordx4 ... lds): lane i's 16 bytes land at lds_wave_base + 16 i (wave-uniform base, it
 // travels in M0); out-of-range lanes deposit zeros. Counts on vmcnt; NOT ordered with ds_* operations: a reader needs
 // gg_wait_vm<0>() in the issuing wave and a barrier.

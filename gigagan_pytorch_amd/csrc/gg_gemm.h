@@ -85,7 +85,6 @@ struct GgGemmParams {
     // gg_gemm2's staged bf16 epilogue, GELU fused around a 1x1 convolution pair (FeedForward, gp.py:726-740): mode 1 = the staged value h
     // is ALSO stored to aux and the output is gelu(h); mode 2 = aux holds h and the output is staged * gelu'(h)
     bf16_t* aux; int aux_mode, ld_aux;
-    int narrow_wb;     // A/B switch (GG_WB_NARROW=1): 8-byte instead of 16-byte lanes in the staged write-back
     int ws_cs, ws_cstore, ws_gmul;   // ... channels per x slot, rows stored per tap, memory rows per ring row
     int buf_ok;        // 31 when both operands' byte extents fit the 32-bit offsets of a buffer descriptor, else 0 (bits: A conv rows,
                        // A dense rows, A reduction-major, B dense rows, B reduction-major)

@@ -483,7 +483,7 @@ GG_DEVICE void gg2_stage_writeback_v(const GgGemmParams& e, int b, const char* s
 
 template <int WTM, int WTN>
 GG_DEVICE void gg2_stage_writeback(const GgGemmParams& e, int b, const char* stage, int stage_pitch, int m_wave, int n_wave, int lane) {
-    const bool wide = !e.narrow_wb && !(e.N & 7) && !(e.ldc & 7) && !(e.c_bs & 7) && !((unsigned long long)e.Cout & 15) &&
+    const bool wide = !(e.N & 7) && !(e.ldc & 7) && !(e.c_bs & 7) && !((unsigned long long)e.Cout & 15) &&
                       (!e.residual || (!(e.ldr & 7) && !((unsigned long long)e.residual & 15))) &&
                       (!e.aux_mode || (!(e.ld_aux & 7) && !((unsigned long long)e.aux & 15)));
     if (wide) gg2_stage_writeback_v<WTM, WTN, 8>(e, b, stage, stage_pitch, m_wave, n_wave, lane);

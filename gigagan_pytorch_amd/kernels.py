@@ -857,7 +857,8 @@ def sconv(x: torch.Tensor, wmix: torch.Tensor, O: int, noise=None, noise_w=None,
 class AconvDesc(C.Structure):        # mirrors gg_aconv_desc (include/gigagan_amd.h)
     _fields_ = ([(f, C.c_void_p) for f in ('x', 'wf', 'y', 's', 'xs', 'a', 'd', 'noise', 'noise_w')] +
                 [(f, C.c_int32) for f in ('b', 'H', 'W', 'C', 'O', 'NB', 'act')] + [('slope', C.c_float)] +
-                [(f, C.c_int32) for f in ('force_tm', 'force_nwn', 'reserved0', 'reserved1')])
+                [(f, C.c_int32) for f in ('force_tm', 'force_nwn')] + [('next_wf', C.c_void_p)] +
+                [(f, C.c_int32) for f in ('next_b', 'next_H', 'next_C', 'next_O', 'next_NB', 'reserved')])
 
 
 def _aconv_desc(b, H, W, Cc, O, NB, force_tm=0, force_nwn=0):
@@ -879,10 +880,11 @@ def aconv_plan(b: int, H: int, W: int, Cc: int, O: int, NB: int, force_tm: int =
 
 
 def aconv(x: torch.Tensor, wf: torch.Tensor, s: torch.Tensor, a, d, O: int, noise=None, noise_w=None, act=None, slope: float = 0.2,
-          xs=None, force_tm: int = 0, force_nwn: int = 0) -> torch.Tensor:
+          xs=None, force_tm: int = 0, force_nwn: int = 0, next_bank=None, _dbg: int = 0) -> torch.Tensor:
     """gg_aconv_fwd: the no-grad adaptive 3x3 convolution on a shared bank in fragment order (PackTable.register_frag /
     frag_pack): x (b, H, W, C) bf16, wf (O/32, NB, 9, C/16, 64, 8) bf16, s (b, C), a (b, NB) | None, d (b, O) | None, xs (b, C) | None,
-    noise (b*H*W,) with noise_w (O,) fp32 -> (b, H, W, O) bf16."""
+    noise (b*H*W,) with noise_w (O,) fp32 -> (b, H, W, O) bf16. `next_bank` = (wf', b', H') of the NEXT aconv launch on this stream: its
+    bank is requested into the L2 by the wavefronts that finish early (a hint; None = no prefetch)."""
     L = _C.lib()
     L.require(x, wf, s, a, d, noise, noise_w, xs)
     b, H, W, Cc = x.shape
@@ -899,6 +901,13 @@ def aconv(x: torch.Tensor, wf: torch.Tensor, s: torch.Tensor, a, d, O: int, nois
     dsc.x, dsc.wf, dsc.y, dsc.s, dsc.xs, dsc.a, dsc.d = ptr(x), ptr(wf), ptr(y), ptr(s), ptr(xs), ptr(a), ptr(d)
     dsc.noise, dsc.noise_w = ptr(noise), ptr(noise_w) if noise is not None else None
     dsc.act, dsc.slope = (1 if act == 'lrelu' else 0), float(slope)
+    dsc.reserved = int(_dbg)            # (timing probes: phases switched off, results then meaningless)
+    if next_bank is not None:
+        nwf, nb_, nh_ = next_bank
+        L.require(nwf)
+        assert nwf.dtype == torch.bfloat16 and nwf.is_contiguous() and nwf.dim() == 6 and tuple(nwf.shape[4:]) == (64, 8) and nwf.shape[2] == 9
+        dsc.next_wf, dsc.next_b, dsc.next_H = ptr(nwf), int(nb_), int(nh_)
+        dsc.next_O, dsc.next_NB, dsc.next_C = nwf.shape[0] * 32, nwf.shape[1], nwf.shape[3] * 16
     L.check(L.lib.gg_aconv_fwd(C.byref(dsc), L.stream(x)), 'gg_aconv_fwd')
     return y
 

@@ -387,7 +387,6 @@ def _ones_col(b, device):
     return t
 
 
-_NO_MODGRAM = bool(os.environ.get('GG_NO_MODGRAM'))      # A/B switch: the adaptive conv's coefficients over (b, o, i, t) instead of through the Gram rows
 _NO_FF_FUSE = bool(os.environ.get('GG_NO_FF_FUSE'))      # A/B switch of the GELU-on-epilogue FeedForward (profiles/r04_ff_fuse_ab.log)
 
 
@@ -602,7 +601,7 @@ class ModCoefFn(Function):
     def forward(ctx, mod, kmod, weights, eps, Ip, Op):
         ctx.set_materialize_grads(False)
         ctx.eps = eps
-        ctx.gram = not _NO_MODGRAM and mod.shape[0] <= K.MODGRAM_MAX_B
+        ctx.gram = mod.shape[0] <= K.MODGRAM_MAX_B
         if ctx.gram:       # through the bank's Gram rows: 17x fewer operations (gg_modcoef.h, second half)
             gram = K.modgram(weights.detach())
             s, a, d, tsum = K.modcoef_gram_fwd(gram, weights.shape[0], mod, kmod, eps, Ip, Op)
@@ -1128,9 +1127,18 @@ class LinearAttnFn(Function):
         d = C // heads
         ctx = torch.empty((b, heads, d, d), dtype=ACT_DTYPE, device=qkv.device)
         out = torch.empty((b, n, C), dtype=ACT_DTYPE, device=qkv.device)
-        for i in range(b):
-            K.gemm(_heads_view(eks[i], heads), _heads_view(v[i], heads), trans_a=True, trans_b=False, out=ctx[i])   # (h, d, e)
-            K.gemm(_heads_view(qs[i], heads), ctx[i], trans_a=False, trans_b=False, out=_heads_view(out[i], heads))
+        # one batched launch per contraction and per HEAD (batch = the images: a head's 64 channels of (b, n, C) are a (b, n, 64) view
+        # with batch stride n C) when there are more images than heads, per IMAGE (batch = the heads, stride 64) otherwise: the
+        # GEMM descriptor carries one batch stride, and (image, head) is a two-level index
+        if b > heads:
+            for h in range(heads):
+                sl = slice(h * d, (h + 1) * d)
+                K.gemm(eks[..., sl], v[..., sl], trans_a=True, trans_b=False, out=ctx[:, h])                           # (b, d, e)
+                K.gemm(qs[..., sl], ctx[:, h], trans_a=False, trans_b=False, out=out[..., sl])
+        else:
+            for i in range(b):
+                K.gemm(_heads_view(eks[i], heads), _heads_view(v[i], heads), trans_a=True, trans_b=False, out=ctx[i])   # (h, d, e)
+                K.gemm(_heads_view(qs[i], heads), ctx[i], trans_a=False, trans_b=False, out=_heads_view(out[i], heads))
         ctx_.cfg = (heads, scale)
         ctx_.save_for_backward(qkv, qs, eks, ctx)
         return out
@@ -1148,13 +1156,23 @@ class LinearAttnFn(Function):
         dqkv = torch.empty_like(qkv)
         dqs = torch.empty((b, n, C), dtype=ACT_DTYPE, device=qkv.device)
         deks = torch.empty((b, n, C), dtype=ACT_DTYPE, device=qkv.device)
-        dctx = torch.empty((heads, d, d), dtype=ACT_DTYPE, device=qkv.device)
-        for i in range(b):
-            gi, qi, ei, vi = (_heads_view(t[i], heads) for t in (g, qs, eks, v))
-            K.gemm(qi, gi, trans_a=True, trans_b=False, out=dctx)                                          # dctx[d, e] = sum_n qs g
-            K.gemm(gi, ctx[i], trans_a=False, trans_b=True, out=_heads_view(dqs[i], heads))               # dqs = g ctx^T
-            K.gemm(vi, dctx, trans_a=False, trans_b=True, out=_heads_view(deks[i], heads))                # deks = v dctx^T
-            K.gemm(ei, dctx, trans_a=False, trans_b=False, out=_heads_view(dqkv[i, :, 2 * C:], heads))    # dv = eks dctx
+        if b > heads:        # (as in the forward: batch = the images of one head)
+            dctx = torch.empty((b, d, d), dtype=ACT_DTYPE, device=qkv.device)
+            dv = dqkv[..., 2 * C:]
+            for h in range(heads):
+                sl = slice(h * d, (h + 1) * d)
+                K.gemm(qs[..., sl], g[..., sl], trans_a=True, trans_b=False, out=dctx)                     # dctx[d, e] = sum_n qs g
+                K.gemm(g[..., sl], ctx[:, h], trans_a=False, trans_b=True, out=dqs[..., sl])               # dqs = g ctx^T
+                K.gemm(v[..., sl], dctx, trans_a=False, trans_b=True, out=deks[..., sl])                   # deks = v dctx^T
+                K.gemm(eks[..., sl], dctx, trans_a=False, trans_b=False, out=dv[..., sl])                  # dv = eks dctx
+        else:
+            dctx = torch.empty((heads, d, d), dtype=ACT_DTYPE, device=qkv.device)
+            for i in range(b):
+                gi, qi, ei, vi = (_heads_view(t[i], heads) for t in (g, qs, eks, v))
+                K.gemm(qi, gi, trans_a=True, trans_b=False, out=dctx)                                          # dctx[d, e] = sum_n qs g
+                K.gemm(gi, ctx[i], trans_a=False, trans_b=True, out=_heads_view(dqs[i], heads))               # dqs = g ctx^T
+                K.gemm(vi, dctx, trans_a=False, trans_b=True, out=_heads_view(deks[i], heads))                # deks = v dctx^T
+                K.gemm(ei, dctx, trans_a=False, trans_b=False, out=_heads_view(dqkv[i, :, 2 * C:], heads))    # dv = eks dctx
         K.linattn_q_bwd(qs, dqs, dqkv[..., :C], scale)
         K.linattn_k_bwd(eks, deks, dqkv[..., C:2 * C])
         return dqkv, None, None
@@ -1524,6 +1542,11 @@ class HipOps:
         outs = K.modw_multi(layers)
         for (weights, mod, path, b, excited), o in zip(metas, outs):
             _prepared[id(weights)] = dict(o, mod_ptr=mod.data_ptr(), path=path, b=b, excited=excited)
+        # the one-launch layers in the order the forward runs them (`specs` order): each one's launch requests the NEXT one's bank
+        # into the L2 (kernels.aconv `next_bank`) - the banks are the traffic of these layers and are cold once per forward
+        chain = [(sp[0], sp[3]) for sp in specs if id(sp[0]) in _prepared and _prepared[id(sp[0])]['path'] == 'aconv']
+        for (w0, _), (w1, h1) in zip(chain, chain[1:]):
+            _prepared[id(w0)]['next_bank'] = (_frag_weight(w1), _prepared[id(w1)]['b'], h1)
         return len(layers)
 
     def modconv_release(self):
@@ -1571,7 +1594,7 @@ class HipOps:
                     s, a, d = rec['s'], rec['a'], rec['d']
                 xs2 = None if in_excite is None else in_excite.reshape(b, I).detach().float().contiguous()
                 y = K.aconv(nhwc(x), _frag_weight(weights), s, a if N > 1 else None, d if demod else None, O, nz, nw, act,
-                            LRELU_SLOPE, xs=xs2)
+                            LRELU_SLOPE, xs=xs2, next_bank=None if rec is None else rec.get('next_bank'))
                 return nchw(y)
             if path == 'sconv':
                 # narrow high-resolution layers: the reference's per-sample weights (a few KiB each) + the streaming convolution
@@ -1586,6 +1609,12 @@ class HipOps:
                 wm = _wmix_rows(weights, b, O, 9 * I)
                 if rec is None:
                     K.modw_fwd(wd, md, km, demod, eps, Ip, Op, coef=False, wmix=wm, layout=1, xs=xs)
+                if xs_late is not None:
+                    # the excitation folded into the (small) per-sample weights by one element-wise launch instead of riding on the
+                    # convolution's operand staging: conv(x * e, w) = conv(x, w * e); gg_conv3's SCALED form measured 91 us against
+                    # 60 us for the plain one on 128 -> 64 @64x64 (profiles/r05_kernel_stats_a.csv), the pass over 4.7 MB of weights ~5 us
+                    wm = K.modulate(wm.view(b, O, 9, I), xs_late).view(b, O, 9 * I)
+                    xs_late = None
                 y = K.conv2d_nhwc(nhwc(x), wm, ksize=3, in_scale=xs_late, noise=nz, noise_w=nw, act=act, act_slope=LRELU_SLOPE,
                                   per_image_weights=True)
                 return nchw(y)
@@ -1859,7 +1888,8 @@ _ACONV = os.environ.get('GG_ACONV', '1') != '0'      # A/B switch: 0 restores th
 # widest image the one-launch kernel takes: measured (profiles/r5_aconv_probe*.log, batch 32, hipGraph-timed incl. the modulation
 # launch) 28 / 38 / 54+32 / 48+32 us against 63 / 79 / 69+52 / 51+35 us on 4x4 / 8x8 / 16x16 / 32x32, but 68+52 against 53+38 us at
 # 64x64 (1024 small workgroups: four rounds of its fixed cost), which therefore stays on per-sample weights + gg_conv3
-_ACONV_MAXW = int(os.environ.get('GG_ACONV_MAXW', '32'))
+_ACONV_MAXW = 32
+
 _aconv_plans: dict = {}
 
 

@@ -441,7 +441,12 @@ typedef struct gg_aconv_desc {
     int32_t act;            /* 0 none, 1 leaky relu */
     float slope;
     int32_t force_tm, force_nwn;
-    int32_t reserved[2];
+    /* optional: the bank of the NEXT gg_aconv_fwd launch on this stream (fragment order) and that launch's geometry. Wavefronts that
+     * have finished their share of this layer request it while the rest of the workgroup finishes, each XCD the slice its own
+     * workgroups of the next launch will stream - the next layer then finds its weights in the L2 instead of in HBM. Pure hint. */
+    const void* next_wf;
+    int32_t next_b, next_H, next_C, next_O, next_NB;
+    int32_t reserved;
 } gg_aconv_desc;
 int gg_aconv_plan(const gg_aconv_desc* d, int32_t* tm, int32_t* nwn, int32_t* nwk, int32_t* lds_bytes, int32_t* grid);
 int gg_aconv_fwd(const gg_aconv_desc* d, void* stream);

@@ -79,6 +79,14 @@ static inline u16x8 gg_buf_load16(GgBuf r, unsigned voff, unsigned soff) {
     if ((unsigned long long)voff + 16 <= r.bytes) memcpy(&v, r.base + voff + soff, 16);
     return v;
 }
+// (a cache hint on the hardware; here: the touched bytes must lie inside the buffer, so that a wrong range shows up in the CPU suite)
+extern unsigned long long gg_emu_touched_bytes;
+static inline void gg_buf_touch16(GgBuf r, unsigned voff) {
+    if ((unsigned long long)voff + 16 > r.bytes) __builtin_trap();
+    volatile char c = r.base[voff + 15];
+    (void)c;
+    gg_emu_touched_bytes += 16;
+}
 static inline void gg_buf_load_lds16(GgBuf r, unsigned voff, unsigned soff, void* lds_wave_base) {
     static const char zeros[16] = {0};
     const void* src = ((unsigned long long)voff + 16 <= r.bytes) ? (const void*)(r.base + voff + soff) : (const void*)zeros;

@@ -201,3 +201,6 @@ void gg_emu_launch(dim3 grid, dim3 block, const std::function<void()>& body) {
             }
     g_body = nullptr;
 }
+
+unsigned long long gg_emu_touched_bytes = 0;
+extern "C" unsigned long long gg_emu_touched(void) { unsigned long long v = gg_emu_touched_bytes; gg_emu_touched_bytes = 0; return v; }

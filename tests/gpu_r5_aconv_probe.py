@@ -91,6 +91,13 @@ def main():
             print(f'   {I}->{O}@{R} tm{pl[0]} n{pl[1]}: {us:.1f} us err {err:.2e}', flush=True)
             tag = 'plan' if (tm, nwn) == (0, 0) else ''
             row.append(f'{tag}(tm{pl[0]} n{pl[1]} k{pl[2]} lds{pl[3] >> 10}K g{pl[4]}): {us:6.1f} us {flops / us / 1e6:5.0f} TF' + ('' if err < 5e-3 else f' ERR {err:.1e}'))
+        if '--phases' in sys.argv:       # where a launch's time goes: phases switched off one at a time (results meaningless)
+            for dbg, what in ((1, 'no reduction loop'), (2, 'no halo staging'), (3, 'neither'), (0, 'no noise / demod / act operands')):
+                if dbg:
+                    fn = lambda: K.aconv(x, wf, s, a, d, O, nz, nw, 'lrelu', _dbg=dbg)
+                else:
+                    fn = lambda: K.aconv(x, wf, s, a, None, O, None, None, None)
+                row.append(f'[{what}: {time_us(fn):6.1f} us]')
         # the same layer through ops.modconv2d: new path (modulation launch + gg_aconv) and the round-3/4 kernels
         conv = AdaptiveConv2DMod(I, O, 3, num_conv_kernels=2).to(dev)
         xc = x.permute(0, 3, 1, 2)

@@ -307,6 +307,10 @@ def check_general_attention(cfg, device):
         for i in range(B):
             km[i, max(2, m - 5 - 11 * i):] = False        # (at least two keys stay: a fully masked row is uniform attention in the
                                                           # reference and zeros here - captions always hold a token)
+        if mask == 2:       # LEADING masked keys as well (without a null token the online softmax is seeded from key 0's score: the
+            for i in range(B):                            # seed must not leak into the result when that key is masked; gp.py:645-647)
+                km[i, :1 + i % 3] = False
+                km[i, 3] = True
     probe = torch.randn(B, h, n, 64).to(device)
 
     def reference():

@@ -1321,12 +1321,15 @@ def test_generator_parameter_gradients_through_the_discriminator_vs_oracle():
     assert rel_err(ga, gb) < 5e-2, rel_err(ga, gb)
 
 
-def test_fused_linear_attention_on_qkv_slices_vs_oracle():
+@pytest.mark.parametrize('shape', [(2, 2, 8, 16), (3, 2, 8, 8)])
+def test_fused_linear_attention_on_qkv_slices_vs_oracle(shape):
     """LinearAttnFn (gg_linattn_q / _k softmax passes + strided head-view GEMMs on the fused to_qkv tensor) vs the oracle's
-    einsum formulation (unet.py:338-348): output and the gradient w.r.t. the fused qkv tensor."""
+    einsum formulation (unet.py:338-348): output and the gradient w.r.t. the fused qkv tensor; batched over the heads of one image
+    (b <= heads) and over the images of one head (b > heads: the upsampler's batch 16 x 8 heads)."""
     torch.manual_seed(0)
     H_, O_ = ops.HipOps(), OracleOps(bf16_operands=True)
-    b, heads, d, x, y = 2, 2, 64, 8, 16
+    b, heads, x, y = shape
+    d = 64
     c = heads * d
     qkv0 = bf(torch.randn(b, 3 * c, x, y) * 1.5).float()
     w = torch.randn(b, c, x, y)
@@ -1421,7 +1424,7 @@ def test_maxpool_highfreq_kernels_vs_torch(shape):
 
 
 @pytest.mark.parametrize('cfg', [(2, 2, 64, 64, False, False, True), (1, 2, 200, 77, False, True, False), (2, 1, 78, 78, True, True, False),
-                                 (1, 1, 130, 130, False, False, True)])
+                                 (1, 1, 130, 130, False, False, True), (3, 1, 96, 77, False, 2, False), (3, 1, 70, 40, True, 2, False)])
 def test_general_fused_attention_forward_backward_vs_autograd(cfg):
     from helpers import check_general_attention
     check_general_attention(cfg, 'cpu')
@@ -1755,3 +1758,34 @@ def test_no_grad_adaptive_conv_takes_the_one_launch_kernel_where_it_can():
                     y0 = conv(x, mod, km, noise=nz, noise_weight=nw, act='lrelu', in_excite=excite)
             assert rel_err(y1, y0) < 1e-2, (I, O, R, excite is not None, rel_err(y1, y0))
     assert ops.HipOps._modconv_path(32, 2, 32, 64, 128, 128) == 'sconv'
+
+
+def test_aconv_requests_exactly_the_next_banks_bytes():
+    """the next-bank hint: every XCD's workgroups together touch exactly the byte range that XCD's workgroups of the NEXT launch will
+    stream (the emulator traps on a touch outside the bank and counts the bytes), and the result of the launch itself is unchanged."""
+    torch.manual_seed(0)
+    lib = _C.lib().lib
+    lib.gg_emu_touched.restype = ctypes.c_ulonglong
+    b, R, Cc, O = 4, 8, 32, 64
+    x = bf(torch.randn(b, R, R, Cc))
+    W = torch.randn(2, O, Cc, 3, 3) * 0.2
+    s, a, d = torch.rand(b, Cc) + 0.5, torch.softmax(torch.randn(b, 2), -1), torch.rand(b, O) + 0.5
+    wf = K.frag_pack(W)
+    y0 = K.aconv(x, wf, s, a, d, O)
+    lib.gg_emu_touched()
+    for nb, nR, nC, nO in ((4, 8, 64, 256), (4, 16, 32, 128), (8, 4, 32, 512)):
+        nwf = K.frag_pack(torch.randn(2, nO, nC, 3, 3))
+        y1 = K.aconv(x, wf, s, a, d, O, next_bank=(nwf, nb, nR))
+        assert torch.equal(y0, y1)
+        tm, nwn, nwk, lds, grid = K.aconv_plan(nb, nR, nR, nC, nO, 2)
+        mt = grid // (nO // (32 * nwn))
+        tn_bytes = nwn * 2 * 9 * (nC // 16) * 1024
+        want = 0
+        for xcd in range(8):
+            q, r = grid >> 3, grid & 7
+            lo = xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q
+            cnt = q + (1 if xcd < r else 0)
+            if cnt:
+                want += min(((lo + cnt - 1) // mt + 1) * tn_bytes, nwf.numel() * 2) - (lo // mt) * tn_bytes
+        got = lib.gg_emu_touched()
+        assert got == want and got >= nwf.numel() * 2, (got, want, nwf.numel() * 2)

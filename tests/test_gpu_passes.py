@@ -415,3 +415,42 @@ def test_training_steps_never_read_uninitialised_memory():
         torch.use_deterministic_algorithms(prev[0], warn_only=prev[1])
         torch.utils.deterministic.fill_uninitialized_memory = prev[2]
         torch.cuda.empty_cache()
+
+
+def test_hinge_ticket_on_64_workgroups_is_deterministic_over_a_thousand_launches():
+    """gg_hinge's forward adds its per-workgroup partial sums in slot order by the LAST workgroup to arrive (a ticket taken with
+    release / acquire fences, put back to zero by its taker). The fiber emulator cannot expose a memory-ordering bug, so here: 64
+    workgroups x 1000 eager launches and 200 replays of a hipGraph holding 5 launches - every result bit-identical to the first and
+    equal to the fp32 formula (gp.py:157-163); both modes; a second stream gets its own scratch."""
+    from gigagan_pytorch_amd import kernels as K
+    d = dev()
+    torch.manual_seed(0)
+    x = torch.randn(4, 64, 8192, device=d).to(torch.bfloat16)          # 2 M elements: 64 workgroups (GG_HINGE_MAXB)
+    xf = x.float()
+    want = {0: xf.mean(), 1: (torch.relu(1 + xf[:, 32:]) + torch.relu(1 - xf[:, :32])).mean()}
+    for mode, split in ((0, 0), (1, 32)):
+        first = K.hinge(x, 64, split, mode)
+        vals = torch.stack([K.hinge(x, 64, split, mode) for _ in range(1000)])
+        torch.cuda.synchronize()
+        assert bool((vals == first).all()), (mode, vals.unique())
+        assert abs(float(first) - float(want[mode])) < 2e-5 * max(1.0, abs(float(want[mode]))), (mode, float(first), float(want[mode]))
+        # captured: five launches per graph, replayed back to back (the graphs share the device's capture scratch)
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                outs = [K.hinge(x, 64, split, mode) for _ in range(5)]
+        torch.cuda.current_stream().wait_stream(side)
+        for _ in range(200):
+            g.replay()
+            for o in outs:
+                assert bool(o == first), (mode, float(o), float(first))
+    # an eager launch on another stream does not share the first stream's ticket
+    s2 = torch.cuda.Stream()
+    s2.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s2):
+        other = K.hinge(x, 64, 0, 0)
+    s2.synchronize()
+    assert bool(other == K.hinge(x, 64, 0, 0))
+    assert len([k for k in K._hinge_scratch if k[0] == x.device and k[1] != 'capture']) >= 2

@@ -534,10 +534,12 @@ def test_fused_adaptive_conv_coefficients_match_tensor_algebra(cfg):
 
 
 @pytest.mark.parametrize('cfg', [(16, 8, 256, 256, False, False, True), (16, 8, 64, 64, False, False, True), (16, 8, 1024, 77, False, True, False),
-                                 (16, 8, 78, 78, True, True, False), (3, 2, 130, 50, True, False, False)])
+                                 (16, 8, 78, 78, True, True, False), (3, 2, 130, 50, True, False, False),
+                                 (6, 8, 1024, 77, False, 2, False), (6, 2, 96, 77, True, 2, False)])
 def test_general_fused_attention_on_gpu(cfg):
     """gg_attn_gen_* at the shapes configs 4 / 5 run: the unet's Attend at 16x16 and 8x8 (8 heads of 64 on slices of to_qkv), the
     generator's cross attention at 32x32 over 77 masked text tokens, the text transformer's attention (78 tokens, null key, mask),
-    and a ragged case - forward and backward against fp32 autograd."""
+    a ragged case, and key masks that switch off the LEADING keys (with and without a null token) - forward and backward against
+    fp32 autograd of the reference's masked_fill formulation (gp.py:645-647)."""
     from helpers import check_general_attention
     check_general_attention(cfg, dev())
