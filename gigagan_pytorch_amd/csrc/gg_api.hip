@@ -8,6 +8,7 @@
 #include "gg_wgrad9.h"
 #include "gg_wgrads.h"
 #include "gg_sfwd.h"
+#include "gg_pgemm.h"
 #include "gg_elementwise.h"
 #include "gg_modconv.h"
 #include "gg_attention.h"
@@ -366,6 +367,8 @@ static std::string gg_plan_key_of(const gg_gemm_desc* d) {
     return gg_plan_key(f);
 }
 
+static bool gg_pgemm_eligible(const gg_gemm_desc* d);
+static GemmPlan gg_pgemm_plan(const gg_gemm_desc* d);
 static bool gg_table_plan(const gg_gemm_desc* d, GemmPlan& pl) {
     if (g_plan_table.empty() || d->force_tile != 0 || d->force_splitk != 0 || d->b_image_stride || d->bank_mix) return false;
     auto it = g_plan_table.find(gg_plan_key_of(d));
@@ -385,6 +388,11 @@ static bool gg_table_plan(const gg_gemm_desc* d, GemmPlan& pl) {
     if (tile == 14) {
         if (!gg_sfwd_eligible(d)) return false;
         pl = gg_sfwd_plan(d);
+        return true;
+    }
+    if (tile == 15) {
+        if (!gg_pgemm_eligible(d)) return false;
+        pl = gg_pgemm_plan(d);
         return true;
     }
     if (tile == 13) {
@@ -727,6 +735,58 @@ static GemmPlan gg_sfwd_substitute(const gg_gemm_desc* d, const GemmPlan& pl) {
     return gg_sfwd_plan(d);
 }
 
+// the persistent short-K contraction (gg_pgemm.h, plan tile 15): row-major A (dense, or a 1x1 / stride 1 convolution gather, which is
+// the same addressing) times row-major B into a bf16 [M][N] output through the staged epilogue (alpha, bias, activation, residual,
+// GELU aux modes). GG_PGEMM=0 disables the substitution (A/B runs); force_tile 15 selects it wherever eligible.
+static int gg_pgemm_policy() {
+    static int policy = -1;
+    if (policy < 0) {
+        const char* e = getenv("GG_PGEMM");
+        policy = e ? atoi(e) : 1;
+        if (policy < 0) policy = 1;
+    }
+    return policy;
+}
+
+static bool gg_pgemm_eligible(const gg_gemm_desc* d) {
+    if (d->a_layout != GG_ROWK || d->b_layout != GG_ROWK || d->batch != 1) return false;
+    if (d->a_conv) {
+        if (d->R != 1 || d->S != 1 || d->conv_stride != 1 || d->conv_pad != 0 || d->CV != d->C || d->K != d->C) return false;
+        if (d->in_scale || d->b_image_stride) return false;
+    }
+    if (d->bank_mix || d->d2s || d->c_is_f32 || d->keep_partials || d->out_scale || d->noise) return false;
+    if ((d->K & 63) || d->K < 64 || (d->N & 7) || (d->ldc & 7) || (d->ldb & 7)) return false;
+    const int pitch = d->a_conv ? d->C : d->lda;
+    if (pitch & 7) return false;
+    if ((((uintptr_t)d->A) | ((uintptr_t)d->B) | ((uintptr_t)d->C_out)) & 15) return false;
+    if (d->residual && d->gelu_mode == 2) return false;     // (one pre-loaded epilogue operand per tile)
+    if (d->residual && ((d->ldr & 7) || (((uintptr_t)d->residual) & 15))) return false;
+    if (d->gelu_mode && ((d->ld_aux & 7) || (((uintptr_t)d->gelu_aux) & 15))) return false;
+    if (d->bias && (((uintptr_t)d->bias) & 15)) return false;
+    if (gg_a_bytes(d) >= (1ll << 32) || gg_b_bytes(d) >= (1ll << 32)) return false;
+    return true;
+}
+
+static GemmPlan gg_pgemm_plan(const gg_gemm_desc* d) {
+    GemmPlan pl;
+    pl.tile = 15; pl.bm = 128; pl.bn = 128; pl.splitk = 1; pl.k_per_split = d->K;
+    const long long tiles = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128);
+    long long wgs = 256;                                 // one 150 KB workgroup per CU, a contiguous run of tiles each
+    if (const char* e = getenv("GG_PGEMM_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;     // (tests: runs of several tiles on small problems)
+    pl.blocks_mn = tiles < wgs ? tiles : wgs;
+    return pl;
+}
+
+static GemmPlan gg_pgemm_substitute(const gg_gemm_desc* d, const GemmPlan& pl) {
+    if (pl.tile < 4 || pl.tile > 6 || pl.splitk != 1 || d->force_tile != 0 || d->force_splitk != 0 || !gg_pgemm_policy()) return pl;
+    if (d->M < 32768 || d->K > 1024 || !gg_pgemm_eligible(d)) return pl;
+    // measured (profiles/r05_pgemm_probe_v2.log): 1.07-1.69x on launches that carry a bias / residual / GELU epilogue and on K <= 256;
+    // the plain alpha-only launches of K >= 512 stay on the 256 x 256 tile (0.86-0.99x)
+    const bool full = d->bias || d->residual || d->act != GG_ACT_NONE || d->gelu_mode;
+    if (!full && d->K > 256) return pl;
+    return gg_pgemm_plan(d);
+}
+
 static GemmPlan gg_wgrads_substitute(const gg_gemm_desc* d, const GemmPlan& pl) {
     if (pl.tile < 1 || pl.tile > 3 || d->force_tile != 0 || d->force_splitk != 0 || !gg_wgrads_policy()) return pl;
     if (d->K < 65536 || !gg_wgrads_eligible(d)) return pl;
@@ -776,7 +836,8 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     if (d->force_tile == 11 && gg_lrconv_eligible(d)) return gg_lrconv_plan(d, d->force_splitk);
     if (d->force_tile == 13 && gg_wgrads_eligible(d)) return gg_wgrads_plan(d, d->force_splitk);
     if (d->force_tile == 14 && gg_sfwd_eligible(d)) return gg_sfwd_plan(d);
-    if (gg_table_plan(d, pl)) return gg_sfwd_substitute(d, gg_wgrads_substitute(d, gg_wgrad9_substitute(d, gg_conv3_substitute(d, pl, false))));
+    if (d->force_tile == 15 && gg_pgemm_eligible(d)) return gg_pgemm_plan(d);
+    if (gg_table_plan(d, pl)) return gg_pgemm_substitute(d, gg_sfwd_substitute(d, gg_wgrads_substitute(d, gg_wgrad9_substitute(d, gg_conv3_substitute(d, pl, false)))));
     if (gg_use_lrconv(d)) return gg_lrconv_plan(d, d->force_splitk);
     if (gg_use_dconv(d)) {
         pl.tile = 9; pl.bm = GG_DC_TH * GG_DC_TW; pl.bn = d->N <= 32 ? 32 : 64;
@@ -827,7 +888,7 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     const int per = (ktiles + pl.splitk - 1) / pl.splitk;
     pl.splitk = (ktiles + per - 1) / per;
     pl.k_per_split = per * tm.bk;
-    return gg_sfwd_substitute(d, gg_wgrads_substitute(d, gg_wgrad9_substitute(d, gg_conv3_substitute(d, pl, true))));
+    return gg_pgemm_substitute(d, gg_sfwd_substitute(d, gg_wgrads_substitute(d, gg_wgrad9_substitute(d, gg_conv3_substitute(d, pl, true)))));
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -892,7 +953,7 @@ extern "C" int gg_gemm_plan_table(const gg_plan_entry* entries, int32_t n) {
     g_plan_table.clear();
     for (int i = 0; i < n; ++i) {
         const gg_plan_entry& e = entries[i];
-        if (e.tile < 1 || e.tile > 14 || e.splitk < 1) return gg_fail(-2, "gg_gemm_plan_table: entry %d has tile %d split-K %d", i, e.tile, e.splitk);
+        if (e.tile < 1 || e.tile > 15 || e.splitk < 1) return gg_fail(-2, "gg_gemm_plan_table: entry %d has tile %d split-K %d", i, e.tile, e.splitk);
         g_plan_table[gg_plan_key(&e.M)] = GgPlanChoice{e.tile, e.splitk};
     }
     return 0;
@@ -950,7 +1011,7 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     p.d2s = d->d2s; p.d2s_t = d->d2s_taps; p.d2s_c = d->d2s_c; p.d2s_oh = d->d2s_oh; p.d2s_ow = d->d2s_ow;
     p.noise = d->noise; p.noise_w = d->noise_w;
     p.act = d->act; p.act_slope = d->act_slope;
-    if (d->gelu_mode && !(pl.tile >= 4 && pl.tile <= 6 && pl.splitk == 1))
+    if (d->gelu_mode && !(((pl.tile >= 4 && pl.tile <= 6) || pl.tile == 15) && pl.splitk == 1))
         return gg_fail(-18, "gg_gemm: gelu_mode runs on the 8-wave tiles' staged epilogue only (planned tile %d, split-K %d)", pl.tile, pl.splitk);
     p.aux = (bf16_t*)d->gelu_aux; p.aux_mode = d->gelu_mode; p.ld_aux = d->ld_aux;
     p.partial = (float*)workspace;
@@ -993,6 +1054,13 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
         else if (ck == 2) GG_SF(2);
         else GG_SF(4);
 #undef GG_SF
+    }
+    else if (pl.tile == 15) {
+        if (d->a_conv) p.lda = d->C;                // (a 1x1 / stride 1 gather reads pixel rows of C channels)
+        if (const char* e = getenv("GG_PGEMM_DBG")) p.xcd_slices = atoi(e);      // (probe runs: phases switched off, results are garbage)
+        const bool full = p.bias || p.act != GG_ACT_NONE;
+        if (full) GG_LAUNCH((gg_pgemm_kernel<true>), grid2, dim3(GG_PG_NT), s, p);
+        else GG_LAUNCH((gg_pgemm_kernel<false>), grid2, dim3(GG_PG_NT), s, p);
     }
     else if (pl.tile == 13) {
         GgWsMode m;

@@ -82,8 +82,8 @@ GG_DEVICE u16x4 gg_lds_read_tr16(const bf16_t* p) {
 
 template <int N>
 GG_DEVICE void gg_wait_vm() {           // s_waitcnt vmcnt(N): at most N vector-memory operations of this wave outstanding
-    static_assert(N == 0, "add the literal");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_assert(N >= 0 && N < 64, "six counter bits");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // s_waitcnt vmcnt(n) for a WAVE-UNIFORM run-time n (the immediate must be a literal: a scalar jump over the literals a streaming
@@ -163,6 +163,9 @@ GG_DEVICE void gg_bufs_load_lds16(GgBufS r, unsigned voff, unsigned soff, void* 
 // in order, so nothing is emitted - the builtin only pins the compiler's schedule; the emulator, whose lanes are independent fibers,
 // makes it a wave rendezvous
 GG_DEVICE void gg_wave_sync() { __builtin_amdgcn_wave_barrier(); }
+// a loaded value declared complete HERE: the empty statement reads the register, so hipcc places the load's s_waitcnt in front of it,
+// and redefines it, so that no later use carries a pending-load state across stores and branches (gg_pgemm.h)
+GG_DEVICE void gg_settle(u16x8& v) { asm volatile("" : "+v"(v)); }
 // a value the program knows to be wave-uniform, moved to a scalar register (loop bounds, LDS bases, branch conditions derived from the
 // wave index would otherwise live in vector registers: divergent-loop code, waterfall loops around scalar operands)
 GG_DEVICE int gg_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }

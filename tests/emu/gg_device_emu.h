@@ -95,6 +95,7 @@ static inline void gg_buf_load_lds16(GgBuf r, unsigned voff, unsigned soff, void
 typedef GgBuf GgBufS;
 static inline GgBufS gg_make_bufs(const void* base, unsigned long long bytes) { return gg_make_buf(base, bytes); }
 static inline void gg_bufs_load_lds16(GgBufS r, unsigned voff, unsigned soff, void* lds_wave_base) { gg_buf_load_lds16(r, voff, soff, lds_wave_base); }
+static inline void gg_settle(u16x8&) {}
 static inline int gg_uniform(int v) { return v; }
 static inline void gg_wave_sync() { (void)gg_emu_shfl(0.f, (int)(threadIdx.x & 63u)); }      // a wave collective: every lane arrives before any leaves
 template <typename T>

@@ -1789,3 +1789,93 @@ def test_aconv_requests_exactly_the_next_banks_bytes():
                 want += min(((lo + cnt - 1) // mt + 1) * tn_bytes, nwf.numel() * 2) - (lo // mt) * tn_bytes
         got = lib.gg_emu_touched()
         assert got == want and got >= nwf.numel() * 2, (got, want, nwf.numel() * 2)
+
+
+# ---- gg_pgemm.h: the persistent short-K contraction (plan tile 15) --------------------------------------------------------------
+
+@pytest.fixture
+def pgemm_wgs(monkeypatch):
+    def set_wgs(n):
+        monkeypatch.setenv('GG_PGEMM_WGS', str(n))
+    return set_wgs
+
+
+@pytest.mark.parametrize('cfg', [
+    # (n, H, W, C = K, N, workgroups, bias, act, residual)
+    (2, 12, 12, 128, 192, 2, True, 'lrelu', True),      # M = 288: a ragged last row tile, a ragged column tile, runs of 3 tiles
+    (1, 16, 16, 64, 128, 1, False, None, False),        # K = 64: one stage per tile, the ring runs three tiles ahead
+    (1, 16, 24, 256, 136, 3, True, None, True),         # four stages per tile, N = 136 (a column tile of 8)
+    (1, 16, 16, 320, 128, 1, True, 'gelu', False),      # five stages per tile: the ring wraps inside a tile
+])
+def test_persistent_short_k_contraction_is_bit_identical_to_the_tiled_kernel(cfg, pgemm_wgs):
+    """gg_pgemm_kernel (plan tile 15) against gg_gemm2_kernel<128,128> (tile 6) on 1x1 convolutions: same k order, same rounding
+    points, same epilogue arithmetic -> the same bits; and against fp32 math. Runs of several tiles per workgroup (GG_PGEMM_WGS)
+    exercise the cross-tile prefetch, the bias slots and the ring wrap."""
+    n, H, W, Cc, N, wgs, with_bias, act, with_res = cfg
+    pgemm_wgs(wgs)
+    torch.manual_seed(0)
+    x = torch.randn(n, H, W, Cc).bfloat16()
+    w = (torch.randn(N, Cc) / Cc ** 0.5).bfloat16()
+    bias = torch.randn(N) if with_bias else None
+    res = torch.randn(n, H, W, N).bfloat16() if with_res else None
+    kw = dict(ksize=1, pad=0, alpha=0.7, bias=bias, bias_scale=0.5, act=act, residual=res, res_scale=0.25)
+    assert K.conv2d_nhwc(x, w, force_tile=15, plan_only=True, **kw) == (15, 1)
+    y15 = K.conv2d_nhwc(x, w, force_tile=15, **kw)
+    y6 = K.conv2d_nhwc(x, w, force_tile=6, **kw)
+    assert torch.equal(y15, y6), float((y15.float() - y6.float()).abs().max())
+    ref = 0.7 * torch.einsum('nhwc,oc->nhwo', x.float(), w.float())
+    if with_bias:
+        ref = ref + 0.5 * bias
+    if act == 'lrelu':
+        ref = F.leaky_relu(ref, 0.2)
+    elif act == 'gelu':
+        ref = F.gelu(ref)
+    if with_res:
+        ref = ref.bfloat16().float() + 0.25 * res.float()
+    assert rel_err(y15, ref) < 6e-3
+
+
+def test_persistent_short_k_contraction_gelu_aux_modes_and_dense_operands(pgemm_wgs):
+    """the FeedForward epilogues (gelu_mode 1: h to aux, gelu(h) out; gelu_mode 2: out = staged * gelu'(aux)) and a dense row-major
+    A with a row pitch larger than K, both bit-identical to tile 6."""
+    pgemm_wgs(2)
+    torch.manual_seed(1)
+    x = torch.randn(1, 16, 20, 128).bfloat16()
+    w = (torch.randn(256, 128) / 128 ** 0.5).bfloat16()
+    bias = torch.randn(256)
+    out = {}
+    for tile in (15, 6):
+        aux = torch.zeros(1, 16, 20, 256).bfloat16()
+        y = K.conv2d_nhwc(x, w, ksize=1, pad=0, bias=bias, gelu_aux=aux, gelu_mode=1, force_tile=tile)
+        g = torch.randn(1, 16, 20, 128, generator=torch.Generator().manual_seed(2)).bfloat16()
+        wt = (torch.randn(256, 128, generator=torch.Generator().manual_seed(3)) / 128 ** 0.5).bfloat16()
+        if tile == 15:
+            assert K.conv2d_nhwc(g, wt, ksize=1, pad=0, gelu_aux=aux, gelu_mode=2, force_tile=15, plan_only=True) == (15, 1)
+        dy = K.conv2d_nhwc(g, wt, ksize=1, pad=0, gelu_aux=aux, gelu_mode=2, force_tile=tile)
+        out[tile] = (y, aux, dy)
+    for a, b in zip(out[15], out[6]):
+        assert torch.equal(a, b)
+    y, aux, _ = out[15]
+    h = torch.einsum('nhwc,oc->nhwo', x.float(), w.float()) + bias
+    assert rel_err(aux, h) < 6e-3 and rel_err(y, F.gelu(aux.float())) < 6e-3
+
+    a = torch.randn(320, 200).bfloat16()[:, :192]        # (row pitch 200 elements)
+    b = (torch.randn(128, 192) / 192 ** 0.5).bfloat16()
+    c15 = K.gemm(a, b, force_tile=15, alpha=1.5)
+    c6 = K.gemm(a, b, force_tile=6, alpha=1.5)
+    assert torch.equal(c15, c6)
+    assert rel_err(c15[0], 1.5 * a.float() @ b.float().t()) < 6e-3
+
+
+def test_persistent_short_k_contraction_is_the_planned_kernel_for_large_short_k_launches():
+    """planner: an eligible row-major launch of >= 32K rows and K <= 1024 that the 8-wave tiles would take runs on tile 15; launches
+    it cannot express (an input scale, a 3x3 window, fp32 output) keep their kernels."""
+    x = torch.zeros(32, 32, 32, 256).bfloat16()
+    w = torch.zeros(512, 256).bfloat16()
+    assert K.conv2d_nhwc(x, w, ksize=1, pad=0, plan_only=True) == (15, 1)
+    assert K.conv2d_nhwc(x, w, ksize=1, pad=0, in_scale=torch.ones(32, 256), plan_only=True)[0] != 15
+    assert K.conv2d_nhwc(x, w, ksize=1, pad=0, out_dtype=torch.float32, plan_only=True)[0] != 15
+    w3 = torch.zeros(512, 9 * 256).bfloat16()
+    assert K.conv2d_nhwc(x, w3, ksize=3, plan_only=True)[0] != 15
+    xs = torch.zeros(2, 32, 32, 256).bfloat16()
+    assert K.conv2d_nhwc(xs, w, ksize=1, pad=0, plan_only=True)[0] != 15          # 2048 rows: the tiled kernels
