@@ -56,7 +56,7 @@ class PlanEntry(C.Structure):        # mirrors gg_plan_entry
     _fields_ = [(f, C.c_int32) for f in FIELDS]
 
 
-PLAN_TABLE = _HERE / 'plans' / 'gfx950.json'
+PLAN_TABLE = Path(os.environ.get('GG_PLAN_TABLE') or _HERE / 'plans' / 'gfx950.json')      # (GG_PLAN_TABLE: A/B runs against another tuning cache)
 
 
 class Library:

@@ -367,6 +367,7 @@ static std::string gg_plan_key_of(const gg_gemm_desc* d) {
     return gg_plan_key(f);
 }
 
+static int gg_pgemm_policy();
 static bool gg_pgemm_eligible(const gg_gemm_desc* d);
 static GemmPlan gg_pgemm_plan(const gg_gemm_desc* d);
 static bool gg_table_plan(const gg_gemm_desc* d, GemmPlan& pl) {
@@ -391,7 +392,7 @@ static bool gg_table_plan(const gg_gemm_desc* d, GemmPlan& pl) {
         return true;
     }
     if (tile == 15) {
-        if (!gg_pgemm_eligible(d)) return false;
+        if (!gg_pgemm_policy() || !gg_pgemm_eligible(d)) return false;
         pl = gg_pgemm_plan(d);
         return true;
     }
@@ -779,9 +780,9 @@ static GemmPlan gg_pgemm_plan(const gg_gemm_desc* d) {
 
 static GemmPlan gg_pgemm_substitute(const gg_gemm_desc* d, const GemmPlan& pl) {
     if (pl.tile < 4 || pl.tile > 6 || pl.splitk != 1 || d->force_tile != 0 || d->force_splitk != 0 || !gg_pgemm_policy()) return pl;
-    if (d->M < 32768 || d->K > 1024 || !gg_pgemm_eligible(d)) return pl;
-    // measured (profiles/r05_pgemm_probe_v2.log): 1.07-1.69x on launches that carry a bias / residual / GELU epilogue and on K <= 256;
-    // the plain alpha-only launches of K >= 512 stay on the 256 x 256 tile (0.86-0.99x)
+    if (d->M < 8192 || d->K > 1024 || !gg_pgemm_eligible(d)) return pl;
+    // measured (profiles/r05_pgemm_probe_v2.log, r05_plan_sweep_pgemm.log): 1.07-1.69x on launches that carry a bias / residual / GELU
+    // epilogue and on K <= 256, down to 8192 rows; the plain alpha-only launches of K >= 512 stay on the 256 x 256 tile (0.86-0.99x)
     const bool full = d->bias || d->residual || d->act != GG_ACT_NONE || d->gelu_mode;
     if (!full && d->K > 256) return pl;
     return gg_pgemm_plan(d);
@@ -837,7 +838,8 @@ GemmPlan gg_plan_gemm(const gg_gemm_desc* d) {
     if (d->force_tile == 13 && gg_wgrads_eligible(d)) return gg_wgrads_plan(d, d->force_splitk);
     if (d->force_tile == 14 && gg_sfwd_eligible(d)) return gg_sfwd_plan(d);
     if (d->force_tile == 15 && gg_pgemm_eligible(d)) return gg_pgemm_plan(d);
-    if (gg_table_plan(d, pl)) return gg_pgemm_substitute(d, gg_sfwd_substitute(d, gg_wgrads_substitute(d, gg_wgrad9_substitute(d, gg_conv3_substitute(d, pl, false)))));
+    // (a measured plan is final as far as tile 15 goes: the sweep timed it against the table's choice, tests/gpu_plan_sweep.py --tiles 15)
+    if (gg_table_plan(d, pl)) return gg_sfwd_substitute(d, gg_wgrads_substitute(d, gg_wgrad9_substitute(d, gg_conv3_substitute(d, pl, false))));
     if (gg_use_lrconv(d)) return gg_lrconv_plan(d, d->force_splitk);
     if (gg_use_dconv(d)) {
         pl.tile = 9; pl.bm = GG_DC_TH * GG_DC_TW; pl.bn = d->N <= 32 ? 32 : 64;

@@ -163,6 +163,9 @@ GG_DEVICE void gg_bufs_load_lds16(GgBufS r, unsigned voff, unsigned soff, void* 
 // in order, so nothing is emitted - the builtin only pins the compiler's schedule; the emulator, whose lanes are independent fibers,
 // makes it a wave rendezvous
 GG_DEVICE void gg_wave_sync() { __builtin_amdgcn_wave_barrier(); }
+// a 16-byte store marked non-temporal (global_store_dwordx4 ... nt): a streamed output row does not displace the operand tiles that the
+// same workgroups keep re-reading from this XCD's L2 (gg_pgemm.h)
+GG_DEVICE void gg_store_nt16(void* p, u16x8 v) { __builtin_nontemporal_store(v, (u16x8*)p); }
 // a loaded value declared complete HERE: the empty statement reads the register, so hipcc places the load's s_waitcnt in front of it,
 // and redefines it, so that no later use carries a pending-load state across stores and branches (gg_pgemm.h)
 GG_DEVICE void gg_settle(u16x8& v) { asm volatile("" : "+v"(v)); }

@@ -695,6 +695,8 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_gemm2_kernel(GgGemmParams p) {
 // stored as 128-byte rows with its eight 16-byte chunks XOR-swizzled: chunk c of row r sits in slot c ^ ((r >> 1) & 7). The
 // fragment reads (32 rows x one chunk per half wave) are conflict-free under the ds_read_b128 lane grouping: rows two apart share
 // banks and get different slots.
+// (Non-temporal stores in gg2_stage_writeback_v - every staged epilogue of gg_gemm2 / gg_conv3 - measured 402.3 / 401.3 -> 401.7 img/s on the
+// step, profiles/r05_nt_wb_ab.log: neutral, not kept; gg_pgemm.h keeps them, -4 % on its own launches.)
 // (A whole-kernel variant of gg_gemm2_kernel staged this way — no staging registers, no ds_write phase — measured within +-2 % of
 // the register-staged kernel on every config-2 layer and 0.0 % on the step, profiles/r02_dma_ab_{off,on}.log: the 256x256 tile is
 // fed at the L2's delivery rate either way. It was deleted; gg_conv3.h attacks the bytes instead.)

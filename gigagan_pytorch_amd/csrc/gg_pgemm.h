@@ -44,7 +44,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_PG_NT) void gg_pgemm_kernel(GgGemmParams p) {
     const int t0 = (int)(wg * T / nwg), t1 = (int)((wg + 1) * T / nwg);
     const int KT = p.K >> 6;
     const int Q = (t1 - t0) * KT;
-    const int dbg = p.xcd_slices;       // probe runs (GG_PGEMM_DBG, tests/gpu_r5_pgemm_probe.py): 1 no MFMAs, 2 no epilogue, 4 no transfers; 0 in the product
+    const int dbg = p.xcd_slices;       // probe runs (GG_PGEMM_DBG, tests/gpu_r5_pgemm_probe.py): 1 no MFMAs, 2 no epilogue, 4 no transfers, 8 no stores; 0 in the product
 
     if (wave >= 8) {
         // ---------------------------------------------------------------- loaders
@@ -197,9 +197,9 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_PG_NT) void gg_pgemm_kernel(GgGemmParams p) {
                 const int row = it * 16 + rr, m = m_wave + i * 32 + row;
                 const u16x4 lo = *(const u16x4*)(stage + row * GG_PG_SP + qc * 16), hh = *(const u16x4*)(stage + row * GG_PG_SP + qc * 16 + 8);
                 u16x8 o = {lo[0], lo[1], lo[2], lo[3], hh[0], hh[1], hh[2], hh[3]};
-                if (inner || (m < p.M && n < p.N)) {
+                if ((inner || (m < p.M && n < p.N)) && !(dbg & 8)) {
                     if (aux1) {                   // FeedForward up-projection: keep the pre-activation, emit gelu of its bf16 value
-                        *(u16x8*)(p.aux + (long long)m * p.ld_aux + n) = o;
+                        gg_store_nt16(p.aux + (long long)m * p.ld_aux + n, o);
 #pragma unroll
                         for (int q = 0; q < 8; ++q) o[q] = gg_f2bf(gg_gelu_f(gg_bf2f(o[q])));
                     } else if (aux2) {            // data gradient of the down-projection: times gelu'(h) = Phi(h) + h phi(h)
@@ -215,7 +215,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_PG_NT) void gg_pgemm_kernel(GgGemmParams p) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) o[q] = gg_f2bf(gg_bf2f(o[q]) + gg_bf2f(rpre[i][it][q]) * p.res_scale);
                     }
-                    *(u16x8*)(cbase + (long long)m * p.ldc + n) = o;
+                    gg_store_nt16(cbase + (long long)m * p.ldc + n, o);
                 }
             }
             gg_wave_sync();                      // (the next sub-tile's staging writes follow this one's reads)

@@ -96,6 +96,8 @@ def _kernel_key(d: GemmDesc, L) -> str:
         name = f'gg_dconv_kernel<C={d.C},TN={1 if d.N <= 32 else 2}>'
     elif tile.value == 10:
         name = 'gg_wgrad9_kernel'
+    elif tile.value == 15:
+        name = 'gg_pgemm_kernel'
     elif tile.value == 14:
         name = f'gg_sfwd_kernel<C={d.C}>'
     elif tile.value == 13:

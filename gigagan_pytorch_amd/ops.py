@@ -1356,8 +1356,8 @@ class HipOps:
         bi = b_in.float().contiguous()
         bo = None if b_out is None else b_out.float().contiguous()
         # both GELU-carrying launches (the up-projection, and the down-projection's data gradient: hid -> dim channels back to hid)
-        # must land on the 8-wave tiles' staged epilogue, unsplit: ask the planner with the launches' own descriptors
-        staged = lambda plan: 4 <= plan[0] <= 6 and plan[1] == 1
+        # must land on a staged epilogue (the 8-wave tiles or the persistent short-K kernel), unsplit: ask the planner with the launches' own descriptors
+        staged = lambda plan: (4 <= plan[0] <= 6 or plan[0] == 15) and plan[1] == 1       # (15: gg_pgemm, the same staged epilogue)
         with_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (n, w_in, b_in, w_out, b_out, residual))
         # (the cached answer belongs to one plan table: kernels.Library.load_plan_table clears this cache)
         key = (tuple(nh.shape), hid, nh.device, nh.dtype, with_grad)

@@ -96,6 +96,7 @@ typedef GgBuf GgBufS;
 static inline GgBufS gg_make_bufs(const void* base, unsigned long long bytes) { return gg_make_buf(base, bytes); }
 static inline void gg_bufs_load_lds16(GgBufS r, unsigned voff, unsigned soff, void* lds_wave_base) { gg_buf_load_lds16(r, voff, soff, lds_wave_base); }
 static inline void gg_settle(u16x8&) {}
+static inline void gg_store_nt16(void* p, u16x8 v) { *(u16x8*)p = v; }
 static inline int gg_uniform(int v) { return v; }
 static inline void gg_wave_sync() { (void)gg_emu_shfl(0.f, (int)(threadIdx.x & 63u)); }      // a wave collective: every lane arrives before any leaves
 template <typename T>

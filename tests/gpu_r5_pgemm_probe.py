@@ -31,7 +31,7 @@ def phases():
     """GG_PGEMM_DBG switches phases of the kernel off (results are garbage): what is left tells where a tile's time goes."""
     import os
     dev = torch.device('cuda', 0)
-    names = {0: 'all', 1: 'no MFMA', 2: 'no epilogue', 3: 'transfers only', 4: 'no transfers', 5: 'epilogue only', 6: 'k-loop only', 7: 'barriers only'}
+    names = {0: 'all', 1: 'no MFMA', 2: 'no epilogue', 3: 'transfers only', 4: 'no transfers', 5: 'epilogue only', 6: 'k-loop only', 7: 'barriers only', 8: 'no stores', 12: 'no stores, no transfers'}
     for M, N, Kd, epi in [(262144, 1024, 256, 'bias'), (262144, 1024, 256, 'aux1'), (131072, 512, 512, 'plain'), (262144, 256, 1024, 'plain')]:
         hw = 32
         n_img = M // (hw * hw)
@@ -42,7 +42,7 @@ def phases():
         kw = dict(ksize=1, pad=0, bias=bias, gelu_aux=aux, gelu_mode=1 if aux is not None else 0, force_tile=15)
         tiles = (M // 128) * (N // 128)
         row = [f'M={M} N={N} K={Kd} {epi} ({tiles / 256:.0f} tiles per CU)']
-        for dbg in range(8):
+        for dbg in list(range(8)) + [8, 12]:
             os.environ['GG_PGEMM_DBG'] = str(dbg)
             t = time_us(lambda: K.conv2d_nhwc(x, w, **kw), iters=4)
             row.append(f'{names[dbg]}: {t:6.1f} us = {t / (tiles / 256):5.2f} us/tile')

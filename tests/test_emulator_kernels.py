@@ -1835,20 +1835,21 @@ def test_persistent_short_k_contraction_is_bit_identical_to_the_tiled_kernel(cfg
     assert rel_err(y15, ref) < 6e-3
 
 
-def test_persistent_short_k_contraction_gelu_aux_modes_and_dense_operands(pgemm_wgs):
+@pytest.mark.parametrize('Kd', [128, 192])          # (two stages per tile: the epilogue follows the k-loop; three: it rides in the next tile's)
+def test_persistent_short_k_contraction_gelu_aux_modes_and_dense_operands(pgemm_wgs, Kd):
     """the FeedForward epilogues (gelu_mode 1: h to aux, gelu(h) out; gelu_mode 2: out = staged * gelu'(aux)) and a dense row-major
     A with a row pitch larger than K, both bit-identical to tile 6."""
     pgemm_wgs(2)
     torch.manual_seed(1)
-    x = torch.randn(1, 16, 20, 128).bfloat16()
-    w = (torch.randn(256, 128) / 128 ** 0.5).bfloat16()
+    x = torch.randn(1, 16, 20, Kd).bfloat16()
+    w = (torch.randn(256, Kd) / Kd ** 0.5).bfloat16()
     bias = torch.randn(256)
     out = {}
     for tile in (15, 6):
         aux = torch.zeros(1, 16, 20, 256).bfloat16()
         y = K.conv2d_nhwc(x, w, ksize=1, pad=0, bias=bias, gelu_aux=aux, gelu_mode=1, force_tile=tile)
-        g = torch.randn(1, 16, 20, 128, generator=torch.Generator().manual_seed(2)).bfloat16()
-        wt = (torch.randn(256, 128, generator=torch.Generator().manual_seed(3)) / 128 ** 0.5).bfloat16()
+        g = torch.randn(1, 16, 20, Kd, generator=torch.Generator().manual_seed(2)).bfloat16()
+        wt = (torch.randn(256, Kd, generator=torch.Generator().manual_seed(3)) / Kd ** 0.5).bfloat16()
         if tile == 15:
             assert K.conv2d_nhwc(g, wt, ksize=1, pad=0, gelu_aux=aux, gelu_mode=2, force_tile=15, plan_only=True) == (15, 1)
         dy = K.conv2d_nhwc(g, wt, ksize=1, pad=0, gelu_aux=aux, gelu_mode=2, force_tile=tile)
@@ -1859,8 +1860,8 @@ def test_persistent_short_k_contraction_gelu_aux_modes_and_dense_operands(pgemm_
     h = torch.einsum('nhwc,oc->nhwo', x.float(), w.float()) + bias
     assert rel_err(aux, h) < 6e-3 and rel_err(y, F.gelu(aux.float())) < 6e-3
 
-    a = torch.randn(320, 200).bfloat16()[:, :192]        # (row pitch 200 elements)
-    b = (torch.randn(128, 192) / 192 ** 0.5).bfloat16()
+    a = torch.randn(320, 264).bfloat16()[:, :Kd + 64]        # (row pitch 264 elements)
+    b = (torch.randn(128, Kd + 64) / 192 ** 0.5).bfloat16()
     c15 = K.gemm(a, b, force_tile=15, alpha=1.5)
     c6 = K.gemm(a, b, force_tile=6, alpha=1.5)
     assert torch.equal(c15, c6)
@@ -1868,7 +1869,7 @@ def test_persistent_short_k_contraction_gelu_aux_modes_and_dense_operands(pgemm_
 
 
 def test_persistent_short_k_contraction_is_the_planned_kernel_for_large_short_k_launches():
-    """planner: an eligible row-major launch of >= 32K rows and K <= 1024 that the 8-wave tiles would take runs on tile 15; launches
+    """planner: an eligible row-major launch of >= 8K rows and K <= 1024 that the 8-wave tiles would take runs on tile 15; launches
     it cannot express (an input scale, a 3x3 window, fp32 output) keep their kernels."""
     x = torch.zeros(32, 32, 32, 256).bfloat16()
     w = torch.zeros(512, 256).bfloat16()
@@ -1879,3 +1880,7 @@ def test_persistent_short_k_contraction_is_the_planned_kernel_for_large_short_k_
     assert K.conv2d_nhwc(x, w3, ksize=3, plan_only=True)[0] != 15
     xs = torch.zeros(2, 32, 32, 256).bfloat16()
     assert K.conv2d_nhwc(xs, w, ksize=1, pad=0, plan_only=True)[0] != 15          # 2048 rows: the tiled kernels
+    w5 = torch.zeros(512, 512).bfloat16()
+    x5 = torch.zeros(32, 32, 32, 512).bfloat16()
+    assert K.conv2d_nhwc(x5, w5, ksize=1, pad=0, plan_only=True)[0] != 15         # alpha-only epilogue at K = 512: the 256 x 256 tile
+    assert K.conv2d_nhwc(x5, w5, ksize=1, pad=0, bias=torch.zeros(512), plan_only=True) == (15, 1)
