@@ -76,7 +76,11 @@ typedef struct gg_gemm_desc {
                            * 9: direct 3x3 convolution (C in {16,32,64}, N <= 64, W %% 32 == 0, H %% 8 == 0);
                            * 11: low-resolution 3x3 convolution (stride 1, pad 1, C %% 32 == 0, 4x4 / 8x8 / 16x16 images: the first
                            *     adaptive convolutions of Generator.forward, gp.py:1184-1245);
-                           * 8 / 12: the halo-staged convolution with 128 / 64 output channels per workgroup (same eligibility as 7),
+                           * 8 / 12: the halo-staged convolution with 128 / 64 output channels per workgroup (same eligibility as 7);
+                           * 13 / 14: the streaming 3x3 weight gradient / forward convolution of the narrow high-resolution layers;
+                           * 15: the persistent short-K contraction (row-major operands or a 1x1 / stride 1 gather, K %% 64 == 0,
+                           *     N, ldc, row pitches multiples of 8, bf16 output, batch 1, no out_scale / noise / in_scale / d2s):
+                           *     the 1x1 convolutions around attention and FeedForward, gp.py:620-740;
                            * else heuristic */
     int32_t conv_stride;  /* >= 1 */
     int32_t conv_pad;     /* >= 0 */
@@ -93,8 +97,8 @@ typedef struct gg_gemm_desc {
                               * 2 banks, 3x3 / stride 1 / pad 1 (gg_lrconv, one image per 256-pixel tile); other shapes are rejected */
     int32_t keep_partials;   /* split-K launches only (fp32 output, alpha-only epilogue): 1 = leave the slices [splitk][M][N] in the workspace
                               * and skip the reduction launch - the caller folds it into its own consumer (gg_finish_multi's nsplit) */
-    int32_t gelu_mode;       /* GELU fused around the 1x1 pair of a FeedForward (gp.py:726-740), bf16 outputs on the 8-wave tiles' staged epilogue
-                              * only (gg_gemm_plan tile 4-6, split-K 1; anything else is rejected): 1 = the result h is ALSO stored to
+    int32_t gelu_mode;       /* GELU fused around the 1x1 pair of a FeedForward (gp.py:726-740), bf16 outputs on a staged epilogue
+                              * only (gg_gemm_plan tile 4-6 or 15, split-K 1; anything else is rejected): 1 = the result h is ALSO stored to
                               * gelu_aux and C_out receives gelu(h); 2 = gelu_aux holds h and C_out receives result * gelu'(h) */
     void* gelu_aux;          /* bf16 [M][ld_aux] */
     int32_t ld_aux, reserved1;
@@ -113,7 +117,7 @@ int gg_gemm_plan_table(const gg_plan_entry* entries, int32_t n);
 
 size_t gg_gemm_workspace_bytes(const gg_gemm_desc* d);
 /* reports the launch plan the library will use for `d`: tile (1: 128x128, 2: 128x64, 3: 128x32, 4: 256x256,
- * 5: 256x128, 6: 128x128 with 8 waves, 7 - 12: the specialised kernels listed at force_tile) and the split-K factor; used by bench.py to attribute measured time to kernel instantiations. */
+ * 5: 256x128, 6: 128x128 with 8 waves, 7 - 15: the specialised kernels listed at force_tile) and the split-K factor; used by bench.py to attribute measured time to kernel instantiations. */
 int gg_gemm_plan(const gg_gemm_desc* d, int32_t* tile, int32_t* splitk);
 int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 

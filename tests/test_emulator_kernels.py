@@ -905,7 +905,8 @@ def test_committed_plan_table_loads_and_is_honoured_by_the_planner():
     from gigagan_pytorch_amd import _C
     L = _C.lib()
     entries = json.loads(_C.PLAN_TABLE.read_text())['entries']
-    assert len(entries) > 50 and all(1 <= e['tile'] <= 12 and e['splitk'] >= 1 for e in entries)
+    assert len(entries) > 50 and all(1 <= e['tile'] <= 15 and e['splitk'] >= 1 for e in entries)
+    assert sum(e['tile'] == 15 for e in entries) >= 50          # (round 5: the persistent short-K contraction's geometries)
     try:
         L.load_plan_table(entries)
         assert L.plan_entries == len(entries)
@@ -918,6 +919,14 @@ def test_committed_plan_table_loads_and_is_honoured_by_the_planner():
         K.conv2d_wgrad_nhwc(x, bf(torch.randn(1, 16, 16, 72)), ksize=3)     # tile 7 is not a weight-gradient kernel: entry ignored
         assert K.plan_log[0] == (10, 2) and K.plan_log[1][0] not in (7, 8), K.plan_log
         assert rel_err(got, K.conv2d_wgrad_nhwc(x, dy, ksize=3, force_tile=1)) < 1e-5
+        # a tile-15 entry (gg_pgemm) on a 1x1 convolution far below the planner's own row threshold; ineligible (fp32 output): ignored
+        k1 = dict(M=256, N=64, K=64, batch=1, a_layout=0, b_layout=0, a_conv=1, H=16, W=16, C=64, CV=64, R=1, conv_stride=1,
+                  conv_pad=0, c_is_f32=0, d2s=0, epi=0, scaled=0)
+        L.load_plan_table([dict(k1, tile=15, splitk=1), dict(k1, c_is_f32=1, tile=15, splitk=1)])
+        x1 = bf(torch.randn(1, 16, 16, 64)); w1 = bf(torch.randn(64, 64) * 0.1)
+        assert K.conv2d_nhwc(x1, w1, ksize=1, pad=0, plan_only=True) == (15, 1)
+        assert K.conv2d_nhwc(x1, w1, ksize=1, pad=0, out_dtype=torch.float32, plan_only=True)[0] != 15
+        assert torch.equal(K.conv2d_nhwc(x1, w1, ksize=1, pad=0), K.conv2d_nhwc(x1, w1, ksize=1, pad=0, force_tile=6))
     finally:
         K.plan_log = None
         L.load_plan_table([])

@@ -432,6 +432,55 @@ def test_halo_staged_conv3_vs_implicit_gemm_and_cpu(cfg):
     assert rel_err(K.conv2d_nhwc(xd, wd, force_tile=tile, force_splitk=2, **kw), K.conv2d_nhwc(xd, wd, force_tile=1, **kw)) < BF16_TOL
 
 
+@pytest.mark.parametrize('cfg', [
+    # (n, H, W, C = K, N, epilogue)
+    (32, 32, 32, 256, 1024, 'aux'), (32, 32, 32, 1024, 256, 'res'), (16, 64, 64, 128, 64, 'bias'), (32, 16, 16, 512, 2048, 'aux'),
+    (3, 50, 50, 192, 136, 'res'), (64, 32, 32, 64, 128, 'plain'), (2, 64, 64, 576, 128, 'plain'),
+])
+def test_persistent_short_k_contraction_vs_tiled_kernel_and_cpu(cfg):
+    """gg_pgemm (plan tile 15: persistent workgroups, LDS-DMA loader waves, runs of 128 x 128 tiles) on the step's 1x1 shapes and on
+    ragged ones (7500 rows, 136 columns): bit-identical to gg_gemm2<128,128> on the same operands - same k order, same rounding
+    points, same epilogue arithmetic - incl. the FeedForward GELU aux modes (gp.py:726-740), and within bf16 rounding of fp32 math."""
+    n, H, W, ci, co, epi = cfg
+    torch.manual_seed(0)
+    x = bf(torch.randn(n, H, W, ci)); w = bf(torch.randn(co, ci) / ci ** 0.5)
+    bias = torch.randn(co); res = bf(torch.randn(n, H, W, co))
+    xd, wd, bd, rd = x.to(dev()), w.to(dev()), bias.to(dev()), res.to(dev())
+    kw = dict(ksize=1, pad=0, alpha=0.75)
+    if epi in ('bias', 'res', 'aux'):
+        kw.update(bias=bd, bias_scale=0.5)
+    if epi == 'res':
+        kw.update(residual=rd, res_scale=0.25, act='lrelu')
+    out = {}
+    for tile in (15, 6):
+        K.plan_log = []
+        if epi == 'aux':
+            aux = torch.zeros(n, H, W, co, device=dev(), dtype=torch.bfloat16)
+            y = K.conv2d_nhwc(xd, wd, gelu_aux=aux, gelu_mode=1, force_tile=tile, **kw)
+            g = K.conv2d_nhwc(xd, wd, gelu_aux=aux, gelu_mode=2, force_tile=tile, ksize=1, pad=0)
+            out[tile] = (y, aux, g)
+        else:
+            out[tile] = (K.conv2d_nhwc(xd, wd, force_tile=tile, **kw),)
+        assert all(p == (tile, 1) for p in K.plan_log), K.plan_log
+        K.plan_log = None
+    for a, b in zip(out[15], out[6]):
+        assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
+    exact = 0.75 * torch.einsum('nhwc,oc->nhwo', x.float(), w.float())
+    if epi != 'plain':
+        exact = exact + 0.5 * bias
+    if epi == 'res':
+        exact = F.leaky_relu(exact, 0.2).bfloat16().float() + 0.25 * res.float()
+    if epi == 'aux':
+        y, aux, g = out[15]
+        assert rel_err(aux.cpu(), exact) < BF16_TOL and rel_err(y.cpu(), F.gelu(aux.cpu().float())) < BF16_TOL
+        h = aux.cpu().float().requires_grad_()
+        F.gelu(h).sum().backward()
+        lin = torch.einsum('nhwc,oc->nhwo', x.float(), w.float())
+        assert rel_err(g.cpu(), lin.bfloat16().float() * h.grad) < BF16_TOL
+    else:
+        assert rel_err(out[15][0].cpu(), exact) < BF16_TOL
+
+
 @pytest.mark.parametrize('cfg', [(32, 8, 8, 512, 2, 512, 8, 8), (32, 16, 16, 256, 2, 256, 8, 4), (5, 8, 8, 64, 3, 264, 7, 0),
                                  (4, 32, 32, 128, 2, 128, 8, 1)])
 def test_halo_staged_conv3_with_bank_modulation_on_the_operand_staging(cfg):
