@@ -26,6 +26,7 @@ sys.path.insert(0, str(ROOT))
 
 GF_PER_IMG = 1192.1       # algorithmic-minimum GFLOP per image per step, 4-step-cycle mean
 MFMA_PEAK_TF = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0     # HBM3E peak, MI355X_MICROARCH.md (achievable: ~6.3 TB/s read, ~7.7 TB/s fill)
 C2_G = dict(dim_capacity=8, dim_max=512, style_network=dict(dim=64, depth=4), num_skip_layers_excite=4, unconditional=True)
 C2_D = dict(dim_capacity=16, dim_max=512, num_skip_layers_excite=4, unconditional=True)
 
@@ -512,6 +513,26 @@ def main():
                             step=dict(achieved=value / world * GF_PER_IMG / 1e3, peak=MFMA_PEAK_TF,
                                       frac=value / world * GF_PER_IMG / 1e3 / MFMA_PEAK_TF,
                                       note='whole-step algorithmic-minimum 1192.1 GF/img vs dense bf16 MFMA peak'))
+
+    if rank == 0 and roofline is not None and shapes:
+        # the persistent short-K contraction (gg_pgemm, plan tile 15) is an HBM problem: algorithmic bytes of its launches in the eager
+        # cycle (operands + output: 2 * M * (K + N) + 2 * N * K; residual / GELU-aux operands are not in the launch key, so this is a
+        # lower bound on the bytes and on the fraction) over their HIP-event time
+        import re
+        pg_bytes = pg_ms = 0.
+        pg_n = 0
+        for key, v in shapes.items():
+            m = re.match(r'gg_pgemm_kernel M=(\d+) N=(\d+) K=(\d+)', key)
+            if m:
+                M_, N_, K_ = map(int, m.groups())
+                pg_bytes += v['launches'] * (2. * M_ * (K_ + N_) + 2. * N_ * K_)
+                pg_ms += v['ms']
+                pg_n += v['launches']
+        if pg_n:
+            gbs = pg_bytes / pg_ms / 1e6
+            roofline['short_k'] = dict(bound='hbm', kernel='gg_pgemm_kernel', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s',
+                                       frac=gbs / HBM_PEAK_GBS, launches_in_cycle=pg_n, ms_in_cycle=round(pg_ms, 3),
+                                       bytes='2*M*(K+N) + 2*N*K per launch (residual / GELU-aux operands not counted)')
 
     if rank == 0 and roofline is not None and args.workload == 'uncond':
         try:
