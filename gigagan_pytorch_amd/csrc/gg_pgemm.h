@@ -123,18 +123,22 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_PG_NT) void gg_pgemm_kernel(GgGemmParams p) {
     const bf16_t* const pre = aux2 ? (const bf16_t*)p.aux : p.residual;
     const int ld_pre = aux2 ? p.ld_aux : p.ldr;
 
+    // (initialised ONCE: a per-tile `rpre = 0` made hipcc put s_waitcnt vmcnt(0) - a drain of the previous tile's stores - at the top of every tile)
+    u16x8 rpre[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) rpre[i][it] = gg_zero8();
     int tm = t0 / tiles_n, tn = t0 - tm * tiles_n, head = 0;
     for (int t = t0; t < t1; ++t) {
         const int m_wave = (tm << 7) + wm * 64, n_wave = (tn << 7) + wn * 32;
         const int n = n_wave + qc * 8;
         const bool inner = m_wave + 64 <= p.M && n_wave + 32 <= p.N;       // (wave-uniform)
-        u16x8 rpre[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
+            for (int it = 0; it < 2; ++it) {     // (rows outside the matrix keep a stale value: their stores are masked)
                 const int m = m_wave + i * 32 + it * 16 + rr;
-                rpre[i][it] = gg_zero8();
                 if (pre && (inner || (m < p.M && n < p.N))) rpre[i][it] = *(const u16x8*)(pre + (long long)m * ld_pre + n);
             }
         f32x16 acc[2];
