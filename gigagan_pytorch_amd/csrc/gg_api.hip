@@ -772,7 +772,7 @@ static GemmPlan gg_pgemm_plan(const gg_gemm_desc* d) {
     GemmPlan pl;
     pl.tile = 15; pl.bm = 128; pl.bn = 128; pl.splitk = 1; pl.k_per_split = d->K;
     const long long tiles = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128);
-    long long wgs = 256;                                 // one 150 KB workgroup per CU, a contiguous run of tiles each
+    long long wgs = 256;                                 // one 150 KB workgroup per CU, every 256th tile each
     if (const char* e = getenv("GG_PGEMM_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;     // (tests: runs of several tiles on small problems)
     pl.blocks_mn = tiles < wgs ? tiles : wgs;
     return pl;
@@ -1059,6 +1059,11 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     }
     else if (pl.tile == 15) {
         if (d->a_conv) p.lda = d->C;                // (a 1x1 / stride 1 gather reads pixel rows of C channels)
+        {   // tile order, measured per shape on one box (profiles/r05_pgemm_probe_v8_orders.log): round-robin wins on narrow outputs (one
+            // or two column tiles; four from K = 512 on) and on launches that read a second M x N operand (GELU data gradient)
+            const int tiles_n = (d->N + 127) / 128;
+            p.pg_order = tiles_n <= 2 || (tiles_n <= 4 && d->K >= 512) || d->gelu_mode == 2;
+        }
         if (const char* e = getenv("GG_PGEMM_DBG")) p.xcd_slices = atoi(e);      // (probe runs: phases switched off, results are garbage)
         const bool full = p.bias || p.act != GG_ACT_NONE;
         if (full) GG_LAUNCH((gg_pgemm_kernel<true>), grid2, dim3(GG_PG_NT), s, p);

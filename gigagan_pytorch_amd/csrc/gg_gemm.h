@@ -86,6 +86,7 @@ struct GgGemmParams {
     // is ALSO stored to aux and the output is gelu(h); mode 2 = aux holds h and the output is staged * gelu'(h)
     bf16_t* aux; int aux_mode, ld_aux;
     int ws_cs, ws_cstore, ws_gmul;   // ... channels per x slot, rows stored per tap, memory rows per ring row
+    int pg_order;      // gg_pgemm: 1 = tiles dealt round-robin over the workgroups, 0 = a contiguous run per workgroup
     int buf_ok;        // 31 when both operands' byte extents fit the 32-bit offsets of a buffer descriptor, else 0 (bits: A conv rows,
                        // A dense rows, A reduction-major, B dense rows, B reduction-major)
 };

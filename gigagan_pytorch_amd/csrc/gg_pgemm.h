@@ -4,7 +4,7 @@
 // These launches move 2 * (K + N) bytes per output row against 2 * K * N flops: at K <= 512 the output store is most of the traffic
 // and the HBM floor sits 2.4-4x under what gg_gemm2 measures on them (profiles/r05_shortk_probe.log: 8 us per 256 x 256 tile spent
 // OUTSIDE the k-loop - first-load latency of a fresh workgroup, its store drain, its exit). This kernel keeps one workgroup per CU
-// alive over a contiguous run of 128 x 128 output tiles and never lets it wait on memory:
+// alive over a sequence of 128 x 128 output tiles and never lets it wait on memory:
 //   * two LOADER waves (wave 4: A tiles + the tile's bias row, wave 5: B tiles) stream 64-wide k-stages HBM / L2 -> LDS by LDS-DMA into
 //     a ring of four 32 KB slots, three stages ahead, ACROSS tile boundaries: while the compute waves run a tile's epilogue, up to
 //     three stages of the next tile land. Their only wait is a counted s_waitcnt vmcnt in front of the stage's raw s_barrier
@@ -15,8 +15,8 @@
 //   * epilogue: bias from LDS (no global load behind the stores), residual / GELU-aux operands of the WHOLE wave tile requested before
 //     the tile's first store (a load issued behind stores waits for them: shared vmcnt), 32 x 32 sub-tiles parked in a wave-private
 //     staging area and written back as 64-byte row halves (the neighbouring wave writes the other half: the L2 merges them).
-//   * tile order: n fastest inside a workgroup's run, runs contiguous per XCD: an A tile is fetched from HBM once and re-read from L2
-//     for the other n-tiles; B (<= 2 MB) lives in every L2.
+//   * tile order: round-robin over the workgroups, n fastest: the workgroups of an XCD work on consecutive tiles at any time, an A tile
+//     is fetched from HBM once and shared through that L2 while hot; B (<= 2 MB) lives in every L2.
 // Algorithmic bytes: 2 * M * (K + N) (+ 2 * M * N per residual / aux operand) + 2 * N * K.
 #pragma once
 #include "gg_gemm2.h"
@@ -41,10 +41,22 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_PG_NT) void gg_pgemm_kernel(GgGemmParams p) {
     const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + pos;
     const int tiles_n = (p.N + 127) >> 7, tiles_m = (p.M + 127) >> 7;
     const long long T = (long long)tiles_m * tiles_n;
-    const int t0 = (int)(wg * T / nwg), t1 = (int)((wg + 1) * T / nwg);
+    // Two tile orders (n fastest inside a row of tiles in both):
+    //  * round-robin (p.pg_order 1): in round r workgroup wg takes tile r * nwg + wg, so that at any time the 32 workgroups of an XCD
+    //    (contiguous wg, above) work on 32 CONSECUTIVE tiles - the n-tiles of a few m-tiles - and an A tile is fetched from HBM once and
+    //    shared through that XCD's L2 while it is hot: rocprofv3 FETCH_SIZE = the A operand, WRITE_SIZE = the output, exactly
+    //    (profiles/r05_pmc_pgemm_v3_roundrobin.log);
+    //  * contiguous runs (0): workgroup wg takes tiles [wg T / nwg, (wg + 1) T / nwg): it re-reads its A tile once per n-tile, 4-5 us apart -
+    //    by then the output stream has pushed it out of the L2 (FETCH_SIZE 3.4x the A operand, r05_pmc_pgemm_v2_nt_vs_plain.log) - but
+    //    the re-reads come from the memory-side cache and a workgroup meets a cold A tile only once per row of tiles.
+    // The host picks by shape (gg_api.hip).
+    const bool rr_order = (p.pg_order != 0) != ((p.xcd_slices & 64) != 0);
+    const int t0 = rr_order ? wg : (int)(wg * T / nwg);
+    const int ntw = rr_order ? (wg < T ? (int)((T - wg + nwg - 1) / nwg) : 0) : (int)((wg + 1) * T / nwg) - t0;      // tiles of this workgroup
+    const int dtm = rr_order ? nwg / tiles_n : 0, dtn = rr_order ? nwg - dtm * tiles_n : 1;                        // tile step as (rows of tiles, tiles)
     const int KT = p.K >> 6;
-    const int Q = (t1 - t0) * KT;
-    const int dbg = p.xcd_slices;       // probe runs (GG_PGEMM_DBG, tests/gpu_r5_pgemm_probe.py): 1 no MFMAs, 2 no epilogue, 4 no transfers, 8 no stores; 0 in the product
+    const int Q = ntw * KT;
+    const int dbg = p.xcd_slices;       // probe runs (GG_PGEMM_DBG, tests/gpu_r5_pgemm_probe.py): 1 no MFMAs, 2 no epilogue, 4 no transfers, 8 no stores, 16 plain stores, 64 the other tile order; 0 in the product
 
     if (wave >= 8) {
         // ---------------------------------------------------------------- loaders
@@ -59,7 +71,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_PG_NT) void gg_pgemm_kernel(GgGemmParams p) {
             const int row = 8 * i + (lane >> 3), chunk = (lane & 7) ^ ((row >> 1) & 7);
             voff[i] = (unsigned)((row * pitch + chunk * 8) * 2);
         }
-        int itm = t0 / tiles_n, itn = t0 - itm * tiles_n, ik = 0, head = 0;
+        int itm = t0 / tiles_n, itn = t0 - itm * tiles_n, ik = 0, head = 0, itk = 0;
         auto issue = [&]() {
             if (dbg & 4) return;
             const int r0 = (isB ? itn : itm) << 7;
@@ -73,15 +85,17 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_PG_NT) void gg_pgemm_kernel(GgGemmParams p) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) gg_bufs_load_lds16(buf, (8 * i + (lane >> 3)) < left ? voff[i] : 0xFFFFFFFFu, soff, dst + i * 1024);
             }
-            if (!isB) {                          // the tile's 128 bias values (zeros without a bias / past N), slot = tile % 4
+            if (!isB) {                          // the tile's 128 bias values (zeros without a bias / past N), slot = (the workgroup's tile count) % 4
                 const int bo = ((itn << 7) + lane * 4) * 4;
                 gg_bufs_load_lds16(bufb, (lane < 32 && bo + 16 <= p.N * 4) ? (unsigned)bo : 0xFFFFFFFFu, 0u,
-                                   smem + GG_PG_BIAS + ((itm * tiles_n + itn) & 3) * 1024);
+                                   smem + GG_PG_BIAS + (itk & 3) * 1024);
             }
             head = (head + 1) & (GG_PG_RING - 1);
             if (++ik == KT) {
                 ik = 0;
-                if (++itn == tiles_n) { itn = 0; ++itm; }
+                ++itk;
+                itm += dtm; itn += dtn;
+                if (itn >= tiles_n) { itn -= tiles_n; ++itm; }
             }
         };
         static_assert(GG_PG_RING == 4, "the literals below: two stages may stay in flight behind the one waited for");
@@ -130,7 +144,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_PG_NT) void gg_pgemm_kernel(GgGemmParams p) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) rpre[i][it] = gg_zero8();
     int tm = t0 / tiles_n, tn = t0 - tm * tiles_n, head = 0;
-    for (int t = t0; t < t1; ++t) {
+    for (int t = 0; t < ntw; ++t) {
         const int m_wave = (tm << 7) + wm * 64, n_wave = (tn << 7) + wn * 32;
         const int n = n_wave + qc * 8;
         const bool inner = m_wave + 64 <= p.M && n_wave + 32 <= p.N;       // (wave-uniform)
@@ -165,7 +179,8 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_PG_NT) void gg_pgemm_kernel(GgGemmParams p) {
         }
 
         if (dbg & 2) {
-            if (++tn == tiles_n) { tn = 0; ++tm; }
+            tm += dtm; tn += dtn;
+            if (tn >= tiles_n) { tn -= tiles_n; ++tm; }
             continue;
         }
         // ---- epilogue: lane owns row m = ... + (lane & 31); register r holds column (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -219,11 +234,13 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_PG_NT) void gg_pgemm_kernel(GgGemmParams p) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) o[q] = gg_f2bf(gg_bf2f(o[q]) + gg_bf2f(rpre[i][it][q]) * p.res_scale);
                     }
-                    gg_store_nt16(cbase + (long long)m * p.ldc + n, o);
+                    if (dbg & 16) *(u16x8*)(cbase + (long long)m * p.ldc + n) = o;
+                    else gg_store_nt16(cbase + (long long)m * p.ldc + n, o);
                 }
             }
             gg_wave_sync();                      // (the next sub-tile's staging writes follow this one's reads)
         }
-        if (++tn == tiles_n) { tn = 0; ++tm; }
+        tm += dtm; tn += dtn;
+        if (tn >= tiles_n) { tn -= tiles_n; ++tm; }
     }
 }

@@ -73,6 +73,14 @@ def main():
         same = torch.equal(y_old, y_new) and (a_old is None or torch.equal(a_old, aux))
         t_old = time_us(lambda: K.conv2d_nhwc(x, w, **kw), iters=4)
         t_new = time_us(lambda: K.conv2d_nhwc(x, w, force_tile=15, **kw), iters=4)
+        if '--orders' in sys.argv:            # the kernel's other tile order (GG_PGEMM_DBG bit 64 flips the host's choice)
+            import os
+            os.environ['GG_PGEMM_DBG'] = '64'
+            t_flip = time_us(lambda: K.conv2d_nhwc(x, w, force_tile=15, **kw), iters=4)
+            os.environ.pop('GG_PGEMM_DBG')
+            tiles_n = (N + 127) // 128
+            rr_default = tiles_n <= 2 or (tiles_n <= 4 and Kd >= 512) or epi == 'aux2'
+            print(f'   orders: round-robin {t_new if rr_default else t_flip:7.1f} us | contiguous runs {t_flip if rr_default else t_new:7.1f} us', flush=True)
         nbytes = 2 * M * (Kd + N) + 2 * N * Kd + (2 * M * N if epi in ('res', 'aux1', 'aux2') else 0)
         floor = nbytes / 6.3e12 * 1e6
         tot_old += t_old

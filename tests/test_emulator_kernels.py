@@ -1816,12 +1816,15 @@ def pgemm_wgs(monkeypatch):
     (1, 16, 24, 256, 136, 3, True, None, True),         # four stages per tile, N = 136 (a column tile of 8)
     (1, 16, 16, 320, 128, 1, True, 'gelu', False),      # five stages per tile: the ring wraps inside a tile
 ])
-def test_persistent_short_k_contraction_is_bit_identical_to_the_tiled_kernel(cfg, pgemm_wgs):
+@pytest.mark.parametrize('other_order', [False, True])     # (the host picks round-robin tiles or contiguous runs by shape; GG_PGEMM_DBG=64 flips it)
+def test_persistent_short_k_contraction_is_bit_identical_to_the_tiled_kernel(cfg, pgemm_wgs, other_order, monkeypatch):
     """gg_pgemm_kernel (plan tile 15) against gg_gemm2_kernel<128,128> (tile 6) on 1x1 convolutions: same k order, same rounding
     points, same epilogue arithmetic -> the same bits; and against fp32 math. Runs of several tiles per workgroup (GG_PGEMM_WGS)
-    exercise the cross-tile prefetch, the bias slots and the ring wrap."""
+    exercise the cross-tile prefetch, the bias slots and the ring wrap, in both tile orders."""
     n, H, W, Cc, N, wgs, with_bias, act, with_res = cfg
     pgemm_wgs(wgs)
+    if other_order:
+        monkeypatch.setenv('GG_PGEMM_DBG', '64')
     torch.manual_seed(0)
     x = torch.randn(n, H, W, Cc).bfloat16()
     w = (torch.randn(N, Cc) / Cc ** 0.5).bfloat16()
