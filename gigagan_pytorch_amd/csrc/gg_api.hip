@@ -1060,7 +1060,8 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
     else if (pl.tile == 15) {
         if (d->a_conv) p.lda = d->C;                // (a 1x1 / stride 1 gather reads pixel rows of C channels)
         {   // tile order, measured per shape on one box (profiles/r05_pgemm_probe_v8_orders.log): round-robin wins on narrow outputs (one
-            // or two column tiles; four from K = 512 on) and on launches that read a second M x N operand (GELU data gradient)
+            // or two column tiles; four from K = 512 on) and on launches that read a second M x N operand (GELU data gradient); in the
+            // step: this rule 411.5 / 411.6 img/s, round-robin everywhere 411.4, contiguous everywhere 409.7 (r05_pgemm_order_ab.log)
             const int tiles_n = (d->N + 127) / 128;
             p.pg_order = tiles_n <= 2 || (tiles_n <= 4 && d->K >= 512) || d->gelu_mode == 2;
         }
@@ -2000,6 +2001,12 @@ extern "C" int gg_modmix_bwd(const void* dy, const void* y, const void* Y, const
 
 // ---- fused self-attention (gg_attention.h) ------------------------------------------------------------------------
 
+static int gg_attn_xcd() {                       // GG_ATTN_XCD=0: blocks in dispatch order (A/B runs)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GG_ATTN_XCD"); v = e ? (atoi(e) != 0) : 1; }
+    return v;
+}
+
 static int gg_attn_common(GgAttnParams& p, const void* q, const void* k, const void* v, const void* k0, const void* v0,
                           int32_t B, int32_t n, int32_t h, float alpha, float beta) {
     if (!q || !k || !v || !k0 || !v0) return gg_fail(-1, "gg_attn: null pointer");
@@ -2009,7 +2016,7 @@ static int gg_attn_common(GgAttnParams& p, const void* q, const void* k, const v
         return gg_fail(-3, "gg_attn: operands must be 16-byte aligned");
     memset(&p, 0, sizeof(p));
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.k0 = (const bf16_t*)k0; p.v0 = (const bf16_t*)v0;
-    p.B = B; p.n = n; p.h = h; p.alpha = alpha; p.beta = beta;
+    p.B = B; p.n = n; p.h = h; p.alpha = alpha; p.beta = beta; p.xcd = gg_attn_xcd();
     return 0;
 }
 
@@ -2054,7 +2061,7 @@ static int gg_attn_gen_common(GgAttnParams& p, const void* q, int64_t ldq, const
         return gg_fail(-3, "gg_attn_gen: operands must be 16-byte aligned");
     memset(&p, 0, sizeof(p));
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.k0 = (const bf16_t*)k0; p.v0 = (const bf16_t*)v0;
-    p.B = B; p.n = n; p.m = m; p.h = h; p.alpha = alpha; p.beta = beta;
+    p.B = B; p.n = n; p.m = m; p.h = h; p.alpha = alpha; p.beta = beta; p.xcd = gg_attn_xcd();
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.kbias = kbias; p.has_null = k0 != nullptr;
     return 0;
 }
@@ -2167,7 +2174,7 @@ extern "C" int gg_attn_bwd2(const void* q, const void* k, const void* v, const v
     p.d_o = (const bf16_t*)d_o; p.aq = (const bf16_t*)aq; p.ak = (const bf16_t*)ak; p.av = (const bf16_t*)av;
     p.ak0 = (const bf16_t*)ak0; p.av0 = (const bf16_t*)av0; p.lse = lse; p.dvec = dvec; p.mu = mu; p.gi = gi;
     p.gq = (bf16_t*)gq; p.gk = (bf16_t*)gk; p.gv = (bf16_t*)gv; p.gdo = (bf16_t*)gdo; p.null_part = null_part;
-    p.B = B; p.n = n; p.h = h; p.alpha = alpha; p.beta = beta;
+    p.B = B; p.n = n; p.h = h; p.alpha = alpha; p.beta = beta; p.xcd = gg_attn_xcd();
     dim3 grid((unsigned)(n / 128), (unsigned)(B * h));
     hipStream_t s = (hipStream_t)stream;
     GG_LAUNCH(gg_attn_bwd2_q_kernel<true>, grid, dim3(256), s, p);

@@ -45,6 +45,7 @@ struct GgAttnParams {
     float* null_part;   // [blocks of the dq kernel][3][64]: partial sums of dk0 (q part), dv0, and [2][0] = dbias0
     int B, n, h;
     float alpha, beta;
+    int xcd;            // 1: XCD-aware block order (gg_attn_block); 0: dispatch order (GG_ATTN_XCD=0, A/B runs)
     // general form (GEN instantiations: cross attention gp.py:617-655, the text transformer's attention gp.py:659-722, the unet's
     // Attend attend.py:64-110): m keys / values per (batch, head) that need not equal the n queries, any n and m (tails are
     // clamped on load and masked), strided q / k / v rows (channel slices of a fused projection), an optional additive per-key
@@ -183,6 +184,21 @@ GG_DEVICE f32x4 gga_rows4(const float* arr, int blk, int g, int lane) {
 #define GGA_LN2 0.6931471805599453f
 #define GGA_TAU 8.0f
 
+// XCD-aware block order of the (key/query block, batch x head) grids. The dispatcher places consecutive workgroups (x fastest) on
+// consecutive XCDs, so the n / 128 blocks of ONE (batch, head) - which all stream that head's whole K and V (or Q and dO) - land on
+// eight different XCDs and every L2 fetches the same tiles: rocprofv3 FETCH_SIZE x 2 = 38 / 49 / 51 GB per four steps for forward / dq /
+// dk-dv against ~9 GB of q, k, v, o (profiles/r05_pmc_step.log) - the kernels ran at 3.8-5.5 TB/s of HBM-side traffic. Remapped: XCD x
+// works through a contiguous range of (batch x head, block) items, so the blocks of a head share one L2.
+GG_DEVICE void gg_attn_block(int xcd_order, int& bx, int& bh) {
+    if (!xcd_order) { bx = blockIdx.x; bh = blockIdx.y; return; }
+    const int gx = gridDim.x, total = gx * gridDim.y;
+    const int lin = blockIdx.y * gx + blockIdx.x;
+    const int xq = total >> 3, xr = total & 7, xcd = lin & 7, pos = lin >> 3;
+    const int item = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + pos;
+    bh = item / gx;
+    bx = item - bh * gx;
+}
+
 template <bool GEN>
 GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_fwd_kernel(GgAttnParams p) {
     GG_SHARED __attribute__((aligned(16))) bf16_t sK[2][64][GGA_KP];
@@ -190,7 +206,9 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_fwd_kernel(GgAttnParams p) {
     GG_SHARED __attribute__((aligned(16))) float sKb[2][64];          // beta' |k_j|^2 of the tile's keys
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
-    const int bh = blockIdx.y, b = bh / p.h, hd = bh % p.h;
+    int bx, bh;
+    gg_attn_block(p.xcd, bx, bh);
+    const int b = bh / p.h, hd = bh % p.h;
     const long long rs = (long long)p.h * GGA_D;
     const long long rsq = GEN ? p.ldq : rs, rsk = GEN ? p.ldk : rs, rsv = GEN ? p.ldv : rs;
     const int nk = GEN ? p.m : p.n;                                   // keys per (batch, head)
@@ -198,7 +216,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_fwd_kernel(GgAttnParams p) {
     const bf16_t* kb = p.k + (long long)b * nk * rsk + hd * GGA_D;
     const bf16_t* vb = p.v + (long long)b * nk * rsv + hd * GGA_D;
     const float* kbias = (GEN && p.kbias) ? p.kbias + (long long)b * nk : nullptr;
-    const int qi0 = blockIdx.x * 128 + wave * 32;
+    const int qi0 = bx * 128 + wave * 32;
     const float a2 = p.alpha * GGA_LOG2E, b2 = p.beta * GGA_LOG2E, inv_a2 = 1.f / a2;
 
     u16x8 qf[4];
@@ -367,7 +385,9 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dq_kernel(GgAttnParams p) {
     GG_SHARED float sRed[4][3][64];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
-    const int bh = blockIdx.y, b = bh / p.h, hd = bh % p.h;
+    int bx, bh;
+    gg_attn_block(p.xcd, bx, bh);
+    const int b = bh / p.h, hd = bh % p.h;
     const long long rs = (long long)p.h * GGA_D;
     const long long boff = (long long)b * p.n * rs + hd * GGA_D;          // dense query-side tensors: o, dO, dq
     const long long rsq = GEN ? p.ldq : rs, rsk = GEN ? p.ldk : rs, rsv = GEN ? p.ldv : rs;
@@ -376,7 +396,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dq_kernel(GgAttnParams p) {
     const bf16_t* kb = p.k + (long long)b * nk * rsk + hd * GGA_D;
     const bf16_t* vb = p.v + (long long)b * nk * rsv + hd * GGA_D;
     const float* kbias = (GEN && p.kbias) ? p.kbias + (long long)b * nk : nullptr;
-    const int qi0 = blockIdx.x * 128 + wave * 32;
+    const int qi0 = bx * 128 + wave * 32;
     const int qi = qi0 + (lane & 31);
     const int qic = (GEN && qi >= p.n) ? p.n - 1 : qi;
     const float a2 = p.alpha * GGA_LOG2E, b2 = p.beta * GGA_LOG2E, inv_a2 = 1.f / a2;
@@ -523,7 +543,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dq_kernel(GgAttnParams p) {
         float s = 0.f;
         if (which < 2 || d == 0)
             for (int w = 0; w < 4; ++w) s += sRed[w][which][d];
-        p.null_part[(((long long)bh * gridDim.x + blockIdx.x) * 3 + which) * 64 + d] = s;
+        p.null_part[(((long long)bh * gridDim.x + bx) * 3 + which) * 64 + d] = s;
     }
 }
 
@@ -539,7 +559,9 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dkv_kernel(GgAttnParams p) {
     GG_SHARED __attribute__((aligned(16))) float sD[64];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
-    const int bh = blockIdx.y, b = bh / p.h, hd = bh % p.h;
+    int bx, bh;
+    gg_attn_block(p.xcd, bx, bh);
+    const int b = bh / p.h, hd = bh % p.h;
     const long long rs = (long long)p.h * GGA_D;
     const long long boff = (long long)b * p.n * rs + hd * GGA_D;           // dense query-side tensors (dO) and, when !GEN, all
     const long long rsq = GEN ? p.ldq : rs, rsk = GEN ? p.ldk : rs, rsv = GEN ? p.ldv : rs;
@@ -548,7 +570,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd_dkv_kernel(GgAttnParams p) {
     const bf16_t* kb = p.k + (long long)b * nk * rsk + hd * GGA_D;
     const bf16_t* vb = p.v + (long long)b * nk * rsv + hd * GGA_D;
     const long long koff = (long long)b * nk * rs + hd * GGA_D;            // dense key-side outputs: dk, dv
-    const int kj0 = blockIdx.x * 128 + wave * 32;
+    const int kj0 = bx * 128 + wave * 32;
     const int kj = kj0 + (lane & 31);
     const int kjc = (GEN && kj >= nk) ? nk - 1 : kj;
 

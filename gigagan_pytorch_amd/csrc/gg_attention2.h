@@ -35,6 +35,7 @@ struct GgAttn2Params {
                                          //                           [2][0] sum_i R0, [2][1] sum_i dS0
     int B, n, h;
     float alpha, beta;
+    int xcd;                             // XCD-aware block order (gg_attn_block)
 };
 
 // one 32-row x 64-d tile: 256 threads, one 16-byte vector each (row t>>3, chunk t&7)
@@ -85,10 +86,12 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd2_q_kernel(GgAttn2Params p) {
     GG_SHARED float sRed[4][3][64];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
-    const int bh = blockIdx.y, b = bh / p.h, hd = bh % p.h;
+    int bx, bh;
+    gg_attn_block(p.xcd, bx, bh);
+    const int b = bh / p.h, hd = bh % p.h;
     const long long rs = (long long)p.h * GGA_D;
     const long long boff = (long long)b * p.n * rs + hd * GGA_D;
-    const int qi0 = blockIdx.x * 128 + wave * 32;
+    const int qi0 = bx * 128 + wave * 32;
     const int qi = qi0 + (lane & 31);
 
     u16x8 qf[4], aqf[4], dof[4];
@@ -257,7 +260,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd2_q_kernel(GgAttn2Params p) {
         float s = 0.f;
         if (which < 2 || d < 2)
             for (int w = 0; w < 4; ++w) s += sRed[w][which][d];
-        p.null_part[(((long long)bh * gridDim.x + blockIdx.x) * 3 + which) * 64 + d] = s;
+        p.null_part[(((long long)bh * gridDim.x + bx) * 3 + which) * 64 + d] = s;
     }
 }
 
@@ -273,10 +276,12 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_attn_bwd2_kv_kernel(GgAttn2Params p) {
     GG_SHARED __attribute__((aligned(16))) float sStat[4][32];   // lse, D, mu, g of the staged queries
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
-    const int bh = blockIdx.y, b = bh / p.h, hd = bh % p.h;
+    int bx, bh;
+    gg_attn_block(p.xcd, bx, bh);
+    const int b = bh / p.h, hd = bh % p.h;
     const long long rs = (long long)p.h * GGA_D;
     const long long boff = (long long)b * p.n * rs + hd * GGA_D;
-    const int kj0 = blockIdx.x * 128 + wave * 32;
+    const int kj0 = bx * 128 + wave * 32;
     const int kj = kj0 + (lane & 31);
 
     u16x8 kf[4], vf[4], akf[4], avf[4];
