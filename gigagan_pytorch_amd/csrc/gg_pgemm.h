@@ -5,7 +5,7 @@
 // and the HBM floor sits 2.4-4x under what gg_gemm2 measures on them (profiles/r05_shortk_probe.log: 8 us per 256 x 256 tile spent
 // OUTSIDE the k-loop - first-load latency of a fresh workgroup, its store drain, its exit). This kernel keeps one workgroup per CU
 // alive over a sequence of 128 x 128 output tiles and never lets it wait on memory:
-//   * two LOADER waves (wave 4: A tiles + the tile's bias row, wave 5: B tiles) stream 64-wide k-stages HBM / L2 -> LDS by LDS-DMA into
+//   * two LOADER waves (wave 8: A tiles + the tile's bias row, wave 9: B tiles) stream 64-wide k-stages HBM / L2 -> LDS by LDS-DMA into
 //     a ring of four 32 KB slots, three stages ahead, ACROSS tile boundaries: while the compute waves run a tile's epilogue, up to
 //     three stages of the next tile land. Their only wait is a counted s_waitcnt vmcnt in front of the stage's raw s_barrier
 //     (17 / 16 transfers per stage and wave: 51 outstanding at most, the counter holds 63);
@@ -15,8 +15,9 @@
 //   * epilogue: bias from LDS (no global load behind the stores), residual / GELU-aux operands of the WHOLE wave tile requested before
 //     the tile's first store (a load issued behind stores waits for them: shared vmcnt), 32 x 32 sub-tiles parked in a wave-private
 //     staging area and written back as 64-byte row halves (the neighbouring wave writes the other half: the L2 merges them).
-//   * tile order: round-robin over the workgroups, n fastest: the workgroups of an XCD work on consecutive tiles at any time, an A tile
-//     is fetched from HBM once and shared through that L2 while hot; B (<= 2 MB) lives in every L2.
+//   * tile order (n fastest): round-robin over the workgroups - the workgroups of an XCD work on consecutive tiles at any time, an A
+//     tile is fetched from HBM once and shared through that L2 while hot - or a contiguous run per workgroup, chosen by shape (below);
+//     B (<= 2 MB) lives in every L2.
 // Algorithmic bytes: 2 * M * (K + N) (+ 2 * M * N per residual / aux operand) + 2 * N * K.
 #pragma once
 #include "gg_gemm2.h"
@@ -34,7 +35,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_PG_NT) void gg_pgemm_kernel(GgGemmParams p) {
     GG_SHARED __attribute__((aligned(1024))) char smem[GG_PG_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = gg_uniform(tid >> 6);
 
-    // XCD-aware run order (block b runs on XCD b % 8): XCD x works through a contiguous range of runs
+    // XCD-aware workgroup numbering (block b runs on XCD b % 8): the workgroups of XCD x are wg = 32 x .. 32 x + 31
     const int nwg = gridDim.x;
     const int xq = nwg >> 3, xr = nwg & 7;
     const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
