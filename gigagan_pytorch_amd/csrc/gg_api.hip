@@ -18,6 +18,7 @@
 #include "gg_modcoef.h"
 #include "gg_modfwd.h"
 #include "gg_aconv.h"
+#include "gg_semlp.h"
 #include "gg_comm.h"
 #include "../../include/gigagan_amd.h"
 
@@ -1808,6 +1809,42 @@ extern "C" int gg_pool_mean_bwd(const void* g, const float* gs, void* y, int32_t
     memset(&p, 0, sizeof(p));
     p.x = (const bf16_t*)g; p.gs = gs; p.y = (bf16_t*)y; p.b = b; p.P = P; p.C = C;
     GG_LAUNCH(gg_pool_bwd_kernel, dim3(gg_grid_for((long long)b * P * (C / 8))), dim3(256), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+static int gg_se_mlp_check(const char* who, int32_t b, int32_t C, int32_t H, int32_t O) {
+    if (b <= 0 || b > 65535 || C <= 0 || H <= 0 || O <= 0 || C > GG_SEMLP_MAX_C || O > GG_SEMLP_MAX_C || H > GG_SEMLP_MAX_H)
+        return gg_fail(-2, "%s: need 0 < b <= 65535, C, O <= %d, H <= %d (b=%d C=%d H=%d O=%d)", who, GG_SEMLP_MAX_C, GG_SEMLP_MAX_H, b, C, H, O);
+    return 0;
+}
+
+extern "C" int gg_se_mlp_fwd(const float* m, const float* w1, const float* b1, const float* w2, const float* b2, float* h, float* hs,
+                             float* e, int32_t b, int32_t C, int32_t H, int32_t O, void* stream) {
+    if (!m || !w1 || !w2 || !h || !hs || !e) return gg_fail(-1, "gg_se_mlp_fwd: null pointer");
+    int rc = gg_se_mlp_check("gg_se_mlp_fwd", b, C, H, O);
+    if (rc) return rc;
+    GgSeMlpParams p;
+    memset(&p, 0, sizeof(p));
+    p.m = m; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.h = h; p.hs = hs; p.e = e; p.b = b; p.C = C; p.H = H; p.O = O;
+    GG_LAUNCH(gg_se_mlp_fwd_kernel, dim3((unsigned)b), dim3(GG_SEMLP_THREADS), (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+extern "C" int gg_se_mlp_bwd(const float* de, const float* e, const float* h, const float* hs, const float* m, const float* w1,
+                             const float* w2, float* dz2, float* dz1, float* dm, float* gw, int32_t b, int32_t C, int32_t H, int32_t O,
+                             void* stream) {
+    if (!de || !e || !h || !hs || !m || !w1 || !w2 || !dz2 || !dz1) return gg_fail(-1, "gg_se_mlp_bwd: null pointer");
+    int rc = gg_se_mlp_check("gg_se_mlp_bwd", b, C, H, O);
+    if (rc) return rc;
+    GgSeMlpParams p;
+    memset(&p, 0, sizeof(p));
+    p.de = de; p.e = (float*)e; p.h = (float*)h; p.hs = (float*)hs; p.m = m; p.w1 = w1; p.w2 = w2; p.dz2 = dz2; p.dz1 = dz1; p.dm = dm;
+    p.gw = gw; p.b = b; p.C = C; p.H = H; p.O = O;
+    GG_LAUNCH(gg_se_mlp_bwd_rows_kernel, dim3((unsigned)b), dim3(GG_SEMLP_THREADS), (hipStream_t)stream, p);
+    rc = gg_check_launch();
+    if (rc || !gw) return rc;
+    const long long n = (long long)H * C + H + (long long)O * H + O;
+    GG_LAUNCH(gg_se_mlp_bwd_weights_kernel, dim3(gg_grid_for(n)), dim3(256), (hipStream_t)stream, p);
     return gg_check_launch();
 }
 

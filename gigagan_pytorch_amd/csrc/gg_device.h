@@ -195,6 +195,17 @@ GG_DEVICE float gg_wave_sum_all(float v) {
     return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16))) +
            (__builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48)));
 }
+// sum over the 16 lanes of one DPP row, returned to every lane of that row (the first four steps of gg_wave_sum_all: four
+// independent sums per wavefront)
+GG_DEVICE float gg_row16_sum(float v) {
+#define GG_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+    GG_DPP_ADD(0xB1);        // quad_perm [1,0,3,2]
+    GG_DPP_ADD(0x4E);        // quad_perm [2,3,0,1]
+    GG_DPP_ADD(0x141);       // row_half_mirror
+    GG_DPP_ADD(0x140);       // row_mirror
+#undef GG_DPP_ADD
+    return v;
+}
 GG_DEVICE void gg_atomic_add(float* p, float v) { atomicAdd(p, v); }
 // "last workgroup to arrive" ticket: release this workgroup's global writes, take a ticket; the taker of the last ticket sees every
 // other workgroup's writes (acquire) and puts the counter back to zero when it is done

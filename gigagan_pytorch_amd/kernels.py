@@ -1219,6 +1219,51 @@ def pool_mean_bwd(gs: torch.Tensor, shape, g=None, inplace: bool = False) -> tor
     return y
 
 
+SEMLP_MAX_C, SEMLP_MAX_H = 2048, 512
+
+
+def _f32c(*ts):
+    for t in ts:
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous()), 'fp32 contiguous tensors'
+
+
+def se_mlp_fwd(m: torch.Tensor, w1: torch.Tensor, b1, w2: torch.Tensor, b2):
+    """SqueezeExcite's excitation MLP in one launch (gg_se_mlp_fwd): m (b, C), w1 (H, C), w2 (O, H), biases or None, all fp32 ->
+    (h (b, H) pre-activation, hs = silu(h), e (b, O) = sigmoid(w2 hs + b2))."""
+    L = _C.lib()
+    L.require(m, w1, b1, w2, b2)
+    _f32c(m, w1, b1, w2, b2)
+    b, Cc = m.shape
+    H, O = w1.shape[0], w2.shape[0]
+    assert w1.shape == (H, Cc) and w2.shape == (O, H) and (b1 is None or b1.numel() == H) and (b2 is None or b2.numel() == O)
+    hh = torch.empty((2, b, H), dtype=torch.float32, device=m.device)
+    e = torch.empty((b, O), dtype=torch.float32, device=m.device)
+    rc = L.lib.gg_se_mlp_fwd(ptr(m), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(hh[0]), ptr(hh[1]), ptr(e), b, Cc, H, O, L.stream(m))
+    L.check(rc, 'gg_se_mlp_fwd')
+    return hh[0], hh[1], e
+
+
+def se_mlp_bwd(de: torch.Tensor, e, h, hs, m, w1, w2, want_dm: bool = True, want_gw: bool = True):
+    """backward of se_mlp_fwd (gg_se_mlp_bwd): de (b, O) -> (dm (b, C) or None, (gW1 (H, C), gb1 (H), gW2 (O, H), gb2 (O)) or None);
+    the parameter gradients are views into one buffer, summed over the samples in sample order."""
+    L = _C.lib()
+    L.require(de, e, h, hs, m, w1, w2)
+    _f32c(de, e, h, hs, m, w1, w2)
+    b, Cc = m.shape
+    H, O = w1.shape[0], w2.shape[0]
+    assert de.shape == (b, O) and e.shape == (b, O) and h.shape == (b, H) and hs.shape == (b, H)
+    dz = torch.empty(b * (O + H), dtype=torch.float32, device=m.device)
+    dm = torch.empty((b, Cc), dtype=torch.float32, device=m.device) if want_dm else None
+    gw = torch.empty(H * Cc + H + O * H + O, dtype=torch.float32, device=m.device) if want_gw else None
+    rc = L.lib.gg_se_mlp_bwd(ptr(de), ptr(e), ptr(h), ptr(hs), ptr(m), ptr(w1), ptr(w2), ptr(dz), ptr(dz[b * O:]), ptr(dm), ptr(gw),
+                             b, Cc, H, O, L.stream(m))
+    L.check(rc, 'gg_se_mlp_bwd')
+    if gw is None:
+        return dm, None
+    n1, n2, n3 = H * Cc, H * Cc + H, H * Cc + H + O * H
+    return dm, (gw[:n1].view(H, Cc), gw[n1:n2], gw[n2:n3].view(O, H), gw[n3:])
+
+
 def poolhf_fwd(x: torch.Tensor):
     """x (b, H, W, C) bf16 NHWC -> (max_pool2d(x, 2) (b, H/2, W/2, C), x - blur(x) (b, H, W, C)) in one pass (gg_poolhf_fwd)."""
     L = _C.lib()

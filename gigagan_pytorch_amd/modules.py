@@ -198,9 +198,27 @@ class PixelShuffleUpsample(nn.Module):
 
 # ---- skip-layer excitation (gp.py:297-307) ----------------------------------------------------------------
 
+class SqueezeExciteNet(nn.Sequential):
+    """the reference's six-slot Sequential (same state-dict keys: `1.weight`, `3.weight`, ...); behind the pool the four middle
+    modules run as one fused op where the op set has one (ops.HipOps.squeeze_excite_mlp), module by module otherwise."""
+
+    def excite(self, m):
+        """pooled (b, C) rows -> (b, O, 1, 1) excitation"""
+        fused = getattr(ops.impl, 'squeeze_excite_mlp', None)
+        e = fused(m, self[1], self[3]) if (fused is not None and len(self) == 6) else None
+        if e is not None:
+            return e[:, :, None, None]
+        for layer in list(self)[1:]:
+            m = layer(m)
+        return m
+
+    def forward(self, x):
+        return self.excite(self[0](x))
+
+
 def SqueezeExcite(dim, dim_out, reduction=4, dim_min=32):
     dim_hidden = max(dim_out // reduction, dim_min)
-    return nn.Sequential(
+    return SqueezeExciteNet(
         Placeholder(lambda x: ops.impl.global_mean(x)),
         Linear(dim, dim_hidden),
         Act(F.silu),
@@ -213,9 +231,7 @@ def SqueezeExcite(dim, dim_out, reduction=4, dim_min=32):
 def squeeze_excite_fork(se, x):
     """(se(x), x'): the excitation of a SqueezeExcite stack and x for the trunk (its gradient and the pool's meet in one pass)."""
     m, x = ops.impl.global_mean(x, fork=True)
-    for layer in list(se)[1:]:
-        m = layer(m)
-    return m, x
+    return se.excite(m), x
 
 
 # ---- adaptive conv (gp.py:315-409) ---------------------------------------------------------------------------

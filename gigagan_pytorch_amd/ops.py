@@ -1049,6 +1049,39 @@ class GlobalMeanFn(Function):
         return nchw(K.pool_mean_bwd(gs, (b, H, W, C), ga, inplace=True)), None
 
 
+class SeMlpFn(Function):
+    """SqueezeExcite's excitation MLP (gp.py:297-307) behind its pool: sigmoid(W2 silu(W1 m + b1) + b2) on the pooled (b, C) fp32 rows
+    as ONE launch on the fp32 parameters where they lie (no operand packing, casts or pointwise passes: ten launches before), the
+    backward as two (per-sample chain, then the parameter gradients summed over the samples), parameter gradients through the queued
+    finishes into the flat .grad views like every other layer's. First order only (the gradient-penalty graphs keep the modules)."""
+
+    @staticmethod
+    def forward(ctx, m, w1, b1, w2, b2):
+        m = m.contiguous()
+        h, hs, e = K.se_mlp_fwd(m, w1, b1, w2, b2)
+        ctx.save_for_backward(m, w1, b1, w2, b2, h, hs, e)
+        return e
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, de):
+        m, w1, b1, w2, b2, h, hs, e = ctx.saved_tensors
+        params = (w1, b1, w2, b2)
+        want = [p_ is not None and ctx.needs_input_grad[1 + i] and not inputs_only for i, p_ in enumerate(params)]
+        de = de.float().contiguous()
+        dm, gw = K.se_mlp_bwd(de, e, h, hs, m, w1, w2, want_dm=ctx.needs_input_grad[0], want_gw=any(want))
+        grads = [None, None, None, None]
+        for i, p_ in enumerate(params):
+            if not want[i]:
+                continue
+            sink = _grad_sink_of(p_)
+            if sink is not None:
+                K.finish_queue.add_axpy(gw[i].reshape(-1), 1.0, sink.view(-1), notify=lambda q=p_: grad_ready(q))
+            else:
+                grads[i] = gw[i].reshape(p_.shape).clone()
+        return (dm, *grads)
+
+
 class GeluFn(Function):
     """exact GELU on a dense bf16 buffer (any shape; the storage order is irrelevant to a pointwise op), one HIP pass;
     backward and the backward of the backward are one pass each (gg_gelu modes 1 / 2)."""
@@ -1414,6 +1447,18 @@ class HipOps:
             return LinearFn.apply(x, weight, bias, float(lr_mul), act)
         y = self.linear(x, weight * lr_mul, None if bias is None else bias * lr_mul)
         return F.leaky_relu(y, LRELU_SLOPE) if act == 'lrelu' else y
+
+    def squeeze_excite_mlp(self, m, lin1, lin2):
+        """the four modules behind SqueezeExcite's pool (gp.py:301-304) as one autograd node / one launch: m (b, C) fp32 pooled rows
+        -> the (b, O) fp32 excitation; None when the fused form does not apply (gradient-penalty graphs, foreign dtypes, widths
+        beyond the kernel's LDS rows): the caller runs the modules."""
+        w1, b1, w2, b2 = lin1.weight, lin1.bias, lin2.weight, lin2.bias
+        ok = (not second_order and m.dim() == 2 and m.dtype == torch.float32 and w1.shape[1] == m.shape[1] and w2.shape[1] == w1.shape[0]
+              and all(t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.device == m.device) for t in (w1, b1, w2, b2))
+              and max(m.shape[1], w2.shape[0]) <= K.SEMLP_MAX_C and w1.shape[0] <= K.SEMLP_MAX_H and m.shape[0] <= 65535)
+        if not ok:
+            return None
+        return SeMlpFn.apply(m, w1, b1, w2, b2)
 
     # -- skip-layer excitation multiply (gp.py:1023-1024, :1812-1813) ----------------------------
     def channel_scale(self, x, s):

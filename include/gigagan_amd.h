@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 10
+#define GG_ABI_VERSION 11
 
 int gg_version(void);
 const char* gg_last_error(void);
@@ -356,6 +356,18 @@ int gg_addcat_bwd(const void* g, void* gfeats, int32_t B, int32_t f, int64_t n, 
 int32_t gg_pool_chunks(int32_t b, int32_t P);
 int gg_pool_mean_fwd(const void* x, float* part, float* out, int32_t b, int32_t P, int32_t C, void* stream);
 int gg_pool_mean_bwd(const void* g, const float* gs, void* y, int32_t b, int32_t P, int32_t C, void* stream);
+
+/* SqueezeExcite's excitation MLP (reference gp.py:297-307: `nn.Linear(dim, dim_hidden), nn.SiLU(), nn.Linear(dim_hidden, dim_out),
+ * nn.Sigmoid()` on the pooled rows) in one launch, fp32 throughout, on the parameters where they lie (nn.Linear's [out][in] rows):
+ *   h [b][H] = W1 m + b1,  hs = silu(h),  e [b][O] = sigmoid(W2 hs + b2)           (m [b][C]; b1 / b2 may be null)
+ * Backward (replaces autograd through the five modules): dz2 = de * e (1 - e), dz1 = (W2^T dz2) * silu'(h), dm [b][C] = W1^T dz1
+ * (dm may be null), and - unless gw is null - the parameter gradients, WRITTEN (not accumulated) to
+ * gw = [gW1 (H*C) | gb1 (H) | gW2 (O*H) | gb2 (O)], sums over the b samples in sample order. dz2 [b][O] and dz1 [b][H] are
+ * caller-owned scratch. Deterministic. Limits: C, O <= 2048, H <= 512. */
+int gg_se_mlp_fwd(const float* m, const float* w1, const float* b1, const float* w2, const float* b2, float* h, float* hs, float* e,
+                  int32_t b, int32_t C, int32_t H, int32_t O, void* stream);
+int gg_se_mlp_bwd(const float* de, const float* e, const float* h, const float* hs, const float* m, const float* w1, const float* w2,
+                  float* dz2, float* dz1, float* dm, float* gw, int32_t b, int32_t C, int32_t H, int32_t O, void* stream);
 
 int32_t gg_rmsnorm_blocks(int64_t rows);
 /* act = 1: y = silu(norm(x)) in the same pass (the unet Block's norm + activation, reference unet.py:224-234, :268-269); the

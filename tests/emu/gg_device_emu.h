@@ -111,6 +111,12 @@ static inline float gg_shfl_xor(float v, int mask) {
 }
 static inline float gg_shfl(float v, int src) { return gg_emu_shfl(v, src & 63); }
 static inline float gg_readlane(float v, int src) { return gg_emu_shfl(v, src & 63); }
+static inline float gg_row16_sum(float v) {        // wave collective; the device version's association: quads, 8, 16
+    v += gg_shfl_xor(v, 1); v += gg_shfl_xor(v, 2);
+    { int lane = (int)(threadIdx.x & 63u); v += gg_emu_shfl(v, (lane & ~7) | (7 - (lane & 7))); }
+    { int lane = (int)(threadIdx.x & 63u); v += gg_emu_shfl(v, (lane & ~15) | (15 - (lane & 15))); }
+    return v;
+}
 static inline float gg_wave_sum_all(float v) {     // wave collective; the device version's association: quads, 8, 16, rows
     v += gg_shfl_xor(v, 1); v += gg_shfl_xor(v, 2);
     { int lane = (int)(threadIdx.x & 63u); v += gg_emu_shfl(v, (lane & ~7) | (7 - (lane & 7))); }

