@@ -36,20 +36,51 @@ GG_DEVICE float gg_semlp_sigmoid(float x) { return 1.f / (1.f + gg_expf(-x)); }
 
 #define GG_SEMLP_THREADS 1024
 
-// y[r] = sum_k w[r][k] * v[k] for the rows r of a row-major matrix: one 16-lane DPP row per matrix row (64 contiguous bytes per
-// load, the 16 partial sums folded by gg_row16_sum), 64 matrix rows in flight per workgroup. `v` and `y` live in LDS.
-GG_DEVICE void gg_semlp_matvec(const float* __restrict__ w, const float* v, float* y, int rows, int K) {
+// y[r] = sum_k w[r][k] * v[k] for the rows r of a row-major matrix: one 16-lane DPP row per matrix row (the 16 partial sums folded by
+// gg_row16_sum), four matrix rows per 16-lane group and pass with their loads issued together (256 matrix rows in flight per workgroup:
+// the chain is latency-bound, ~0.5 MB of L2-resident parameters per sample). 16-byte loads when K % 4 == 0 and the rows are 16-byte
+// aligned (VEC), 4-byte loads otherwise. `v` and `y` live in LDS.
+template <bool VEC>
+GG_DEVICE void gg_semlp_matvec_impl(const float* __restrict__ w, const float* v, float* y, int rows, int K) {
+    constexpr int R = 4;
     const int t = threadIdx.x, g = t >> 4, l = t & 15;
-    for (int r0 = 0; r0 < rows; r0 += GG_SEMLP_THREADS / 16) {        // (every lane takes part in the row sum: no early exit)
-        const int r = r0 + g;
-        float acc = 0.f;
-        if (r < rows) {
-            const float* wr = w + (long long)r * K;
-            for (int k = l; k < K; k += 16) acc += wr[k] * v[k];
+    for (int r0 = 0; r0 < rows; r0 += R * (GG_SEMLP_THREADS / 16)) {        // (every lane takes part in the row sums: no early exit)
+        float acc[R];
+        const float* wr[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int r = r0 + g + j * (GG_SEMLP_THREADS / 16);
+            acc[j] = 0.f;
+            wr[j] = w + (long long)(r < rows ? r : 0) * K;
         }
-        acc = gg_row16_sum(acc);
-        if (r < rows && l == 0) y[r] = acc;
+        if (VEC) {
+            for (int k = 4 * l; k < K; k += 64) {
+                const f32x4 vv = *(const f32x4*)(v + k);
+                f32x4 ww[R];
+#pragma unroll
+                for (int j = 0; j < R; ++j) ww[j] = *(const f32x4*)(wr[j] + k);
+#pragma unroll
+                for (int j = 0; j < R; ++j) acc[j] += (ww[j][0] * vv[0] + ww[j][1] * vv[1]) + (ww[j][2] * vv[2] + ww[j][3] * vv[3]);
+            }
+        } else {
+            for (int k = l; k < K; k += 16) {
+                const float vv = v[k];
+#pragma unroll
+                for (int j = 0; j < R; ++j) acc[j] += wr[j][k] * vv;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int r = r0 + g + j * (GG_SEMLP_THREADS / 16);
+            const float s = gg_row16_sum(acc[j]);
+            if (r < rows && l == 0) y[r] = s;
+        }
     }
+}
+
+GG_DEVICE void gg_semlp_matvec(const float* w, const float* v, float* y, int rows, int K) {
+    if ((K & 3) == 0 && ((unsigned long long)w & 15) == 0) gg_semlp_matvec_impl<true>(w, v, y, rows, K);
+    else gg_semlp_matvec_impl<false>(w, v, y, rows, K);
 }
 
 // y[c] = sum_r v[r] * w[r][c] (the transposed product): adjacent threads take adjacent columns (coalesced matrix rows), `parts`
@@ -65,6 +96,7 @@ GG_DEVICE void gg_semlp_matvec_t(const float* __restrict__ w, const float* v, fl
         float acc = 0.f;
         if (c < cols) {
             const int r0 = l * per, r1 = r0 + per < rows ? r0 + per : rows;
+#pragma unroll 8
             for (int r = r0; r < r1; ++r) acc += v[r] * w[(long long)r * cols + c];
         }
         part[t] = acc;
@@ -79,8 +111,8 @@ GG_DEVICE void gg_semlp_matvec_t(const float* __restrict__ w, const float* v, fl
 }
 
 GG_KERNEL GG_LAUNCH_BOUNDS(GG_SEMLP_THREADS) void gg_se_mlp_fwd_kernel(GgSeMlpParams p) {
-    GG_SHARED float ms[GG_SEMLP_MAX_C];          // the pooled row, then the excitation pre-activations
-    GG_SHARED float hl[GG_SEMLP_MAX_H];
+    GG_SHARED __attribute__((aligned(16))) float ms[GG_SEMLP_MAX_C];          // the pooled row, then the excitation pre-activations
+    GG_SHARED __attribute__((aligned(16))) float hl[GG_SEMLP_MAX_H];
     const int t = threadIdx.x, img = blockIdx.x;
     for (int c = t; c < p.C; c += GG_SEMLP_THREADS) ms[c] = p.m[(long long)img * p.C + c];
     gg_sync();
@@ -133,16 +165,20 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_se_mlp_bwd_weights_kernel(GgSeMlpParams 
         float s = 0.f;
         if (i < n1) {                   // gW1[j][c] = sum_b dz1[b][j] m[b][c]
             const int j = (int)(i / p.C), c = (int)(i - (long long)j * p.C);
+#pragma unroll 4
             for (int b = 0; b < p.b; ++b) s += p.dz1[(long long)b * p.H + j] * p.m[(long long)b * p.C + c];
         } else if (i < n2) {            // gb1[j]
             const int j = (int)(i - n1);
+#pragma unroll 4
             for (int b = 0; b < p.b; ++b) s += p.dz1[(long long)b * p.H + j];
         } else if (i < n3) {            // gW2[o][j] = sum_b dz2[b][o] hs[b][j]
             const long long r = i - n2;
             const int o = (int)(r / p.H), j = (int)(r - (long long)o * p.H);
+#pragma unroll 4
             for (int b = 0; b < p.b; ++b) s += p.dz2[(long long)b * p.O + o] * p.hs[(long long)b * p.H + j];
         } else {                        // gb2[o]
             const int o = (int)(i - n3);
+#pragma unroll 4
             for (int b = 0; b < p.b; ++b) s += p.dz2[(long long)b * p.O + o];
         }
         p.gw[i] = s;

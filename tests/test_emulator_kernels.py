@@ -1898,7 +1898,7 @@ def test_persistent_short_k_contraction_is_the_planned_kernel_for_large_short_k_
     assert K.conv2d_nhwc(x5, w5, ksize=1, pad=0, bias=torch.zeros(512), plan_only=True) == (15, 1)
 
 
-@pytest.mark.parametrize('cfg', [(5, 40, 32, 24, True), (3, 8, 4, 8, False), (2, 300, 70, 130, True), (1, 1100, 20, 33, True)])
+@pytest.mark.parametrize('cfg', [(5, 40, 32, 24, True), (3, 8, 4, 8, False), (2, 300, 70, 130, True), (1, 1100, 20, 33, True), (2, 30, 10, 13, True)])
 def test_squeeze_excite_mlp_kernels_match_the_module_stack(cfg):
     """gg_se_mlp_fwd / _bwd on the emulator: ragged widths (rows shorter / longer than a 16-lane DPP row, column counts below and
     above the workgroup), with and without biases, against fp32 autograd through Linear -> SiLU -> Linear -> Sigmoid."""
