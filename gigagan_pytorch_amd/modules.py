@@ -29,8 +29,10 @@ def tile_batch(t, batch):
     """reference `repeat(t, 'b ... -> (s b) ...')`: the multi-scale batch is scale-major (gp.py:365-366)."""
     if t.shape[0] == batch:
         return t
-    if t.dim() == 4:    # cat keeps channels_last storage; repeat() would hand back an NCHW tensor and every consumer
-        return torch.cat([t] * (batch // t.shape[0]), dim=0)        # (add, cat, conv) would fall onto strided kernels
+    if t.dim() == 4 and t.shape[2] * t.shape[3] > 1:    # cat keeps channels_last storage; repeat() would hand back an NCHW tensor and
+        return torch.cat([t] * (batch // t.shape[0]), dim=0)        # every consumer (add, cat, conv) would fall onto strided kernels
+    # ((b, C, 1, 1) rows - a skip-layer excitation - have no storage order to keep: repeat's backward is ONE sum, cat's was a slice and an
+    # accumulation per copy)
     return t.repeat(batch // t.shape[0], *((1,) * (t.dim() - 1)))
 
 

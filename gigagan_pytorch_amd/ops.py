@@ -603,7 +603,14 @@ class ModCoefFn(Function):
         ctx.eps = eps
         ctx.gram = mod.shape[0] <= K.MODGRAM_MAX_B
         if ctx.gram:       # through the bank's Gram rows: 17x fewer operations (gg_modcoef.h, second half)
-            gram = K.modgram(weights.detach())
+            # the rows only change when the weights do: a FlatAdamW-owned bank keeps them in its pack table (kind 'gram', refreshed by
+            # the one gg_pack_weights launch after the optimizer step - the same sums in the same order as gg_modgram)
+            gram = None
+            if (isinstance(weights, torch.nn.Parameter) and getattr(weights, '_gg_pack_table', None) is not None and not _DEBUG_NO_TABLE
+                    and weights.dtype == torch.float32 and weights.is_contiguous()):
+                gram = _table_pack(weights, 'gram')
+            if gram is None:
+                gram = K.modgram(weights.detach())
             s, a, d, tsum = K.modcoef_gram_fwd(gram, weights.shape[0], mod, kmod, eps, Ip, Op)
             ctx.save_for_backward(kmod, weights, s, d, gram, tsum)
         else:

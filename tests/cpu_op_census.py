@@ -29,7 +29,7 @@ it = cycle(SyntheticImages(2, 32))
 gan.train_discriminator_step(dl_iter=it, apply_gradient_penalty=False)
 gan.train_generator_step(batch_size=2, dl_iter=it)
 SKIP = ('view', 'reshape', 'permute', 'transpose', 'expand', 'slice', 'select', 'unsqueeze', 'squeeze', 'detach', 'alias',
-        'as_strided', 't.default', 'unbind', 'split', '_unsafe_view', 'empty', 'lift_fresh', '_local_scalar', 'chunk', 'narrow',
+        'as_strided', '::t.default', 'unbind', 'split', '_unsafe_view', 'empty', 'lift_fresh', '_local_scalar', 'chunk', 'narrow',
         'unflatten', 'new_empty', 'is_same_size', 'record_function', 'profiler')
 
 
