@@ -296,6 +296,17 @@ def _check_act_residual(act, residual, *tensors):
                            'the leaky-relu mask from the sign of the stored output); apply the residual in a separate op')
 
 
+def _bias8(bias, o8):
+    """a bias of O % 8 != 0 channels (rgb / logit convolutions) as the o8 floats the kernels read: a FlatAdamW-owned parameter sits in a
+    zero-padded 256-float slot of the flat buffer (optimizer.FlatAdamW._build: the tail is never written - zero gradient, zero moments,
+    zero decay), so the longer view IS the zero-padded bias; anything else is padded by a copy."""
+    slot = bias.__dict__.get('_gg_slot') if isinstance(bias, torch.nn.Parameter) else None
+    if (slot is not None and slot[0] == bias.data_ptr() and slot[1] >= o8 and bias.dim() == 1 and bias.dtype == torch.float32
+            and bias.untyped_storage().nbytes() >= (bias.storage_offset() + o8) * 4):
+        return torch.as_strided(bias.detach(), (o8,), (1,), bias.storage_offset())
+    return F.pad(bias, (0, o8 - bias.shape[0]))
+
+
 class ConvFn(Function):
     """y = act(alpha * (conv(x * in_scale, w) + bias)) + res_scale * residual ;  x: (b,H,W,C8) bf16, w: float parameter layout."""
 
@@ -310,7 +321,7 @@ class ConvFn(Function):
         o8 = wmat.shape[0]
         b8 = bias
         if bias is not None and bias.shape[0] != o8:
-            b8 = F.pad(bias, (0, o8 - bias.shape[0]))
+            b8 = _bias8(bias, o8)
         y = K.conv2d_nhwc(x, wmat, ksize=ksize, stride=stride, pad=pad, in_scale=in_scale, bias=b8, bias_scale=alpha,
                           alpha=alpha, act=act, act_slope=LRELU_SLOPE, residual=residual, res_scale=res_scale)
         ctx.act, ctx.geom, ctx.alpha, ctx.res_scale = act, geom, alpha, res_scale

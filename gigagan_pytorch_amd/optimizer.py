@@ -64,6 +64,7 @@ class FlatAdamW(torch.optim.Optimizer):
             self.flat_p[off:off + n].copy_(p.detach().reshape(-1))
             p.data = self.flat_p[off:off + n].view(p.shape)
             p.grad = self.flat_g[off:off + n].view(p.shape)
+            p._gg_slot = (p.data_ptr(), (n + ALIGN - 1) // ALIGN * ALIGN)     # (the slot's tail beyond n stays zero: ops._bias8)
             fl = (0 if id(p) in self._inactive else 1) | (2 if id(p) in decay_ids else 0)
             flags[off // ALIGN:(off + n + ALIGN - 1) // ALIGN] = fl
             st = self.state[p]

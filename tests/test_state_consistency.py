@@ -179,3 +179,28 @@ def test_shard_dataloader_keeps_custom_sampling_schemes_and_refuses_what_it_cann
         is_rank_sharded = True
     assert shard_dataloader(PerRank(stream), 0, 2) is not None
     assert shard_dataloader(stream, 0, 1) is stream
+
+
+def test_ragged_bias_reads_its_zero_padded_flat_slot():
+    """a bias of O % 8 != 0 channels (rgb / logit convolutions): for a FlatAdamW-owned parameter the o8 floats the kernels read are a
+    longer VIEW of its 256-float slot in the flat buffer (no pad launch per forward) whose tail stays zero across optimizer steps and
+    follows load_state_dict; any other tensor is padded by a copy. The conv result equals the explicitly padded one either way."""
+    torch.manual_seed(0)
+    conv = Conv2d(8, 3, 3, padding=1)
+    b0 = ops._bias8(conv.bias, 8)
+    assert b0.shape == (8,) and b0.data_ptr() != conv.bias.data_ptr() and torch.equal(b0[:3], conv.bias.detach()) and not b0[3:].any()
+    opt = FlatAdamW(list(conv.parameters()), lr=1e-2)
+    b1 = ops._bias8(conv.bias, 8)
+    assert b1.data_ptr() == conv.bias.data_ptr() and torch.equal(b1[:3], conv.bias.detach()) and not b1[3:].any()
+    x = torch.randn(2, 8, 6, 6)
+    for _ in range(3):
+        opt.zero_grad()
+        y = conv(x)
+        assert y.shape == (2, 3, 6, 6)
+        with ops.sinking():
+            y.float().square().mean().backward()
+        opt.step()
+        b2 = ops._bias8(conv.bias, 8)
+        assert b2.data_ptr() == conv.bias.data_ptr() and torch.equal(b2[:3], conv.bias.detach()) and not b2[3:].any()
+    conv.load_state_dict({'weight': conv.weight.detach().clone(), 'bias': torch.tensor([1., 2., 3.])})
+    assert torch.equal(ops._bias8(conv.bias, 8), torch.tensor([1., 2., 3., 0., 0., 0., 0., 0.]))
