@@ -278,7 +278,8 @@ def test_in_backward_gradient_exchange_is_captured_with_the_step(tmp_path):
     GradReducer issues the sliced all-reduce from inside the backward pass - forked onto the communicator's side stream behind
     an event, joined before the optimizer - and the whole thing is captured into the step's hipGraph (distributed.GradReducer,
     gigagan.py `_run_graphed`). Checks: the captures succeed, slices did go out during the backward, and four steps (plain and
-    gradient-penalty, replayed) leave the parameters of the same run with the exchange issued after the backward (to run-to-run noise)."""
+    gradient-penalty, replayed) leave the parameters of the same run with the exchange issued after the backward (to run-to-run noise and
+    what AdamW makes of it: see the bound at the end)."""
     from gigagan_pytorch_amd import GigaGAN, distributed as gdist
     from gigagan_pytorch_amd.data import SyntheticImages
     from gigagan_pytorch_amd.gigagan import cycle
@@ -314,7 +315,15 @@ def test_in_backward_gradient_exchange_is_captured_with_the_step(tmp_path):
         # fp32 atomics, tests/gpu_overlap_probe.py -> profiles/r03_overlap_probe.log); a slice exchanged before its last gradient
         # write, or skipped, moves parameters by ~lr = 2e-4 per step
         diff = (digests[0] - digests[1]).abs()
-        assert float(diff.max()) <= 1e-6 and int((diff > 0).sum()) <= 64, (float(diff.max()), int((diff > 0).sum()))
+        # (round 5: the old bound - max <= 1e-6, <= 64 entries - failed 2 runs in 16, on the round's first tree as on its last, always with
+        # the same figures: max 1.117e-4 on one entry, every other entry a hair off. Not the exchange: gg_colsum_finish folds a bias
+        # gradient's partial rows with one fp32 atomic add per workgroup (<= 32 of them), so its last bit depends on their arrival order;
+        # AdamW divides by sqrt(v) + 1e-8, which turns a +-1e-8 gradient of a parameter whose true gradient is zero into a step of up to
+        # lr, and from there the two trajectories differ everywhere by second-order amounts. A slice that missed a gradient write, or was
+        # skipped, moves a sixth of the parameters by ~lr per step: that is what the bounds below still reject.)
+        stats = (float(diff.max()), float(diff.mean()), float((diff > 1e-5).float().mean()), int((diff > 0).sum()))
+        print('overlap-vs-post parameter differences (max, mean, fraction > 1e-5, entries > 0):', stats)
+        assert stats[0] <= 1e-3 and stats[1] <= 5e-6 and stats[2] <= 2e-2, stats
     finally:
         gdist.shutdown()
 
