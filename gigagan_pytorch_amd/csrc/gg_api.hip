@@ -1242,11 +1242,22 @@ extern "C" int gg_wgrad_finish(const float* g, float* dst, int32_t O, int32_t I,
     return gg_check_launch();
 }
 
+// workgroups that share one column block of a column-sum finish (16 partial rows each, at most 32). Each issues ONE fp32 atomic add per
+// channel, so with more than one the sum's last bit depends on their arrival order: the run-to-run noise of every bias gradient (DESIGN
+// §6 round 5). GG_COLSUM_GROUPS=1: one workgroup per column block folds all partial rows in a fixed order - bit-reproducible bias
+// gradients, measured +0.8 ms per step (profiles/r05_colsum_det_ab.log: 78.5-78.95 against 77.85 ms), hence not the default.
+static int gg_colsum_groups(int P) {
+    static int cap = -1;
+    if (cap < 0) { const char* e = getenv("GG_COLSUM_GROUPS"); cap = e ? atoi(e) : 32; if (cap < 1) cap = 1; if (cap > 32) cap = 32; }
+    int groups = (P + 15) / 16;
+    if (groups > cap) groups = cap;
+    return groups < 1 ? 1 : groups;
+}
+
 extern "C" int gg_colsum_finish(const float* part, float* dst, int32_t P, int32_t C, int32_t n, float alpha, void* stream) {
     if (!part || !dst) return gg_fail(-1, "gg_colsum_finish: null pointer");
     if (P <= 0 || C <= 0 || n <= 0 || n > C) return gg_fail(-2, "gg_colsum_finish: bad extents");
-    int groups = (P + 15) / 16;
-    if (groups > 32) groups = 32;
+    int groups = gg_colsum_groups(P);
     GG_LAUNCH(gg_colsum_finish_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)groups), dim3(256), (hipStream_t)stream, part,
               dst, (int)P, (int)C, (int)n, alpha);
     return gg_check_launch();
@@ -1296,8 +1307,7 @@ extern "C" int gg_finish_multi(const gg_finish_item* items, int32_t n, void* str
                 wgs += ((it.O + 31) / 32) * ((it.I + GG_WF_IB - 1) / GG_WF_IB);
             } else if (it.kind == 1) {        // column sums: O = partial rows P, I = row pitch C, T = columns n
                 if (it.O <= 0 || it.I <= 0 || it.T <= 0 || it.T > it.I) return gg_fail(-2, "gg_finish_multi: item %d: bad extents", i0 + j);
-                int groups = (it.O + 15) / 16;
-                if (groups > 32) groups = 32;
+                const int groups = gg_colsum_groups(it.O);
                 o.O = it.O; o.I = it.I; o.T = it.T; o.C8 = groups; o.O8 = 0;
                 wgs += ((it.T + 63) / 64) * groups;
             } else if (it.kind == 2) {        // dst += alpha * src over O elements
