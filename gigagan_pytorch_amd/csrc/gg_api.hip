@@ -1242,13 +1242,14 @@ extern "C" int gg_wgrad_finish(const float* g, float* dst, int32_t O, int32_t I,
     return gg_check_launch();
 }
 
-// workgroups that share one column block of a column-sum finish (16 partial rows each, at most 32). Each issues ONE fp32 atomic add per
-// channel, so with more than one the sum's last bit depends on their arrival order: the run-to-run noise of every bias gradient (DESIGN
-// §6 round 5). GG_COLSUM_GROUPS=1: one workgroup per column block folds all partial rows in a fixed order - bit-reproducible bias
-// gradients, measured +0.8 ms per step (profiles/r05_colsum_det_ab.log: 78.5-78.95 against 77.85 ms), hence not the default.
+// workgroups that share one column block of a column-sum finish. Each issues ONE fp32 atomic add per channel, so with more than one the
+// sum's last bit depends on their arrival order: that was the run-to-run noise of every bias gradient. ONE workgroup
+// per column block folds all partial rows in a fixed order (eight rows in flight per wavefront): bit-reproducible bias gradients at
+// +0.0 ... +0.2 ms per step (profiles/r05_colsum_det_ab.log; +0.8 ms before the loads were batched). GG_COLSUM_GROUPS=32 restores the
+// spread form (16 partial rows per workgroup, at most 32 workgroups).
 static int gg_colsum_groups(int P) {
     static int cap = -1;
-    if (cap < 0) { const char* e = getenv("GG_COLSUM_GROUPS"); cap = e ? atoi(e) : 32; if (cap < 1) cap = 1; if (cap > 32) cap = 32; }
+    if (cap < 0) { const char* e = getenv("GG_COLSUM_GROUPS"); cap = e ? atoi(e) : 1; if (cap < 1) cap = 1; if (cap > 32) cap = 32; }
     int groups = (P + 15) / 16;
     if (groups > cap) groups = cap;
     return groups < 1 ? 1 : groups;

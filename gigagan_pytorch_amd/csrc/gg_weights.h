@@ -299,8 +299,20 @@ GG_DEVICE void gg_colsum_finish_body(const float* part, float* dst, int P, int C
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = bx * 64 + lane;
     float s = 0.f;
-    if (c < n)
-        for (int q = by * 4 + wave; q < P; q += 4 * groups) s += part[(long long)q * C + c];
+    if (c < n) {
+        // (eight rows in flight per wavefront: with one workgroup per column block - GG_COLSUM_GROUPS=1 - a wavefront folds up to 256 rows,
+        // and one load at a time made that a chain of round trips)
+        const int step = 4 * groups;
+        int q = by * 4 + wave;
+        for (; q + 7 * step < P; q += 8 * step) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = part[(long long)(q + k * step) * C + c];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; q < P; q += step) s += part[(long long)q * C + c];
+    }
     red[wave][lane] = s;
     gg_sync();
     if (wave == 0 && c < n) gg_atomic_add(dst + c, alpha * ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])));

@@ -320,7 +320,9 @@ def test_in_backward_gradient_exchange_is_captured_with_the_step(tmp_path):
         # gradient's partial rows with one fp32 atomic add per workgroup (<= 32 of them), so its last bit depends on their arrival order;
         # AdamW divides by sqrt(v) + 1e-8, which turns a +-1e-8 gradient of a parameter whose true gradient is zero into a step of up to
         # lr, and from there the two trajectories differ everywhere by second-order amounts. A slice that missed a gradient write, or was
-        # skipped, moves a sixth of the parameters by ~lr per step: that is what the bounds below still reject.)
+        # skipped, moves a sixth of the parameters by ~lr per step: that is what the bounds below still reject. Since then the finish
+        # folds in ONE workgroup per column block by default - fixed order, no atomics race - and 12 runs in 12 printed (0.0, 0.0, 0.0, 0)
+        # here; the bounds stay loose for GG_COLSUM_GROUPS=32.)
         stats = (float(diff.max()), float(diff.mean()), float((diff > 1e-5).float().mean()), int((diff > 0).sum()))
         print('overlap-vs-post parameter differences (max, mean, fraction > 1e-5, entries > 0):', stats)
         assert stats[0] <= 1e-3 and stats[1] <= 5e-6 and stats[2] <= 2e-2, stats
