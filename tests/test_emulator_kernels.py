@@ -1958,3 +1958,21 @@ def test_squeeze_excite_container_runs_the_fused_node_and_matches_the_modules():
     e_2, gx_2, gp_2, kind_2 = run(ops.HipOps(), second_order=True)       # twice-differentiable graphs keep the modules
     assert kind_2 == 'modules'
     assert rel_err(e_2, e_o) < 1e-2 and rel_err(gx_2, gx_o) < 2e-2
+
+
+@pytest.mark.parametrize('P,C,n', [(1, 8, 8), (7, 64, 50), (31, 72, 72), (32, 64, 64), (100, 136, 130), (1024, 64, 64)])
+def test_bias_gradient_finish_folds_every_partial_row_in_one_workgroup_per_column_block(P, C, n):
+    """gg_colsum_finish (and gg_finish_multi's column-sum items) with the default one workgroup per 64-channel block: the batched-load
+    loop (eight rows in flight per wavefront) and its remainder, ragged column counts, accumulate mode - against the fp64 column sums."""
+    torch.manual_seed(P + C)
+    part = torch.randn(P, C)
+    want = 0.5 * part[:, :n].double().sum(0)
+    got = K.colsum_finish(part, n, 0.5)
+    assert rel_err(got.double(), want) < 1e-6
+    acc = torch.full((n,), 2.0)
+    K.colsum_finish(part, n, 0.5, out=acc, accumulate=True)
+    assert rel_err(acc.double(), want + 2.0) < 1e-6
+    sink = torch.full((n,), -1.0)
+    K.finish_queue.add_colsum(part, n, 0.5, sink)
+    K.finish_queue.flush()
+    assert rel_err(sink.double(), want - 1.0) < 1e-6
