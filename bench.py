@@ -174,7 +174,7 @@ def modconv_forward_roofline(gan, batch, dev):
     2*b*O*I*9*H*W per layer (171.5 GF at batch 32) / the time of one hipGraph replay of exactly these launches."""
     from gigagan_pytorch_amd import ops, kernels as K
     rec, calls, prep = [], [], []
-    orig, orig_prep = ops.HipOps.modconv2d, ops.HipOps.modconv_prepare
+    orig, orig_prep, orig_pair = ops.HipOps.modconv2d, ops.HipOps.modconv_prepare, ops.HipOps.modconv_pair
 
     with K.LaunchProfiler() as prof:
         def timed(self, x, weights, mod, kernel_mod=None, demod=True, **kw):
@@ -191,6 +191,25 @@ def modconv_forward_roofline(gan, batch, dev):
             calls.append((x, weights, mod, kernel_mod, dict(kw, demod=demod)))
             return y
 
+        def timed_pair(self, x, first, second):
+            # a block's two layers as one launch (gg_spair_fwd); None = not fused: the two modconv2d calls follow and are recorded there
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n0 = len(prof.records)
+            e0.record()
+            y = orig_pair(self, x, first, second)
+            e1.record()
+            if y is None:
+                return None
+            b, _, H, W = x.shape
+            fl, chain = 0., []
+            for d in (first, second):
+                O, I = d['weights'].shape[1], d['weights'].shape[2]
+                fl += 2.0 * b * O * I * 9 * H * W
+                chain += [I, O] if not chain else [O]
+            rec.append((e0, e1, fl, '->'.join(map(str, chain)) + f'@{H}x{W} (fused pair)', n0, len(prof.records)))
+            calls.append(('pair', x, first, second))
+            return y
+
         def timed_prep(self, specs):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             n0 = len(prof.records)
@@ -199,7 +218,7 @@ def modconv_forward_roofline(gan, batch, dev):
             e1.record()
             prep.append((specs, e0, e1, n0, len(prof.records), n))
             return n
-        ops.HipOps.modconv2d, ops.HipOps.modconv_prepare = timed, timed_prep
+        ops.HipOps.modconv2d, ops.HipOps.modconv_prepare, ops.HipOps.modconv_pair = timed, timed_prep, timed_pair
         try:
             with torch.no_grad():
                 for _ in range(3):
@@ -209,7 +228,7 @@ def modconv_forward_roofline(gan, batch, dev):
                     gan.G(noise=torch.randn(batch, gan.G.style_network_dim, device=dev))
             torch.cuda.synchronize()
         finally:
-            ops.HipOps.modconv2d, ops.HipOps.modconv_prepare = orig, orig_prep
+            ops.HipOps.modconv2d, ops.HipOps.modconv_prepare, ops.HipOps.modconv_pair = orig, orig_prep, orig_pair
     # the same launches, on the inputs they saw, replayed as ONE hipGraph: their GPU time as the training step executes them
     # (back to back, kernel boundaries included, no host launch gaps - an eager split-K launch pair is ~10 us apart)
     graph_ms = None
@@ -219,8 +238,11 @@ def modconv_forward_roofline(gan, batch, dev):
         def run_all():
             for specs, *_ in prep:
                 orig_prep(impl, specs)
-            for x, w, m, km, kw in calls:
-                orig(impl, x, w, m, km, **kw)
+            for c in calls:
+                if isinstance(c[0], str):
+                    orig_pair(impl, *c[1:])
+                else:
+                    orig(impl, *c[:4], **c[4])
             impl.modconv_release()
         with torch.no_grad():
             side = torch.cuda.Stream(device=dev)

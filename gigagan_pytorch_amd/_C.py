@@ -82,7 +82,7 @@ class Library:
         L.gg_gemm_plan.argtypes = [C.POINTER(GemmDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         self._declare_elementwise()
         self.is_emulator = bool(L.gg_is_emulator())
-        if L.gg_version() != 11:
+        if L.gg_version() != 12:
             raise RuntimeError(f'gigagan_pytorch_amd: ABI version mismatch in {path}')
         L.gg_gemm_plan_table.restype = C.c_int
         L.gg_gemm_plan_table.argtypes = [C.POINTER(PlanEntry), C.c_int32]

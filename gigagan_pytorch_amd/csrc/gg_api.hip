@@ -18,6 +18,7 @@
 #include "gg_modcoef.h"
 #include "gg_modfwd.h"
 #include "gg_aconv.h"
+#include "gg_spair.h"
 #include "gg_semlp.h"
 #include "gg_comm.h"
 #include "../../include/gigagan_amd.h"
@@ -2006,6 +2007,51 @@ extern "C" int gg_sconv_fwd(const void* x, const void* w, int64_t w_bs, void* y,
     else if (C == 32) GG_LAUNCH((gg_sconv_kernel<32>), dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, p);
     else GG_LAUNCH((gg_sconv_kernel<64>), dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, p);
     return gg_check_launch();
+}
+
+// ---- gg_spair_fwd: two adaptive 3x3 convolutions of one generator block in one launch (csrc/gg_spair.h) ----------------------------
+template <int C0, int C1, int PT, int NCW>
+static int gg_spair_launch(GgSpairParams& p, int32_t b, void* stream) {
+    typedef GgSpGeom<C0, C1, PT, NCW> G;
+    const int lds = G::bytes(p.C2);
+    if (lds > 160 * 1024) return gg_fail(-2, "gg_spair_fwd: C2 = %d needs %d bytes of LDS", p.C2, lds);
+    // output rows per workgroup: one workgroup per CU in ONE round where the batch allows it (the halo - two conv1 rows and four x rows
+    // per strip - is the price of a shorter strip)
+    int rows = p.H;
+    while (rows > 8 && (long long)b * ((p.H + rows - 1) / rows) < 256) rows >>= 1;
+    p.rows = rows;
+    p.strips = (p.H + rows - 1) / rows;
+    GG_LAUNCH_DYN((gg_spair_kernel<C0, C1, PT, NCW>), dim3((unsigned)(b * p.strips)), dim3(G::NT), lds, (hipStream_t)stream, p);
+    return gg_check_launch();
+}
+
+extern "C" int gg_spair_supported(int32_t H, int32_t W, int32_t C0, int32_t C1, int32_t C2) {
+    if (H <= 0 || C2 <= 0 || C2 > 32 || (C2 & 7)) return 0;
+    if (W == 256 && C0 == 32 && C1 == 16) return GgSpGeom<32, 16, 1, 8>::bytes(C2) <= 160 * 1024;
+    if (W == 128 && C0 == 64 && C1 == 32) return GgSpGeom<64, 32, 1, 4>::bytes(C2) <= 160 * 1024;
+    return 0;
+}
+
+extern "C" int gg_spair_fwd(const void* x, const void* w1, int64_t w1_bs, const void* w2, int64_t w2_bs, void* y,
+                            const float* noise1, const float* nw1, const float* noise2, const float* nw2, const float* xs,
+                            int32_t b, int32_t H, int32_t W, int32_t C0, int32_t C1, int32_t C2, int32_t act1, int32_t act2,
+                            float slope, void* stream) {
+    if (!x || !w1 || !w2 || !y) return gg_fail(-1, "gg_spair_fwd: null pointer");
+    if (b <= 0 || !gg_spair_supported(H, W, C0, C1, C2))
+        return gg_fail(-2, "gg_spair_fwd: supported geometries are (W 256, C0 32, C1 16) and (W 128, C0 64, C1 32) with C2 <= 32, C2 %% 8 == 0 "
+                           "(b=%d H=%d W=%d C0=%d C1=%d C2=%d)", b, H, W, C0, C1, C2);
+    if ((noise1 != nullptr) != (nw1 != nullptr) || (noise2 != nullptr) != (nw2 != nullptr))
+        return gg_fail(-1, "gg_spair_fwd: a noise map and its weights go together");
+    if (act1 < 0 || act1 > 1 || act2 < 0 || act2 > 1) return gg_fail(-3, "gg_spair_fwd: activation must be none (0) or leaky-relu (1)");
+    if ((((uintptr_t)x) | ((uintptr_t)w1) | ((uintptr_t)w2) | ((uintptr_t)y) | ((uintptr_t)xs) | ((uintptr_t)noise1) | ((uintptr_t)noise2)) & 15)
+        return gg_fail(-4, "gg_spair_fwd: 16-byte alignment required");
+    GgSpairParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)x; p.w1 = (const bf16_t*)w1; p.w2 = (const bf16_t*)w2; p.y = (bf16_t*)y; p.w1_bs = w1_bs; p.w2_bs = w2_bs;
+    p.noise1 = noise1; p.nw1 = nw1; p.noise2 = noise2; p.nw2 = nw2; p.xs = xs;
+    p.b = b; p.H = H; p.C2 = C2; p.act1 = act1; p.act2 = act2; p.slope = slope;
+    if (C0 == 32) return gg_spair_launch<32, 16, 1, 8>(p, b, stream);
+    return gg_spair_launch<64, 32, 1, 4>(p, b, stream);
 }
 
 static int gg_modmix_common(GgModMixParams& p, int32_t b, int32_t P, int32_t O, int32_t Os, int32_t N, int32_t act, float slope) {

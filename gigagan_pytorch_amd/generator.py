@@ -20,6 +20,18 @@ class BaseGenerator(nn.Module):
     pass
 
 
+def _pair_args(conv, batch, mod, kernel_mod, noise, noise_weight, in_excite):
+    """one AdaptiveConv2DMod call (modules.AdaptiveConv2DMod.forward) as the keyword dict ops.modconv_pair takes."""
+    from .modules import tile_batch
+    mod = tile_batch(mod, batch)
+    kmod = None
+    if conv.adaptive:
+        assert exists(kernel_mod) and kernel_mod.numel() > 0
+        kmod = tile_batch(kernel_mod, batch)
+    return dict(weights=conv.weights, mod=mod, kernel_mod=kmod, demod=conv.demod, eps=conv.eps, noise=noise, noise_weight=noise_weight,
+                act='lrelu', in_excite=in_excite)
+
+
 def is_power_of_two(n):
     return log2(n).is_integer()
 
@@ -237,10 +249,20 @@ class Generator(BaseGenerator):
 
             h, w = x.shape[-2:]
             # noise draws: same order, shape and device as the reference's Noise modules (gp.py:938)
-            x = conv1(x, mod=next(conv_mods), kernel_mod=next(conv_mods), in_excite=excite,
-                      noise=torch.randn(batch, 1, h, w, device=device), noise_weight=noise1.weight, act='lrelu')
-            x = conv2(x, mod=next(conv_mods), kernel_mod=next(conv_mods),
-                      noise=torch.randn(batch, 1, h, w, device=device), noise_weight=noise2.weight, act='lrelu')
+            mod1, kmod1, mod2, kmod2 = next(conv_mods), next(conv_mods), next(conv_mods), next(conv_mods)
+            nz1 = torch.randn(batch, 1, h, w, device=device)
+            nz2 = torch.randn(batch, 1, h, w, device=device)
+            y = None
+            if not torch.is_grad_enabled() and hasattr(ops.impl, 'modconv_pair'):
+                # no-grad pass: conv1 -> noise -> leaky-relu -> conv2 -> noise -> leaky-relu as ONE launch where the op set has a fused
+                # form for the geometry (the 128x128 / 256x256 blocks: the intermediate map stays on chip); None = run them one by one
+                y = ops.impl.modconv_pair(x, _pair_args(conv1, batch, mod1, kmod1, nz1, noise1.weight, excite),
+                                          _pair_args(conv2, batch, mod2, kmod2, nz2, noise2.weight, None))
+            if y is None:
+                x = conv1(x, mod=mod1, kernel_mod=kmod1, in_excite=excite, noise=nz1, noise_weight=noise1.weight, act='lrelu')
+                x = conv2(x, mod=mod2, kernel_mod=kmod2, noise=nz2, noise_weight=noise2.weight, act='lrelu')
+            else:
+                x = y
 
             if exists(self_attn):
                 x = self_attn(x)

@@ -856,6 +856,32 @@ def sconv(x: torch.Tensor, wmix: torch.Tensor, O: int, noise=None, noise_w=None,
     return y
 
 
+def spair_supported(H: int, W: int, C0: int, C1: int, C2: int) -> bool:
+    return bool(_C.lib().lib.gg_spair_supported(H, W, C0, C1, C2))
+
+
+def spair(x: torch.Tensor, wmix1: torch.Tensor, wmix2: torch.Tensor, C1: int, C2: int, noise1=None, noise_w1=None, noise2=None,
+          noise_w2=None, act1=None, act2=None, slope: float = 0.2, xs=None) -> torch.Tensor:
+    """two streaming 3x3 convolutions with per-image filter banks in one launch, the intermediate map kept in LDS (gg_spair_fwd):
+    y = act2(conv(act1(conv(x * xs, w1) + noise1 * nw1), w2) + noise2 * nw2); x (b, H, W, C0) bf16, wmix1 (b, 9, C0/16, 32, 16),
+    wmix2 (b, 9, C1/16, 32, 16) bf16 (or (1, ...) shared) -> (b, H, W, C2) bf16. Bit-identical to sconv(sconv(x))."""
+    L = _C.lib()
+    L.require(x, wmix1, wmix2, noise1, noise_w1, noise2, noise_w2, xs)
+    b, H, W, C0 = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    for wm, ci in ((wmix1, C0), (wmix2, C1)):
+        assert wm.dtype == torch.bfloat16 and wm.is_contiguous() and wm.shape[1:] == (9, ci // 16, 32, 16) and wm.shape[0] in (1, b)
+    if xs is not None:
+        assert xs.dtype == torch.float32 and xs.is_contiguous() and xs.shape == (b, C0)
+    y = torch.empty((b, H, W, C2), dtype=torch.bfloat16, device=x.device)
+    rc = L.lib.gg_spair_fwd(ptr(x), ptr(wmix1), wmix1.stride(0) if wmix1.shape[0] > 1 else 0, ptr(wmix2),
+                            wmix2.stride(0) if wmix2.shape[0] > 1 else 0, ptr(y), ptr(noise1), ptr(noise_w1), ptr(noise2),
+                            ptr(noise_w2), ptr(xs), b, H, W, C0, C1, C2, 1 if act1 == 'lrelu' else 0, 1 if act2 == 'lrelu' else 0,
+                            float(slope), L.stream(x))
+    L.check(rc, 'gg_spair_fwd')
+    return y
+
+
 class AconvDesc(C.Structure):        # mirrors gg_aconv_desc (include/gigagan_amd.h)
     _fields_ = ([(f, C.c_void_p) for f in ('x', 'wf', 'y', 's', 'xs', 'a', 'd', 'noise', 'noise_w')] +
                 [(f, C.c_int32) for f in ('b', 'H', 'W', 'C', 'O', 'NB', 'act')] + [('slope', C.c_float)] +

@@ -1615,6 +1615,55 @@ class HipOps:
     def modconv_release(self):
         _prepared.clear()
 
+    def modconv_pair(self, x, first, second):
+        """the two adaptive 3x3 convolutions of one generator block (gp.py:1219-1229: conv1 -> Noise -> leaky_relu -> conv2 -> Noise ->
+        leaky_relu, nothing in between) in ONE launch where both are streaming layers of a geometry gg_spair_fwd carries (config 2:
+        64 -> 32 -> 32 at 128x128, 32 -> 16 -> 16 at 256x256): the intermediate map stays in LDS. `first` / `second`: dicts with the
+        keyword arguments of modconv2d (weights, mod, kernel_mod, demod, eps, noise, noise_weight, act, in_excite). Returns None when
+        the pair does not qualify - the caller then runs the two layers one by one. Bit-identical to that (same kernels' arithmetic)."""
+        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for d in (first, second)
+                                           for t in (x, d['weights'], d['mod'], d.get('kernel_mod'), d.get('noise_weight'),
+                                                     d.get('in_excite'))):
+            return None
+        if not _SPAIR or second.get('in_excite') is not None:
+            return None
+        x = to_act(x)
+        b, _, H, W = x.shape
+        w1, w2 = first['weights'], second['weights']
+        N1, O1, I1, k1, _ = w1.shape
+        N2, O2, I2, k2, _ = w2.shape
+        if (k1 != 3 or k2 != 3 or I2 != O1 or x.shape[1] != I1 or not first.get('demod', True) or not second.get('demod', True)
+                or first.get('act') not in (None, 'lrelu') or second.get('act') not in (None, 'lrelu')):
+            return None
+        for w, N, I in ((w1, N1, I1), (w2, N2, I2)):
+            if w.dtype != torch.float32 or not w.is_contiguous() or not K.modw_eligible(b, N, I, 9):
+                return None
+        if (self._modconv_path(b, N1, O1, I1, H, W) != 'sconv' or self._modconv_path(b, N2, O2, I2, H, W) != 'sconv'
+                or not K.spair_supported(H, W, I1, O1, O2)):
+            return None
+        banks = []
+        for d, w, N, O, I in ((first, w1, N1, O1, I1), (second, w2, N2, O2, I2)):
+            mod, kmod, exc = d['mod'], d.get('kernel_mod'), d.get('in_excite')
+            rec = _prepared.pop(id(w), None)
+            if rec is not None and (rec['excited'] != (exc is not None) or rec['mod_ptr'] != mod.data_ptr() or rec['path'] != 'sconv'
+                                    or rec['b'] != b):
+                rec = None
+            wm = _wmix_buffer(w, b, I)
+            xs_late = None
+            if rec is None:     # not announced: this layer's own launch (the excitation folded into its per-sample weights)
+                K.modw_fwd(w.detach(), _rows_f32(mod), _rows_f32(kmod) if N > 1 else None, True, d.get('eps', 1e-8), I, O, coef=False,
+                           wmix=wm, layout=2, xs=None if exc is None else _rows_f32(exc.reshape(b, I)))
+            elif exc is not None:
+                xs_late = exc.reshape(b, I).detach().float().contiguous()
+            nz = nw = None
+            if d.get('noise') is not None:
+                nz = d['noise'].reshape(-1).float().contiguous()
+                nw = d['noise_weight'].detach().reshape(-1).float().contiguous()
+            banks.append((wm, nz, nw, d.get('act'), xs_late))
+        (wm1, nz1, nw1, act1, xs1), (wm2, nz2, nw2, act2, _) = banks
+        y = K.spair(nhwc(x), wm1, wm2, O1, O2, nz1, nw1, nz2, nw2, act1, act2, LRELU_SLOPE, xs=xs1)
+        return nchw(y)
+
     def modconv2d(self, x, weights, mod, kernel_mod=None, demod=True, eps=1e-8, noise=None, noise_weight=None,
                   act=None, in_excite=None):
         """`in_excite` (b, I[, 1, 1]): a per-sample scale of the input activation (the skip-layer excitation the generator applies
@@ -1947,6 +1996,7 @@ class HipOps:
         return nchw(ResampleFn.apply(nhwc(xa), K.ResampleSpec.nearest(H, W, *size)))
 
 
+_SPAIR = os.environ.get('GG_SPAIR', '1') != '0'      # A/B switch: 0 runs the 128x128 / 256x256 adaptive convs one launch each (gg_sconv)
 _ACONV = os.environ.get('GG_ACONV', '1') != '0'      # A/B switch: 0 restores the round-3/4 kernels on the 4x4 .. 32x32 adaptive convs
 # widest image the one-launch kernel takes: measured (profiles/r5_aconv_probe*.log, batch 32, hipGraph-timed incl. the modulation
 # launch) 28 / 38 / 54+32 / 48+32 us against 63 / 79 / 69+52 / 51+35 us on 4x4 / 8x8 / 16x16 / 32x32, but 68+52 against 53+38 us at

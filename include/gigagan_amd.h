@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 11
+#define GG_ABI_VERSION 12
 
 int gg_version(void);
 const char* gg_last_error(void);
@@ -439,6 +439,21 @@ int gg_sconv_fwd(const void* x, const void* w, int64_t w_bs, void* y, const floa
                  int32_t b, int32_t H, int32_t W, int32_t C, int32_t O, int32_t act, float slope, void* stream);
 int gg_modulate_bank_fwd(const void* x, const float* s, const float* a, void* out, int32_t b, int32_t P, int32_t Cin, int32_t Cout,
                          void* stream);
+
+/* ---- gg_spair_fwd (ABI 12): the two adaptive 3x3 convolutions of one generator block in ONE launch (csrc/gg_spair.h): reference
+ * Generator.forward's resnet block gp.py:1219-1229 (conv1 -> Noise gp.py:925-940 -> leaky_relu gp.py:109 -> conv2 -> Noise ->
+ * leaky_relu) on the per-sample kernels of AdaptiveConv2DMod.forward gp.py:378-409 as gg_modw_fwd / gg_modw_multi_fwd write them
+ * (layout 2), at the 128x128 / 256x256 stages where the layers are HBM-bound:
+ *     mid = act1(conv3x3(x * xs, w1[b]) + noise1[b][p] * nw1[c])   (rounded to bf16, kept in LDS)
+ *     y   = act2(conv3x3(mid,    w2[b]) + noise2[b][p] * nw2[c])
+ * x (b, H, W, C0) bf16 NHWC, w1 [b][9][C0/16][32][16], w2 [b][9][C1/16][32][16] (w*_bs = elements between banks, 0 = shared),
+ * y (b, H, W, C2) bf16; noise maps [b][H*W] fp32 (16-byte aligned; each goes with its weights or is null), xs optional [b][C0] (the
+ * skip-layer excitation, gp.py:1023-1024). Bit-identical to gg_sconv_fwd(gg_sconv_fwd(x)). Geometries: gg_spair_supported
+ * (W 256 / C0 32 / C1 16 and W 128 / C0 64 / C1 32, C2 <= 32, C2 %% 8 == 0); anything else: -2. */
+int gg_spair_supported(int32_t H, int32_t W, int32_t C0, int32_t C1, int32_t C2);
+int gg_spair_fwd(const void* x, const void* w1, int64_t w1_bs, const void* w2, int64_t w2_bs, void* y, const float* noise1,
+                 const float* nw1, const float* noise2, const float* nw2, const float* xs, int32_t b, int32_t H, int32_t W, int32_t C0,
+                 int32_t C1, int32_t C2, int32_t act1, int32_t act2, float slope, void* stream);
 
 /* ---- gg_aconv_fwd (ABI 10): the no-grad adaptive convolution on a SHARED kernel bank in one launch (csrc/gg_aconv.h): reference
  * AdaptiveConv2DMod.forward gp.py:344-409 (softmax-mixed bank, style modulation, demodulation) + Noise gp.py:925-940 + leaky_relu

@@ -1156,6 +1156,50 @@ def test_streaming_conv_matches_per_sample_convolution(cfg):
     assert rel_err(y1.permute(0, 3, 1, 2), ref1) < 4e-3
 
 
+def _layout2(wps, C):
+    b, O = wps.shape[:2]
+    wm = torch.zeros(b, 9, C // 16, 32, 16, dtype=torch.bfloat16)
+    wm[:, :, :, :O] = wps.reshape(b, O, C // 16, 16, 9).permute(0, 4, 2, 1, 3)
+    return wm
+
+
+@pytest.mark.parametrize('model', ['early', 'late', 'early-reverse'])
+@pytest.mark.parametrize('cfg', [
+    # b, H, W, C0, C1, C2, excitation, noise, shared banks
+    (1, 11, 256, 32, 16, 16, True, True, False),       # the 256x256 pair of config 2 (two strips: 8 + 3 rows), every operand
+    (2, 5, 128, 64, 32, 32, True, True, False),        # the 128x128 pair (conv2's bank in LDS), one strip per image
+    (1, 4, 256, 32, 16, 8, False, False, True),        # no noise maps, no excitation, shared banks, ragged output channel count
+    (1, 19, 128, 64, 32, 24, False, True, True),       # three strips (8 + 8 + 3 rows)
+])
+def test_fused_streaming_pair_is_bit_identical_to_two_streaming_convolutions(cfg, model, monkeypatch):
+    """gg_spair_fwd (loader wave + LDS-DMA x ring with the two noise maps riding along, conv1 -> bf16 mid ring in LDS -> conv2, one
+    barrier per row) against gg_sconv_fwd(gg_sconv_fwd(x)): the same accumulation order and epilogue expressions, so torch.equal -
+    under both DMA landing models of the emulator and both fiber orders (a mis-counted wait or a ring slot refilled too early shows)."""
+    b, H, W, C0, C1, C2, excite, noise, shared = cfg
+    if model.startswith('late'):
+        monkeypatch.setenv('GG_EMU_DMA', 'late')
+    if model.endswith('reverse'):
+        monkeypatch.setenv('GG_EMU_REVERSE', '1')
+    assert K.spair_supported(H, W, C0, C1, C2) and not K.spair_supported(H, W, C0, C1 * 2, C2)
+    torch.manual_seed(0)
+    x = bf(torch.randn(b, H, W, C0))
+    nb = 1 if shared else b
+    w1 = _layout2(bf(torch.randn(nb, C1, C0, 3, 3) * 0.1), C0)
+    w2 = _layout2(bf(torch.randn(nb, C2, C1, 3, 3) * 0.2), C1)
+    xs = torch.rand(b, C0) + 0.5 if excite else None
+    n1 = n2 = nw1 = nw2 = None
+    if noise:
+        n1, n2 = torch.randn(b * H * W), torch.randn(b * H * W)
+        nw1, nw2 = torch.randn(C1) * 0.3, torch.randn(C2) * 0.3
+    mid = K.sconv(x, w1, C1, n1, nw1, 'lrelu', xs=xs)
+    want = K.sconv(mid, w2, C2, n2, nw2, 'lrelu')
+    got = K.spair(x, w1, w2, C1, C2, n1, nw1, n2, nw2, 'lrelu', 'lrelu', xs=xs)
+    assert got.shape == want.shape and torch.equal(got, want)
+    if not noise:       # the plain epilogues (no activation on either stage)
+        want = K.sconv(K.sconv(x, w1, C1, xs=xs), w2, C2)
+        assert torch.equal(K.spair(x, w1, w2, C1, C2, xs=xs), want)
+
+
 def test_modulate_bank_lays_the_kernels_side_by_side():
     torch.manual_seed(0)
     x, s, a = bf(torch.randn(2, 4, 4, 16)), torch.rand(2, 16) + 0.5, torch.rand(2, 3)
@@ -1182,6 +1226,49 @@ def test_no_grad_adaptive_conv_paths_match_oracle(cfg):
         with ops.use_impl(OracleOps(bf16_operands=True)):
             y0 = conv(x, mod, km, noise=nz, noise_weight=nw, act='lrelu')
     assert rel_err(y1, y0) < 1e-2
+
+
+def test_no_grad_block_pair_runs_as_one_launch_and_matches_the_two_layer_path():
+    """ops.modconv_pair (what Generator._synthesise calls for a block's conv1 -> noise -> leaky-relu -> conv2 -> noise -> leaky-relu in a
+    no-grad pass): at a geometry gg_spair_fwd carries both layers run as ONE launch, bit-identical to the two modconv2d calls - with
+    the first layer behind a skip-layer excitation, announced (modconv_prepare) or not; other geometries return None."""
+    from gigagan_pytorch_amd.modules import AdaptiveConv2DMod
+    torch.manual_seed(0)
+    b, H, W = 2, 128, 128
+    c1, c2 = AdaptiveConv2DMod(64, 32, 3, num_conv_kernels=2), AdaptiveConv2DMod(32, 32, 3, num_conv_kernels=2)
+    x = torch.randn(b, 64, H, W)
+    m1, k1, m2, k2 = torch.randn(b, 64) * 0.3, torch.randn(b, 2), torch.randn(b, 32) * 0.3, torch.randn(b, 2)
+    n1, n2 = torch.randn(b, 1, H, W), torch.randn(b, 1, H, W)
+    nw1, nw2 = torch.randn(32, 1, 1) * 0.1, torch.randn(32, 1, 1) * 0.1
+    exc = torch.rand(b, 64, 1, 1) + 0.5
+    impl = ops.HipOps()
+    first = dict(weights=c1.weights, mod=m1, kernel_mod=k1, demod=True, eps=1e-8, noise=n1, noise_weight=nw1, act='lrelu', in_excite=exc)
+    second = dict(weights=c2.weights, mod=m2, kernel_mod=k2, demod=True, eps=1e-8, noise=n2, noise_weight=nw2, act='lrelu', in_excite=None)
+    calls = []
+    real = K.spair
+    K.spair = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        with torch.no_grad(), ops.use_impl(impl):
+            mid = c1(x, m1, k1, noise=n1, noise_weight=nw1, act='lrelu', in_excite=exc)
+            want = c2(mid, m2, k2, noise=n2, noise_weight=nw2, act='lrelu')
+            got = impl.modconv_pair(x, first, second)
+            assert calls == [1] and torch.equal(got, want)
+            # announced: the per-sample weights come from the forward's batched launch, the excitation rides on the pair's weight staging
+            specs = [(c1.weights, m1, k1, H, W, True, True, 1e-8), (c2.weights, m2, k2, H, W, False, True, 1e-8)]
+            assert impl.modconv_prepare(specs) == 2
+            want2 = c2(c1(x, m1, k1, noise=n1, noise_weight=nw1, act='lrelu', in_excite=exc), m2, k2, noise=n2, noise_weight=nw2, act='lrelu')
+            assert impl.modconv_prepare(specs) == 2
+            got2 = impl.modconv_pair(x, first, second)
+            impl.modconv_release()
+            assert calls == [1, 1] and torch.equal(got2, want2)
+            assert rel_err(got2, want) < 8e-3          # ((w s d) rounded, then * e rounded: one rounding more than (w s e d))
+            # a pair the kernel does not carry (64 -> 64): the caller runs the layers one by one
+            c3 = AdaptiveConv2DMod(32, 64, 3, num_conv_kernels=2)
+            assert impl.modconv_pair(mid, dict(second, weights=c3.weights, noise_weight=torch.randn(64, 1, 1)), second) is None
+        with ops.use_impl(impl):                                         # gradients flow: never fused
+            assert impl.modconv_pair(x.requires_grad_(), first, second) is None
+    finally:
+        K.spair = real
 
 
 def test_forked_conv_and_norm_match_the_plain_fork_first_and_second_order():

@@ -365,10 +365,57 @@ def test_captured_collectives_never_outlive_the_communicator(tmp_path):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize('cfg', [(64, 32, 32, 128), (32, 16, 16, 256)])
+def test_fused_block_pair_at_config2_shapes_batch_32(cfg):
+    """the generator's 128x128 / 256x256 blocks at the bench batch (gp.py:1219-1229, no-grad pass): (a) gg_spair_fwd is bit-identical
+    to gg_sconv_fwd(gg_sconv_fwd(x)) on the same per-sample banks, noise maps and skip-layer excitation (torch.equal: same
+    accumulation order, same epilogue expressions, the intermediate map rounded to bf16 exactly as the unfused path stores it);
+    (b) ops.modconv_pair, announced as the generator announces it, against the oracle's two layers with bf16-rounded operands."""
+    from gigagan_pytorch_amd.modules import AdaptiveConv2DMod
+    from gigagan_pytorch_amd import kernels as K
+    C0, C1, C2, R = cfg
+    b, d = 32, dev()
+    torch.manual_seed(0)
+    c1, c2 = AdaptiveConv2DMod(C0, C1, 3, num_conv_kernels=2), AdaptiveConv2DMod(C1, C2, 3, num_conv_kernels=2)
+    x = torch.randn(b, C0, R, R)
+    m1, k1, m2, k2 = torch.randn(b, C0) * 0.3, torch.randn(b, 2), torch.randn(b, C1) * 0.3, torch.randn(b, 2)
+    n1, n2 = torch.randn(b, 1, R, R), torch.randn(b, 1, R, R)
+    nw1, nw2 = torch.randn(C1, 1, 1) * 0.1, torch.randn(C2, 1, 1) * 0.1
+    exc = torch.rand(b, C0, 1, 1) + 0.5
+    with torch.no_grad():
+        with ops.use_impl(OracleOps(bf16_operands=True)):
+            y0 = c2(c1(x * exc, m1, k1, noise=n1, noise_weight=nw1, act='lrelu'), m2, k2, noise=n2, noise_weight=nw2, act='lrelu')
+        c1, c2 = c1.to(d), c2.to(d)
+        g = lambda t: t.to(d)
+        impl = ops.HipOps()
+        first = dict(weights=c1.weights, mod=g(m1), kernel_mod=g(k1), demod=True, eps=1e-8, noise=g(n1), noise_weight=g(nw1), act='lrelu',
+                     in_excite=g(exc))
+        second = dict(weights=c2.weights, mod=g(m2), kernel_mod=g(k2), demod=True, eps=1e-8, noise=g(n2), noise_weight=g(nw2), act='lrelu',
+                      in_excite=None)
+        specs = [(c1.weights, first['mod'], first['kernel_mod'], R, R, True, True, 1e-8),
+                 (c2.weights, second['mod'], second['kernel_mod'], R, R, False, True, 1e-8)]
+        xd = g(x)
+        with ops.use_impl(impl):
+            assert impl.modconv_prepare(specs) == 2
+            mid = c1(xd, first['mod'], first['kernel_mod'], noise=first['noise'], noise_weight=first['noise_weight'], act='lrelu',
+                     in_excite=first['in_excite'])
+            two = c2(mid, second['mod'], second['kernel_mod'], noise=second['noise'], noise_weight=second['noise_weight'], act='lrelu')
+            assert impl.modconv_prepare(specs) == 2
+            K.plan_log = []
+            try:
+                one = impl.modconv_pair(xd, first, second)
+            finally:
+                plans, K.plan_log = K.plan_log, None
+            impl.modconv_release()
+    assert one is not None and not plans
+    assert torch.equal(one, two)
+    assert rel_err(one.float().cpu(), y0) < 1e-2
+
+
 @pytest.mark.parametrize('cfg', [(512, 512, 4, 32, 'aconv'), (512, 512, 8, 32, 'aconv'), (512, 256, 16, 32, 'aconv'),
                                  (256, 256, 16, 32, 'aconv'), (256, 128, 32, 32, 'aconv'), (128, 128, 32, 32, 'aconv'),
-                                 (128, 64, 64, 8, 'pimg'), (64, 64, 64, 8, 'pimg'), (128, 64, 64, 32, 'pimg'),
-                                 (64, 32, 128, 8, 'sconv'), (32, 32, 128, 8, 'sconv'), (32, 16, 256, 4, 'sconv'), (16, 16, 256, 4, 'sconv')])
+                                 (128, 64, 64, 32, 'pimg'), (64, 64, 64, 32, 'pimg'),
+                                 (64, 32, 128, 32, 'sconv'), (32, 32, 128, 32, 'sconv'), (32, 16, 256, 32, 'sconv'), (16, 16, 256, 32, 'sconv')])
 def test_no_grad_adaptive_conv_at_config2_layer_shapes(cfg):
     """the generator's demodulated 3x3 adaptive convs (gp.py:344-409 + noise + leaky-relu) at EVERY BASELINE config-2 layer shape,
     no-grad path, against the oracle with bf16-rounded operands: 1e-2 relative L2 (bf16 output rounding; the oracle rounds the
