@@ -47,7 +47,15 @@ struct GgAconvParams {
     int pf_tn_bytes, pf_mt, pf_grid;
     int dbg;                // probes only (gg_aconv_desc.reserved): 1 = no reduction loop, 2 = no halo staging, 4 = one wavefront finishes nothing
     long long x_bytes, wf_bytes;
+#if defined(GG_AC_PROBE)        // tests/probes/aconv_probe.hip only: phase time stamps (s_memtime) of every workgroup's first and last wavefront
+    long long* stamps;          // [workgroup][2][8]
+#endif
 };
+#if defined(GG_AC_PROBE)
+#define GG_AC_STAMP(slot) do { if (lane == 0 && (wave == 0 || wave == NW - 1)) p.stamps[((long long)blockIdx.x * 2 + (wave != 0)) * 8 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GG_AC_STAMP(slot) do {} while (0)
+#endif
 
 // k-steps of weight fragments in flight per wavefront (multiples of 3: they divide every slice length the host picks). What the
 // first measurements said (profiles/r5_aconv_probe*.log): the weight stream runs at what the L2 delivers (64 B/clk per CU, ~25-30 TB/s
@@ -66,6 +74,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(64 * NWN * NWK) void gg_aconv_kernel(GgAconvParams p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = gg_uniform(tid >> 6);
     const int wn = wave % NWN, wk = wave / NWN;
+    GG_AC_STAMP(0);
 
     // XCD-aware tile order (workgroup -> XCD is round-robin in blockIdx): the pixel tiles of one output-channel tile - the readers of
     // one weight stream - are consecutive in `wg`, so they share an XCD's L2 and the bank leaves HBM once per XCD slice
@@ -168,7 +177,9 @@ GG_KERNEL GG_LAUNCH_BOUNDS(64 * NWN * NWK) void gg_aconv_kernel(GgAconvParams p)
                 *(u16x8*)(smem + (dst[u] & 0xFFFFFF)) = h;
             }
     }
+    GG_AC_STAMP(1);
     gg_sync();
+    GG_AC_STAMP(2);
 
     // ---- the reduction: this wavefront's 32 output channels x BMT pixels x its k-steps; no barrier, no LDS write ------------------
     int a_base[TM];
@@ -236,6 +247,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(64 * NWN * NWK) void gg_aconv_kernel(GgAconvParams p)
         }
     }
 
+    GG_AC_STAMP(3);
     // ---- mix the banks (fp32), sum the K-slices through LDS in slice order, finish -----------------------------------------------
     const GgAconvParams e = *gg_late_params(p);
     f32x16 out[TM];
@@ -260,6 +272,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS(64 * NWN * NWK) void gg_aconv_kernel(GgAconvParams p)
                 for (int q = 0; q < 16; ++q) red[((((wk - 1) * NWN + wn) * TM + i) * 16 + q) * 64 + lane] = out[i][q];
         }
         gg_sync();
+        GG_AC_STAMP(4);
         if (wk > 0) {
             // this wavefront is done: request the slice of the NEXT layer's bank that the workgroups of the next launch on THIS XCD will
             // stream (same blockIdx -> XCD dealing), split over this XCD's workgroups - it lands in this XCD's L2 while the finishing
@@ -308,4 +321,5 @@ GG_KERNEL GG_LAUNCH_BOUNDS(64 * NWN * NWK) void gg_aconv_kernel(GgAconvParams p)
             *(u16x4*)(e.y + pix * e.O + chb + 8 * g) = o4;
         }
     }
+    GG_AC_STAMP(5);
 }
