@@ -291,6 +291,21 @@ def modconv_forward_roofline(gan, batch, dev):
 
 
 # ---- the multi-rank half of the contract, as functions a world-2 gloo test can drive (tests/test_distributed_cpu.py) ------------
+def check_comm_for_measurement(world: int, dry: bool, backend: str, comm_world, reducers: bool):
+    """None when the run may be reported, else why not: at N > 1 on GPUs the gradient exchange must be gg_comm/rccl with N ranks in the
+    communicator and both flat-gradient reducers wired - never the torch.distributed fallback. (The CPU dry run states its transport in
+    the line instead: gloo, or the gloo-backed double of the native communicator.)"""
+    if world <= 1 or dry:
+        return None
+    if backend != 'gg_comm/rccl':
+        return f'--gpus {world}: the gradient exchange is {backend!r}, not the native RCCL path (gg_comm/rccl): refusing to report a number'
+    if comm_world != world:
+        return f'--gpus {world}: the RCCL communicator holds {comm_world} rank(s): refusing to report a number'
+    if not reducers:
+        return f'--gpus {world}: the trainer has no in-backward gradient reducers on its flat buffers: refusing to report a number'
+    return None
+
+
 def max_over_ranks(dt: float, world: int, dev) -> float:
     """the step time that counts is the slowest rank's: MAX-reduce over the default process group (RCCL on GPUs, gloo in the dry run)."""
     if world <= 1:
@@ -453,6 +468,13 @@ def main():
         warmup += 1
     comm = gdist.native_comm()
     graphs_on = bool(gan._graphable(1))
+    # a multi-GPU number must be THE path it claims: the native RCCL exchange (gg_comm_*) with every rank in the communicator. The
+    # trainer keeps a torch.distributed fallback for bring-up; a measurement never takes it silently
+    comm_problem = check_comm_for_measurement(world, dry, gdist.comm_backend(), None if comm is None else comm.world,
+                                              gan.D_red is not None and gan.G_red is not None)
+    if comm_problem:
+        print(f'bench.py: {comm_problem}', file=sys.stderr, flush=True)
+        sys.exit(3)
     # exposed share of the gradient exchange = how long the compute stream waits at the join behind the in-backward slices.
     # HIP events cannot be recorded inside a hipGraph replay, so with graphs on it is taken from the eager cycle further down.
     time_comm_here = comm is not None and world > 1 and not graphs_on
@@ -591,6 +613,9 @@ def main():
                                        'boxes only): efficiency is for the driver to compute from its own per-N runs'),
                         hip_graphs=bool(gan._graphable(1)), graph_memset_nodes_repaired=sum(gan._graph_memsets.values()), comm=gdist.comm_backend(),
                         comm_world=(comm.world if comm is not None else (world if world > 1 else 0)),
+                        rccl_ranks=(comm.world if (comm is not None and gdist.comm_backend() == 'gg_comm/rccl') else None),
+                        exposed_comm_ms_per_step_by_rank=(None if per_rank is None else
+                                                          [r.get('exposed_comm_ms_per_step') for r in per_rank]),
                         comm_overlap=('in-backward slices: D %d, G %d' % (gan.D_red.n, gan.G_red.n)
                                       if (gan.D_red is not None and gan.overlap_grad_reduce) else 'none')),
             roofline=roofline, cpu_baseline=cpu,

@@ -45,7 +45,7 @@ struct GgAconvParams {
     const bf16_t* pf_wf;
     long long pf_bytes;
     int pf_tn_bytes, pf_mt, pf_grid;
-    int dbg;                // probes only (gg_aconv_desc.reserved): 1 = no reduction loop, 2 = no halo staging, 4 = one wavefront finishes nothing
+    int dbg;                // probe builds only (-DGG_PROBE; gg_aconv_desc.reserved): 1 = no reduction loop, 2 = no halo staging; ignored by the product library
     long long x_bytes, wf_bytes;
 #if defined(GG_AC_PROBE)        // tests/probes/aconv_probe.hip only: phase time stamps (s_memtime) of every workgroup's first and last wavefront
     long long* stamps;          // [workgroup][2][8]
@@ -140,7 +140,11 @@ GG_KERNEL GG_LAUNCH_BOUNDS(64 * NWN * NWK) void gg_aconv_kernel(GgAconvParams p)
         for (int n = 0; n < NB; ++n) av[i][n] = (p.a ? p.a : p.s)[p.a ? (long long)ic * NB + n : 0];
     }
     u16x8 bq[PD][NB];
+#if defined(GG_PROBE)
     const int nvec_run = (p.dbg & 2) ? 0 : nvec;
+#else
+    const int nvec_run = nvec;
+#endif
     for (int v0 = tid; v0 < nvec_run || v0 == tid; v0 += NT * GG_AC_XV) {     // (at least once for EVERY thread: the first pass starts the weight stream)
         u16x8 xv[GG_AC_XV];
         int dst[GG_AC_XV];
@@ -222,7 +226,11 @@ GG_KERNEL GG_LAUNCH_BOUNDS(64 * NWN * NWK) void gg_aconv_kernel(GgAconvParams p)
     };
     if (FIN_EARLY) load_fin();
 
+#if defined(GG_PROBE)
     const int k_end = (p.dbg & 1) ? k_lo : k_hi;
+#else
+    const int k_end = k_hi;
+#endif
     for (int k0 = k_lo; k0 < k_end; k0 += PD) {
 #pragma unroll
         for (int u = 0; u < PD; ++u) {

@@ -293,15 +293,7 @@ static double gg_plan_cost(const gg_gemm_desc* d, const GgTileModel& tm, int sk,
 
 // the direct convolution (gg_dconv.h, plan tile 9): narrow 3x3 / stride 1 / pad 1 layers on large feature maps.
 // GG_DCONV=0 disables it (A/B runs); force_tile 9 selects it wherever eligible, any other force_tile bypasses it.
-static int gg_dconv_policy() {
-    static int policy = -1;
-    if (policy < 0) {
-        const char* e = getenv("GG_DCONV");
-        policy = e ? atoi(e) : 1;
-        if (policy < 0) policy = 1;
-    }
-    return policy;
-}
+static int gg_dconv_policy() { return 1; }     // (round 6: the GG_DCONV A/B switch is gone - settled since its round; tests reach the other kernels with force_tile)
 
 static bool gg_dconv_eligible(const gg_gemm_desc* d) {
     if (!d->a_conv || d->a_layout != GG_ROWK || d->b_layout != GG_ROWK) return false;
@@ -432,15 +424,7 @@ static bool gg_table_plan(const gg_gemm_desc* d, GemmPlan& pl) {
 // whole image rows or whole images; 7: 256 output channels per workgroup, 8: 128). It takes over every unsplit 256-row implicit-GEMM
 // choice of the planner on eligible layers (measured +17-36 % per layer, profiles/r02_conv3_ab.log); GG_CONV3=0 disables that
 // (A/B runs); force_tile 7 / 8 selects it wherever eligible.
-static int gg_conv3_policy() {
-    static int policy = -1;
-    if (policy < 0) {
-        const char* e = getenv("GG_CONV3");
-        policy = e ? atoi(e) : 1;
-        if (policy < 0) policy = 1;
-    }
-    return policy;
-}
+static int gg_conv3_policy() { return 1; }     // (round 6: the GG_CONV3 A/B switch is gone - settled since its round; tests reach the other kernels with force_tile)
 
 static bool gg_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
@@ -512,15 +496,7 @@ static GemmPlan gg_conv3_plan(const gg_gemm_desc* d, int tile, int splitk) {
 // two images. It takes over the 8-wave implicit-GEMM weight gradient wherever the planner chose a 256-row tile on an eligible layer
 // (measured +16-35 % per layer on the 256/512-channel layers, +1.9 % on the step: profiles/r02_wgrad9_ab.log); GG_WGRAD9=0 disables
 // that (A/B runs); force_tile 10 selects it wherever eligible.
-static int gg_wgrad9_policy() {
-    static int policy = -1;
-    if (policy < 0) {
-        const char* e = getenv("GG_WGRAD9");
-        policy = e ? atoi(e) : 1;
-        if (policy < 0) policy = 1;
-    }
-    return policy;
-}
+static int gg_wgrad9_policy() { return 1; }     // (round 6: the GG_WGRAD9 A/B switch is gone - settled since its round; tests reach the other kernels with force_tile)
 
 static bool gg_wgrad9_eligible(const gg_gemm_desc* d) {
     if (!d->a_conv || d->a_layout != GG_KROW || d->b_layout != GG_KROW) return false;
@@ -612,15 +588,7 @@ static GemmPlan gg_lrconv_plan(const gg_gemm_desc* d, int splitk) {
 // or cost model) would run a 3x3 / stride 1 / pad 1, 1x1, 2x2 / stride 2 or 1x1 / stride 2 weight gradient with <= 64 input and output
 // channels over >= 64K pixels
 // on the 4-wave kernel. GG_WGRADS=0 disables that (A/B runs); force_tile 13 selects it wherever eligible.
-static int gg_wgrads_policy() {
-    static int policy = -1;
-    if (policy < 0) {
-        const char* e = getenv("GG_WGRADS");
-        policy = e ? atoi(e) : 1;
-        if (policy < 0) policy = 1;
-    }
-    return policy;
-}
+static int gg_wgrads_policy() { return 1; }     // (round 6: the GG_WGRADS A/B switch is gone - settled since its round; tests reach the other kernels with force_tile)
 
 struct GgWsMode { int kh, kw, halo, rpr, cs, cstore, gmul, spx, depth; };
 
@@ -677,15 +645,7 @@ static GemmPlan gg_wgrads_plan(const gg_gemm_desc* d, int splitk) {
 // the streaming forward / data-gradient convolution (gg_sfwd.h, plan tile 14): 3x3 / stride 1 / pad 1, <= 64 channels either side,
 // 64..256-wide images, shared or per-image weights. Takes over from the direct convolution (tile 9) and from the 4-wave kernel
 // (tiles 1-3) on eligible launches of >= 64K pixels. GG_SFWD=0 disables that (A/B runs); force_tile 14 selects it wherever eligible.
-static int gg_sfwd_policy() {
-    static int policy = -1;
-    if (policy < 0) {
-        const char* e = getenv("GG_SFWD");
-        policy = e ? atoi(e) : 1;
-        if (policy < 0) policy = 1;
-    }
-    return policy;
-}
+static int gg_sfwd_policy() { return 1; }     // (round 6: the GG_SFWD A/B switch is gone - settled since its round; tests reach the other kernels with force_tile)
 
 static bool gg_sfwd_shape(const gg_gemm_desc* d, int* spx_out, int* depth_out) {
     if (!d->a_conv || d->a_layout != GG_ROWK || d->b_layout != GG_ROWK) return false;
@@ -741,15 +701,7 @@ static GemmPlan gg_sfwd_substitute(const gg_gemm_desc* d, const GemmPlan& pl) {
 // the persistent short-K contraction (gg_pgemm.h, plan tile 15): row-major A (dense, or a 1x1 / stride 1 convolution gather, which is
 // the same addressing) times row-major B into a bf16 [M][N] output through the staged epilogue (alpha, bias, activation, residual,
 // GELU aux modes). GG_PGEMM=0 disables the substitution (A/B runs); force_tile 15 selects it wherever eligible.
-static int gg_pgemm_policy() {
-    static int policy = -1;
-    if (policy < 0) {
-        const char* e = getenv("GG_PGEMM");
-        policy = e ? atoi(e) : 1;
-        if (policy < 0) policy = 1;
-    }
-    return policy;
-}
+static int gg_pgemm_policy() { return 1; }     // (round 6: the GG_PGEMM A/B switch is gone - settled since its round; tests reach the other kernels with force_tile)
 
 static bool gg_pgemm_eligible(const gg_gemm_desc* d) {
     if (d->a_layout != GG_ROWK || d->b_layout != GG_ROWK || d->batch != 1) return false;
@@ -1067,7 +1019,11 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
             const int tiles_n = (d->N + 127) / 128;
             p.pg_order = tiles_n <= 2 || (tiles_n <= 4 && d->K >= 512) || d->gelu_mode == 2;
         }
-        if (const char* e = getenv("GG_PGEMM_DBG")) p.xcd_slices = atoi(e);      // (probe runs: phases switched off, results are garbage)
+        // GG_PGEMM_ORDER=flip: the other tile order (same results bit for bit: tests/test_emulator_kernels.py runs both; the order probe)
+        if (const char* e = getenv("GG_PGEMM_ORDER")) if (e[0] == 'f') p.pg_order = !p.pg_order;
+#if defined(GG_PROBE)
+        if (const char* e = getenv("GG_PGEMM_DBG")) p.xcd_slices = atoi(e);      // (probe builds: phases switched off, results are garbage)
+#endif
         const bool full = p.bias || p.act != GG_ACT_NONE;
         if (full) GG_LAUNCH((gg_pgemm_kernel<true>), grid2, dim3(GG_PG_NT), s, p);
         else GG_LAUNCH((gg_pgemm_kernel<false>), grid2, dim3(GG_PG_NT), s, p);
@@ -1627,7 +1583,10 @@ extern "C" int gg_aconv_fwd(const gg_aconv_desc* d, void* stream) {
     p.s = d->s; p.xs = d->xs; p.a = d->a; p.d = d->d; p.noise = d->noise; p.noise_w = d->noise_w;
     p.b = d->b; p.H = d->H; p.W = d->W; p.C = d->C; p.O = d->O;
     p.w_shift = gg_log2i(d->W); p.hw_shift = gg_log2i(d->H * d->W); p.c8_shift = gg_log2i(d->C / 8);
-    p.act = d->act; p.slope = d->slope; p.mt = pl.mt; p.dbg = d->reserved;
+    p.act = d->act; p.slope = d->slope; p.mt = pl.mt;
+#if defined(GG_PROBE)
+    p.dbg = d->reserved;        // (probe builds: phases switched off)
+#endif
     {
         const int bmt = 32 * pl.tm, hw = d->H * d->W;
         const int rt = hw >= bmt ? bmt / d->W : d->H;
@@ -2095,11 +2054,7 @@ extern "C" int gg_modmix_bwd(const void* dy, const void* y, const void* Y, const
 
 // ---- fused self-attention (gg_attention.h) ------------------------------------------------------------------------
 
-static int gg_attn_xcd() {                       // GG_ATTN_XCD=0: blocks in dispatch order (A/B runs)
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("GG_ATTN_XCD"); v = e ? (atoi(e) != 0) : 1; }
-    return v;
-}
+static int gg_attn_xcd() { return 1; }     // (round 6: the GG_ATTN_XCD A/B switch is gone: XCD-aware block order, profiles/r05_attn_xcd_ab.log)
 
 static int gg_attn_common(GgAttnParams& p, const void* q, const void* k, const void* v, const void* k0, const void* v0,
                           int32_t B, int32_t n, int32_t h, float alpha, float beta) {

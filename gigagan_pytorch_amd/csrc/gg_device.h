@@ -27,12 +27,16 @@
 // kernels whose LDS need depends on the launch geometry (gg_aconv.h): one `extern __shared__` array, sized at launch. More than 64 KB
 // of it must be allowed per kernel once (hipFuncAttributeMaxDynamicSharedMemorySize: a host-side attribute, no stream work)
 #define GG_DYN_SHARED(name) extern __shared__ __attribute__((aligned(1024))) char name[]
+// (the attribute is per device: one flag per device ordinal; a refused attribute is left unset so that the launch below reports it)
 #define GG_LAUNCH_DYN(kernel, grid, block, lds_bytes, stream, ...)                                                      \
     do {                                                                                                                \
-        static bool gg_lds_allowed_ = false;                                                                            \
-        if (!gg_lds_allowed_) {                                                                                         \
-            (void)hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
-            gg_lds_allowed_ = true;                                                                                     \
+        static bool gg_lds_allowed_[64] = {false};                                                                      \
+        int gg_dev_ = 0;                                                                                                \
+        if (hipGetDevice(&gg_dev_) != hipSuccess || gg_dev_ < 0 || gg_dev_ >= 64) gg_dev_ = 0;                          \
+        if (!gg_lds_allowed_[gg_dev_]) {                                                                                \
+            if (hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess) \
+                gg_lds_allowed_[gg_dev_] = true;                                                                        \
+            else (void)hipGetLastError();                                                                               \
         }                                                                                                               \
         hipLaunchKernelGGL(kernel, grid, block, (size_t)(lds_bytes), stream, __VA_ARGS__);                              \
     } while (0)

@@ -51,13 +51,19 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG_PG_NT) void gg_pgemm_kernel(GgGemmParams p) {
     //    by then the output stream has pushed it out of the L2 (FETCH_SIZE 3.4x the A operand, r05_pmc_pgemm_v2_nt_vs_plain.log) - but
     //    the re-reads come from the memory-side cache and a workgroup meets a cold A tile only once per row of tiles.
     // The host picks by shape (gg_api.hip).
-    const bool rr_order = (p.pg_order != 0) != ((p.xcd_slices & 64) != 0);
+    const bool rr_order = p.pg_order != 0;
     const int t0 = rr_order ? wg : (int)(wg * T / nwg);
     const int ntw = rr_order ? (wg < T ? (int)((T - wg + nwg - 1) / nwg) : 0) : (int)((wg + 1) * T / nwg) - t0;      // tiles of this workgroup
     const int dtm = rr_order ? nwg / tiles_n : 0, dtn = rr_order ? nwg - dtm * tiles_n : 1;                        // tile step as (rows of tiles, tiles)
     const int KT = p.K >> 6;
     const int Q = ntw * KT;
-    const int dbg = p.xcd_slices;       // probe runs (GG_PGEMM_DBG, tests/gpu_r5_pgemm_probe.py): 1 no MFMAs, 2 no epilogue, 4 no transfers, 8 no stores, 16 plain stores, 64 the other tile order; 0 in the product
+    // probe builds only (-DGG_PROBE, GG_PGEMM_DBG in the environment, tests/gpu_r5_pgemm_probe.py): 1 no MFMAs, 2 no epilogue, 4 no transfers,
+    // 8 no stores, 16 plain stores. The product library compiles the constant 0: no switch in it can turn results into garbage
+#if defined(GG_PROBE)
+    const int dbg = p.xcd_slices;
+#else
+    constexpr int dbg = 0;
+#endif
 
     if (wave >= 8) {
         // ---------------------------------------------------------------- loaders

@@ -123,6 +123,13 @@ def shard_dataloader(dl, rank: int, world: int, seed: int = 0):
     common = dict(num_workers=dl.num_workers, collate_fn=dl.collate_fn, pin_memory=dl.pin_memory,
                   persistent_workers=getattr(dl, 'persistent_workers', False) and dl.num_workers > 0)
     stock = (torch.utils.data.SequentialSampler, torch.utils.data.RandomSampler)
+    # the round-robin paths below iterate the caller's sampler in full on every rank: a RANDOM sampler that draws from the process-global
+    # generator (`generator=None`: RandomSampler, WeightedRandomSampler, SubsetRandomSampler) would give every rank its own stream and
+    # the shards would overlap. accelerate synchronises the sampler RNG across ranks; here every rank installs the same seeded generator
+    # (`seed` is the trainer's, identical on all ranks; the generator's state carries over the epochs, identically everywhere)
+    for smp in (dl.sampler, getattr(dl.batch_sampler, 'sampler', None)):
+        if smp is not None and hasattr(smp, 'generator') and smp.generator is None and not isinstance(smp, torch.utils.data.SequentialSampler):
+            smp.generator = torch.Generator().manual_seed(seed)
     if dl.batch_sampler is None:            # automatic batching off: the sampler's indices ARE the batches
         return DataLoader(dl.dataset, batch_size=None, sampler=RoundRobinShard(dl.sampler, rank, world), **common)
     stock_batches = type(dl.batch_sampler) is torch.utils.data.BatchSampler and dl.batch_size is not None

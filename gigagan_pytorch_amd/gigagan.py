@@ -323,6 +323,7 @@ class GigaGAN(nn.Module):
             opt.flat_p.copy_(p)
             opt.flat_m.copy_(m)
             opt.flat_v.copy_(v)
+            opt.zero_slot_tails()       # (ops._bias8 reads ragged biases through their slots' zero tails)
             opt.step_count = t
             opt._steps_dirty = True
             ops.pack_cache_clear()
@@ -507,9 +508,10 @@ class GigaGAN(nn.Module):
                 graph, outs, self._graph_memsets[key] = K.capture_graph(fn, capture_error_mode=mode)
                 ops.pack_cache_clear()        # ... and nothing outside may keep tensors of its private pool
                 entry = self._graphs[key] = (graph, outs)
-            except (RuntimeError, TypeError, AttributeError) as e:
-                # RuntimeError: what HIP / torch raise when a capture is refused. TypeError / AttributeError: a torch older than 2.8
-                # without CUDAGraph(keep_graph=True) / raw_cuda_graph() / instantiate(), which the memset repair needs
+            except RuntimeError as e:
+                # RuntimeError: what HIP / torch raise when a capture is refused; kernels.GraphApiMissing (a RuntimeError): a torch older
+                # than 2.8 without CUDAGraph(keep_graph=True) / raw_cuda_graph() / instantiate(), which the memset repair needs. A
+                # TypeError / AttributeError out of the step itself is a programming error and propagates
                 import warnings
                 msg = (f'hipGraph capture of the {key} step failed ({type(e).__name__}: {e}); running eagerly from here on - '
                        f'expect roughly half the throughput')

@@ -546,12 +546,22 @@ def colsum_finish(part: torch.Tensor, n: int, alpha: float = 1.0, out: torch.Ten
     return out
 
 
+class GraphApiMissing(RuntimeError):
+    """this torch has no CUDAGraph(keep_graph=True) / raw_cuda_graph() / instantiate() (older than 2.8): the memset repair a captured
+    step needs cannot be applied, so steps run eagerly."""
+
+
 def capture_graph(fn, capture_error_mode: str = 'global'):
     """capture `fn()` into a hipGraph, repair it (gg_graph_patch_memsets: this HIP runtime replays captured memset nodes with a
     corrupted value, which breaks every PyTorch split reduction inside the graph from the second replay on), instantiate it.
     Returns (graph, fn's outputs, number of memset nodes repaired). The caller has warmed `fn` up on a side stream."""
     L = _C.lib()
-    graph = torch.cuda.CUDAGraph(keep_graph=True)
+    if not (hasattr(torch.cuda.CUDAGraph, 'raw_cuda_graph') and hasattr(torch.cuda.CUDAGraph, 'instantiate')):
+        raise GraphApiMissing('torch.cuda.CUDAGraph lacks raw_cuda_graph() / instantiate() (torch < 2.8)')
+    try:
+        graph = torch.cuda.CUDAGraph(keep_graph=True)
+    except TypeError as e:      # (the constructor of an older torch: the ONLY TypeError that means "no graph API" - fn's own errors propagate)
+        raise GraphApiMissing(f'torch.cuda.CUDAGraph(keep_graph=True) is not available: {e}') from e
     with torch.cuda.graph(graph, capture_error_mode=capture_error_mode):
         outs = fn()
     n = C.c_int32(0)

@@ -106,8 +106,10 @@ def bump_weight_epoch():
         tab.dirty = True
 
 
-_DEBUG_NO_TABLE = bool(os.environ.get('GG_DEBUG_NO_PACK_TABLE'))
-_DEBUG_NO_SINK = bool(os.environ.get('GG_DEBUG_NO_GRAD_SINK'))
+# bisect aids (module attributes a debugging session flips by hand; no environment switch since round 6): weights packed per call instead
+# of through the models' pack tables / gradients through autograd's AccumulateGrad instead of the sinking finishes
+_DEBUG_NO_TABLE = False
+_DEBUG_NO_SINK = False
 
 
 def _refresh_table(tab):
@@ -398,7 +400,7 @@ def _ones_col(b, device):
     return t
 
 
-_NO_FF_FUSE = bool(os.environ.get('GG_NO_FF_FUSE'))      # A/B switch of the GELU-on-epilogue FeedForward (profiles/r04_ff_fuse_ab.log)
+_NO_FF_FUSE = False      # (round 6: the GG_NO_FF_FUSE A/B switch is gone - GELU on the 1x1 pair's epilogues, profiles/r04_ff_fuse_ab.log)
 
 
 class HingeFn(Function):
@@ -1856,7 +1858,7 @@ class HipOps:
             if key_mask is not None:
                 kb = torch.zeros(key_mask.shape, dtype=torch.float32, device=q.device).masked_fill(~key_mask, -1e30).contiguous()
             o = FlashAttnGenFn.apply(_rows_view(q), _rows_view(k), _rows_view(v), None, None, kb, h, float(scale))
-            return o.view(B, n, h, dh).transpose(1, 2)
+            return _fully_masked_rows(o.view(B, n, h, dh).transpose(1, 2), v, key_mask)
         mp = _round8(m)
         q2 = q.reshape(B * h, n, dh).to(ACT_DTYPE).contiguous()
         k2 = k.reshape(B * h, m, dh).to(ACT_DTYPE)
@@ -1879,7 +1881,7 @@ class HipOps:
             bias = neg if bias is None else bias + neg
         attn = AttnProbsFn.apply(q2, k2, None if bias is None else bias.contiguous(), alpha, m)   # bf16 (BH, n, mp)
         out = GemmFn.apply(attn, v2, True, False, (n, dh, mp), None, None, 1.0, False)  # (BH, n, dh)
-        return out.reshape(B, h, n, dh)
+        return _fully_masked_rows(out.reshape(B, h, n, dh), v, key_mask)
 
     def self_attention(self, q, k, v, null_kv, *, heads, scale, l2):
         """SelfAttention.forward after the projections (gp.py:562-592); q, k, v logical (b, heads*d, x, y)."""
@@ -1997,7 +1999,7 @@ class HipOps:
 
 
 _SPAIR = os.environ.get('GG_SPAIR', '1') != '0'      # A/B switch: 0 runs the 128x128 / 256x256 adaptive convs one launch each (gg_sconv)
-_ACONV = os.environ.get('GG_ACONV', '1') != '0'      # A/B switch: 0 restores the round-3/4 kernels on the 4x4 .. 32x32 adaptive convs
+_ACONV = True      # (round 6: the GG_ACONV A/B switch is gone; the round-3/4 formulations stay reachable for the shapes gg_aconv does not carry)
 # widest image the one-launch kernel takes: measured (profiles/r5_aconv_probe*.log, batch 32, hipGraph-timed incl. the modulation
 # launch) 28 / 38 / 54+32 / 48+32 us against 63 / 79 / 69+52 / 51+35 us on 4x4 / 8x8 / 16x16 / 32x32, but 68+52 against 53+38 us at
 # 64x64 (1024 small workgroups: four rounds of its fixed cost), which therefore stays on per-sample weights + gg_conv3
@@ -2044,6 +2046,18 @@ def _rows_f32(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         t = t.float()
     return t if (t.dim() == 2 and t.stride(1) == 1) else t.contiguous()
+
+
+def _fully_masked_rows(o, v, key_mask):
+    """reference semantics where a batch item keeps NO key (gp.py:645-647: `sim.masked_fill(~mask, -finfo.max)` makes every score of
+    the row the same number, so its softmax is uniform over ALL keys and the output is the plain mean of the values); the kernels'
+    per-key bias gives such a row zeros. No host synchronisation: the rows are selected on the device (two small launches, text
+    conditioning only)."""
+    if key_mask is None:
+        return o
+    keep = key_mask.any(dim=-1)[:, None, None, None]                     # (B, 1, 1, 1)
+    mean_v = v.float().mean(dim=2, keepdim=True).to(o.dtype)            # (B, h, 1, dh)
+    return torch.where(keep, o, mean_v.expand_as(o))
 
 
 def _wmix_buffer(weights, b: int, I: int):

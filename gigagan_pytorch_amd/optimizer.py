@@ -73,6 +73,13 @@ class FlatAdamW(torch.optim.Optimizer):
             st['exp_avg_sq'] = self.flat_v[off:off + n].view(p.shape)
         self.flags = flags.to(device)
         self._flags_host = flags
+        # INVARIANT: the tail of every parameter's 256-float slot (the floats between its last element and the next slot) is zero.
+        # ops._bias8 hands the kernels a view that runs into that tail (a ragged bias read as its zero-padded 8-multiple). It holds by
+        # construction - the buffers start as zeros and AdamW with g = m = v = 0 writes 0 - and is re-established after every write
+        # that does not go through the optimizer (zero_slot_tails: snapshot restore, state-dict loads)
+        tails = [torch.arange(off + p.numel(), off + (p.numel() + ALIGN - 1) // ALIGN * ALIGN) for p, off in zip(self._all, offs)
+                 if p.numel() % ALIGN]
+        self._tail_idx = (torch.cat(tails) if tails else torch.zeros(0, dtype=torch.long)).to(device)
         self._flag_variants = {}
         # conv weights: persistent bf16 GEMM operands, re-packed by one launch per epoch (ops._table_pack)
         from .kernels import PackTable
@@ -83,6 +90,16 @@ class FlatAdamW(torch.optim.Optimizer):
         for p in self._all:
             if p.ndim >= 4 or p.ndim == 2:      # conv weights / kernel banks; linear weights (ops.LinearFn)
                 p._gg_pack_table = self.pack_table
+
+    @torch.no_grad()
+    def zero_slot_tails(self):
+        """re-establish the slot-tail invariant (see _build) after a write that bypassed the optimizer."""
+        if self._tail_idx.numel():
+            for buf in (self.flat_p, self.flat_m, self.flat_v):
+                buf.index_fill_(0, self._tail_idx, 0.)
+
+    def slot_tails_are_zero(self) -> bool:
+        return self._tail_idx.numel() == 0 or not bool(self.flat_p.index_select(0, self._tail_idx).ne(0).any())
 
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()
@@ -151,6 +168,7 @@ class FlatAdamW(torch.optim.Optimizer):
             for k in ('lr', 'betas', 'eps'):
                 if k in sg:
                     grp[k] = sg[k]
+        self.zero_slot_tails()
 
 
 def get_optimizer(params, lr=1e-4, wd=1e-2, betas=(0.9, 0.99), eps=1e-8, filter_by_requires_grad=True,

@@ -28,7 +28,8 @@ SHAPES = [
 
 
 def phases():
-    """GG_PGEMM_DBG switches phases of the kernel off (results are garbage): what is left tells where a tile's time goes."""
+    """GG_PGEMM_DBG switches phases of the kernel off (results are garbage): what is left tells where a tile's time goes. Needs a PROBE
+    build of the library (hipcc ... -DGG_PROBE): the product build compiles the mask out (round 6)."""
     import os
     dev = torch.device('cuda', 0)
     names = {0: 'all', 1: 'no MFMA', 2: 'no epilogue', 3: 'transfers only', 4: 'no transfers', 5: 'epilogue only', 6: 'k-loop only', 7: 'barriers only', 8: 'no stores', 12: 'no stores, no transfers'}
@@ -46,7 +47,7 @@ def phases():
             os.environ['GG_PGEMM_DBG'] = str(dbg)
             t = time_us(lambda: K.conv2d_nhwc(x, w, **kw), iters=4)
             row.append(f'{names[dbg]}: {t:6.1f} us = {t / (tiles / 256):5.2f} us/tile')
-        os.environ.pop('GG_PGEMM_DBG')
+        os.environ.pop('GG_PGEMM_ORDER', None); os.environ.pop('GG_PGEMM_DBG', None)
         print('\n   '.join(row), flush=True)
 
 
@@ -73,11 +74,11 @@ def main():
         same = torch.equal(y_old, y_new) and (a_old is None or torch.equal(a_old, aux))
         t_old = time_us(lambda: K.conv2d_nhwc(x, w, **kw), iters=4)
         t_new = time_us(lambda: K.conv2d_nhwc(x, w, force_tile=15, **kw), iters=4)
-        if '--orders' in sys.argv:            # the kernel's other tile order (GG_PGEMM_DBG bit 64 flips the host's choice)
+        if '--orders' in sys.argv:            # the kernel's other tile order (GG_PGEMM_ORDER=flip takes the one the host did not choose)
             import os
-            os.environ['GG_PGEMM_DBG'] = '64'
+            os.environ['GG_PGEMM_ORDER'] = 'flip'
             t_flip = time_us(lambda: K.conv2d_nhwc(x, w, force_tile=15, **kw), iters=4)
-            os.environ.pop('GG_PGEMM_DBG')
+            os.environ.pop('GG_PGEMM_ORDER', None); os.environ.pop('GG_PGEMM_DBG', None)
             tiles_n = (N + 127) // 128
             rr_default = tiles_n <= 2 or (tiles_n <= 4 and Kd >= 512) or epi == 'aux2'
             print(f'   orders: round-robin {t_new if rr_default else t_flip:7.1f} us | contiguous runs {t_flip if rr_default else t_new:7.1f} us', flush=True)

@@ -305,8 +305,8 @@ def check_general_attention(cfg, device):
     if mask:
         km = torch.ones(B, m, dtype=torch.bool, device=device)
         for i in range(B):
-            km[i, max(2, m - 5 - 11 * i):] = False        # (at least two keys stay: a fully masked row is uniform attention in the
-                                                          # reference and zeros here - captions always hold a token)
+            km[i, max(2, m - 5 - 11 * i):] = False        # (at least two keys stay: the KERNEL gives a fully masked row zeros; ops.attention
+                                                          # puts the reference's uniform average there: test_fully_masked_rows_..)
         if mask == 2:       # LEADING masked keys as well (without a null token the online softmax is seeded from key 0's score: the
             for i in range(B):                            # seed must not leak into the result when that key is masked; gp.py:645-647)
                 km[i, :1 + i % 3] = False

@@ -311,3 +311,18 @@ def test_bench_multi_rank_control_flow_runs_on_two_gloo_ranks():
     assert abs(rec['value'] - 4 * rec['steps'] / (rec['ms_per_step'] * rec['steps'] / 1e3)) < 1e-6 * rec['value']
     assert rec['ms_per_step'] >= max(r['ms_per_step'] for r in rec['per_rank']) - 1e-6
     assert rec['finite'] and rec['cpu_baseline'] is None and 'DRY RUN' in rec['metric']
+
+
+def test_bench_refuses_a_multi_gpu_number_on_the_fallback_exchange():
+    """bench.check_comm_for_measurement: at N > 1 on GPUs the line is only printed when the gradient exchange is gg_comm/rccl with all N
+    ranks in the communicator and the in-backward reducers wired; the torch.distributed fallback (or a short communicator) makes
+    bench.py exit non-zero instead of reporting a number that is not the path it names."""
+    import bench
+    ok = bench.check_comm_for_measurement
+    assert ok(1, False, 'none', None, False) is None                       # one GPU: nothing to exchange
+    assert ok(2, True, 'torch.distributed/gloo', None, True) is None       # the CPU dry run names its transport in the line
+    assert ok(8, False, 'gg_comm/rccl', 8, True) is None
+    assert 'not the native RCCL path' in ok(8, False, 'torch.distributed/nccl', None, True)
+    assert 'holds 4 rank' in ok(8, False, 'gg_comm/rccl', 4, True)
+    assert 'no in-backward gradient reducers' in ok(2, False, 'gg_comm/rccl', 2, False)
+

@@ -1228,6 +1228,32 @@ def test_no_grad_adaptive_conv_paths_match_oracle(cfg):
     assert rel_err(y1, y0) < 1e-2
 
 
+@pytest.mark.parametrize('dh', [64, 32])
+def test_fully_masked_rows_attend_uniformly_like_the_reference(dh):
+    """a batch item whose key mask keeps nothing: the reference fills every score with -finfo.max (gp.py:645-647), so the softmax is
+    uniform over all keys and the output the plain mean of the values - ops.attention returns that (fused family at 64 features per
+    head, probability-tensor path otherwise), output and gradients, next to ordinary and leading-masked items."""
+    torch.manual_seed(0)
+    B, h, n, m = 3, 2, 16, 12
+    q, k, v = (bf(torch.randn(B, h, t, dh)).float().requires_grad_() for t in (n, m, m))
+    mask = torch.ones(B, m, dtype=torch.bool)
+    mask[0, 7:] = False
+    mask[1] = False                      # the caption without a single token
+    mask[2, :2] = False
+    probe = torch.randn(B, h, n, dh)
+    sim = torch.einsum('bhid,bhjd->bhij', q, k) * dh ** -0.5
+    sim = sim.masked_fill(~mask[:, None, None, :], -torch.finfo(sim.dtype).max)
+    want = torch.einsum('bhij,bhjd->bhid', sim.softmax(-1), v)
+    gw = torch.autograd.grad((want * probe).sum(), (q, k, v))
+    got = ops.HipOps().attention(q, k, v, scale=dh ** -0.5, key_mask=mask)
+    gg = torch.autograd.grad((got.float() * probe).sum(), (q, k, v))
+    assert rel_err(got[1], v[1].mean(dim=1, keepdim=True).expand(-1, n, -1)) < 8e-3
+    assert rel_err(got, want) < 8e-3
+    for a, b_ in zip(gg, gw):
+        assert rel_err(a, b_) < 2e-2
+    assert float(gg[0][1].abs().max()) == 0 and float(gg[1][1].abs().max()) == 0      # a uniform row does not depend on q or k
+
+
 def test_no_grad_block_pair_runs_as_one_launch_and_matches_the_two_layer_path():
     """ops.modconv_pair (what Generator._synthesise calls for a block's conv1 -> noise -> leaky-relu -> conv2 -> noise -> leaky-relu in a
     no-grad pass): at a geometry gg_spair_fwd carries both layers run as ONE launch, bit-identical to the two modconv2d calls - with
@@ -1265,6 +1291,11 @@ def test_no_grad_block_pair_runs_as_one_launch_and_matches_the_two_layer_path():
             # a pair the kernel does not carry (64 -> 64): the caller runs the layers one by one
             c3 = AdaptiveConv2DMod(32, 64, 3, num_conv_kernels=2)
             assert impl.modconv_pair(mid, dict(second, weights=c3.weights, noise_weight=torch.randn(64, 1, 1)), second) is None
+            ops._SPAIR, keep = False, ops._SPAIR                            # GG_SPAIR=0: the A/B switch hands every pair back
+            try:
+                assert impl.modconv_pair(x, first, second) is None
+            finally:
+                ops._SPAIR = keep
         with ops.use_impl(impl):                                         # gradients flow: never fused
             assert impl.modconv_pair(x.requires_grad_(), first, second) is None
     finally:
@@ -1903,7 +1934,7 @@ def pgemm_wgs(monkeypatch):
     (1, 16, 24, 256, 136, 3, True, None, True),         # four stages per tile, N = 136 (a column tile of 8)
     (1, 16, 16, 320, 128, 1, True, 'gelu', False),      # five stages per tile: the ring wraps inside a tile
 ])
-@pytest.mark.parametrize('other_order', [False, True])     # (the host picks round-robin tiles or contiguous runs by shape; GG_PGEMM_DBG=64 flips it)
+@pytest.mark.parametrize('other_order', [False, True])     # (the host picks round-robin tiles or contiguous runs by shape; GG_PGEMM_ORDER=flip takes the other)
 def test_persistent_short_k_contraction_is_bit_identical_to_the_tiled_kernel(cfg, pgemm_wgs, other_order, monkeypatch):
     """gg_pgemm_kernel (plan tile 15) against gg_gemm2_kernel<128,128> (tile 6) on 1x1 convolutions: same k order, same rounding
     points, same epilogue arithmetic -> the same bits; and against fp32 math. Runs of several tiles per workgroup (GG_PGEMM_WGS)
@@ -1911,7 +1942,7 @@ def test_persistent_short_k_contraction_is_bit_identical_to_the_tiled_kernel(cfg
     n, H, W, Cc, N, wgs, with_bias, act, with_res = cfg
     pgemm_wgs(wgs)
     if other_order:
-        monkeypatch.setenv('GG_PGEMM_DBG', '64')
+        monkeypatch.setenv('GG_PGEMM_ORDER', 'flip')
     torch.manual_seed(0)
     x = torch.randn(n, H, W, Cc).bfloat16()
     w = (torch.randn(N, Cc) / Cc ** 0.5).bfloat16()

@@ -3,6 +3,7 @@ gp.py:2603), softmax / RMSNorm second-order passes (what the gradient penalty's 
 resampling stencil and its adjoint (gp.py:246-261, :1683-1687), the squeeze-excite pool (gp.py:297-307) — each on the MI355X
 against fp32 torch math of the same op at model-sized shapes. Expectations are stated per test."""
 import math
+import os
 
 import pytest
 import torch
@@ -325,7 +326,13 @@ def test_in_backward_gradient_exchange_is_captured_with_the_step(tmp_path):
         # here; the bounds stay loose for GG_COLSUM_GROUPS=32.)
         stats = (float(diff.max()), float(diff.mean()), float((diff > 1e-5).float().mean()), int((diff > 0).sum()))
         print('overlap-vs-post parameter differences (max, mean, fraction > 1e-5, entries > 0):', stats)
-        assert stats[0] <= 1e-3 and stats[1] <= 5e-6 and stats[2] <= 2e-2, stats
+        if os.environ.get('GG_COLSUM_GROUPS', '1') in ('', '1'):
+            # the default (one workgroup per column block, fixed order) step is bit-reproducible: the exchange issued inside the backward
+            # must leave EXACTLY the parameters of the exchange issued behind it (round 6: the loose bound below could hide a late slice
+            # that moves few parameters a little)
+            assert torch.equal(digests[0], digests[1]), stats
+        else:
+            assert stats[0] <= 1e-3 and stats[1] <= 5e-6 and stats[2] <= 2e-2, stats
     finally:
         gdist.shutdown()
 

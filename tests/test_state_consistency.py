@@ -161,6 +161,15 @@ def test_shard_dataloader_keeps_custom_sampling_schemes_and_refuses_what_it_cann
     got = [[b[0].flatten().tolist() for b in shard_dataloader(weighted(), r, 2)] for r in range(2)]
     assert got[0] == ref[0::2] and got[1] == ref[1::2]
     assert set(sum(got[0], [])).isdisjoint(sum(got[1], []))
+    # an UNSEEDED random sampler (generator=None draws from each rank's global RNG: the shards would overlap): every rank gets the same
+    # seeded generator installed, so the ranks still deal out one stream
+    def unseeded(r):
+        torch.manual_seed(100 + r)          # the ranks' global generators differ
+        return DataLoader(ds, batch_size=5, sampler=WeightedRandomSampler(torch.ones(40), 40, replacement=False))
+    got = [[b[0].flatten().tolist() for b in shard_dataloader(unseeded(r), r, 2, seed=7)] for r in range(2)]
+    assert set(sum(got[0], [])).isdisjoint(sum(got[1], [])) and len(sum(got[0], [])) == len(sum(got[1], [])) == 20
+    got = [[float(b[0][0]) for b in shard_dataloader(DataLoader(ds, batch_size=None, shuffle=True), r, 2)] for r in range(2)]
+    assert set(got[0]).isdisjoint(got[1]) and len(got[0]) == len(got[1]) == 20
     # automatic batching off: the dataset yields ready batches, the sampler's indices are dealt out
     class Ready(torch.utils.data.Dataset):
         def __len__(self):
@@ -204,3 +213,10 @@ def test_ragged_bias_reads_its_zero_padded_flat_slot():
         assert b2.data_ptr() == conv.bias.data_ptr() and torch.equal(b2[:3], conv.bias.detach()) and not b2[3:].any()
     conv.load_state_dict({'weight': conv.weight.detach().clone(), 'bias': torch.tensor([1., 2., 3.])})
     assert torch.equal(ops._bias8(conv.bias, 8), torch.tensor([1., 2., 3., 0., 0., 0., 0., 0.]))
+    # the invariant behind the view (optimizer.FlatAdamW._build): slot tails are zero; a write that bypasses the optimizer and dirties
+    # them (a whole-buffer copy from elsewhere) is repaired by zero_slot_tails, which snapshot restores and state-dict loads call
+    assert opt.slot_tails_are_zero()
+    opt.flat_p.add_(1.)
+    assert not opt.slot_tails_are_zero()
+    opt.zero_slot_tails()
+    assert opt.slot_tails_are_zero() and not ops._bias8(conv.bias, 8)[3:].any() and torch.equal(conv.bias.detach(), torch.tensor([2., 3., 4.]))
