@@ -584,6 +584,12 @@ def main():
         except Exception as e:    # noqa: BLE001 - a secondary measurement must not take the bench line down
             roofline['modconv_forward'] = dict(error=f'{type(e).__name__}: {e}')
 
+    if rank == 0 and roofline is not None:
+        # the secondary fractions where the driver's parser looks (scalars at the top level of `roofline`)
+        mf, sk = roofline.get('modconv_forward') or {}, roofline.get('short_k') or {}
+        roofline['modconv_forward_frac'] = mf.get('frac')
+        roofline['short_k_frac'] = sk.get('frac')
+
     per_rank = gather_per_rank(mine, world)
 
     cpu = None
