@@ -44,13 +44,18 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_conv3_kernel(GgGemmParams p) {
     constexpr int BNV = Gg2Dma<BN>::NV, BBYTES = Gg2Dma<BN>::BYTES;
     constexpr int SP = WTN * 2 + 8;
     constexpr int SC_BYTES = SCALED ? GG_C3_SC_FLOATS * 4 : 0;
-    constexpr int TILE_BYTES = GG_C3_HBYTES + 2 * BBYTES + SC_BYTES, STAGE_BYTES = 8 * WTM * SP;
+    // taps per barrier interval: the 64-column tile does 8 MFMAs per wave and tap - a whole kernel row (3 taps, 24 MFMAs) rides on one
+    // weight transfer + barrier there (round 6, same results bit for bit; the adaptive 64x64 layers on per-sample weights 48.5-50.4 -> 47.0 us
+    // and 35.7 -> 32.1 us across boxes, profiles/r06_conv3_row_of_taps.log: the barrier count was not what bounds this tile)
+    constexpr int U = BN == 64 ? 3 : 1;
+    constexpr int WBUF = U * BBYTES;
+    constexpr int TILE_BYTES = GG_C3_HBYTES + 2 * WBUF + SC_BYTES, STAGE_BYTES = 8 * WTM * SP;
     static_assert(GG_C3_MAX_SLOTS * GG_C3_PITCH + GG_C3_MAX_ROWS * GG_C3_ROWPAD <= GG_C3_HBYTES, "halo area");
 
     GG_SHARED __attribute__((aligned(1024))) char smem[TILE_BYTES > STAGE_BYTES ? TILE_BYTES : STAGE_BYTES];
     char* const halo = smem;
-    auto tileB = [&](int buf) { return smem + GG_C3_HBYTES + buf * BBYTES; };
-    float* const scl = (float*)(smem + GG_C3_HBYTES + 2 * BBYTES);      // SCALED only
+    auto tileB = [&](int buf) { return smem + GG_C3_HBYTES + buf * WBUF; };
+    float* const scl = (float*)(smem + GG_C3_HBYTES + 2 * WBUF);      // SCALED only
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -156,11 +161,14 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_conv3_kernel(GgGemmParams p) {
     }
     // per-image weight operand (the adaptive conv's per-sample weights): a tile lies inside one image then (TI == 1, host)
     const long long b_img = p.b_img_stride ? (long long)img0 * p.b_img_stride : 0;
-    auto dma_b = [&](int buf, int tap, int c) {
-        const unsigned soff = (unsigned)((b_img + (long long)n0 * p.ldb + tap * p.CV + c * GG2_BK) * 2);
-        char* lb = tileB(buf) + wave * (BNV * 1024);
+    auto dma_b = [&](int buf, int tap, int c) {              // the weight tiles of taps tap .. tap + U - 1
 #pragma unroll
-        for (int i = 0; i < BNV; ++i) gg_buf_load_lds16(bufB, bvoff[i], soff, lb + i * 1024);
+        for (int u = 0; u < U; ++u) {
+            const unsigned soff = (unsigned)((b_img + (long long)n0 * p.ldb + (tap + u) * p.CV + c * GG2_BK) * 2);
+            char* lb = tileB(buf) + u * BBYTES + wave * (BNV * 1024);
+#pragma unroll
+            for (int i = 0; i < BNV; ++i) gg_buf_load_lds16(bufB, bvoff[i], soff, lb + i * 1024);
+        }
     };
 
     // fragment addressing. A: pixel row r of the tile -> its halo slot at tap (0, 0); a tap adds kh halo rows and kw slots
@@ -196,31 +204,34 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_conv3_kernel(GgGemmParams p) {
         if (c + 1 < nchunks) load_halo(c + 1);              // lands in registers while this chunk's nine taps run
         int toff = 0;                                        // byte offset of the tap inside the halo
         for (int kh = 0; kh < 3; ++kh) {
-            for (int kw = 0; kw < 3; ++kw, ++step) {
+            for (int kw0 = 0; kw0 < 3; kw0 += U, ++step) {
                 const int buf = step & 1;
-                const int tap = kh * 3 + kw;
-                // the other weight buffer was released by the barrier that ended the previous tap
-                if (tap < 8) dma_b(buf ^ 1, tap + 1, c);
+                const int tap = kh * 3 + kw0;
+                // the other weight buffer was released by the barrier that ended the previous interval
+                if (tap + U < 9) dma_b(buf ^ 1, tap + U, c);
                 else if (c + 1 < nchunks) dma_b(buf ^ 1, 0, c + 1);
-                const char* ta = halo + toff;
-                const char* tb = tileB(buf) + b_lane;
 #pragma unroll
-                for (int kk = 0; kk < GG2_BK / 16; ++kk) {
-                    u16x8 fa[TM], fb[TN];
-                    const int fo = fx ^ (kk * 32);
+                for (int u = 0; u < U; ++u) {
+                    const char* ta = halo + toff;
+                    const char* tb = tileB(buf) + u * BBYTES + b_lane;
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) fa[i] = *(const u16x8*)(ta + a_addr[i] + kk * 32);
+                    for (int kk = 0; kk < GG2_BK / 16; ++kk) {
+                        u16x8 fa[TM], fb[TN];
+                        const int fo = fx ^ (kk * 32);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) fb[j] = *(const u16x8*)(tb + j * 32 * 128 + fo);
+                        for (int i = 0; i < TM; ++i) fa[i] = *(const u16x8*)(ta + a_addr[i] + kk * 32);
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
+                        for (int j = 0; j < TN; ++j) fb[j] = *(const u16x8*)(tb + j * 32 * 128 + fo);
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = gg_mfma_32x32x16_bf16(fb[j], fa[i], acc[i][j]);
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = gg_mfma_32x32x16_bf16(fb[j], fa[i], acc[i][j]);
+                    }
+                    toff += GG_C3_PITCH;
                 }
                 gg_wait_vm<0>();
                 gg_sync();
-                toff += GG_C3_PITCH;
             }
             toff += RSB - 3 * GG_C3_PITCH;
         }
