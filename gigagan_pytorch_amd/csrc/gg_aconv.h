@@ -203,28 +203,27 @@ GG_KERNEL GG_LAUNCH_BOUNDS(64 * NWN * NWK) void gg_aconv_kernel(GgAconvParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[n][i][r] = 0.f;
 
-    // the finishing operands (demodulation, noise): requested where they cost no round trip of their own - in front of the reduction
-    // when the accumulators leave registers for them (TM <= 2), otherwise behind it, before the K-slices meet in LDS (their round trip
-    // then runs under the barriers). Always issued, from clamped addresses (loads under a condition are waited for on the spot).
-    constexpr bool FIN_EARLY = TM <= 2;
+    // Who finishes what (round 6): the K-slices used to meet in the wk == 0 wavefronts, which then ran the whole epilogue (NWN of eight
+    // wavefronts: 6 k cycles behind the last MFMA on a 128-pixel tile, profiles/r06_aconv_probe_hot_cold_mall.log). Now every wavefront
+    // owns the register quads Q = 4 i + g (pixel block i, channels chb + 8 g .. + 3) with Q % NWK == wk of its column block: it sums
+    // THOSE over the slices (slice order 0, 1, .. as before: the same bits) and stores them - the sum and the epilogue spread over all
+    // wavefronts. The finishing operands (demodulation, noise) of the owned quads are requested in front of the reduction (always
+    // issued, from clamped addresses: loads under a condition are waited for on the spot).
+    constexpr int NQ = TM * 4, OWN = (NQ + NWK - 1) / NWK;    // quads of a column block, quads a wavefront owns at most
     const int chb = n0 + wn * 32 + 4 * (lane >> 5);           // output channel of accumulator register q: chb + (q & 3) + 8 * (q >> 2)
-    f32x4 dv[TM][4], nwv[4];
-    float nzv[TM];
-    auto load_fin = [&]() {
+    f32x4 dv[OWN], nwv[OWN];
+    float nzv[OWN];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) nwv[g] = *(const f32x4*)((p.noise ? p.noise_w : p.s) + (p.noise ? chb + 8 * g : 0));
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const long long pix = (long long)m0 + i * 32 + (lane & 31);
-            const int img = (int)(pix >> hs);
-            const int ic = img < p.b ? img : p.b - 1;
-            const long long pc = img < p.b ? pix : 0;
-            nzv[i] = (p.noise ? p.noise : p.s)[p.noise ? pc : 0];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) dv[i][g] = *(const f32x4*)((p.d ? p.d + (long long)ic * p.O + chb + 8 * g : p.s));
-        }
-    };
-    if (FIN_EARLY) load_fin();
+    for (int j = 0; j < OWN; ++j) {
+        const int Q = (wk + j * NWK) % NQ, i = Q >> 2, g = Q & 3;          // (beyond NQ: a clamped duplicate, never used)
+        const long long pix = (long long)m0 + i * 32 + (lane & 31);
+        const int img = (int)(pix >> hs);
+        const int ic = img < p.b ? img : p.b - 1;
+        const long long pc = img < p.b ? pix : 0;
+        nzv[j] = (p.noise ? p.noise : p.s)[p.noise ? pc : 0];
+        nwv[j] = *(const f32x4*)((p.noise ? p.noise_w : p.s) + (p.noise ? chb + 8 * g : 0));
+        dv[j] = *(const f32x4*)((p.d ? p.d + (long long)ic * p.O + chb + 8 * g : p.s));
+    }
 
 #if defined(GG_PROBE)
     const int k_end = (p.dbg & 1) ? k_lo : k_hi;
@@ -269,64 +268,70 @@ GG_KERNEL GG_LAUNCH_BOUNDS(64 * NWN * NWK) void gg_aconv_kernel(GgAconvParams p)
             out[i][q] = v;
         }
     }
-    if (!FIN_EARLY) load_fin();
+    auto finish = [&](int j, int i, int g, const f32x4& sum) {
+        const long long pix = (long long)m0 + i * 32 + (lane & 31);              // global pixel index (images are contiguous)
+        if ((int)(pix >> hs) >= e.b) return;
+        const float nz = e.noise ? nzv[j] : 0.f;
+        u16x4 o4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float dd = e.d ? dv[j][c] : 1.f, nn = e.noise ? nwv[j][c] : 0.f;
+            float v = gg_fmaf(sum[c], dd, nz * nn);
+            if (e.act == 1) v = v > 0.f ? v : v * e.slope;
+            o4[c] = gg_f2bf(v);
+        }
+        *(u16x4*)(e.y + pix * e.O + chb + 8 * g) = o4;
+    };
     if (NWK > 1) {
         gg_sync();                                           // every wavefront is past its last read of the halo
-        float* red = (float*)smem;                           // [wk - 1][wn][tm][16][64]
-        if (wk > 0) {
+        f32x4* red = (f32x4*)smem;                           // [wk][wn][Q][64 lanes] quads
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) red[((((wk - 1) * NWN + wn) * TM + i) * 16 + q) * 64 + lane] = out[i][q];
-        }
+        for (int Q = 0; Q < NQ; ++Q)
+            if (Q % NWK != wk) {                             // (wave uniform) somebody else's quad: hand this slice's share over
+                const f32x4 v = {out[Q >> 2][(Q & 3) * 4], out[Q >> 2][(Q & 3) * 4 + 1], out[Q >> 2][(Q & 3) * 4 + 2], out[Q >> 2][(Q & 3) * 4 + 3]};
+                red[((wk * NWN + wn) * NQ + Q) * 64 + lane] = v;
+            }
         gg_sync();
         GG_AC_STAMP(4);
-        if (wk > 0) {
-            // this wavefront is done: request the slice of the NEXT layer's bank that the workgroups of the next launch on THIS XCD will
-            // stream (same blockIdx -> XCD dealing), split over this XCD's workgroups - it lands in this XCD's L2 while the finishing
-            // wavefronts write the tile. The loads are never waited for (s_endpgm retires them).
-            if (e.pf_wf) {
-                const int g2 = e.pf_grid, q2 = g2 >> 3, r2 = g2 & 7;
-                const int lo = xcd < r2 ? xcd * (q2 + 1) : r2 * (q2 + 1) + (xcd - r2) * q2;
-                const int cnt = q2 + (xcd < r2 ? 1 : 0);
-                if (cnt > 0) {
-                    const long long b_lo = (long long)(lo / e.pf_mt) * e.pf_tn_bytes;
-                    long long b_hi = (long long)((lo + cnt - 1) / e.pf_mt + 1) * e.pf_tn_bytes;
-                    b_hi = b_hi < e.pf_bytes ? b_hi : e.pf_bytes;
-                    const int mine = (nwg + 7 - xcd) >> 3;                     // workgroups of THIS launch on this XCD; `pos` is ours
-                    const long long share = (((b_hi - b_lo) / mine + 1023) >> 10) << 10;
-                    const long long s_lo = b_lo + share * pos;
-                    const long long s_hi = s_lo + share < b_hi ? s_lo + share : b_hi;
-                    GgBuf bufP = gg_make_buf((const void*)e.pf_wf, (unsigned long long)e.pf_bytes);
-                    constexpr int NPT = 64 * NWN * (NWK - 1);
-                    for (long long o = s_lo + (long long)(tid - 64 * NWN) * 16; o < s_hi; o += NPT * 16) gg_buf_touch16(bufP, (unsigned)o);
+#pragma unroll
+        for (int j = 0; j < OWN; ++j)
+#pragma unroll
+            for (int Q = j * NWK; Q < (j + 1) * NWK && Q < NQ; ++Q)
+                if (Q % NWK == wk) {                         // (wave uniform) this wavefront's quad: the slices in order, its own from registers
+                    const f32x4 mine = {out[Q >> 2][(Q & 3) * 4], out[Q >> 2][(Q & 3) * 4 + 1], out[Q >> 2][(Q & 3) * 4 + 2], out[Q >> 2][(Q & 3) * 4 + 3]};
+                    f32x4 sum = wk == 0 ? mine : red[((0 * NWN + wn) * NQ + Q) * 64 + lane];
+#pragma unroll
+                    for (int sl = 1; sl < NWK; ++sl) {
+                        const f32x4 t = sl == wk ? mine : red[((sl * NWN + wn) * NQ + Q) * 64 + lane];
+                        sum = sum + t;
+                    }
+                    finish(j, Q >> 2, Q & 3, sum);
                 }
+        if (wk > 0 && e.pf_wf) {
+            // request the slice of the NEXT layer's bank that the workgroups of the next launch on THIS XCD will stream (same blockIdx ->
+            // XCD dealing), split over this XCD's workgroups - it lands in this XCD's L2 behind the tile's stores. The loads are never
+            // waited for (s_endpgm retires them).
+            const int g2 = e.pf_grid, q2 = g2 >> 3, r2 = g2 & 7;
+            const int lo = xcd < r2 ? xcd * (q2 + 1) : r2 * (q2 + 1) + (xcd - r2) * q2;
+            const int cnt = q2 + (xcd < r2 ? 1 : 0);
+            if (cnt > 0) {
+                const long long b_lo = (long long)(lo / e.pf_mt) * e.pf_tn_bytes;
+                long long b_hi = (long long)((lo + cnt - 1) / e.pf_mt + 1) * e.pf_tn_bytes;
+                b_hi = b_hi < e.pf_bytes ? b_hi : e.pf_bytes;
+                const int mine = (nwg + 7 - xcd) >> 3;                     // workgroups of THIS launch on this XCD; `pos` is ours
+                const long long share = (((b_hi - b_lo) / mine + 1023) >> 10) << 10;
+                const long long s_lo = b_lo + share * pos;
+                const long long s_hi = s_lo + share < b_hi ? s_lo + share : b_hi;
+                GgBuf bufP = gg_make_buf((const void*)e.pf_wf, (unsigned long long)e.pf_bytes);
+                constexpr int NPT = 64 * NWN * (NWK - 1);
+                for (long long o = s_lo + (long long)(tid - 64 * NWN) * 16; o < s_hi; o += NPT * 16) gg_buf_touch16(bufP, (unsigned)o);
             }
-            return;
         }
-#pragma unroll 1
-        for (int s = 0; s < NWK - 1; ++s)       // (one slice at a time: unrolled, the loads of all slices are hoisted and spill)
+    } else {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) out[i][q] += red[(((s * NWN + wn) * TM + i) * 16 + q) * 64 + lane];
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const long long pix = (long long)m0 + i * 32 + (lane & 31);              // global pixel index (images are contiguous)
-        if ((int)(pix >> hs) >= e.b) continue;
-        const float nz = e.noise ? nzv[i] : 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            u16x4 o4;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float dd = e.d ? dv[i][g][c] : 1.f, nn = e.noise ? nwv[g][c] : 0.f;
-                float v = gg_fmaf(out[i][g * 4 + c], dd, nz * nn);
-                if (e.act == 1) v = v > 0.f ? v : v * e.slope;
-                o4[c] = gg_f2bf(v);
-            }
-            *(u16x4*)(e.y + pix * e.O + chb + 8 * g) = o4;
+        for (int Q = 0; Q < NQ; ++Q) {
+            const f32x4 mine = {out[Q >> 2][(Q & 3) * 4], out[Q >> 2][(Q & 3) * 4 + 1], out[Q >> 2][(Q & 3) * 4 + 2], out[Q >> 2][(Q & 3) * 4 + 3]};
+            finish(Q, Q >> 2, Q & 3, mine);
         }
     }
     GG_AC_STAMP(5);

@@ -1544,7 +1544,7 @@ static int gg_aconv_plan_of(const gg_aconv_desc* d, GgAconvPlan* out) {
             if (d->O % (32 * nwn)) continue;
             const int nwk = 8 / nwn;
             if (d->NB * tm * 16 > 128) continue;                       // accumulator registers of a wavefront
-            const long long red = (long long)(nwk - 1) * nwn * tm * 4096;
+            const long long red = nwk > 1 ? (long long)nwk * nwn * tm * 4096 : 0;      // every slice's quads, [wk][wn][4 tm][64 lanes] x 16 bytes
             const long long lds = halo > red ? halo : red;
             if (lds > 152 * 1024) continue;
             const long long grid = (long long)mt * (d->O / (32 * nwn));

@@ -37,7 +37,7 @@ static void run(const char* name, int b, int R, int C, int O) {
     const int mt = (b * hw + bmt - 1) / bmt, grid = mt * (O / BN);
     const int rt = hw >= bmt ? bmt / R : R, ti = hw >= bmt ? 1 : bmt / hw;
     const int lds_halo = ti * (rt + 2) * (R + 2) * (C * 2 + 16);
-    const int lds_red = (NWK - 1) * NWN * TM * 16 * 64 * 4;
+    const int lds_red = NWK * NWN * TM * 16 * 64 * 4;
     const int lds = std::max(lds_halo, lds_red);
     hipMalloc(&st, (size_t)grid * 2 * 8 * 8);
     GgAconvParams p;
