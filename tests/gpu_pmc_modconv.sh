@@ -26,7 +26,7 @@ dur = collections.defaultdict(list)
 for i in (1, 2, 3):
     for r in rows(i):
         name = r.get('Kernel_Name', '')
-        if not any(k in name for k in ('gg_sconv', 'gg_aconv', 'gg_lrconv', 'gg_conv3', 'gg_modw', 'gg_splitk', 'gg_gemm', 'gg_modulate')):
+        if not any(k in name for k in ('gg_sconv', 'gg_spair', 'gg_aconv', 'gg_lrconv', 'gg_conv3', 'gg_modw', 'gg_splitk', 'gg_gemm', 'gg_modulate')):
             continue
         key = (name.split('(')[0].replace('void ', ''), r.get('Grid_Size') or r.get('Grid_Size_X') or '')
         agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
