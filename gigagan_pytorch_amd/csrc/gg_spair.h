@@ -15,7 +15,7 @@
 //     front of the iteration's raw s_barrier (the compute waves store: their vmcnt cannot count transfers);
 //   * iteration r: conv1 of mid row r + 1 from x rows r .. r + 2 -> noise, leaky-relu, bf16 -> LDS mid ring (4 rows); conv2 of
 //     output row r - 1 from mid rows r - 2 .. r (complete since the iteration's barrier) -> noise, leaky-relu -> the wave's staging
-//     area -> 16-byte-per-lane row stores. ONE barrier per row; mid rows above / below the image are zeros (conv2's padding), the
+//     (8-byte-per-lane row stores from the registers). ONE barrier per row; mid rows above / below the image are zeros (conv2's padding), the
 //     x rows there arrive as zeros from the DMA's range check; one zero pixel left and right of every ring row;
 //   * both rings are XOR-swizzled by the pixel's x coordinate so that the 16 lanes a ds_read_b128 serves per cycle hit 16 distinct
 //     bank quads (the loader picks which global chunk each DMA lane fetches; the mid row is written swizzled);
@@ -63,7 +63,7 @@ template <int C0, int C1, int PT, int NCW>
 struct GgSpGeom {
     static constexpr int W = 32 * NCW * PT;
     static constexpr int NT = (NCW + 1) * 64;                      // + the loader wave
-    static constexpr int NSX = (PT == 2 && NCW == 4) ? 6 : 5;      // x ring rows: three being read, the rest in flight (what LDS allows)
+    static constexpr int NSX = C0 <= 32 ? 6 : 5;                   // x ring rows: three being read, the rest in flight (what LDS allows)
     static constexpr int P0 = C0 * 2, P1 = C1 * 2;                 // bytes per pixel in the rings
     static constexpr int XS = (W + 2) * P0, MS = (W + 2) * P1;     // bytes per ring row
     static constexpr int XSLOT = XS + 2048;                        // + the noise rows that travel with an x row (1 KB each: conv1's, conv2's)
@@ -72,8 +72,7 @@ struct GgSpGeom {
     static constexpr int xring = 0;
     static constexpr int mring = NSX * XSLOT;
     static constexpr int epi = mring + 4 * MS;                     // nw1 [32] | nw2 [32] floats
-    static constexpr int stage = epi + 256;                        // NCW waves x PT * 32 pixels x (2 C2 + 16) bytes
-    static constexpr int w2l(int C2) { return stage + NCW * PT * 32 * (2 * C2 + 16); }     // conv2's bank (9 * KC1 KB) when not in registers
+    static constexpr int w2l(int) { return epi + 256; }            // conv2's bank (9 * KC1 KB) when it does not live in registers
     static constexpr int bytes(int C2) { return w2l(C2) + (W2REG ? 0 : 9 * KC1 * 1024); }
 };
 
@@ -189,7 +188,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS((NCW + 1) * 64) void gg_spair_kernel(GgSpairParams p)
     // -------------------------------------------------------------------- compute waves
     const int pl = lane & 31, hi = lane >> 5;
     const int xw = wave * PT * 32;                        // first pixel column of this wave
-    const int C2 = p.C2, SP = 2 * C2 + 16;                // staging pitch per pixel (bank spread)
+    const int C2 = p.C2;
 
     // zero pixels left and right of every ring row (the DMA and the mid-row writes never touch them); epilogue constants
     {
@@ -273,16 +272,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS((NCW + 1) * 64) void gg_spair_kernel(GgSpairParams p)
     }
 
     const float* epi = (const float*)(smem + G::epi);
-    char* stage = smem + G::stage + wave * (PT * 32 * SP);
-    const int cpp = C2 >> 3, total_chunks = PT * 32 * cpp;
-    constexpr int WBI = PT * 2;
-    int wb_lds[WBI], wb_out[WBI];
-#pragma unroll
-    for (int it = 0; it < WBI; ++it) {
-        const int c = lane + 64 * it, pix = c / cpp, ch = c - pix * cpp;
-        wb_lds[it] = c < total_chunks ? pix * SP + ch * 16 : -1;
-        wb_out[it] = (xw + pix) * C2 + ch * 8;
-    }
+    const int cpp = C2 >> 3;
     const float slope1 = p.act1 == 1 ? p.slope : 1.f, slope2 = p.act2 == 1 ? p.slope : 1.f;
     const bool has_n1 = p.noise1 != nullptr, has_n2 = p.noise2 != nullptr;
     const long long img_pix0 = (long long)img * H * W;
@@ -455,7 +445,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS((NCW + 1) * 64) void gg_spair_kernel(GgSpairParams p)
         }
         GG_SP_STAMP(3);
 
-        // ---- conv2's epilogue -> the wave's staging area -> 16-byte-per-lane row stores
+        // ---- conv2's epilogue -> row stores
         if (do2) {
 #pragma unroll
             for (int t = 0; t < PT; ++t) {
@@ -469,20 +459,14 @@ GG_KERNEL GG_LAUNCH_BOUNDS((NCW + 1) * 64) void gg_spair_kernel(GgSpairParams p)
                             const float v = acc2[t][q * 4 + e] + nz2[t] * w4[e];
                             o4[e] = gg_f2bf(fmaxf(v, v * slope2));
                         }
-                        *(u16x4*)(stage + (t * 32 + pl) * SP + q * 16 + 8 * hi) = o4;
+                        // (8 bytes per lane straight from the registers, as gg_sconv stores: parking the row in LDS for 16-byte row
+                        // stores cost a wave hand-over and an LDS round trip per row - 73.2 -> 70.2 us at 256x256, 49.1 -> 46.6 us at
+                        // 128x128 same-box, profiles/r06_spair_direct_stores_ab.txt)
+                        if (!GG_SP_OFF(4)) *(u16x4*)(p.y + (img_pix0 + (long long)o * W + xw + t * 32 + pl) * C2 + 8 * q + 4 * hi) = o4;
                     }
                 }
             }
-            gg_wave_sync();
             GG_SP_STAMP(5);
-            // write-back: 16 bytes per lane, the wave's PT * 32 pixels are contiguous in memory
-            bf16_t* outp = p.y + (img_pix0 + (long long)o * W) * C2;
-#pragma unroll
-            for (int it = 0; it < WBI; ++it)
-                if (64 * it < total_chunks && !GG_SP_OFF(4)) {      // (wave uniform)
-                    if (wb_lds[it] >= 0) *(u16x8*)(outp + wb_out[it]) = *(const u16x8*)(stage + wb_lds[it]);
-                }
-            gg_wave_sync();               // (the next iteration's staging writes follow these reads)
         }
 
         GG_SP_STAMP(6);

@@ -866,8 +866,17 @@ def sconv(x: torch.Tensor, wmix: torch.Tensor, O: int, noise=None, noise_w=None,
     return y
 
 
+_spair_ok: dict = {}
+
+
 def spair_supported(H: int, W: int, C0: int, C1: int, C2: int) -> bool:
-    return bool(_C.lib().lib.gg_spair_supported(H, W, C0, C1, C2))
+    """gg_spair_supported, asked once per geometry and library (a pure function of its arguments)."""
+    L = _C.lib()
+    key = (id(L), H, W, C0, C1, C2)
+    ok = _spair_ok.get(key)
+    if ok is None:
+        ok = _spair_ok[key] = bool(L.lib.gg_spair_supported(H, W, C0, C1, C2))
+    return ok
 
 
 def spair(x: torch.Tensor, wmix1: torch.Tensor, wmix2: torch.Tensor, C1: int, C2: int, noise1=None, noise_w1=None, noise2=None,
