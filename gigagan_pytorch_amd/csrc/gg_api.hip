@@ -1969,9 +1969,9 @@ extern "C" int gg_sconv_fwd(const void* x, const void* w, int64_t w_bs, void* y,
 }
 
 // ---- gg_spair_fwd: two adaptive 3x3 convolutions of one generator block in one launch (csrc/gg_spair.h) ----------------------------
-template <int C0, int C1, int PT, int NCW>
+template <int C0, int C1, int PT, int NCW, bool M16 = false>
 static int gg_spair_launch(GgSpairParams& p, int32_t b, void* stream) {
-    typedef GgSpGeom<C0, C1, PT, NCW> G;
+    typedef GgSpGeom<C0, C1, PT, NCW, M16> G;
     const int lds = G::bytes(p.C2);
     if (lds > 160 * 1024) return gg_fail(-2, "gg_spair_fwd: C2 = %d needs %d bytes of LDS", p.C2, lds);
     // output rows per workgroup: one workgroup per CU in ONE round where the batch allows it (the halo - two conv1 rows and four x rows
@@ -1980,7 +1980,7 @@ static int gg_spair_launch(GgSpairParams& p, int32_t b, void* stream) {
     while (rows > 8 && (long long)b * ((p.H + rows - 1) / rows) < 256) rows >>= 1;
     p.rows = rows;
     p.strips = (p.H + rows - 1) / rows;
-    GG_LAUNCH_DYN((gg_spair_kernel<C0, C1, PT, NCW>), dim3((unsigned)(b * p.strips)), dim3(G::NT), lds, (hipStream_t)stream, p);
+    GG_LAUNCH_DYN((gg_spair_kernel<C0, C1, PT, NCW, M16>), dim3((unsigned)(b * p.strips)), dim3(G::NT), lds, (hipStream_t)stream, p);
     return gg_check_launch();
 }
 
@@ -2009,6 +2009,9 @@ extern "C" int gg_spair_fwd(const void* x, const void* w1, int64_t w1_bs, const 
     p.x = (const bf16_t*)x; p.w1 = (const bf16_t*)w1; p.w2 = (const bf16_t*)w2; p.y = (bf16_t*)y; p.w1_bs = w1_bs; p.w2_bs = w2_bs;
     p.noise1 = noise1; p.nw1 = nw1; p.noise2 = noise2; p.nw2 = nw2; p.xs = xs;
     p.b = b; p.H = H; p.C2 = C2; p.act1 = act1; p.act2 = act2; p.slope = slope;
+    // 32 -> 16 -> <= 16 channels (the 256x256 block): 16 channels are a whole row block of v_mfma_f32_16x16x32_bf16 - half the matrix-pipe
+    // time of the 32x32x16 form, which multiplies 16 zero weight rows (profiles/r06_spair_m16_ab.txt)
+    if (C0 == 32 && C2 <= 16) return gg_spair_launch<32, 16, 1, 8, true>(p, b, stream);
     if (C0 == 32) return gg_spair_launch<32, 16, 1, 8>(p, b, stream);
     return gg_spair_launch<64, 32, 1, 4>(p, b, stream);
 }

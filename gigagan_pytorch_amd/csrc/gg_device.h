@@ -73,6 +73,14 @@ GG_DEVICE f32x16 gg_mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c) {
                                                    __builtin_bit_cast(gg_bf16x8_native, b), c, 0, 0, 0);
 }
 
+// D[i][j] += sum_k Aop[i][k] * Bop[k][j], 16x16x32, one wave (v_mfma_f32_16x16x32_bf16: the matrix-pipe time of HALF a 32x32x16).
+//   Aop: lane l holds Aop[i = l&15][k = 8*(l>>4) + e], e = 0..7;   Bop: lane l holds Bop[k = 8*(l>>4) + e][j = l&15]
+//   D  : lane l, reg r holds D[i = 4*(l>>4) + r][j = l&15]
+// (both operands share the k labelling: element e of lane group l>>4 meets element e of the same group, whatever the hardware calls it)
+GG_DEVICE f32x4 gg_mfma_16x16x32_bf16(u16x8 a, u16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gg_bf16x8_native, a), __builtin_bit_cast(gg_bf16x8_native, b), c, 0, 0, 0);
+}
+
 // ds_read_b64_tr_b16: every lane supplies the LDS address of 4 contiguous bf16 (8-byte aligned); inside each group
 // of 16 lanes, lane i receives element (i & 3) of the quads addressed by lanes 4*j + (i >> 2), j = 0..3 (measured on
 // gfx950 with tests/probes/tr_probe.hip). With lane s pointing at row (s >> 2), columns 4*(s & 3).. of a

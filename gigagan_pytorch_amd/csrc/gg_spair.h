@@ -59,7 +59,9 @@ struct GgSpairParams {
 
 // NCW compute waves (one per SIMD, or two: the second hides the first one's epilogue and LDS latencies - a lone wave pays every one of
 // them: profiles/r06_spair_probe_v1.log) x PT 32-pixel blocks each = one image row
-template <int C0, int C1, int PT, int NCW>
+// M16 (C0 = 32, C1 = 16, C2 <= 16: the 256x256 block): the convolutions run on v_mfma_f32_16x16x32_bf16 - 16 output channels are a
+// whole MFMA row block there, where the 32x32x16 form spends half its matrix-pipe time on zero weight rows
+template <int C0, int C1, int PT, int NCW, bool M16 = false>
 struct GgSpGeom {
     static constexpr int W = 32 * NCW * PT;
     static constexpr int NT = (NCW + 1) * 64;                      // + the loader wave
@@ -68,7 +70,7 @@ struct GgSpGeom {
     static constexpr int XS = (W + 2) * P0, MS = (W + 2) * P1;     // bytes per ring row
     static constexpr int XSLOT = XS + 2048;                        // + the noise rows that travel with an x row (1 KB each: conv1's, conv2's)
     static constexpr int KC0 = C0 / 16, KC1 = C1 / 16;
-    static constexpr bool W2REG = C0 <= 32 && NCW == 4;             // (nine waves: 168 registers each)
+    static constexpr bool W2REG = M16 || (C0 <= 32 && NCW == 4);    // (nine waves: 168 registers each; M16: 9 + 5 fragments in all)
     static constexpr int xring = 0;
     static constexpr int mring = NSX * XSLOT;
     static constexpr int epi = mring + 4 * MS;                     // nw1 [32] | nw2 [32] floats
@@ -76,9 +78,13 @@ struct GgSpGeom {
     static constexpr int bytes(int C2) { return w2l(C2) + (W2REG ? 0 : 9 * KC1 * 1024); }
 };
 
-// swizzle key of pixel x for a ring with P bytes per pixel: chunk c of the pixel sits at position c ^ key
-template <int P>
+// swizzle key of pixel x for a ring with P bytes per pixel: chunk c of the pixel sits at position c ^ key. The 32x32x16 fragments read 32
+// consecutive pixels at one chunk index per half wave; the 16x16x32 ones (M16) read 16 pixels at chunk index lane >> 4, and the 16 lanes a
+// ds_read_b128 serves per cycle mix two chunk indices (lanes {0-3, 12-15} of one, {20-27} of the next): 64-byte pixels then want the
+// key table {0, 2, 3, 1}[(x >> 2) & 3], 32-byte pixels none
+template <int P, bool M16 = false>
 GG_DEVICE int gg_sp_key(int X) {
+    if (M16) return P == 64 ? (0x78 >> (2 * ((X >> 2) & 3))) & 3 : 0;
     return P == 128 ? (X >> 1) & 7 : (P == 64 ? (X >> 2) & 3 : (X >> 3) & 1);
 }
 
@@ -114,9 +120,10 @@ GG_DEVICE void gg_sp_pipeline_both() {
 #endif
 }
 
-template <int C0, int C1, int PT, int NCW>
+template <int C0, int C1, int PT, int NCW, bool M16 = false>
 GG_KERNEL GG_LAUNCH_BOUNDS((NCW + 1) * 64) void gg_spair_kernel(GgSpairParams p) {
-    typedef GgSpGeom<C0, C1, PT, NCW> G;
+    typedef GgSpGeom<C0, C1, PT, NCW, M16> G;
+    static_assert(!M16 || (C0 == 32 && C1 == 16 && PT == 1), "the 16-row form is written for the 32 -> 16 -> <= 16 block");
     constexpr int W = G::W, P0 = G::P0, P1 = G::P1, XS = G::XS, XSLOT = G::XSLOT, MS = G::MS, KC0 = G::KC0, KC1 = G::KC1, NSX = G::NSX;
     constexpr bool W2REG = G::W2REG;
     GG_DYN_SHARED(smem);
@@ -150,7 +157,7 @@ GG_KERNEL GG_LAUNCH_BOUNDS((NCW + 1) * 64) void gg_spair_kernel(GgSpairParams p)
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             const int j = i * 64 + lane, px = j / CH, pos = j % CH;
-            voff[i] = (unsigned)((px * CH + (pos ^ gg_sp_key<P0>(px))) * 16);      // chunk (pos ^ key) of pixel px lands at position pos
+            voff[i] = (unsigned)((px * CH + (pos ^ gg_sp_key<P0, M16>(px))) * 16);      // chunk (pos ^ key) of pixel px lands at position pos
         }
         const unsigned nvoff = lane * 16 < W * 4 ? (unsigned)(lane * 16) : 0xFFFFFFFFu;
         int head = 0;
@@ -214,6 +221,164 @@ GG_KERNEL GG_LAUNCH_BOUNDS((NCW + 1) * 64) void gg_spair_kernel(GgSpairParams p)
             else v = (p.noise2 && n < C2) ? p.nw2[n] : 0.f;
             ((float*)(smem + G::epi))[tid] = v;
         }
+    }
+
+    if constexpr (M16) {
+        // ================================================================ 16x16x32 form (32 -> 16 -> <= 16 channels)
+        // lane = (pixel n = lane & 15 of a 16-pixel half block, k-group g = lane >> 4); a wave's 32 pixels are two half blocks.
+        // conv1: K = 32 is one tap's 32 input channels (chunk g of the pixel): 9 MFMAs per half block.
+        // conv2: K = 32 is TWO taps' 16 channels (g < 2: tap 2 j, chunk g; g >= 2: tap 2 j + 1, chunk g - 2): 5 MFMAs per half block,
+        //        the ninth tap paired with zero weights.
+        // accumulator register r of lane (n, g): channel 4 g + r of pixel n.
+        const int n16 = lane & 15, g = lane >> 4;
+        u16x8 w1f[9], w2f[5];
+        {
+            const bf16_t* wb = p.w1 + (long long)img * p.w1_bs;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) w1f[t] = *(const u16x8*)(wb + ((t * 2 + (g >> 1)) * 32 + n16) * 16 + (g & 1) * 8);
+            if (p.xs) {
+                const float* sp = p.xs + (long long)img * C0 + g * 8;
+                const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    u16x8 v = w1f[t];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = gg_f2bf(gg_bf2f(v[e]) * s0[e]);
+                        v[e + 4] = gg_f2bf(gg_bf2f(v[e + 4]) * s1[e]);
+                    }
+                    w1f[t] = v;
+                }
+            }
+            const bf16_t* wc = p.w2 + (long long)img * p.w2_bs;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int t = 2 * j + (g >> 1);
+                u16x8 v = *(const u16x8*)(wc + ((t < 9 ? t : 8) * 32 + n16) * 16 + (g & 1) * 8);
+                if (t >= 9) v = gg_zero8();
+                w2f[j] = v;
+            }
+        }
+        // fragment byte offsets inside a ring row, per lane: conv1 [half block][tap column]; conv2 [half block][tap pair] (the pair's row
+        // and column differ per lane half: lanes g < 2 read tap 2 j, lanes g >= 2 tap 2 j + 1)
+        int fo1[2][3], fo2[2][5], ky2[5];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int X = xw + h * 16 + n16 + dx - 1;
+                fo1[h][dx] = (X + 1) * P0 + ((g ^ gg_sp_key<P0, true>(X)) << 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int t = 2 * j + (g >> 1), tc = t < 9 ? t : 8;
+                const int X = xw + h * 16 + n16 + tc % 3 - 1;
+                fo2[h][j] = (X + 1) * P1 + ((g & 1) << 4);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int t = 2 * j + (g >> 1), tc = t < 9 ? t : 8;
+            ky2[j] = tc / 3;                                 // (per lane half)
+        }
+        int mo[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) mo[h] = (xw + h * 16 + n16 + 1) * P1 + 8 * g;     // channels 4 g .. + 3: byte 8 g of the pixel's 32
+        const float* epi = (const float*)(smem + G::epi);
+        const float slope1 = p.act1 == 1 ? p.slope : 1.f, slope2 = p.act2 == 1 ? p.slope : 1.f;
+        const bool has_n1 = p.noise1 != nullptr, has_n2 = p.noise2 != nullptr;
+        const long long img_pix0 = (long long)img * H * W;
+        const bool own2 = 4 * g < C2;                        // this lane group's four output channels exist (C2 is a multiple of 8)
+
+        int xs0 = 0, mi = 0;
+        for (int r = r_first; r <= r_last; ++r) {
+            GG_SP_STAMP(0);
+            gg_barrier_lds();             // x rows r .. r + 2 have landed (the loader waited), mid rows up to r are written
+            GG_SP_STAMP(1);
+            int eo = 0;
+#if !defined(GG_HOST_EMULATION)
+            asm volatile("" : "+v"(eo));
+#endif
+            const int m = r + 1, o = r - 1;
+            const bool do1 = r <= y1 - 1, do2 = r >= y0 + 1;
+            const bool m_in = (unsigned)m < (unsigned)H;
+            int xslot[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                int sl = xs0 + ky;
+                sl = sl >= NSX ? sl - NSX : sl;
+                xslot[ky] = G::xring + sl * XSLOT;
+            }
+            int rbv[5];                                      // conv2: the ring row of each tap pair's lane half
+#pragma unroll
+            for (int j = 0; j < 5; ++j) rbv[j] = G::mring + ((mi + 1 + ky2[j]) & 3) * MS;
+            const bool c1 = do1 && m_in && !GG_SP_OFF(1), c2 = do2 && !GG_SP_OFF(2);
+            f32x4 acc1[2], acc2[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acc1[h] = acc2[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // (plain loops: pinning the 28 fragment reads six slots ahead of their MFMAs cut this phase from 1,670 to 1,300 cycles and the
+            // kernel not at all - 56.7 vs 55.9 us: with half the MFMA time gone the row is bound by the stream, r06_spair_probe_v7_m16.log)
+            if (c1) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        acc1[h] = gg_mfma_16x16x32_bf16(w1f[t], *(const u16x8*)(smem + xslot[t / 3] + fo1[h][t % 3]), acc1[h]);
+            }
+            if (c2) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        acc2[h] = gg_mfma_16x16x32_bf16(w2f[j], *(const u16x8*)(smem + rbv[j] + fo2[h][j]), acc2[h]);
+            }
+            GG_SP_STAMP(2);
+            // conv1's epilogue -> mid ring row of m (zeros outside the image: conv2's padding)
+            if (do1 && !GG_SP_OFF(16)) {
+                char* mrow = smem + G::mring + mi * MS;
+                if (m_in) {
+                    const f32x4 w4 = *(const f32x4*)(epi + eo + 4 * g);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float a = *(const float*)(smem + xslot[1] + XS + (xw + h * 16 + n16) * 4);
+                        const float nz = has_n1 ? a : 0.f;
+                        u16x4 o4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = acc1[h][e] + nz * w4[e];
+                            o4[e] = gg_f2bf(fmaxf(v, v * slope1));
+                        }
+                        *(u16x4*)(mrow + mo[h]) = o4;
+                    }
+                } else {
+                    const u16x4 z4 = {0, 0, 0, 0};
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) *(u16x4*)(mrow + mo[h]) = z4;
+                }
+            }
+            GG_SP_STAMP(3);
+            // conv2's epilogue -> row stores (8 bytes per lane: four channels of one pixel)
+            if (do2) {
+                const f32x4 w4 = *(const f32x4*)(epi + eo + 32 + 4 * g);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float c = *(const float*)(smem + xslot[1] + XS + 1024 + (xw + h * 16 + n16) * 4);
+                    const float nz = has_n2 ? c : 0.f;
+                    u16x4 o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = acc2[h][e] + nz * w4[e];
+                        o4[e] = gg_f2bf(fmaxf(v, v * slope2));
+                    }
+                    if (own2 && !GG_SP_OFF(4)) *(u16x4*)(p.y + (img_pix0 + (long long)o * W + xw + h * 16 + n16) * C2 + 4 * g) = o4;
+                }
+                GG_SP_STAMP(5);
+            }
+            GG_SP_STAMP(6);
+            xs0 = xs0 + 1 == NSX ? 0 : xs0 + 1;
+            mi = (mi + 1) & 3;
+        }
+        return;
     }
 
     // weights as MFMA A fragments: [tap][k-step] 8 bf16 of output channel pl, input channels kc * 16 + 8 * hi .. + 7

@@ -44,6 +44,7 @@ extern gg_emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 void gg_emu_launch(dim3 grid, dim3 block, const std::function<void()>& body);
 void gg_emu_syncthreads();
 f32x16 gg_emu_mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c);
+f32x4 gg_emu_mfma_16x16x32_bf16(u16x8 a, u16x8 b, f32x4 c);
 float gg_emu_shfl(float v, int src_lane);
 u16x4 gg_emu_lds_read_tr16(const bf16_t* p);
 
@@ -104,6 +105,7 @@ static inline const T* gg_late_params(const T& by_value) { return &by_value; }
 static inline f32x16 gg_mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c) {
     return gg_emu_mfma_32x32x16_bf16(a, b, c);
 }
+static inline f32x4 gg_mfma_16x16x32_bf16(u16x8 a, u16x8 b, f32x4 c) { return gg_emu_mfma_16x16x32_bf16(a, b, c); }
 static inline u16x4 gg_lds_read_tr16(const bf16_t* p) { return gg_emu_lds_read_tr16(p); }
 static inline float gg_shfl_xor(float v, int mask) {
     int lane = (int)(threadIdx.x & 63u);

@@ -121,6 +121,29 @@ f32x16 gg_emu_mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c) {
     return out;
 }
 
+// v_mfma_f32_16x16x32_bf16 (gg_device.h: lane l holds A[i = l & 15][k = 8 (l >> 4) + e] / B[k][j = l & 15]; D[i = 4 (l >> 4) + r][j = l & 15])
+f32x4 gg_emu_mfma_16x16x32_bf16(u16x8 a, u16x8 b, f32x4 c) {
+    WaveState& w = g_waves[g_cur / 64];
+    int lane = g_cur & 63;
+    w.a[lane] = a;
+    w.b[lane] = b;
+    wave_sync();
+    f32x4 out;
+    int j = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        int i = 4 * (lane >> 4) + r;
+        float s = c[r];
+        for (int k = 0; k < 32; ++k) {
+            float av = bf2f_(w.a[(k >> 3) * 16 + i][k & 7]);
+            float bv = bf2f_(w.b[(k >> 3) * 16 + j][k & 7]);
+            s += av * bv;
+        }
+        out[r] = s;
+    }
+    wave_sync();
+    return out;
+}
+
 float gg_emu_shfl(float v, int src_lane) {
     WaveState& w = g_waves[g_cur / 64];
     int lane = g_cur & 63;

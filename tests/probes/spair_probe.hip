@@ -10,9 +10,9 @@
 #include <string.h>
 #include <vector>
 
-template <int C0, int C1, int PT, int NCW>
+template <int C0, int C1, int PT, int NCW, bool M16 = false>
 static void run(int C2, int b, int H, int rows) {
-    typedef GgSpGeom<C0, C1, PT, NCW> G;
+    typedef GgSpGeom<C0, C1, PT, NCW, M16> G;
     const int W = G::W;
     const size_t nx = (size_t)b * H * W * C0, ny = (size_t)b * H * W * C2, nw1 = (size_t)b * 9 * (C0 / 16) * 512, nw2 = (size_t)b * 9 * (C1 / 16) * 512;
     std::vector<unsigned short> hx(nx), hw1(nw1), hw2(nw2);
@@ -35,7 +35,7 @@ static void run(int C2, int b, int H, int rows) {
     p.noise1 = n1; p.nw1 = nw; p.noise2 = n2; p.nw2 = nw; p.xs = xs; p.b = b; p.H = H; p.C2 = C2; p.act1 = p.act2 = 1; p.slope = 0.2f;
     p.rows = rows; p.strips = (H + rows - 1) / rows; p.stamps = st;
     const int grid = b * p.strips, lds = G::bytes(C2);
-    hipFuncSetAttribute((const void*)gg_spair_kernel<C0, C1, PT, NCW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)gg_spair_kernel<C0, C1, PT, NCW, M16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const double mb = (nx + ny) * 2 / 1e6;
@@ -43,9 +43,9 @@ static void run(int C2, int b, int H, int rows) {
     const int offs[] = {0, 1, 2, 3, 4, 8, 16, 1 | 2 | 16, 1 | 2 | 4 | 16, 1 | 2 | 4 | 8 | 16};
     for (int off : offs) {
         p.probe_off = off; p.probe_wg = -1;
-        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gg_spair_kernel<C0, C1, PT, NCW>), dim3(grid), dim3(G::NT), lds, 0, p);
+        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gg_spair_kernel<C0, C1, PT, NCW, M16>), dim3(grid), dim3(G::NT), lds, 0, p);
         hipEventRecord(e0);
-        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((gg_spair_kernel<C0, C1, PT, NCW>), dim3(grid), dim3(G::NT), lds, 0, p);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((gg_spair_kernel<C0, C1, PT, NCW, M16>), dim3(grid), dim3(G::NT), lds, 0, p);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -55,7 +55,7 @@ static void run(int C2, int b, int H, int rows) {
     // stamps of one workgroup in the middle of the grid, full kernel
     p.probe_off = 0; p.probe_wg = grid / 2 + 1;
     hipMemset(st, 0, 128 * 8 * 8);
-    hipLaunchKernelGGL((gg_spair_kernel<C0, C1, PT, NCW>), dim3(grid), dim3(G::NT), lds, 0, p);
+    hipLaunchKernelGGL((gg_spair_kernel<C0, C1, PT, NCW, M16>), dim3(grid), dim3(G::NT), lds, 0, p);
     hipDeviceSynchronize();
     std::vector<long long> hs(128 * 8);
     hipMemcpy(hs.data(), st, 128 * 8 * 8, hipMemcpyDeviceToHost);
@@ -71,8 +71,9 @@ static void run(int C2, int b, int H, int rows) {
 }
 
 int main() {
-    run<32, 16, 2, 4>(16, 32, 256, 32);
     run<32, 16, 1, 8>(16, 32, 256, 32);
+    printf("(next: the 16x16x32 form)\n");
+    run<32, 16, 1, 8, true>(16, 32, 256, 32);
     run<64, 32, 1, 4>(32, 32, 128, 16);
     return 0;
 }

@@ -1170,6 +1170,7 @@ def _layout2(wps, C):
     (2, 5, 128, 64, 32, 32, True, True, False),        # the 128x128 pair (conv2's bank in LDS), one strip per image
     (1, 4, 256, 32, 16, 8, False, False, True),        # no noise maps, no excitation, shared banks, ragged output channel count
     (1, 19, 128, 64, 32, 24, False, True, True),       # three strips (8 + 8 + 3 rows)
+    (1, 6, 256, 32, 16, 24, True, True, False),        # 24 output channels at 256 wide: the 32x32x16 form of that geometry
 ])
 def test_fused_streaming_pair_is_bit_identical_to_two_streaming_convolutions(cfg, model, monkeypatch):
     """gg_spair_fwd (loader wave + LDS-DMA x ring with the two noise maps riding along, conv1 -> bf16 mid ring in LDS -> conv2, one
@@ -1194,10 +1195,13 @@ def test_fused_streaming_pair_is_bit_identical_to_two_streaming_convolutions(cfg
     mid = K.sconv(x, w1, C1, n1, nw1, 'lrelu', xs=xs)
     want = K.sconv(mid, w2, C2, n2, nw2, 'lrelu')
     got = K.spair(x, w1, w2, C1, C2, n1, nw1, n2, nw2, 'lrelu', 'lrelu', xs=xs)
-    assert got.shape == want.shape and torch.equal(got, want)
+    # the 32 -> 16 -> <= 16 block runs on 16x16x32 MFMAs (K = 32 per instruction, conv2's taps paired): the same products in another
+    # summation order - equal to bf16 rounding, and exact on integer operands (tests/test_exact_integer.py); every other geometry: the same bits
+    same = (lambda a, b_: torch.equal(a, b_)) if not (C0 == 32 and C2 <= 16) else (lambda a, b_: rel_err(a, b_) < 4e-3)
+    assert got.shape == want.shape and same(got, want)
     if not noise:       # the plain epilogues (no activation on either stage)
         want = K.sconv(K.sconv(x, w1, C1, xs=xs), w2, C2)
-        assert torch.equal(K.spair(x, w1, w2, C1, C2, xs=xs), want)
+        assert same(K.spair(x, w1, w2, C1, C2, xs=xs), want)
 
 
 def test_modulate_bank_lays_the_kernels_side_by_side():

@@ -415,7 +415,10 @@ def test_fused_block_pair_at_config2_shapes_batch_32(cfg):
                 plans, K.plan_log = K.plan_log, None
             impl.modconv_release()
     assert one is not None and not plans
-    assert torch.equal(one, two)
+    if C0 == 32:        # (the 256x256 block: 16x16x32 MFMAs, conv2's taps paired - the same products, another summation order)
+        assert rel_err(one, two) < 4e-3
+    else:
+        assert torch.equal(one, two)
     assert rel_err(one.float().cpu(), y0) < 1e-2
 
 
