@@ -883,7 +883,8 @@ def spair(x: torch.Tensor, wmix1: torch.Tensor, wmix2: torch.Tensor, C1: int, C2
           noise_w2=None, act1=None, act2=None, slope: float = 0.2, xs=None) -> torch.Tensor:
     """two streaming 3x3 convolutions with per-image filter banks in one launch, the intermediate map kept in LDS (gg_spair_fwd):
     y = act2(conv(act1(conv(x * xs, w1) + noise1 * nw1), w2) + noise2 * nw2); x (b, H, W, C0) bf16, wmix1 (b, 9, C0/16, 32, 16),
-    wmix2 (b, 9, C1/16, 32, 16) bf16 (or (1, ...) shared) -> (b, H, W, C2) bf16. Bit-identical to sconv(sconv(x))."""
+    wmix2 (b, 9, C1/16, 32, 16) bf16 (or (1, ...) shared) -> (b, H, W, C2) bf16. Bit-identical to sconv(sconv(x)) on the 32x32x16 form
+    (W 128; W 256 with C2 > 16), equal to bf16 rounding on the 16x16x32 form (W 256, C2 <= 16)."""
     L = _C.lib()
     L.require(x, wmix1, wmix2, noise1, noise_w1, noise2, noise_w2, xs)
     b, H, W, C0 = x.shape

@@ -1622,7 +1622,8 @@ class HipOps:
         leaky_relu, nothing in between) in ONE launch where both are streaming layers of a geometry gg_spair_fwd carries (config 2:
         64 -> 32 -> 32 at 128x128, 32 -> 16 -> 16 at 256x256): the intermediate map stays in LDS. `first` / `second`: dicts with the
         keyword arguments of modconv2d (weights, mod, kernel_mod, demod, eps, noise, noise_weight, act, in_excite). Returns None when
-        the pair does not qualify - the caller then runs the two layers one by one. Bit-identical to that (same kernels' arithmetic)."""
+        the pair does not qualify - the caller then runs the two layers one by one. The same arithmetic (128x128: the same bits; 256x256: the
+        16-row MFMA form sums in another order)."""
         if torch.is_grad_enabled() and any(t is not None and t.requires_grad for d in (first, second)
                                            for t in (x, d['weights'], d['mod'], d.get('kernel_mod'), d.get('noise_weight'),
                                                      d.get('in_excite'))):

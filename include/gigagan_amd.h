@@ -448,7 +448,9 @@ int gg_modulate_bank_fwd(const void* x, const float* s, const float* a, void* ou
  *     y   = act2(conv3x3(mid,    w2[b]) + noise2[b][p] * nw2[c])
  * x (b, H, W, C0) bf16 NHWC, w1 [b][9][C0/16][32][16], w2 [b][9][C1/16][32][16] (w*_bs = elements between banks, 0 = shared),
  * y (b, H, W, C2) bf16; noise maps [b][H*W] fp32 (16-byte aligned; each goes with its weights or is null), xs optional [b][C0] (the
- * skip-layer excitation, gp.py:1023-1024). Bit-identical to gg_sconv_fwd(gg_sconv_fwd(x)). Geometries: gg_spair_supported
+ * skip-layer excitation, gp.py:1023-1024). W 128: bit-identical to gg_sconv_fwd(gg_sconv_fwd(x)); W 256 with C2 <= 16 runs on
+ * v_mfma_f32_16x16x32_bf16 (16 output channels = one row block): the same products in another summation order - equal to bf16 rounding,
+ * exact on integer operands. Geometries: gg_spair_supported
  * (W 256 / C0 32 / C1 16 and W 128 / C0 64 / C1 32, C2 <= 32, C2 %% 8 == 0); anything else: -2. */
 int gg_spair_supported(int32_t H, int32_t W, int32_t C0, int32_t C1, int32_t C2);
 int gg_spair_fwd(const void* x, const void* w1, int64_t w1_bs, const void* w2, int64_t w2_bs, void* y, const float* noise1,
