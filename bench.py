@@ -291,6 +291,49 @@ def modconv_forward_roofline(gan, batch, dev):
 
 
 # ---- the multi-rank half of the contract, as functions a world-2 gloo test can drive (tests/test_distributed_cpu.py) ------------
+def operand_activity_probe(dev):
+    """How much of the dominant kernel's distance to the MFMA peak is the chip's power management rather than the kernel: ONE launch shape
+    of gg_conv3<256> (the discriminator's stage-4 second conv at the bench batch: 256 images x 16x16, 512 -> 512 channels, 3x3 = 309.2
+    GFLOP) timed from a hipGraph on operands of different bit activity - N(0,1) activations / N(0, 0.05) weights as in training, the
+    constant 1.0, zeros. Same instruction stream, same bytes moved, same launch; only the switching in the operand paths and the
+    multiplier arrays differs (round 6: 1250 / 1663 / 1753 TFLOP/s, profiles/r06_power_probe.log)."""
+    from gigagan_pytorch_amd import kernels as K
+    n, R, ci, co = 256, 16, 512, 512
+    flops = 2.0 * n * R * R * co * ci * 9
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    cases = (('training_like', lambda *sh: torch.randn(*sh, device=dev, generator=g), 0.05),
+             ('constant_one', lambda *sh: torch.ones(*sh, device=dev), 1.0),
+             ('zeros', lambda *sh: torch.zeros(*sh, device=dev), 1.0))
+    out = dict(kernel='gg_conv3_kernel<256, 2, 4, ...>', shape=f'{n} x {R}x{R}, {ci} -> {co}, 3x3', gflop=flops / 1e9, peak=MFMA_PEAK_TF,
+               note='the same launch on operands of different bit activity (hipGraph of 10 launches, HIP events); frac = TFLOP/s / peak')
+    for name, make, wscale in cases:
+        x = make(n, R, R, ci).to(torch.bfloat16)
+        w = (make(co, 9 * ci) * wscale).to(torch.bfloat16)
+        fn = lambda: K.conv2d_nhwc(x, w, ksize=3, force_tile=7)     # noqa: E731
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(10):
+                    fn()
+        torch.cuda.current_stream().wait_stream(side)
+        graph.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 30 * 1e3
+        out[name] = dict(launch_us=round(us, 1), tflops=round(flops / us / 1e6, 1), frac=round(flops / us / 1e6 / MFMA_PEAK_TF, 4))
+    return out
+
+
 def check_comm_for_measurement(world: int, dry: bool, backend: str, comm_world, reducers: bool):
     """None when the run may be reported, else why not: at N > 1 on GPUs the gradient exchange must be gg_comm/rccl with N ranks in the
     communicator and both flat-gradient reducers wired - never the torch.distributed fallback. (The CPU dry run states its transport in
@@ -583,6 +626,12 @@ def main():
             roofline['modconv_forward'] = modconv_forward_roofline(gan, args.batch, dev)
         except Exception as e:    # noqa: BLE001 - a secondary measurement must not take the bench line down
             roofline['modconv_forward'] = dict(error=f'{type(e).__name__}: {e}')
+
+    if rank == 0 and roofline is not None and args.workload == 'uncond' and not dry:
+        try:
+            roofline['operand_activity'] = operand_activity_probe(dev)
+        except Exception as e:    # noqa: BLE001 - a secondary measurement must not take the bench line down
+            roofline['operand_activity'] = dict(error=f'{type(e).__name__}: {e}')
 
     if rank == 0 and roofline is not None:
         # the secondary fractions where the driver's parser looks (scalars at the top level of `roofline`)
