@@ -35,8 +35,17 @@
 #define GG_C3_NVH ((GG_C3_MAX_SLOTS * 8 + GG2_NT - 1) / GG2_NT)    // 16-byte halo vectors per thread: 7
 #define GG_C3_SC_FLOATS 4096                              // SCALED: (images of a tile) x (channels of a k-slice) scale values in LDS
 
-template <int BN, int WM, int WN, bool FULL_EPI, bool SCALED = false>
-GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_conv3_kernel(GgGemmParams p) {
+// PAIR (round 6; the 64-column tile on images of 32 / 64 pixels a side, instantiated as BN_ = GG_C3_BN64_PAIR so that the other
+// instantiations keep their names and code): two workgroups per CU - the halo area cut to what ten halo rows need (59 KB instead of
+// 66), one tap per weight buffer (16 KB instead of 48): 75 KB of LDS, <= 128 registers. One workgroup's prologue, epilogue and barriers
+// overlap the other's tap loop.
+#define GG_C3_HBYTES_WIDE 60416                           // 400 slots x 144 + 10 rows x 224, rounded up to 1 KB
+#define GG_C3_BN64_PAIR 1064
+template <int BN_, int WM, int WN, bool FULL_EPI, bool SCALED = false>
+GG_KERNEL GG_LAUNCH_BOUNDS2(GG2_NT, BN_ >= 1000 ? 4 : 2) void gg_conv3_kernel(GgGemmParams p) {
+    constexpr bool PAIR = BN_ >= 1000;
+    constexpr int BN = BN_ % 1000;
+    static_assert(!PAIR || (BN == 64 && !SCALED), "the paired form carries the unscaled 64-column tile");
     static_assert(WM * WN == 8, "8 wavefronts per workgroup");
     constexpr int BM = 256;
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -47,15 +56,16 @@ GG_KERNEL GG_LAUNCH_BOUNDS(GG2_NT) void gg_conv3_kernel(GgGemmParams p) {
     // taps per barrier interval: the 64-column tile does 8 MFMAs per wave and tap - a whole kernel row (3 taps, 24 MFMAs) rides on one
     // weight transfer + barrier there (round 6, same results bit for bit; the adaptive 64x64 layers on per-sample weights 48.5-50.4 -> 47.0 us
     // and 35.7 -> 32.1 us across boxes, profiles/r06_conv3_row_of_taps.log: the barrier count was not what bounds this tile)
-    constexpr int U = BN == 64 ? 3 : 1;
+    constexpr int U = (BN == 64 && !PAIR) ? 3 : 1;
+    constexpr int HBYTES = PAIR ? GG_C3_HBYTES_WIDE : GG_C3_HBYTES;
     constexpr int WBUF = U * BBYTES;
-    constexpr int TILE_BYTES = GG_C3_HBYTES + 2 * WBUF + SC_BYTES, STAGE_BYTES = 8 * WTM * SP;
+    constexpr int TILE_BYTES = HBYTES + 2 * WBUF + SC_BYTES, STAGE_BYTES = 8 * WTM * SP;
     static_assert(GG_C3_MAX_SLOTS * GG_C3_PITCH + GG_C3_MAX_ROWS * GG_C3_ROWPAD <= GG_C3_HBYTES, "halo area");
 
     GG_SHARED __attribute__((aligned(1024))) char smem[TILE_BYTES > STAGE_BYTES ? TILE_BYTES : STAGE_BYTES];
     char* const halo = smem;
-    auto tileB = [&](int buf) { return smem + GG_C3_HBYTES + buf * WBUF; };
-    float* const scl = (float*)(smem + GG_C3_HBYTES + 2 * WBUF);      // SCALED only
+    auto tileB = [&](int buf) { return smem + HBYTES + buf * WBUF; };
+    float* const scl = (float*)(smem + HBYTES + 2 * WBUF);      // SCALED only
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;

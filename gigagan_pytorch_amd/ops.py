@@ -1556,9 +1556,13 @@ class HipOps:
         """which no-grad formulation a demodulated 3x3 adaptive conv runs in (see modconv2d)."""
         if I in (16, 32, 64) and O <= 32 and W % 32 == 0 and b * H * W >= 32768:
             return 'sconv'
-        if _ACONV and _aconv_ok(b, N, O, I, H, W):
+        pimg_ok = H * W % 128 == 0 and H * W >= 1024 and b * O * I * 9 <= (16 << 20)
+        # 32x32 (round 6): per-sample weights + gg_conv3's 64-column tile with two workgroups per CU beats the shared bank's doubled
+        # reduction where its grid fills the chip (b * tiles * column tiles >= 256 workgroups: config 2's batch 32; 44.9 -> 39.4 us and
+        # 26.5 -> 24.7 us, the modulation launch + 6 us: forward graph 0.506 -> 0.490 ms same-box, profiles/r06_conv3_pair_ab.log)
+        if _ACONV and _aconv_ok(b, N, O, I, H, W) and not (W == 32 and pimg_ok and I % 64 == 0 and b * (H * W // 256) * ((O + 63) // 64) >= 256):
             return 'aconv'
-        if H * W % 128 == 0 and H * W >= 1024 and b * O * I * 9 <= (16 << 20):
+        if pimg_ok:
             return 'pimg'
         return 'bank'
 

@@ -423,20 +423,22 @@ def test_fused_block_pair_at_config2_shapes_batch_32(cfg):
 
 
 @pytest.mark.parametrize('cfg', [(512, 512, 4, 32, 'aconv'), (512, 512, 8, 32, 'aconv'), (512, 256, 16, 32, 'aconv'),
-                                 (256, 256, 16, 32, 'aconv'), (256, 128, 32, 32, 'aconv'), (128, 128, 32, 32, 'aconv'),
-                                 (128, 64, 64, 32, 'pimg'), (64, 64, 64, 32, 'pimg'),
+                                 (256, 256, 16, 32, 'aconv'), (256, 128, 32, 32, 'pimg'), (128, 128, 32, 32, 'pimg'),
+                                 (256, 128, 32, 16, 'aconv'), (128, 64, 64, 32, 'pimg'), (64, 64, 64, 32, 'pimg'),
                                  (64, 32, 128, 32, 'sconv'), (32, 32, 128, 32, 'sconv'), (32, 16, 256, 32, 'sconv'), (16, 16, 256, 32, 'sconv')])
 def test_no_grad_adaptive_conv_at_config2_layer_shapes(cfg):
     """the generator's demodulated 3x3 adaptive convs (gp.py:344-409 + noise + leaky-relu) at EVERY BASELINE config-2 layer shape,
     no-grad path, against the oracle with bf16-rounded operands: 1e-2 relative L2 (bf16 output rounding; the oracle rounds the
     per-sample weights to bf16 AFTER modulation / demodulation, as the reference's autocast conv does, the kernels round the bank and
-    the modulated activation). The last entry of a case is the formulation it must run in: 'aconv' = gg_aconv_fwd (4x4 .. 64x64: one
-    launch on the fragment-ordered shared bank, round 5), 'pimg' = per-sample weights through gg_conv3 (64x64, plan tile 8), 'sconv' =
-    gg_sconv on per-sample weights; aconv / sconv do not go through gg_gemm_bf16 (no contraction plan is logged)."""
+    the modulated activation). The last entry of a case is the formulation it must run in: 'aconv' = gg_aconv_fwd (4x4 .. 16x16, and
+    32x32 where the per-image grid would not fill the chip - the batch-16 case: one launch on the fragment-ordered shared bank,
+    round 5), 'pimg' = per-sample weights through gg_conv3's 64-column tile, two workgroups per CU (64x64: plan tile 8; 32x32 at batch
+    32: tile 12, round 6), 'sconv' = gg_sconv on per-sample weights; aconv / sconv do not go through gg_gemm_bf16 (no contraction
+    plan is logged)."""
     from gigagan_pytorch_amd.modules import AdaptiveConv2DMod
     from gigagan_pytorch_amd import kernels as K
     I, O, R, b, want_path = cfg
-    want_tile = 8 if want_path == 'pimg' else 0          # (64x64: per-sample weights on gg_conv3's 64-column tile)
+    want_tile = (8 if O <= 64 else 12) if want_path == 'pimg' else 0          # (per-sample weights on gg_conv3's 64-column tile)
     assert ops.HipOps._modconv_path(b, 2, O, I, R, R) == want_path
     torch.manual_seed(0)
     conv = AdaptiveConv2DMod(I, O, 3, num_conv_kernels=2)
