@@ -1064,6 +1064,10 @@ extern "C" int gg_gemm_bf16(const gg_gemm_desc* d, void* workspace, size_t works
             }                                                                                                   \
         } while (0)
         if (pl.tile == 7) GG_C3(256, 2, 4);
+        else if ((pl.tile == 12 || d->N <= 64) && d->W >= 32 && scaled && pl.k_per_split <= GG_C3_SC_FLOATS_PAIR) {
+            if (full) GG_LAUNCH((gg_conv3_kernel<GG_C3_BN64_PAIR, 8, 1, true, true>), grid2, dim3(GG2_NT), s, p);
+            else GG_LAUNCH((gg_conv3_kernel<GG_C3_BN64_PAIR, 8, 1, false, true>), grid2, dim3(GG2_NT), s, p);
+        }
         else if ((pl.tile == 12 || d->N <= 64) && !scaled && d->W >= 32) {
             // images of 32 / 64 pixels a side: two workgroups per CU (gg_conv3.h PAIR; the adaptive 64x64 layers on per-sample weights
             // 50.7 -> 35.2 us and 31.8 -> 26.4 us same-box, profiles/r06_conv3_pair_ab.log)

@@ -41,18 +41,19 @@
 // overlap the other's tap loop.
 #define GG_C3_HBYTES_WIDE 60416                           // 400 slots x 144 + 10 rows x 224, rounded up to 1 KB
 #define GG_C3_BN64_PAIR 1064
+#define GG_C3_SC_FLOATS_PAIR 512
 template <int BN_, int WM, int WN, bool FULL_EPI, bool SCALED = false>
 GG_KERNEL GG_LAUNCH_BOUNDS2(GG2_NT, BN_ >= 1000 ? 4 : 2) void gg_conv3_kernel(GgGemmParams p) {
     constexpr bool PAIR = BN_ >= 1000;
     constexpr int BN = BN_ % 1000;
-    static_assert(!PAIR || (BN == 64 && !SCALED), "the paired form carries the unscaled 64-column tile");
+    static_assert(!PAIR || BN == 64, "the paired form carries the 64-column tile");
     static_assert(WM * WN == 8, "8 wavefronts per workgroup");
     constexpr int BM = 256;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int BNV = Gg2Dma<BN>::NV, BBYTES = Gg2Dma<BN>::BYTES;
     constexpr int SP = WTN * 2 + 8;
-    constexpr int SC_BYTES = SCALED ? GG_C3_SC_FLOATS * 4 : 0;
+    constexpr int SC_BYTES = SCALED ? (BN_ >= 1000 ? GG_C3_SC_FLOATS_PAIR : GG_C3_SC_FLOATS) * 4 : 0;     // (PAIR: one image, <= 512 channels per k-slice: host)
     // taps per barrier interval: the 64-column tile does 8 MFMAs per wave and tap - a whole kernel row (3 taps, 24 MFMAs) rides on one
     // weight transfer + barrier there (round 6, same results bit for bit; the adaptive 64x64 layers on per-sample weights 48.5-50.4 -> 47.0 us
     // and 35.7 -> 32.1 us across boxes, profiles/r06_conv3_row_of_taps.log: the barrier count was not what bounds this tile)

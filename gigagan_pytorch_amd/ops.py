@@ -1728,10 +1728,13 @@ class HipOps:
                 wm = _wmix_rows(weights, b, O, 9 * I)
                 if rec is None:
                     K.modw_fwd(wd, md, km, demod, eps, Ip, Op, coef=False, wmix=wm, layout=1, xs=xs)
-                if xs_late is not None:
-                    # the excitation folded into the (small) per-sample weights by one element-wise launch instead of riding on the
-                    # convolution's operand staging: conv(x * e, w) = conv(x, w * e); gg_conv3's SCALED form measured 91 us against
-                    # 60 us for the plain one on 128 -> 64 @64x64 (profiles/r05_kernel_stats_a.csv), the pass over 4.7 MB of weights ~5 us
+                if xs_late is not None and (O > 64 or I > 512):
+                    # the excitation folded into the (small) per-sample weights by one element-wise launch: conv(x * e, w) = conv(x, w * e).
+                    # (Up to round 5 every excited layer went this way - gg_conv3's SCALED form with one workgroup per CU measured 91 us
+                    # against 60 us for the plain one on 128 -> 64 @64x64. Round 6: the 64-column tile with two workgroups per CU takes the
+                    # scale on its halo staging at no visible cost - 8.8 + 33.0 us -> 38.5 us in one launch, profiles/r06_conv3_pair_ab.log -
+                    # so only shapes that tile does not certainly carry (more than 64 output channels: the planner may pick a wider tile) fold the
+                    # scale into the weights.)
                     wm = K.modulate(wm.view(b, O, 9, I), xs_late).view(b, O, 9 * I)
                     xs_late = None
                 y = K.conv2d_nhwc(nhwc(x), wm, ksize=3, in_scale=xs_late, noise=nz, noise_w=nw, act=act, act_slope=LRELU_SLOPE,

@@ -459,6 +459,46 @@ def test_no_grad_adaptive_conv_at_config2_layer_shapes(cfg):
     assert ([t for t, _ in plans] == [want_tile]) if want_tile else not plans, plans
 
 
+@pytest.mark.parametrize('cfg', [(128, 64, 64, 32), (64, 64, 64, 8), (128, 128, 32, 32)])
+def test_excited_per_image_adaptive_conv_takes_the_scale_on_its_operand_staging(cfg):
+    """a 64x64 adaptive conv behind a skip-layer excitation (gp.py:1023-1024: x * excitation, then the block's first conv), announced
+    as the generator announces it: per-sample weights WITHOUT the excitation from the batched modulation launch, the excitation as the
+    per-(image, channel) scale of gg_conv3's halo staging (64-column tile, two workgroups per CU; round 6) - or, for more than 64 output
+    channels, folded into the weights by one gg_modulate launch. Against the oracle with bf16-rounded operands, 1e-2 relative L2; the
+    launches are counted."""
+    from gigagan_pytorch_amd.modules import AdaptiveConv2DMod
+    from gigagan_pytorch_amd import kernels as K
+    I, O, R, b = cfg
+    torch.manual_seed(1)
+    conv = AdaptiveConv2DMod(I, O, 3, num_conv_kernels=2)
+    x, mod, km = torch.randn(b, I, R, R), torch.randn(b, I) * 0.3, torch.randn(b, 2)
+    exc = torch.rand(b, I, 1, 1) + 0.5
+    nz, nw = torch.randn(b, 1, R, R), torch.randn(O, 1, 1) * 0.1
+    with torch.no_grad():
+        with ops.use_impl(OracleOps(bf16_operands=True)):
+            y0 = conv(x * exc, mod, km, noise=nz, noise_weight=nw, act='lrelu')
+        d = dev()
+        conv = conv.to(d)
+        impl = ops.HipOps()
+        calls = []
+        real_mod = K.modulate
+        K.modulate = lambda *a, **kw: (calls.append('modulate'), real_mod(*a, **kw))[1]
+        K.plan_log = []
+        try:
+            with ops.use_impl(impl):
+                md, kd = mod.to(d), km.to(d)
+                assert impl.modconv_prepare([(conv.weights, md, kd, R, R, True, conv.demod, conv.eps)]) == 1
+                y1 = conv(x.to(d), md, kd, noise=nz.to(d), noise_weight=nw.to(d), act='lrelu', in_excite=exc.to(d))
+                impl.modconv_release()
+        finally:
+            K.modulate = real_mod
+            plans, K.plan_log = K.plan_log, None
+    assert rel_err(y1.float().cpu(), y0) < 1e-2
+    assert ops.HipOps._modconv_path(b, 2, O, I, R, R) == 'pimg'
+    assert len(plans) == 1 and plans[0][0] in (8, 12), plans
+    assert calls == ([] if O <= 64 else ['modulate']), calls
+
+
 def test_training_steps_never_read_uninitialised_memory():
     """torch.empty() poisoned with NaN (deterministic-mode fill): four replayed config-2 steps (plain D, gradient-penalty D, G step
     kinds; every workspace, partial-sum and padded buffer the kernels are handed) leave losses and both flat parameter buffers
