@@ -61,7 +61,10 @@ struct GgAconvParams {
 // first measurements said (profiles/r5_aconv_probe*.log): the weight stream runs at what the L2 delivers (64 B/clk per CU, ~25-30 TB/s
 // chip-wide) whatever the depth; what dominated was a FIXED ~15 us per workgroup: three dependent round trips in front of the loop
 // (halo loads in batches behind integer divisions, then the first weight fragments) and one behind it (demodulation / noise operands).
-template <int NB, int TM> struct GgAcDepth { static constexpr int PD = TM == 1 ? 12 : (TM == 2 ? 6 : 3) * (NB == 1 ? 2 : 1); };
+// (Round 6, last day: the two-kernel bank on a 32-pixel tile - the 4x4 layers - ran twelve deep with 256 registers and 68-100 bytes of scratch
+// per lane: its finishing operands were spilled across the loop, the spill stores waiting for their loads in FRONT of it. Nine deep: 244
+// registers, no scratch, 22.6 -> 19.8 us per layer same-box, profiles/r06_aconv_4x4_spill_ab.log.)
+template <int NB, int TM> struct GgAcDepth { static constexpr int PD = TM == 1 ? (NB == 1 ? 12 : 9) : (TM == 2 ? 6 : 3) * (NB == 1 ? 2 : 1); };
 
 #define GG_AC_XV 16         // halo vectors a thread keeps in flight (all of them on every shape the model has)
 
