@@ -571,33 +571,51 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_bias_act_bwd_kernel(GgBiasActBwdParams p
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > p.rows) r1 = p.rows;
-    for (int cg = cgl; cg < ncg; cg += lanes_per_row) {
+    for (int cg0 = 0; cg0 < ncg; cg0 += lanes_per_row) {       // (workgroup-uniform trip count: the barriers below are inside)
+        const int cg = cg0 + cgl;
+        const bool live = rl < row_lanes && cg < ncg;
         float acc[8];
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-        if (rl < row_lanes) {
-            for (long long r = r0 + rl; r < r1; r += row_lanes) {
-                const long long off = r * p.C + cg * 8;
-                u16x8 g = *(const u16x8*)(p.dy + off);
-                float f[8];
-                if (p.y) {
-                    u16x8 yv = *(const u16x8*)(p.y + off);
-                    u16x8 o;
-                    for (int e = 0; e < 8; ++e) {
-                        f[e] = gg_bf2f(g[e]) * (gg_bf2f(yv[e]) > 0.f ? 1.f : p.slope);
-                        o[e] = gg_f2bf(f[e]);
-                        f[e] = gg_bf2f(o[e]);
-                    }
-                    *(u16x8*)(p.dz + off) = o;
-                } else {
-                    for (int e = 0; e < 8; ++e) f[e] = gg_bf2f(g[e]);
+        if (live) {
+            // four rows per trip, their loads issued together (round 6: one row per trip kept 32 bytes in flight per thread - at 1,024
+            // workgroups that is ~8 MB chip-wide, i.e. the 4.1-4.8 TB/s this kernel ran at is its latency bound, not the memory's);
+            // rows are still accumulated one after the other in the old order: the column sums keep their bits
+            constexpr int UR = 4;
+            for (long long rb = r0 + rl; rb < r1; rb += (long long)row_lanes * UR) {
+                u16x8 g[UR], yv[UR];
+#pragma unroll
+                for (int u = 0; u < UR; ++u) {
+                    const long long r = rb + (long long)u * row_lanes;
+                    const long long off = (r < r1 ? r : r1 - 1) * p.C + cg * 8;
+                    g[u] = *(const u16x8*)(p.dy + off);
+                    if (p.y) yv[u] = *(const u16x8*)(p.y + off);
                 }
-                for (int e = 0; e < 8; ++e) acc[e] += f[e];
+#pragma unroll
+                for (int u = 0; u < UR; ++u) {
+                    const long long r = rb + (long long)u * row_lanes;
+                    if (r < r1) {
+                        const long long off = r * p.C + cg * 8;
+                        float f[8];
+                        if (p.y) {
+                            u16x8 o;
+                            for (int e = 0; e < 8; ++e) {
+                                f[e] = gg_bf2f(g[u][e]) * (gg_bf2f(yv[u][e]) > 0.f ? 1.f : p.slope);
+                                o[e] = gg_f2bf(f[e]);
+                                f[e] = gg_bf2f(o[e]);
+                            }
+                            *(u16x8*)(p.dz + off) = o;
+                        } else {
+                            for (int e = 0; e < 8; ++e) f[e] = gg_bf2f(g[u][e]);
+                        }
+                        for (int e = 0; e < 8; ++e) acc[e] += f[e];
+                    }
+                }
             }
         }
         if (p.db) {
-            for (int e = 0; e < 8; ++e) red[t][e] = (rl < row_lanes) ? acc[e] : 0.f;
+            for (int e = 0; e < 8; ++e) red[t][e] = live ? acc[e] : 0.f;
             gg_sync();
-            if (rl == 0) {
+            if (rl == 0 && cg < ncg) {
                 for (int k = 1; k < row_lanes; ++k)
                     for (int e = 0; e < 8; ++e) acc[e] += red[k * lanes_per_row + cgl][e];
                 for (int e = 0; e < 8; ++e) p.db[(long long)blockIdx.x * p.C + cg * 8 + e] = acc[e];

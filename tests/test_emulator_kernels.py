@@ -2098,3 +2098,19 @@ def test_bias_gradient_finish_folds_every_partial_row_in_one_workgroup_per_colum
     K.finish_queue.add_colsum(part, n, 0.5, sink)
     K.finish_queue.flush()
     assert rel_err(sink.double(), want - 1.0) < 1e-6
+
+
+@pytest.mark.parametrize('rows,C', [(1, 8), (7, 16), (37, 32), (1030, 64), (4099, 24), (301, 2056)])
+def test_bias_activation_backward_on_ragged_row_counts(rows, C):
+    """gg_bias_act_bwd (autograd of bias + leaky_relu, gp.py:109, :1608-1621) walks its rows four per trip with the loads batched
+    (round 6): row counts that are not a multiple of anything, a single row, more than 256 column groups. dz bit for bit against
+    the tensor expression; the column sums against fp64 sums of that dz."""
+    torch.manual_seed(rows + C)
+    dy, y = bf(torch.randn(rows, C)), bf(torch.randn(rows, C))
+    dz, db = K.bias_act_bwd(dy, y, True)
+    want = bf(dy.float() * torch.where(y.float() > 0, 1.0, 0.2))
+    assert torch.equal(dz, want)
+    ref = want.double().sum(0)
+    assert (db.double() - ref).abs().max() <= 1e-5 * (1 + want.double().abs().sum(0).max())
+    same, db2 = K.bias_act_bwd(dy, None, True)
+    assert same is dy and (db2.double() - dy.double().sum(0)).abs().max() <= 1e-5 * (1 + dy.double().abs().sum(0).max())
