@@ -64,29 +64,44 @@ GG_KERNEL GG_LAUNCH_BOUNDS(256) void gg_modulate_bwd_kernel(GgModulateParams p) 
     const int r0 = chunk * rows_per_chunk;
     int r1 = r0 + rows_per_chunk;
     if (r1 > p.P) r1 = p.P;
-    for (int cg = cgl; cg < ncg; cg += lanes_per_row) {
+    for (int cg0 = 0; cg0 < ncg; cg0 += lanes_per_row) {       // (workgroup-uniform trip count: the barriers below are inside)
+        const int cg = cg0 + cgl;
+        const bool live = rl < row_lanes && cg < ncg;
         float acc[8];
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-        if (rl < row_lanes) {
+        if (live) {
             const float* sc = p.s + (long long)img * p.C + cg * 8;
             float sv[8];
             for (int e = 0; e < 8; ++e) sv[e] = sc[e];
-            for (int r = r0 + rl; r < r1; r += row_lanes) {
-                const long long off = ((long long)img * p.P + r) * p.C + cg * 8;
-                u16x8 gv = *(const u16x8*)(p.g + off);
-                u16x8 xv = *(const u16x8*)(p.x + off);
-                u16x8 o;
-                for (int e = 0; e < 8; ++e) {
-                    float gf = gg_bf2f(gv[e]);
-                    o[e] = gg_f2bf(gf * sv[e]);
-                    acc[e] += gf * gg_bf2f(xv[e]);
+            // four rows per trip, their loads issued together (as gg_bias_act_bwd, round 6); accumulated in the old order: same bits
+            constexpr int UR = 4;
+            for (int rb = r0 + rl; rb < r1; rb += row_lanes * UR) {
+                u16x8 gv[UR], xv[UR];
+#pragma unroll
+                for (int u = 0; u < UR; ++u) {
+                    const int r = rb + u * row_lanes;
+                    const long long off = ((long long)img * p.P + (r < r1 ? r : r1 - 1)) * p.C + cg * 8;
+                    gv[u] = *(const u16x8*)(p.g + off);
+                    xv[u] = *(const u16x8*)(p.x + off);
                 }
-                *(u16x8*)(p.out + off) = o;
+#pragma unroll
+                for (int u = 0; u < UR; ++u) {
+                    const int r = rb + u * row_lanes;
+                    if (r < r1) {
+                        u16x8 o;
+                        for (int e = 0; e < 8; ++e) {
+                            float gf = gg_bf2f(gv[u][e]);
+                            o[e] = gg_f2bf(gf * sv[e]);
+                            acc[e] += gf * gg_bf2f(xv[u][e]);
+                        }
+                        *(u16x8*)(p.out + ((long long)img * p.P + r) * p.C + cg * 8) = o;
+                    }
+                }
             }
         }
-        for (int e = 0; e < 8; ++e) red[t][e] = (rl < row_lanes) ? acc[e] : 0.f;
+        for (int e = 0; e < 8; ++e) red[t][e] = live ? acc[e] : 0.f;
         gg_sync();
-        if (rl == 0) {
+        if (rl == 0 && cg < ncg) {
             for (int k = 1; k < row_lanes; ++k)
                 for (int e = 0; e < 8; ++e) acc[e] += red[k * lanes_per_row + cgl][e];
             float* dst = p.ds_part + ((long long)img * p.chunks + chunk) * p.C + cg * 8;
